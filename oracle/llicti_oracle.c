@@ -1,0 +1,672 @@
+/*
+ * llicti_oracle.c -- CPU ORACLE (test infrastructure only; see llicti_oracle.h for scope and citations).
+ * Build: oracle/Makefile  (gcc -O2 -mfma -ffp-contract=off -fopenmp).
+ *
+ * All floating point below is written operation by operation: no contraction (-ffp-contract=off),
+ * explicit fmaf() where the spec says "fused", IEEE division, round-to-nearest-even throughout.
+ */
+#include "llicti_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static int g_threads = 0;
+void orc_set_threads(int n) { g_threads = n; }
+static int nthreads(void)
+{
+#ifdef _OPENMP
+    return g_threads > 0 ? g_threads : omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------ numerics spec v1: scalar functions */
+static inline float bits2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t f2bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+/* coefficients derived by tools/gen_numerics_coeffs.py */
+static const float ERFC_P[11] = {
+    0x1.058672p+0f, -0x1.5fd388p-1f, 0x1.1e2deep-2f, -0x1.2a869p-5f, -0x1.606bd2p-6f, 0x1.a7e3c6p-8f,
+    0x1.93b74ap-9f, -0x1.a18b0cp-11f, -0x1.3ddc9cp-11f, -0x1.d399c2p-18f, 0x1.73901ap-15f };
+static const float EXP_Q[5] = { 0x1.0p-1f, 0x1.5554dcp-3f, 0x1.5554eap-5f, 0x1.120b74p-7f, 0x1.6d4328p-10f };
+#define LOG2E_F   0x1.715476p+0f
+#define LN2_HI_F  0x1.62e4p-1f
+#define LN2_LO_F  0x1.7f7d1cp-20f
+
+/* exp(y) for y in [-49, 0]:  2^j * (1 + f + f^2 R(f)),  j = rint(y log2 e),  f = y - j ln2 (two fma steps) */
+static inline float exp_spec(float y)
+{
+    float j = rintf(y * LOG2E_F);
+    float f = fmaf(j, -LN2_HI_F, y);
+    f = fmaf(j, -LN2_LO_F, f);
+    float q = EXP_Q[4];
+    q = fmaf(q, f, EXP_Q[3]);
+    q = fmaf(q, f, EXP_Q[2]);
+    q = fmaf(q, f, EXP_Q[1]);
+    q = fmaf(q, f, EXP_Q[0]);
+    float f2 = f * f;
+    q = fmaf(q, f2, f);
+    q = q + 1.0f;
+    int32_t ji = (int32_t)j;
+    return bits2f(f2bits(q) + ((uint32_t)ji << 23));
+}
+
+/* erfc(x), x >= 0:  r = 1/(x+2), t = (x-2) r,  P(t) exp(-x^2) r;  := 0 for x >= 7 (and for NaN) */
+static inline float erfc_pos(float x)
+{
+    if (!(x < 7.0f)) return 0.0f;
+    float r = 1.0f / (x + 2.0f);
+    float t = (x - 2.0f) * r;
+    float p = ERFC_P[10];
+    for (int i = 9; i >= 0; --i) p = fmaf(p, t, ERFC_P[i]);
+    float s = x * x;
+    float e = fmaf(x, x, -s);          /* exact rounding error of s */
+    float ex = exp_spec(-s);
+    ex = fmaf(-e, ex, ex);             /* exp(-(s+e)) ~= exp(-s) (1 - e) */
+    return (p * ex) * r;
+}
+static inline float erfc_spec(float x)
+{
+    float v = erfc_pos(fabsf(x));
+    return (x < 0.0f) ? 2.0f - v : v;
+}
+float orc_erfc(float x) { return erfc_spec(x); }
+
+/* compressai constants: scale bound 0.11/255 and weight bound 1e-6 are float32 buffers
+ * (entropy_layer_nets.py:149-158); const = -(2**-0.5) (compressai _standardized_cumulative). */
+#define SCALE_BOUND ((float)(0.11 / 255.0))
+#define WEIGHT_BOUND (1e-6f)
+#define NEG_RSQRT2 ((float)(-0.70710678118654752440))
+
+typedef struct { float sig[5], mu[5], wn[5]; } mix_t;
+
+/* entropy_layer_nets.py:197-200 + LLICTI_nets.py:385-392: slice, cross-channel mean update, bounds, normalise */
+static inline void mix_prepare(const float *par, int clr, float yv, float cov, mix_t *m)
+{
+    float w[5];
+    for (int k = 0; k < 5; ++k) {
+        float sg = par[5 * clr + k];
+        float mu = par[15 + 5 * clr + k];
+        float wk = par[30 + 5 * clr + k];
+        if (clr == 1) {
+            float t = par[45 + k] * yv;
+            mu = mu + t;
+        } else if (clr == 2) {
+            float t1 = par[50 + k] * yv;
+            float t2 = par[55 + k] * cov;
+            float t = t1 + t2;
+            mu = mu + t;
+        }
+        m->sig[k] = (sg > SCALE_BOUND) ? sg : SCALE_BOUND;
+        m->mu[k] = mu;
+        w[k] = (wk > WEIGHT_BOUND) ? wk : WEIGHT_BOUND;
+    }
+    float s = (((w[0] + w[1]) + w[2]) + w[3]) + w[4];
+    float den = 1e-9f + s;
+    for (int k = 0; k < 5; ++k) m->wn[k] = w[k] / den;
+}
+
+static inline float mix_cdf(const mix_t *m, float pt)
+{
+    float acc = 0.0f;
+    for (int k = 0; k < 5; ++k) {
+        float z = (pt - m->mu[k]) / m->sig[k];
+        float c = 0.5f * erfc_spec(NEG_RSQRT2 * z);
+        float t = m->wn[k] * c;
+        acc = (k == 0) ? t : acc + t;
+    }
+    return acc;
+}
+
+/* sample point of table entry i (LLICTI_nets.py:941-942): half-integers / 255 in fp32, the two end
+ * points pushed out by 20 and computed in double like the reference's Python scalars */
+static inline float sample_pt(int i, int Lp, int minv, int maxv)
+{
+    if (i == 0) return (float)(((double)minv - 0.5 - 20.0) / 255.0);
+    if (i == Lp - 1) return (float)(((double)maxv + 0.5 + 20.0) / 255.0);
+    return ((float)minv - 0.5f + (float)i) / 255.0f;
+}
+
+/* LLICTI_nets.py:955-983: round(cdf * (65536 - (Lp-1))) -> 16-bit wrap -> + index */
+static inline uint16_t cdf_entry(const mix_t *m, int i, int Lp, int minv, int maxv)
+{
+    float scale = (float)(65536 - (Lp - 1));
+    float q = rintf(mix_cdf(m, sample_pt(i, Lp, minv, maxv)) * scale);
+    return (uint16_t)((int32_t)q + i);
+}
+
+void orc_cdf_row(const float *par, int clr, float yv, float cov, int minv, int maxv, uint16_t *row)
+{
+    mix_t m;
+    mix_prepare(par, clr, yv, cov, &m);
+    int Lp = maxv - minv + 2;
+    for (int i = 0; i < Lp; ++i) row[i] = cdf_entry(&m, i, Lp, minv, maxv);
+}
+
+float orc_cdf_float(const float *par, int clr, float yv, float cov, float pt)
+{
+    mix_t m;
+    mix_prepare(par, clr, yv, cov, &m);
+    return mix_cdf(&m, pt);
+}
+
+/* ------------------------------------------------------------------ integer colour lift */
+static inline int fdiv2(int a) { return a >> 1; }   /* floor division by 2 (torch >= 1.13 '//' on int16) */
+
+void orc_lift(const uint8_t *rgb, int H, int W, int16_t *planes, int16_t minmax[6])
+{
+    long n = (long)H * W;
+    int mnCo = 32767, mxCo = -32768, mnCg = 32767, mxCg = -32768;
+    for (long p = 0; p < n; ++p) {
+        int R = rgb[p], G = rgb[n + p], B = rgb[2 * n + p];
+        int Co = R - B;
+        int t = B + fdiv2(Co);
+        int Cg = G - t;
+        int Y = t + fdiv2(Cg);
+        planes[p] = (int16_t)(Y - 127);
+        planes[n + p] = (int16_t)Co;
+        planes[2 * n + p] = (int16_t)Cg;
+        if (Co < mnCo) mnCo = Co;
+        if (Co > mxCo) mxCo = Co;
+        if (Cg < mnCg) mnCg = Cg;
+        if (Cg > mxCg) mxCg = Cg;
+    }
+    minmax[0] = 0; minmax[1] = (int16_t)mnCo; minmax[2] = (int16_t)mnCg;
+    minmax[3] = 255; minmax[4] = (int16_t)mxCo; minmax[5] = (int16_t)mxCg;
+}
+
+void orc_unlift(const int16_t *planes, int H, int W, uint8_t *rgb)
+{
+    long n = (long)H * W;
+    for (long p = 0; p < n; ++p) {
+        int Y = planes[p] + 127, Co = planes[n + p], Cg = planes[2 * n + p];
+        int t = Y - fdiv2(Cg);
+        int G = Cg + t;
+        int B = t - fdiv2(Co);
+        int R = B + Co;
+        rgb[p] = (uint8_t)R; rgb[n + p] = (uint8_t)G; rgb[2 * n + p] = (uint8_t)B;
+    }
+}
+
+/* ------------------------------------------------------------------ level geometry / band access */
+void orc_level_geom(int H, int W, int lvl, int *Hl, int *Wl, int *h, int *w, int *padH, int *padW)
+{
+    int st = 1 << lvl;
+    *Hl = (H + st - 1) / st;
+    *Wl = (W + st - 1) / st;
+    *h = (*Hl + 1) / 2;
+    *w = (*Wl + 1) / 2;
+    *padH = *Hl & 1;
+    *padW = *Wl & 1;
+}
+
+static const int BAND_OI[4] = { 0, 1, 0, 1 };   /* source order x00, x11, x01, x10 (lazyDWT cat order) */
+static const int BAND_OJ[4] = { 0, 1, 1, 0 };
+/* band to predict b = 0,1,2 is x11, x01, x10 = source index b+1 */
+
+/* value of sub-band `src` at band coordinate (i, j) of level lvl, with the conv's replicate clamp in
+ * band space and lazyDWT's replicate pad of the odd edge (LLICTI_nets.py:226-240, :511-530) */
+static inline int band_px(const int16_t *plane, int H, int W, int lvl, int Hl, int Wl, int h, int w,
+                          int src, int i, int j)
+{
+    if (i < 0) i = 0;
+    if (i > h - 1) i = h - 1;
+    if (j < 0) j = 0;
+    if (j > w - 1) j = w - 1;
+    int r = 2 * i + BAND_OI[src];
+    int c = 2 * j + BAND_OJ[src];
+    if (r >= Hl) r -= 2;
+    if (c >= Wl) c -= 2;
+    (void)H;
+    return plane[((long)r << lvl) * W + ((long)c << lvl)];
+}
+
+/* layer-0 tap tables: per band a list of (src, kh, kw, top pad, left pad) (LLICTI_nets.py:651-675) */
+typedef struct { int src, kh, kw, pt, pl; } conv_t;
+static const conv_t CONVS[3][3] = {
+    { { 0, 4, 4, 1, 1 }, { -1, 0, 0, 0, 0 }, { -1, 0, 0, 0, 0 } },
+    { { 0, 3, 4, 1, 1 }, { 1, 4, 3, 2, 1 }, { -1, 0, 0, 0, 0 } },
+    { { 0, 4, 3, 1, 1 }, { 1, 3, 4, 1, 2 }, { 2, 4, 4, 1, 2 } },
+};
+
+typedef struct { int src, ci, dy, dx; } tap_t;
+static int build_taps(int band, tap_t *taps)
+{
+    int k = 0;
+    for (int c = 0; c < 3; ++c) {
+        const conv_t *cv = &CONVS[band][c];
+        if (cv->src < 0) break;
+        for (int ci = 0; ci < 3; ++ci)
+            for (int ky = 0; ky < cv->kh; ++ky)
+                for (int kx = 0; kx < cv->kw; ++kx) {
+                    taps[k].src = cv->src; taps[k].ci = ci;
+                    taps[k].dy = ky - cv->pt; taps[k].dx = kx - cv->pl;
+                    ++k;
+                }
+    }
+    return k;
+}
+
+/* ------------------------------------------------------------------ interpolator CNN */
+void orc_band_params(const int16_t *planes, int H, int W, int lvl, int band,
+                     const orc_band_weights *bw, float *out)
+{
+    int Hl, Wl, h, w, padH, padW;
+    orc_level_geom(H, W, lvl, &Hl, &Wl, &h, &w, &padH, &padW);
+    const int K0 = bw->K0;
+    tap_t taps[120];
+    int nk = build_taps(band, taps);
+    if (nk != K0) abort();
+    /* transposed copies so the inner loops run over output channels (each channel keeps its own
+     * k-ordered fmaf chain; vectorising across channels does not change any chain) */
+    float *w0t = (float *)malloc(sizeof(float) * K0 * ORC_NCH);
+    float *w1t = (float *)malloc(sizeof(float) * ORC_HEAD * ORC_NCH);
+    float *w2t = (float *)malloc(sizeof(float) * ORC_HEAD * 64);
+    for (int c = 0; c < ORC_NCH; ++c)
+        for (int k = 0; k < K0; ++k) w0t[k * ORC_NCH + c] = bw->w0[c * K0 + k];
+    for (int c = 0; c < ORC_NCH; ++c)
+        for (int i = 0; i < ORC_HEAD; ++i) w1t[i * ORC_NCH + c] = bw->w1[c * ORC_HEAD + i];
+    memset(w2t, 0, sizeof(float) * ORC_HEAD * 64);
+    for (int o = 0; o < ORC_NPAR; ++o)
+        for (int i = 0; i < ORC_HEAD; ++i) w2t[i * 64 + (o / 15) * 16 + (o % 15)] = bw->w2[o * ORC_HEAD + i];
+    const long plane_sz = (long)H * W;
+
+#pragma omp parallel for schedule(static) num_threads(nthreads())
+    for (long pos = 0; pos < (long)h * w; ++pos) {
+        int i = (int)(pos / w), j = (int)(pos % w);
+        float x[120];
+        float h0[ORC_NCH], h1[ORC_NCH], o2[64];
+        for (int k = 0; k < K0; ++k) {
+            int v = band_px(planes + taps[k].ci * plane_sz, H, W, lvl, Hl, Wl, h, w,
+                            taps[k].src, i + taps[k].dy, j + taps[k].dx);
+            x[k] = (float)v / 255.0f;
+        }
+        for (int c = 0; c < ORC_NCH; ++c) h0[c] = bw->b0[c];
+        for (int k = 0; k < K0; ++k) {
+            const float xv = x[k];
+            const float *wr = w0t + (long)k * ORC_NCH;
+            for (int c = 0; c < ORC_NCH; ++c) h0[c] = fmaf(wr[c], xv, h0[c]);
+        }
+        for (int c = 0; c < ORC_NCH; ++c) h0[c] = (h0[c] > 0.0f) ? h0[c] : 0.0f;
+        for (int c = 0; c < ORC_NCH; ++c) h1[c] = bw->b1[c];
+        for (int g = 0; g < 4; ++g)
+            for (int ii = 0; ii < ORC_HEAD; ++ii) {
+                const float xv = h0[g * ORC_HEAD + ii];
+                const float *wr = w1t + (long)ii * ORC_NCH + g * ORC_HEAD;
+                float *hp = h1 + g * ORC_HEAD;
+                for (int c = 0; c < ORC_HEAD; ++c) hp[c] = fmaf(wr[c], xv, hp[c]);
+            }
+        for (int c = 0; c < ORC_NCH; ++c) h1[c] = (h1[c] > 0.0f) ? h1[c] : 0.0f;
+        for (int g = 0; g < 4; ++g)
+            for (int o = 0; o < 16; ++o) o2[g * 16 + o] = (o < 15) ? bw->b2[g * 15 + o] : 0.0f;
+        for (int g = 0; g < 4; ++g)
+            for (int ii = 0; ii < ORC_HEAD; ++ii) {
+                const float xv = h1[g * ORC_HEAD + ii];
+                const float *wr = w2t + (long)ii * 64 + g * 16;
+                float *op = o2 + g * 16;
+                for (int o = 0; o < 16; ++o) op[o] = fmaf(wr[o], xv, op[o]);
+            }
+        float *dst = out + pos * ORC_NPAR;
+        for (int g = 0; g < 4; ++g)
+            for (int o = 0; o < 15; ++o) dst[g * 15 + o] = o2[g * 16 + o];
+    }
+    free(w0t); free(w1t); free(w2t);
+}
+
+/* ------------------------------------------------------------------ arithmetic coder (torchac 0.9.3 algorithm) */
+typedef struct { uint8_t *out; long cap, n; uint8_t cache; int count; int overflow; } bitw_t;
+static inline void bw_put(bitw_t *b, int bit)
+{
+    b->cache = (uint8_t)((b->cache << 1) | bit);
+    if (++b->count == 8) {
+        if (b->n < b->cap) b->out[b->n] = b->cache; else b->overflow = 1;
+        b->n++;
+        b->count = 0;
+    }
+}
+static inline void bw_put_pending(bitw_t *b, int bit, uint64_t *pending)
+{
+    bw_put(b, bit);
+    while (*pending > 0) { bw_put(b, !bit); (*pending)--; }
+}
+
+typedef struct { uint32_t low, high; uint64_t pending; bitw_t bw; } acenc_t;
+static void acenc_init(acenc_t *e, uint8_t *out, long cap)
+{
+    e->low = 0; e->high = 0xFFFFFFFFu; e->pending = 0;
+    e->bw.out = out; e->bw.cap = cap; e->bw.n = 0; e->bw.cache = 0; e->bw.count = 0; e->bw.overflow = 0;
+}
+static inline void acenc_put(acenc_t *e, uint32_t c_low, uint32_t c_high)
+{
+    const uint64_t span = (uint64_t)e->high - (uint64_t)e->low + 1;
+    e->high = (e->low - 1) + (uint32_t)((span * (uint64_t)c_high) >> 16);
+    e->low = e->low + (uint32_t)((span * (uint64_t)c_low) >> 16);
+    for (;;) {
+        if (e->high < 0x80000000u) {
+            bw_put_pending(&e->bw, 0, &e->pending);
+            e->low <<= 1; e->high <<= 1; e->high |= 1;
+        } else if (e->low >= 0x80000000u) {
+            bw_put_pending(&e->bw, 1, &e->pending);
+            e->low <<= 1; e->high <<= 1; e->high |= 1;
+        } else if (e->low >= 0x40000000u && e->high < 0xC0000000u) {
+            e->pending++;
+            e->low <<= 1; e->low &= 0x7FFFFFFFu;
+            e->high <<= 1; e->high |= 0x80000001u;
+        } else break;
+    }
+}
+static long acenc_finish(acenc_t *e)
+{
+    e->pending += 1;
+    if (e->low < 0x40000000u) bw_put_pending(&e->bw, 0, &e->pending);
+    else bw_put_pending(&e->bw, 1, &e->pending);
+    if (e->bw.count > 0) { while (e->bw.count != 0) bw_put(&e->bw, 0); }
+    return e->bw.overflow ? -1 : e->bw.n;
+}
+
+typedef struct { const uint8_t *in; long nbytes, ptr; uint8_t cache; int cached; uint32_t low, high, value; } acdec_t;
+static inline void acdec_get(acdec_t *d)
+{
+    if (d->cached == 0) {
+        if (d->ptr == d->nbytes) { d->value <<= 1; return; }
+        d->cache = d->in[d->ptr++];
+        d->cached = 8;
+    }
+    d->value <<= 1;
+    d->value |= (uint32_t)((d->cache >> (d->cached - 1)) & 1);
+    d->cached--;
+}
+static void acdec_init(acdec_t *d, const uint8_t *in, long nbytes)
+{
+    d->in = in; d->nbytes = nbytes; d->ptr = 0; d->cache = 0; d->cached = 0;
+    d->low = 0; d->high = 0xFFFFFFFFu; d->value = 0;
+    for (int i = 0; i < 32; ++i) acdec_get(d);
+}
+static inline uint16_t acdec_count(const acdec_t *d)
+{
+    const uint64_t span = (uint64_t)d->high - (uint64_t)d->low + 1;
+    return (uint16_t)((((uint64_t)d->value - (uint64_t)d->low + 1) * 0x10000u - 1) / span);
+}
+static inline void acdec_update(acdec_t *d, uint32_t c_low, uint32_t c_high)
+{
+    const uint64_t span = (uint64_t)d->high - (uint64_t)d->low + 1;
+    d->high = (d->low - 1) + (uint32_t)((span * (uint64_t)c_high) >> 16);
+    d->low = d->low + (uint32_t)((span * (uint64_t)c_low) >> 16);
+    for (;;) {
+        if (d->low >= 0x80000000u || d->high < 0x80000000u) {
+            d->low <<= 1; d->high <<= 1; d->high |= 1;
+            acdec_get(d);
+        } else if (d->low >= 0x40000000u && d->high < 0xC0000000u) {
+            d->low <<= 1; d->low &= 0x7FFFFFFFu;
+            d->high <<= 1; d->high |= 0x80000001u;
+            d->value -= 0x40000000u;
+            acdec_get(d);
+        } else break;
+    }
+}
+
+long orc_ac_encode_tables(const uint16_t *cdf, int Lp, const int16_t *sym, long N, uint8_t *out, long cap)
+{
+    acenc_t e;
+    acenc_init(&e, out, cap);
+    const int max_symbol = Lp - 2;
+    for (long i = 0; i < N; ++i) {
+        int s = sym[i];
+        uint32_t c_low = cdf[i * Lp + s];
+        uint32_t c_high = (s == max_symbol) ? 0x10000u : cdf[i * Lp + s + 1];
+        acenc_put(&e, c_low, c_high);
+    }
+    return acenc_finish(&e);
+}
+
+long orc_ac_encode_pairs(const uint32_t *clow, const uint32_t *chigh, long N, uint8_t *out, long cap)
+{
+    acenc_t e;
+    acenc_init(&e, out, cap);
+    for (long i = 0; i < N; ++i) acenc_put(&e, clow[i], chigh[i]);
+    return acenc_finish(&e);
+}
+
+void orc_ac_decode_tables(const uint16_t *cdf, int Lp, const uint8_t *in, long nbytes, long N, int16_t *sym)
+{
+    acdec_t d;
+    acdec_init(&d, in, nbytes);
+    const uint16_t max_symbol = (uint16_t)(Lp - 2);
+    for (long i = 0; i < N; ++i) {
+        const uint16_t count = acdec_count(&d);
+        const uint16_t *row = cdf + i * Lp;
+        uint16_t left = 0, right = (uint16_t)(max_symbol + 1);
+        int found = -1;
+        while (left + 1 < right) {
+            uint16_t m = (uint16_t)((left + right) / 2);
+            uint16_t v = row[m];
+            if (v < count) left = m; else if (v > count) right = m; else { found = m; break; }
+        }
+        uint16_t s = (found >= 0) ? (uint16_t)found : left;
+        sym[i] = (int16_t)s;
+        if (i == N - 1) break;
+        uint32_t c_low = row[s];
+        uint32_t c_high = (s == max_symbol) ? 0x10000u : row[s + 1];
+        acdec_update(&d, c_low, c_high);
+    }
+}
+
+/* ------------------------------------------------------------------ stream geometry */
+static void stream_dims(int h, int w, int padH, int padW, int band, int *hc, int *wc)
+{
+    /* LLICTI_nets.py:396-397: rows cropped for x11 (b0) and x10 (b2), columns for x11 (b0) and x01 (b1) */
+    *hc = (band == 0 || band == 2) ? h - padH : h;
+    *wc = (band == 0 || band == 1) ? w - padW : w;
+}
+
+long orc_stream_pairs(const int16_t *planes, int H, int W, const int16_t minmax[6], int lvl, int band, int clr,
+                      const float *params, uint32_t *clow, uint32_t *chigh, int16_t *sym)
+{
+    int Hl, Wl, h, w, padH, padW, hc, wc;
+    orc_level_geom(H, W, lvl, &Hl, &Wl, &h, &w, &padH, &padW);
+    stream_dims(h, w, padH, padW, band, &hc, &wc);
+    const long plane_sz = (long)H * W;
+    const int minv = (clr == 0) ? -127 : minmax[clr];
+    const int maxv = (clr == 0) ? 128 : minmax[3 + clr];
+    const int shift = (clr == 0) ? 127 : -minmax[clr];   /* _adjust_mean_shifts, LLICTI_nets.py:544-547 */
+    const int Lp = maxv - minv + 2;
+    const int src = band + 1;
+#pragma omp parallel for schedule(static) num_threads(nthreads())
+    for (long n = 0; n < (long)hc * wc; ++n) {
+        int i = (int)(n / wc), j = (int)(n % wc);
+        long off = ((long)(2 * i + BAND_OI[src]) << lvl) * W + ((long)(2 * j + BAND_OJ[src]) << lvl);
+        int yv = planes[off], cov = planes[plane_sz + off];
+        int v = planes[clr * plane_sz + off];
+        int s = v + shift;
+        mix_t m;
+        mix_prepare(params + ((long)i * w + j) * ORC_NPAR, clr, (float)yv / 255.0f, (float)cov / 255.0f, &m);
+        clow[n] = cdf_entry(&m, s, Lp, minv, maxv);
+        chigh[n] = (s == Lp - 2) ? 0x10000u : cdf_entry(&m, s + 1, Lp, minv, maxv);
+        sym[n] = (int16_t)s;
+    }
+    return (long)hc * wc;
+}
+
+/* ------------------------------------------------------------------ whole-image encode */
+long orc_encode_image(const uint8_t *rgb, int H, int W, const orc_weights *wts, int full_tables,
+                      uint8_t *out, long cap, int32_t seg_len[49])
+{
+    if (H < 32 || W < 32 || H > 8160 || W > 8160) return -2;
+    const long plane_sz = (long)H * W;
+    int16_t *planes = (int16_t *)malloc(sizeof(int16_t) * 3 * plane_sz);
+    int16_t minmax[6];
+    orc_lift(rgb, H, W, planes, minmax);
+    int Hl, Wl, h, w, padH, padW;
+    long pos = 0;
+    /* header (LLICTI_nets.py:346-354) */
+    orc_level_geom(H, W, 4, &Hl, &Wl, &h, &w, &padH, &padW);
+    const int h4 = h, w4 = w;
+    if (cap < 17 + 3L * h4 * w4) { free(planes); return -1; }
+    out[pos++] = ORC_NLEV; out[pos++] = (uint8_t)h4; out[pos++] = (uint8_t)w4;
+    seg_len[0] = 3;
+    memcpy(out + pos, minmax, 12); pos += 12; seg_len[1] = 12;
+    int padint = 0;
+    for (int l = 0; l < ORC_NLEV; ++l) {
+        orc_level_geom(H, W, l, &Hl, &Wl, &h, &w, &padH, &padW);
+        padint = 4 * padint + 2 * padH + padW;          /* LLICTI_nets.py:230, level 0 most significant */
+    }
+    int16_t padi16 = (int16_t)padint;
+    memcpy(out + pos, &padi16, 2); pos += 2; seg_len[2] = 2;
+    for (int c = 0; c < 3; ++c)                          /* raw DC band = x[::32, ::32], uint8 CHW (:248-252) */
+        for (int i = 0; i < h4; ++i)
+            for (int j = 0; j < w4; ++j) out[pos++] = rgb[c * plane_sz + (long)(32 * i) * W + 32 * j];
+    seg_len[3] = 3 * h4 * w4;
+
+    int si = 4;
+    for (int lvl = ORC_NLEV - 1; lvl >= 0; --lvl) {
+        orc_level_geom(H, W, lvl, &Hl, &Wl, &h, &w, &padH, &padW);
+        float *params = (float *)malloc(sizeof(float) * (long)h * w * ORC_NPAR);
+        uint32_t *clow = (uint32_t *)malloc(sizeof(uint32_t) * (long)h * w);
+        uint32_t *chigh = (uint32_t *)malloc(sizeof(uint32_t) * (long)h * w);
+        int16_t *sym = (int16_t *)malloc(sizeof(int16_t) * (long)h * w);
+        for (int band = 0; band < 3; ++band) {
+            orc_band_params(planes, H, W, lvl, band, &wts->band[band], params);
+            for (int clr = 0; clr < 3; ++clr) {
+                long n;
+                long wrote;
+                if (!full_tables) {
+                    n = orc_stream_pairs(planes, H, W, minmax, lvl, band, clr, params, clow, chigh, sym);
+                    wrote = orc_ac_encode_pairs(clow, chigh, n, out + pos, cap - pos);
+                } else {
+                    /* reference structure: materialise the whole [N][Lp] table, then code from it */
+                    int hc, wc;
+                    stream_dims(h, w, padH, padW, band, &hc, &wc);
+                    n = (long)hc * wc;
+                    const int minv = (clr == 0) ? -127 : minmax[clr];
+                    const int maxv = (clr == 0) ? 128 : minmax[3 + clr];
+                    const int shift = (clr == 0) ? 127 : -minmax[clr];
+                    const int Lp = maxv - minv + 2;
+                    const int src = band + 1;
+                    uint16_t *tab = (uint16_t *)malloc(sizeof(uint16_t) * n * Lp);
+#pragma omp parallel for schedule(static) num_threads(nthreads())
+                    for (long q = 0; q < n; ++q) {
+                        int i = (int)(q / wc), j = (int)(q % wc);
+                        long off = ((long)(2 * i + BAND_OI[src]) << lvl) * W + ((long)(2 * j + BAND_OJ[src]) << lvl);
+                        orc_cdf_row(params + ((long)i * w + j) * ORC_NPAR, clr, (float)planes[off] / 255.0f,
+                                    (float)planes[plane_sz + off] / 255.0f, minv, maxv, tab + q * Lp);
+                        sym[q] = (int16_t)(planes[clr * plane_sz + off] + shift);
+                    }
+                    wrote = orc_ac_encode_tables(tab, Lp, sym, n, out + pos, cap - pos);
+                    free(tab);
+                }
+                if (wrote < 0) { free(params); free(clow); free(chigh); free(sym); free(planes); return -1; }
+                seg_len[si++] = (int32_t)wrote;
+                pos += wrote;
+            }
+        }
+        free(params); free(clow); free(chigh); free(sym);
+    }
+    free(planes);
+    return pos;
+}
+
+/* ------------------------------------------------------------------ whole-image decode */
+void orc_header_dims(const uint8_t *in, const int32_t seg_len[49], int *H_out, int *W_out)
+{
+    (void)seg_len;
+    int h4 = in[1], w4 = in[2];
+    int16_t padi16;
+    memcpy(&padi16, in + 15, 2);
+    int padint = padi16;
+    /* _get_padHW_lev_list (LLICTI_nets.py:533-542): two bits per level, level 4 in the lowest bits */
+    int Hc = h4, Wc = w4;
+    for (int l = ORC_NLEV - 1; l >= 0; --l) {
+        int padW = padint & 1; padint >>= 1;
+        int padH = padint & 1; padint >>= 1;
+        Hc = 2 * Hc - padH;     /* H_l = 2 h_l - padH_l, and h_l = H_{l+1} */
+        Wc = 2 * Wc - padW;
+    }
+    *H_out = Hc; *W_out = Wc;
+}
+
+int orc_decode_image(const uint8_t *in, const int32_t seg_len[49], const orc_weights *wts, int full_tables,
+                     uint8_t *rgb, long rgb_cap, int *H_out, int *W_out)
+{
+    if (seg_len[0] != 3 || seg_len[1] != 12 || seg_len[2] != 2) return -3;
+    if (in[0] != ORC_NLEV) return -4;                     /* assert num_scales (LLICTI_nets.py:424) */
+    int H, W;
+    orc_header_dims(in, seg_len, &H, &W);
+    *H_out = H; *W_out = W;
+    const long plane_sz = (long)H * W;
+    if (rgb_cap < 3 * plane_sz) return -1;
+    int16_t minmax[6];
+    memcpy(minmax, in + 3, 12);
+    const int h4 = in[1], w4 = in[2];
+    if (seg_len[3] != 3 * h4 * w4) return -3;
+    int16_t *planes = (int16_t *)calloc(3 * plane_sz, sizeof(int16_t));
+    /* DC band: uint8 RGB -> YCoCg-R (LLICTI_nets.py:430, :443-444) */
+    const uint8_t *dc = in + 17;
+    for (int i = 0; i < h4; ++i)
+        for (int j = 0; j < w4; ++j) {
+            int R = dc[i * w4 + j], G = dc[h4 * w4 + i * w4 + j], B = dc[2 * h4 * w4 + i * w4 + j];
+            int Co = R - B, t = B + fdiv2(Co), Cg = G - t, Y = t + fdiv2(Cg);
+            long off = (long)(32 * i) * W + 32 * j;
+            planes[off] = (int16_t)(Y - 127);
+            planes[plane_sz + off] = (int16_t)Co;
+            planes[2 * plane_sz + off] = (int16_t)Cg;
+        }
+    long pos = 17 + seg_len[3];
+    int si = 4;
+    int Hl, Wl, h, w, padH, padW;
+    for (int lvl = ORC_NLEV - 1; lvl >= 0; --lvl) {
+        orc_level_geom(H, W, lvl, &Hl, &Wl, &h, &w, &padH, &padW);
+        float *params = (float *)malloc(sizeof(float) * (long)h * w * ORC_NPAR);
+        for (int band = 0; band < 3; ++band) {
+            orc_band_params(planes, H, W, lvl, band, &wts->band[band], params);
+            const int src = band + 1;
+            int hc, wc;
+            stream_dims(h, w, padH, padW, band, &hc, &wc);
+            const long n = (long)hc * wc;
+            for (int clr = 0; clr < 3; ++clr) {
+                const int minv = (clr == 0) ? -127 : minmax[clr];
+                const int maxv = (clr == 0) ? 128 : minmax[3 + clr];
+                const int shift = (clr == 0) ? 127 : -minmax[clr];
+                const int Lp = maxv - minv + 2;
+                const uint16_t max_symbol = (uint16_t)(Lp - 2);
+                acdec_t d;
+                acdec_init(&d, in + pos, seg_len[si]);
+                uint16_t *row = (uint16_t *)malloc(sizeof(uint16_t) * Lp);
+                for (long q = 0; q < n; ++q) {
+                    int i = (int)(q / wc), j = (int)(q % wc);
+                    long off = ((long)(2 * i + BAND_OI[src]) << lvl) * W + ((long)(2 * j + BAND_OJ[src]) << lvl);
+                    mix_t m;
+                    mix_prepare(params + ((long)i * w + j) * ORC_NPAR, clr, (float)planes[off] / 255.0f,
+                                (float)planes[plane_sz + off] / 255.0f, &m);
+                    if (full_tables)
+                        for (int e = 0; e < Lp; ++e) row[e] = cdf_entry(&m, e, Lp, minv, maxv);
+                    const uint16_t count = acdec_count(&d);
+                    /* torchac binsearch, entries evaluated on demand (same values as the table's) */
+                    uint16_t left = 0, right = (uint16_t)(max_symbol + 1);
+                    int found = -1;
+                    while (left + 1 < right) {
+                        uint16_t mid = (uint16_t)((left + right) / 2);
+                        uint16_t v = full_tables ? row[mid] : cdf_entry(&m, mid, Lp, minv, maxv);
+                        if (v < count) left = mid; else if (v > count) right = mid; else { found = mid; break; }
+                    }
+                    uint16_t s = (found >= 0) ? (uint16_t)found : left;
+                    planes[clr * plane_sz + off] = (int16_t)((int)s - shift);   /* _convert_int16cpu_to_float32gpu */
+                    if (q == n - 1) break;
+                    uint32_t c_low = full_tables ? row[s] : cdf_entry(&m, s, Lp, minv, maxv);
+                    uint32_t c_high = (s == max_symbol) ? 0x10000u
+                                    : (full_tables ? row[s + 1] : cdf_entry(&m, s + 1, Lp, minv, maxv));
+                    acdec_update(&d, c_low, c_high);
+                }
+                free(row);
+                pos += seg_len[si++];
+            }
+        }
+        free(params);
+    }
+    orc_unlift(planes, H, W, rgb);
+    free(planes);
+    return 0;
+}

@@ -1,0 +1,109 @@
+/*
+ * llicti_oracle.h -- CPU ORACLE for the LLICTI encode/decode hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under llicti_amd/ (the product) may include, link or call this.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, and only as the checker.
+ *
+ * It restates, in plain C, the algorithm of the reference (kamisli-icpl/LLICTI @ 2024_08_07):
+ *   graphs/models/LLICTI_nets.py:62-88      integer YCoCg-R lift / inverse lift
+ *   graphs/models/LLICTI_nets.py:125-252    compress / decompres / lazyDWT / DC band
+ *   graphs/models/LLICTI_nets.py:344-583    entropy layer: header, stage loop, pad / crop, symbol shifts
+ *   graphs/models/LLICTI_nets.py:644-753    interpolator CNN (layer0 convs + grouped 1x1 tail), :822-825
+ *   graphs/models/LLICTI_nets.py:938-983    CDF sample grid and 16-bit integerisation
+ *   graphs/layers/entropy_layer_nets.py:185-204   5-component Gaussian-mixture CDF
+ * and of its two third-party dependencies that are NOT in /root/reference:
+ *   compressai==1.1.8  GaussianConditional._standardized_cumulative (0.5*erfc(-x/sqrt2)), LowerBound (max)
+ *   torchac==0.9.3     32-bit binary arithmetic coder with 16-bit CDFs
+ *
+ * Floating point follows the "LLICTI-MI355X numerics spec v1" (DESIGN.md section 4): every fp32
+ * operation, its order and its rounding are fixed (k-ordered fmaf chains for the convolutions, a
+ * polynomial erfc with fixed coefficients, IEEE division), so the HIP kernels can reproduce the
+ * oracle bit for bit.  Against the reference's PyTorch ops this agrees to ~1e-6 (params) and to
+ * +-1 count on a few per cent of 16-bit table entries; the integer parts (lift, split, header,
+ * symbols, coder) are exact.
+ *
+ * PARITY PINNING: pinned against fixtures generated from the reference-owned Python
+ * (tests/golden/make_fixtures.py) for everything except the arithmetic coder's byte output:
+ * torchac is absent from this image, so the coder is "parity unpinned" (restated from its
+ * published algorithm; only self-consistency and hand-computed vectors are checked).
+ */
+#ifndef LLICTI_ORACLE_H
+#define LLICTI_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_NCH   352          /* hidden channels = 4 heads x 88 (configs/llicti_A.json chs[0]=88, mwsa separate) */
+#define ORC_HEAD   88
+#define ORC_NPAR   60          /* 15 sigma | 15 mu | 15 weight | 5 a | 5 b | 5 d */
+#define ORC_NLEV    5
+#define ORC_NSTREAM 45         /* 5 levels x 3 bands x 3 colour channels */
+
+/* Canonical packed weights of one band network (band 0: x00->x11, 1: x00,x11->x01, 2: x00,x11,x01->x10).
+ * w0 is the concatenation along K of the band's layer-0 conv weights, each flattened (ci, ky, kx)
+ * row-major, in source order x00, x11, x01  (K0 = 48 / 72 / 120); b0 is the fp32 sum of their biases
+ * taken left to right. */
+typedef struct {
+    int K0;
+    const float *w0;   /* [352][K0] */
+    const float *b0;   /* [352]     */
+    const float *w1;   /* [352][88] (grouped 1x1: row c reads inputs of head c/88) */
+    const float *b1;   /* [352]     */
+    const float *w2;   /* [60][88]  (row o reads inputs of head o/15) */
+    const float *b2;   /* [60]      */
+} orc_band_weights;
+
+typedef struct { orc_band_weights band[3]; } orc_weights;
+
+/* ---- integer colour lift (LLICTI_nets.py:62-74, :76-88, :571-582); planes are Y-127, Co, Cg ---- */
+void orc_lift(const uint8_t *rgb, int H, int W, int16_t *planes, int16_t minmax[6]);
+void orc_unlift(const int16_t *planes, int H, int W, uint8_t *rgb);
+
+/* level geometry: Hl = ceil(H / 2^l); band grid h = ceil(Hl/2); padH = Hl & 1 */
+void orc_level_geom(int H, int W, int lvl, int *Hl, int *Wl, int *h, int *w, int *padH, int *padW);
+
+/* ---- interpolator CNN for one (level, band): out[i*w + j][60] on the full (padded) h x w grid ---- */
+void orc_band_params(const int16_t *planes, int H, int W, int lvl, int band,
+                     const orc_band_weights *bw, float *out);
+
+/* ---- one row of the integer CDF table (LLICTI_nets.py:938-983 + entropy_layer_nets.py:185-204) ----
+ * par: the 60 raw CNN outputs of the position; yv/cov: the band's own Y / Co pixel as int/255
+ * (cross-channel mean update, LLICTI_nets.py:389-392); row gets Lp = maxv-minv+2 uint16 entries. */
+void orc_cdf_row(const float *par, int clr, float yv, float cov, int minv, int maxv, uint16_t *row);
+/* float mixture CDF at one sample point, before integerisation (for tolerance checks) */
+float orc_cdf_float(const float *par, int clr, float yv, float cov, float pt);
+float orc_erfc(float x);        /* the spec's erfc, exported for unit tests */
+
+/* ---- torchac-compatible arithmetic coder on explicit tables (the reference's third-party seam) ----
+ * cdf: [N][Lp] uint16 (int16 reinterpreted), sym: [N] int16.  Returns bytes written (<= cap) or -1. */
+long orc_ac_encode_tables(const uint16_t *cdf, int Lp, const int16_t *sym, long N, uint8_t *out, long cap);
+void orc_ac_decode_tables(const uint16_t *cdf, int Lp, const uint8_t *in, long nbytes, long N, int16_t *sym);
+/* encoder on (c_low, c_high) pairs (c_high up to 0x10000) */
+long orc_ac_encode_pairs(const uint32_t *clow, const uint32_t *chigh, long N, uint8_t *out, long cap);
+
+/* ---- whole image (LLICTI.compress / LLICTI.decompres) ----
+ * Output container = the reference's bytestream_list flattened: 4 header segments
+ * [S,h4,w4 u8] [6 x int16 min/max] [int16 padHW] [raw DC band u8 CHW] followed by the 45 streams in
+ * order scale 4..0, band 0..2, clr Y,Co,Cg.  seg_len[49] receives the segment lengths.
+ * full_tables != 0 materialises every Lp-entry table like the reference does (slow; cpu_baseline);
+ * 0 evaluates only the entries the coder reads -- identical bytes by construction. */
+long orc_encode_image(const uint8_t *rgb, int H, int W, const orc_weights *wts, int full_tables,
+                      uint8_t *out, long cap, int32_t seg_len[49]);
+/* returns 0 on success; rgb must hold 3*H*W bytes where H, W are derived from the header */
+int orc_decode_image(const uint8_t *in, const int32_t seg_len[49], const orc_weights *wts, int full_tables,
+                     uint8_t *rgb, long rgb_cap, int *H_out, int *W_out);
+void orc_header_dims(const uint8_t *in, const int32_t seg_len[49], int *H_out, int *W_out);
+
+/* per-symbol (c_low, c_high) of one stream, in stream order (cropped raster); returns symbol count */
+long orc_stream_pairs(const int16_t *planes, int H, int W, const int16_t minmax[6], int lvl, int band, int clr,
+                      const float *params /* [h*w][60] from orc_band_params */,
+                      uint32_t *clow, uint32_t *chigh, int16_t *sym);
+
+void orc_set_threads(int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
