@@ -1,0 +1,157 @@
+/*
+ * llicti_hip.h -- C-ABI of the MI355X-native LLICTI encode/decode hot path (libllicti_hip.so).
+ *
+ * The reference (kamisli-icpl/LLICTI) has no FFI: its seam for this path is Python-method level
+ * (SURVEY.md section 8b).  Every entry point below names the reference call site it replaces; the
+ * ctypes binding a maintainer would add on the reference side is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C types only; device buffers are raw pointers obtained from the caller's allocator
+ *     (e.g. torch.Tensor.data_ptr()); `stream` is a hipStream_t passed as void* (NULL = default stream)
+ *   - every function returns 0 on success or a negative LLICTI_E* code; llicti_last_error() gives the
+ *     message of the calling thread's last failure
+ *   - nothing allocates device memory except llicti_create / llicti_set_band_weights (weights) --
+ *     all working memory comes from the caller-sized workspace (llicti_workspace_bytes)
+ *   - launches are asynchronous on `stream`; functions that return host-visible results say so and
+ *     synchronise the stream themselves
+ *   - one context per GPU / host thread; a context is not thread-safe
+ *   - all images of one call share H x W (32 <= H, W <= 8160: the header stores h4, w4 as uint8,
+ *     LLICTI_nets.py:347)
+ *
+ * Data layout in HBM
+ *   rgb     uint8  [B][3][H][W]   planar
+ *   planes  int16  [B][3][H][W]   Y-127, Co, Cg (YCoCg-R); the polyphase bands of every level are
+ *                                 strided views of these planes: band (oi,oj) of level l, pixel (i,j)
+ *                                 is planes[.., (2i+oi)<<l, (2j+oj)<<l]  (lazyDWT, LLICTI_nets.py:218-225)
+ *   fplanes float  [B][3][H][W]   planes / 255 (one IEEE division, LLICTI_nets.py:143-144)
+ *   params  float  [B][h*w][60]   raw CNN outputs on the band grid of one (level, band)
+ *   tables  uint16 [B][hc*wc][stride]  integer CDF rows of one stream (stride = Lp rounded up to 8)
+ */
+#ifndef LLICTI_HIP_H
+#define LLICTI_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LLICTI_OK            0
+#define LLICTI_EINVAL       -1   /* bad argument (shape, pointer, level/band index) */
+#define LLICTI_EHIP         -2   /* a HIP runtime call failed */
+#define LLICTI_ENOWEIGHTS   -3   /* llicti_set_band_weights has not been called for every band */
+#define LLICTI_ENOSPACE     -4   /* workspace or output buffer too small */
+#define LLICTI_EFORMAT      -5   /* malformed container (decode) */
+#define LLICTI_ENODEVICE    -6   /* no usable gfx950 device */
+
+#define LLICTI_NLEVELS   5
+#define LLICTI_NSTREAMS 45      /* 5 levels x 3 bands x 3 colour channels per image */
+#define LLICTI_NSEG     49      /* 4 header segments + 45 streams (the reference's bytestream_list) */
+#define LLICTI_NPARAMS  60
+
+typedef struct llicti_ctx llicti_ctx;
+
+const char *llicti_last_error(void);
+const char *llicti_version(void);
+
+/* Context on HIP device `device`.  Fails with LLICTI_ENODEVICE when no GPU is present: there is no
+ * CPU fallback. */
+int llicti_create(llicti_ctx **ctx, int device);
+int llicti_destroy(llicti_ctx *ctx);
+
+/* Upload one band network in canonical packed form (host pointers, float32):
+ *   w0 [352][K0] (K0 = 48 / 72 / 120), b0 [352], w1 [352][88], b1 [352], w2 [60][88], b2 [60].
+ * Replaces LLICTIEntropyModel4.__init__ / load_state_dict for the eval path
+ * (LLICTI_nets.py:651-675, :695-712; agents/base.py:51-76). */
+int llicti_set_band_weights(llicti_ctx *ctx, int band, int K0, const float *w0, const float *b0,
+                            const float *w1, const float *b1, const float *w2, const float *b2);
+
+/* Level geometry helper (host only): Hl = ceil(H/2^l), band grid h = ceil(Hl/2), pad flag = Hl odd;
+ * coded (cropped) size of `band`'s streams in hc, wc (LLICTI_nets.py:226-230, :396-397). */
+int llicti_level_geom(int H, int W, int lvl, int band, int *Hl, int *Wl, int *h, int *w,
+                      int *padH, int *padW, int *hc, int *wc);
+
+/* ---- kernel-level entry points ------------------------------------------------------------------ */
+
+/* K1-K3: uint8 RGB -> YCoCg-R planes (+ float copy) and per-image min/max of Co, Cg.
+ * d_minmax: int32 [B][4] = minCo, minCg, maxCo, maxCg.
+ * Replaces get_YCoCg_R_from_RGB__intOps + min()/max().item() + x/255 (LLICTI_nets.py:62-74, :137-144). */
+int llicti_lift_u8(llicti_ctx *ctx, const uint8_t *d_rgb, int B, int H, int W,
+                   int16_t *d_planes, float *d_fplanes, int32_t *d_minmax, void *stream);
+
+/* K13: planes -> uint8 RGB.  Replaces get_RGB_from_YCoCg_R__intOps (LLICTI_nets.py:76-88, :174-175). */
+int llicti_unlift_u8(llicti_ctx *ctx, const int16_t *d_planes, int B, int H, int W, uint8_t *d_rgb, void *stream);
+
+/* K4+K5: interpolator CNN of one (level, band) for every position of the h x w band grid of every
+ * image -> d_params [B][h*w][60].  fp32 MFMA, k-ordered accumulation (bit-exact to the numerics spec).
+ * Replaces LLICTIEntropyModel4.get_params (LLICTI_nets.py:721-753, :822-825). */
+int llicti_band_params_f32(llicti_ctx *ctx, const float *d_fplanes, int B, int H, int W, int lvl, int band,
+                           float *d_params, void *stream);
+
+/* K6-K8 (full table): integer CDF rows of stream (lvl, band, clr) for every coded position:
+ * d_tables [B][hc*wc][row_stride] uint16, row_stride >= Lp (entries beyond Lp are 0xFFFF).
+ * Replaces the cross-channel mean update + LLICTIEntropyModel4.get_cdfs(int_cdf=True)
+ * (LLICTI_nets.py:385-392, :938-983; entropy_layer_nets.py:185-204). */
+int llicti_cdf_u16(llicti_ctx *ctx, const int16_t *d_planes, const float *d_params, const int32_t *d_minmax,
+                   int B, int H, int W, int lvl, int band, int clr, uint16_t *d_tables, int row_stride, void *stream);
+
+/* K6-K9 (encoder form): for every coded position of (lvl, band) and each colour channel, only the two
+ * table entries the coder reads, packed (c_high & 0xFFFF) << 16 | c_low (c_high == 0x10000 is stored as 0),
+ * written in stream order to d_pairs[clr][B][hc*wc]. */
+int llicti_cdf_pairs_u32(llicti_ctx *ctx, const int16_t *d_planes, const float *d_params, const int32_t *d_minmax,
+                         int B, int H, int W, int lvl, int band, uint32_t *d_pairs, void *stream);
+
+/* K10: torchac-compatible arithmetic ENCODER on explicit tables -- the reference's third-party seam
+ * torchac.encode_int16_normalized_cdf(cdf, sym) (LLICTI_nets.py:406-407).  n_streams independent
+ * streams of N symbols; d_cdf [n_streams][N][row_stride] uint16 (Lp valid entries), d_sym [n_streams][N]
+ * int16; bytes of stream s go to d_out + s*out_stride, its length to d_len[s]. */
+int llicti_ac_encode_u16cdf(llicti_ctx *ctx, const uint16_t *d_cdf, int Lp, int row_stride, const int16_t *d_sym,
+                            int n_streams, long N, uint8_t *d_out, long out_stride, int32_t *d_len, void *stream);
+
+/* K11: the matching DECODER, torchac.decode_int16_normalized_cdf (LLICTI_nets.py:492-493).
+ * d_in + s*in_stride holds stream s (4-byte aligned, in_stride a multiple of 4, readable and zero for
+ * 16 bytes past d_len[s]). */
+int llicti_ac_decode_u16cdf(llicti_ctx *ctx, const uint16_t *d_cdf, int Lp, int row_stride, const uint8_t *d_in,
+                            long in_stride, const int32_t *d_len, int n_streams, long N, int16_t *d_sym, void *stream);
+
+/* ---- whole-batch entry points (LLICTI.compress / LLICTI.decompres, LLICTI_nets.py:125-179) -------
+ * Containers stay in HBM.  Image b's container is the reference's bytestream_list flattened: its 49
+ * segments concatenated tightly at d_out + b*out_stride, lengths in d_seg_len[b][49]; segment order
+ * [S,h4,w4 u8] | 6 x int16 min/max | int16 padHW | raw DC band u8 CHW | 45 streams, scale 4..0 x band
+ * x (Y,Co,Cg)  (LLICTI_nets.py:347-354, :411).  Both calls are asynchronous on `stream` and never
+ * synchronise; device-side failures (malformed header, stream overflow) are latched in the context
+ * and reported by llicti_check_status. */
+
+/* Bytes of device workspace the two calls below need for B images of H x W (mode 0 = AC container). */
+size_t llicti_workspace_bytes(int B, int H, int W, int mode);
+/* Upper bound of the container size of ONE image: the minimum out_stride / in_stride. */
+size_t llicti_max_container_bytes(int H, int W);
+
+int llicti_encode_images(llicti_ctx *ctx, const uint8_t *d_rgb, int B, int H, int W, int mode,
+                         void *d_workspace, size_t workspace_bytes,
+                         uint8_t *d_out, size_t out_stride, int32_t *d_seg_len, void *stream);
+
+/* H and W must be the size the headers describe (llicti_header_dims on a host copy of the first 17
+ * bytes); every image of the call has that size. */
+int llicti_decode_images(llicti_ctx *ctx, const uint8_t *d_in, size_t in_stride, const int32_t *d_seg_len,
+                         int B, int H, int W, int mode, void *d_workspace, size_t workspace_bytes,
+                         uint8_t *d_rgb, void *stream);
+
+/* Synchronises `stream` and returns the latched device-side status of the calls issued since the
+ * last check (LLICTI_OK, LLICTI_EFORMAT, LLICTI_ENOSPACE). */
+int llicti_check_status(llicti_ctx *ctx, void *stream);
+
+/* Image size from a container's first 17 header bytes (host memory). */
+int llicti_header_dims(const uint8_t *h_hdr17, int *H, int *W);
+
+/* Device-resident timing of the last llicti_encode_images / llicti_decode_images call, measured with
+ * HIP events on `stream`: ms[0] = whole call, ms[1] = sum of the band-CNN kernel launches,
+ * n_launch = number of band-CNN launches.  Used by bench.py for the roofline figure. */
+int llicti_last_timing(llicti_ctx *ctx, float ms[4], int *n_launch);
+/* enable / disable the per-kernel event timing above (off by default: it adds event records). */
+int llicti_set_profiling(llicti_ctx *ctx, int enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,111 @@
+"""`LLICTIAgent.eval_model` on the MI355X hot path (reference: agents/llicti_agent.py:122-164,
+agents/base.py:14-28, :102-123; graphs/losses/rate_dist.py:125-135).
+
+Per test image: time `compress`, time `decompres`, bits per sub-pixel over ALL streams including the
+header ones, and the lossless self-check `max|x - x_reco| * 255 < 0.5`, logged in the reference's line
+format.  Training / validation modes are outside the hot path and raise.
+"""
+from __future__ import annotations
+
+import logging
+import os
+import time
+
+import numpy as np
+import torch
+
+from ..graphs.models.LLICTI_nets import LLICTI
+
+
+class CompressionRLossList:
+    """graphs/losses/rate_dist.py:125-135: bpp of every stream, len*8/numel*3."""
+
+    def forward(self, numel_x, bytestream_list):
+        self.rate1list = [[len(s) * 8 / numel_x * 3 for s in row] for row in bytestream_list]
+        return self.rate1list
+
+
+def _iter_test_images(config, device):
+    """Test loader, batch 1, no crop (dataloaders/image_dl.py:40-45, :106-111): float32 1x3xHxW = uint8/255.
+    `test_data` is a directory of .png/.jpg or "synthetic:HxWxN" (seeded uniform RGB)."""
+    src = config.test_data
+    if isinstance(src, str) and src.startswith("synthetic:"):
+        H, W, N = (int(v) for v in src.split(":")[1].split("x"))
+        for i in range(N):
+            rgb = np.random.default_rng(i).integers(0, 256, size=(3, H, W), dtype=np.uint8)
+            yield torch.from_numpy(rgb.astype(np.float32) / np.float32(255)).unsqueeze(0).to(device)
+        return
+    from PIL import Image
+    names = sorted(f for f in os.listdir(src) if f.lower().endswith((".png", ".jpg")))
+    for f in names:
+        rgb = np.asarray(Image.open(os.path.join(src, f)).convert("RGB"), dtype=np.uint8).transpose(2, 0, 1)
+        yield torch.from_numpy(np.ascontiguousarray(rgb).astype(np.float32) / np.float32(255)).unsqueeze(0).to(device)
+
+
+class LLICTIAgent:
+    def __init__(self, config):
+        self.config = config
+        self.logger = logging.getLogger("Agent")
+        self.cuda = torch.cuda.is_available() and bool(config.cuda)
+        if not self.cuda:
+            raise RuntimeError("LLICTIAgent (MI355X hot path) needs a GPU: there is no CPU fallback")
+        torch.cuda.set_device(config.gpu_device)
+        self.device = torch.device("cuda", config.gpu_device)
+        torch.manual_seed(config.seed)              # base.py:21-28 (one seed for the default init)
+        assert config.wtr_type in ("lazydwt", "x")
+        self.model = LLICTI(config).to(self.device)
+        self.compr_loss = CompressionRLossList()
+        self.results = []
+        if config.mode in ("test", "validate", "debug", "eval_model"):
+            self.load_checkpoint("model_best.pth.tar")
+
+    def load_checkpoint(self, filename):
+        """base.py:51-81: a missing checkpoint is tolerated (the run continues with the seeded init)."""
+        path = os.path.join(getattr(self.config, "checkpoint_dir", "") if "checkpoint_dir" in self.config else "", filename)
+        try:
+            ckpt = torch.load(path, map_location=self.device)
+            sd = ckpt["state_dict"]
+            own = self.model.state_dict()
+            # compressai's extra buffers (scale_table, _offset, _quantized_cdf, ...) are not parameters of the codec
+            self.model.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=False)
+            self.logger.info("Checkpoint loaded from '%s'", path)
+        except OSError:
+            self.logger.info("No checkpoint at '%s' -- running with the seeded default init", path)
+
+    def run(self):
+        if self.config.mode == "eval_model":
+            return self.eval_model()
+        raise NameError("'" + str(self.config.mode) + "' is not available on the MI355X hot path (only eval_model)")
+
+    @torch.no_grad()
+    def eval_model(self):
+        self.model.eval()
+        self.results = []
+        for batch_idx, x in enumerate(_iter_test_images(self.config, self.device)):
+            print_text = "{:3d} {:3d}x{:3d} ".format(batch_idx, x.shape[2], x.shape[3])
+            torch.cuda.synchronize()
+            t0 = time.time()
+            bytestream_list, xorg = self.model.compress(x)
+            torch.cuda.synchronize()
+            enc_time = time.time() - t0
+            rate1_list = self.compr_loss.forward(torch.numel(x), bytestream_list)
+            total = sum(len(s) * 8 for row in bytestream_list for s in row)
+            t0 = time.time()
+            x_reco = self.model.decompres(bytestream_list, self.device)
+            torch.cuda.synchronize()
+            dec_time = time.time() - t0
+            maxx_abserr = float(((x - x_reco) * 255).abs().max())
+            bpsp = total / torch.numel(x)
+            if maxx_abserr >= 0.5:
+                self.logger.info(print_text + "bpsp= {:.3f} Enc/Dec-Times:{:.3f}/{:.3f} "
+                                 "(Error: Decoded img does NOT match original image perfectly! "
+                                 "The maximum of absolute error is {:.4f})".format(bpsp, enc_time, dec_time, maxx_abserr))
+            else:
+                self.logger.info(print_text + "bpsp= {:.3f} Enc/Dec-Times:{:.3f}/{:.3f} "
+                                 "(Check: Decoded img matches original)".format(bpsp, enc_time, dec_time))
+            self.results.append({"idx": batch_idx, "H": int(x.shape[2]), "W": int(x.shape[3]), "bpsp": bpsp,
+                                 "enc_s": enc_time, "dec_s": dec_time, "max_abs_err": maxx_abserr, "rates": rate1_list})
+        return self.results
+
+    def finalize(self):
+        self.logger.info("Please wait while finalizing the operation.. Thank you")

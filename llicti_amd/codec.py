@@ -1,0 +1,222 @@
+"""Host side of the HIP codec: device memory, streams and container plumbing on torch-ROCm tensors.
+
+`HipCodec` owns one C-ABI context (one per GPU / process) and exposes
+  - the kernel-level entry points on torch tensors (used by the parity tests), and
+  - `encode(rgb_u8[B,3,H,W]) -> (containers, seg_len)` / `decode(...)`, which keep the containers in HBM,
+  - helpers turning a device container into the reference's `bytestream_list` and back.
+PyTorch is plumbing here (allocation, streams, host copies); every computation happens in the HIP
+library.  Nothing in this module imports the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .weights import pack_state_dict
+
+NSEG = 49
+MODE_AC = 0
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if isinstance(t, torch.Tensor):
+        assert t.is_contiguous()
+        return C.c_void_p(t.data_ptr())
+    if isinstance(t, np.ndarray):
+        assert t.flags["C_CONTIGUOUS"]
+        return C.c_void_p(t.ctypes.data)
+    raise TypeError(type(t))
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class HipCodec:
+    def __init__(self, device=None):
+        if not torch.cuda.is_available():
+            raise _lib.LlictiError(_lib.ENODEVICE, "no GPU visible to PyTorch-ROCm: the LLICTI hot path has no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.L = _lib.lib()
+        ctx = C.c_void_p()
+        _lib.check(self.L.llicti_create(C.byref(ctx), self.device.index))
+        self.ctx = ctx
+        self._ws = None
+        self._ws_key = None
+        self.have_weights = False
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.L.llicti_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, sd):
+        """Reference-keyed state_dict (or the canonical packed dict) -> device."""
+        packed = sd if (isinstance(sd, dict) and 0 in sd) else pack_state_dict(sd)
+        for b in range(3):
+            d = packed[b]
+            _lib.check(self.L.llicti_set_band_weights(self.ctx, b, int(d["K0"]), _ptr(d["w0"]), _ptr(d["b0"]),
+                                                      _ptr(d["w1"]), _ptr(d["b1"]), _ptr(d["w2"]), _ptr(d["b2"])))
+        self.have_weights = True
+
+    # ------------------------------------------------------------------ kernel-level wrappers
+    def lift(self, rgb):
+        B, _, H, W = rgb.shape
+        planes = torch.empty((B, 3, H, W), dtype=torch.int16, device=self.device)
+        fplanes = torch.empty((B, 3, H, W), dtype=torch.float32, device=self.device)
+        mm = torch.empty((B, 4), dtype=torch.int32, device=self.device)
+        _lib.check(self.L.llicti_lift_u8(self.ctx, _ptr(rgb), B, H, W, _ptr(planes), _ptr(fplanes), _ptr(mm), _stream_ptr(self.device)))
+        return planes, fplanes, mm
+
+    def unlift(self, planes):
+        B, _, H, W = planes.shape
+        rgb = torch.empty((B, 3, H, W), dtype=torch.uint8, device=self.device)
+        _lib.check(self.L.llicti_unlift_u8(self.ctx, _ptr(planes), B, H, W, _ptr(rgb), _stream_ptr(self.device)))
+        return rgb
+
+    def band_params(self, fplanes, lvl, band):
+        B, _, H, W = fplanes.shape
+        _, _, h, w, _, _, _, _ = _lib.level_geom(H, W, lvl, band)
+        out = torch.empty((B, h * w, 60), dtype=torch.float32, device=self.device)
+        _lib.check(self.L.llicti_band_params_f32(self.ctx, _ptr(fplanes), B, H, W, lvl, band, _ptr(out), _stream_ptr(self.device)))
+        return out.view(B, h, w, 60)
+
+    def cdf_tables(self, planes, params, mm, lvl, band, clr, row_stride=512):
+        B, _, H, W = planes.shape
+        *_, hc, wc = _lib.level_geom(H, W, lvl, band)
+        out = torch.empty((B, hc * wc, row_stride), dtype=torch.int16, device=self.device)
+        _lib.check(self.L.llicti_cdf_u16(self.ctx, _ptr(planes), _ptr(params), _ptr(mm), B, H, W, lvl, band, clr,
+                                         _ptr(out), row_stride, _stream_ptr(self.device)))
+        return out
+
+    def cdf_pairs(self, planes, params, mm, lvl, band):
+        B, _, H, W = planes.shape
+        *_, hc, wc = _lib.level_geom(H, W, lvl, band)
+        out = torch.empty((3, B, hc * wc), dtype=torch.int32, device=self.device)
+        _lib.check(self.L.llicti_cdf_pairs_u32(self.ctx, _ptr(planes), _ptr(params), _ptr(mm), B, H, W, lvl, band,
+                                               _ptr(out), _stream_ptr(self.device)))
+        return out
+
+    def ac_encode_tables(self, cdf, sym):
+        """cdf int16/uint16 [S, N, stride] (Lp = stride valid entries unless Lp given), sym int16 [S, N]."""
+        S, N, stride = cdf.shape
+        out_stride = 2 * N + 32
+        out = torch.zeros((S, out_stride), dtype=torch.uint8, device=self.device)
+        ln = torch.zeros((S,), dtype=torch.int32, device=self.device)
+        _lib.check(self.L.llicti_ac_encode_u16cdf(self.ctx, _ptr(cdf), self._lp, stride, _ptr(sym), S, N, _ptr(out), out_stride,
+                                                  _ptr(ln), _stream_ptr(self.device)))
+        _lib.check(self.L.llicti_check_status(self.ctx, _stream_ptr(self.device)))
+        return out, ln
+
+    def ac_encode(self, cdf, sym, Lp):
+        self._lp = int(Lp)
+        return self.ac_encode_tables(cdf, sym)
+
+    def ac_decode(self, cdf, Lp, streams, lens, N):
+        S, _, stride = cdf.shape
+        in_stride = streams.shape[1]
+        sym = torch.empty((S, N), dtype=torch.int16, device=self.device)
+        _lib.check(self.L.llicti_ac_decode_u16cdf(self.ctx, _ptr(cdf), int(Lp), stride, _ptr(streams), in_stride, _ptr(lens),
+                                                  S, N, _ptr(sym), _stream_ptr(self.device)))
+        return sym
+
+    # ------------------------------------------------------------------ whole batch
+    def workspace(self, B, H, W, mode=MODE_AC):
+        key = (B, H, W, mode)
+        if self._ws_key != key:
+            n = self.L.llicti_workspace_bytes(B, H, W, mode)
+            if n == 0:
+                _lib.check(_lib.EINVAL)
+            self._ws = None
+            self._ws = torch.empty((n,), dtype=torch.uint8, device=self.device)
+            self._ws_key = key
+        return self._ws
+
+    def max_container_bytes(self, H, W):
+        n = self.L.llicti_max_container_bytes(H, W)
+        if n == 0:
+            _lib.check(_lib.EINVAL)
+        return int(n)
+
+    def encode(self, rgb, mode=MODE_AC, out=None, seg_len=None):
+        """rgb uint8 [B,3,H,W] on this device -> (containers uint8 [B, stride], seg_len int32 [B,49]), async."""
+        assert rgb.dtype == torch.uint8 and rgb.is_cuda and rgb.dim() == 4 and rgb.shape[1] == 3
+        rgb = rgb.contiguous()
+        B, _, H, W = rgb.shape
+        ws = self.workspace(B, H, W, mode)
+        stride = self.max_container_bytes(H, W)
+        if out is None:
+            out = torch.empty((B, stride), dtype=torch.uint8, device=self.device)
+        if seg_len is None:
+            seg_len = torch.zeros((B, NSEG), dtype=torch.int32, device=self.device)
+        _lib.check(self.L.llicti_encode_images(self.ctx, _ptr(rgb), B, H, W, mode, _ptr(ws), ws.numel(), _ptr(out), out.shape[1],
+                                               _ptr(seg_len), _stream_ptr(self.device)))
+        return out, seg_len
+
+    def decode(self, containers, seg_len, H, W, mode=MODE_AC, out=None):
+        """device containers -> uint8 [B,3,H,W], async."""
+        B = containers.shape[0]
+        ws = self.workspace(B, H, W, mode)
+        if out is None:
+            out = torch.empty((B, 3, H, W), dtype=torch.uint8, device=self.device)
+        _lib.check(self.L.llicti_decode_images(self.ctx, _ptr(containers), containers.shape[1], _ptr(seg_len), B, H, W, mode,
+                                               _ptr(ws), ws.numel(), _ptr(out), _stream_ptr(self.device)))
+        return out
+
+    def check(self):
+        _lib.check(self.L.llicti_check_status(self.ctx, _stream_ptr(self.device)))
+
+    def set_profiling(self, on=True):
+        _lib.check(self.L.llicti_set_profiling(self.ctx, int(bool(on))))
+
+    def last_timing(self):
+        ms = (C.c_float * 4)()
+        n = C.c_int()
+        _lib.check(self.L.llicti_last_timing(self.ctx, ms, C.byref(n)))
+        return list(ms), n.value
+
+
+# ---------------------------------------------------------------------- container <-> bytestream_list
+def container_to_bytestream_list(buf: np.ndarray, seg_len: np.ndarray):
+    """Flat container of one image -> the reference's list of 6 lists x 9 `bytes`
+    (LLICTI_nets.py:352-354, :411; loggers/rate.py:133 needs 9 entries per row)."""
+    segs, pos = [], 0
+    for n in seg_len:
+        segs.append(bytes(buf[pos:pos + int(n)]))
+        pos += int(n)
+    em = b""
+    bl = [[segs[0], segs[1], segs[2], segs[3], em, em, em, em, em]]
+    for s in range(5):
+        bl.append(segs[4 + 9 * s: 4 + 9 * (s + 1)])
+    return bl
+
+
+def bytestream_list_to_container(bl):
+    if len(bl) != 6 or any(len(r) != 9 for r in bl):
+        raise ValueError("bytestream_list must be 6 lists of 9 byte strings")
+    segs = list(bl[0][:4])
+    for s in range(1, 6):
+        segs += list(bl[s])
+    seg_len = np.array([len(s) for s in segs], dtype=np.int32)
+    return np.frombuffer(b"".join(segs), dtype=np.uint8).copy(), seg_len
+
+
+def header_dims(hdr17: bytes):
+    H, W = C.c_int(), C.c_int()
+    buf = (C.c_uint8 * 17).from_buffer_copy(bytes(hdr17[:17]).ljust(17, b"\0"))
+    _lib.check(_lib.lib().llicti_header_dims(buf, C.byref(H), C.byref(W)))
+    return H.value, W.value

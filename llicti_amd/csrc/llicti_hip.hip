@@ -1,0 +1,1284 @@
+// llicti_hip.hip -- gfx950 (MI355X / CDNA4) kernels and the C-ABI of include/llicti_hip.h.
+//
+// Kernels (reference call sites in include/llicti_hip.h):
+//   lift_kernel / unlift_kernel       integer YCoCg-R lift, min/max, float planes          (HBM bound)
+//   band_params_kernel<BAND>          interpolator CNN: 3 chained fp32-MFMA GEMMs per pixel tile,
+//                                     weights of one 88-channel head resident in LDS        (MFMA bound)
+//   cdf_pairs_kernel                  encoder: the two table entries per symbol (10 erfc)   (VALU)
+//   cdf_table_kernel                  decoder: full Lp-entry uint16 rows                    (HBM / VALU bound)
+//   ac_encode_*_kernel                torchac-algorithm range encoder, one lane per stream  (latency bound)
+//   ac_decode_kernel                  matching decoder, one wavefront per stream            (latency bound)
+//   header / pack / unpack kernels    container assembly in HBM
+//
+// No CPU path exists in this library: every entry point needs a gfx950 device.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/llicti_hip.h"
+#include "numerics.hpp"
+
+using namespace llicti;
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(x)                                                                                    \
+    do {                                                                                             \
+        hipError_t e_ = (x);                                                                         \
+        if (e_ != hipSuccess) return fail(LLICTI_EHIP, "%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" const char *llicti_last_error(void) { return g_err.c_str(); }
+extern "C" const char *llicti_version(void) { return "llicti_hip 0.1 (gfx950, numerics spec v1)"; }
+
+// ------------------------------------------------------------------------------------------------ geometry
+struct Geom {
+    int B, H, W, lvl;
+    int Hl, Wl, h, w, padH, padW;
+    long plane;   // H*W
+};
+static Geom make_geom(int B, int H, int W, int lvl)
+{
+    Geom g;
+    g.B = B; g.H = H; g.W = W; g.lvl = lvl;
+    const int st = 1 << lvl;
+    g.Hl = (H + st - 1) / st;
+    g.Wl = (W + st - 1) / st;
+    g.h = (g.Hl + 1) / 2;
+    g.w = (g.Wl + 1) / 2;
+    g.padH = g.Hl & 1;
+    g.padW = g.Wl & 1;
+    g.plane = (long)H * W;
+    return g;
+}
+static void coded_dims(const Geom &g, int band, int *hc, int *wc)
+{
+    *hc = (band == 0 || band == 2) ? g.h - g.padH : g.h;   // LLICTI_nets.py:396-397
+    *wc = (band == 0 || band == 1) ? g.w - g.padW : g.w;
+}
+extern "C" int llicti_level_geom(int H, int W, int lvl, int band, int *Hl, int *Wl, int *h, int *w,
+                                 int *padH, int *padW, int *hc, int *wc)
+{
+    if (H < 1 || W < 1 || lvl < 0 || lvl >= LLICTI_NLEVELS || band < 0 || band > 2) return fail(LLICTI_EINVAL, "level_geom: bad argument");
+    Geom g = make_geom(1, H, W, lvl);
+    if (Hl) *Hl = g.Hl;
+    if (Wl) *Wl = g.Wl;
+    if (h) *h = g.h;
+    if (w) *w = g.w;
+    if (padH) *padH = g.padH;
+    if (padW) *padW = g.padW;
+    int a, b;
+    coded_dims(g, band, &a, &b);
+    if (hc) *hc = a;
+    if (wc) *wc = b;
+    return LLICTI_OK;
+}
+static int check_dims(int B, int H, int W)
+{
+    if (B < 1 || H < 32 || W < 32 || H > 8160 || W > 8160) return fail(LLICTI_EINVAL, "bad shape B=%d H=%d W=%d (need B>=1, 32<=H,W<=8160)", B, H, W);
+    return 0;
+}
+
+// source sub-bands in lazyDWT cat order x00, x11, x01, x10 (LLICTI_nets.py:241); band b predicts source b+1
+__device__ __constant__ int c_oi[4] = { 0, 1, 0, 1 };
+__device__ __constant__ int c_oj[4] = { 0, 1, 1, 0 };
+
+// ------------------------------------------------------------------------------------------------ lift
+__global__ void minmax_init_kernel(int32_t *mm, int B)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) { mm[4 * i + 0] = 32767; mm[4 * i + 1] = 32767; mm[4 * i + 2] = -32768; mm[4 * i + 3] = -32768; }
+}
+
+__global__ __launch_bounds__(256) void lift_kernel(const uint8_t *__restrict__ rgb, long plane, int16_t *__restrict__ planes,
+                                                   float *__restrict__ fplanes, int32_t *__restrict__ mm)
+{
+    const int b = blockIdx.y;
+    const uint8_t *src = rgb + (long)b * 3 * plane;
+    int16_t *dst = planes + (long)b * 3 * plane;
+    float *fdst = fplanes + (long)b * 3 * plane;
+    int mnCo = 32767, mnCg = 32767, mxCo = -32768, mxCg = -32768;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < plane; p += (long)gridDim.x * blockDim.x) {
+        const int R = src[p], G = src[plane + p], Bl = src[2 * plane + p];
+        const int Co = R - Bl;
+        const int t = Bl + (Co >> 1);        // floor division (torch >= 1.13 '//'; JVT YCoCg-R '>> 1')
+        const int Cg = G - t;
+        const int Y = t + (Cg >> 1) - 127;
+        dst[p] = (int16_t)Y; dst[plane + p] = (int16_t)Co; dst[2 * plane + p] = (int16_t)Cg;
+        fdst[p] = (float)Y / 255.0f; fdst[plane + p] = (float)Co / 255.0f; fdst[2 * plane + p] = (float)Cg / 255.0f;
+        mnCo = min(mnCo, Co); mxCo = max(mxCo, Co); mnCg = min(mnCg, Cg); mxCg = max(mxCg, Cg);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mnCo = min(mnCo, __shfl_xor(mnCo, o)); mxCo = max(mxCo, __shfl_xor(mxCo, o));
+        mnCg = min(mnCg, __shfl_xor(mnCg, o)); mxCg = max(mxCg, __shfl_xor(mxCg, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&mm[4 * b + 0], mnCo); atomicMin(&mm[4 * b + 1], mnCg);
+        atomicMax(&mm[4 * b + 2], mxCo); atomicMax(&mm[4 * b + 3], mxCg);
+    }
+}
+
+__global__ __launch_bounds__(256) void unlift_kernel(const int16_t *__restrict__ planes, long plane, uint8_t *__restrict__ rgb)
+{
+    const int b = blockIdx.y;
+    const int16_t *src = planes + (long)b * 3 * plane;
+    uint8_t *dst = rgb + (long)b * 3 * plane;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < plane; p += (long)gridDim.x * blockDim.x) {
+        const int Y = src[p] + 127, Co = src[plane + p], Cg = src[2 * plane + p];
+        const int t = Y - (Cg >> 1);
+        const int G = Cg + t;
+        const int Bl = t - (Co >> 1);
+        const int R = Bl + Co;
+        dst[p] = (uint8_t)R; dst[plane + p] = (uint8_t)G; dst[2 * plane + p] = (uint8_t)Bl;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ band CNN
+// Layer-0 taps of band b: k -> (src, ci, dy, dx), k ordered conv by conv (sources x00, x11, x01), each
+// conv flattened (ci, ky, kx) row-major: the K order of the canonical packed w0 (llicti_amd/weights.py).
+// kernel sizes / pads: LLICTI_nets.py:651-675.  packed: src | ci<<2 | (dy+2)<<4 | (dx+2)<<8
+struct ConvDef { int src, kh, kw, pt, pl; };
+static const ConvDef kConvs[3][3] = {
+    { { 0, 4, 4, 1, 1 }, { -1, 0, 0, 0, 0 }, { -1, 0, 0, 0, 0 } },
+    { { 0, 3, 4, 1, 1 }, { 1, 4, 3, 2, 1 }, { -1, 0, 0, 0, 0 } },
+    { { 0, 4, 3, 1, 1 }, { 1, 3, 4, 1, 2 }, { 2, 4, 4, 1, 2 } },
+};
+__device__ __constant__ int c_taps[3][120];
+static int build_taps_host(int band, int *taps)
+{
+    int k = 0;
+    for (int c = 0; c < 3; ++c) {
+        const ConvDef &cv = kConvs[band][c];
+        if (cv.src < 0) break;
+        for (int ci = 0; ci < 3; ++ci)
+            for (int ky = 0; ky < cv.kh; ++ky)
+                for (int kx = 0; kx < cv.kw; ++kx)
+                    taps[k++] = cv.src | (ci << 2) | ((ky - cv.pt + 2) << 4) | ((kx - cv.pl + 2) << 8);
+    }
+    return k;
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kHead = 88;          // channels per head (configs/llicti_A.json chs[0])
+constexpr int kMT = 6;             // 16-row MFMA tiles per head (88 -> 96, rows >= 88 are zero)
+constexpr int kKS1 = 22;           // k-steps of the 88-deep layers (88 / 4)
+constexpr int kNT = 2;             // pixel tiles (16 positions each) per wavefront work unit
+constexpr int kCnnThreads = 512;   // 8 wavefronts: 2 per SIMD
+
+// Per (band, head) weight pack, in MFMA-fragment order so that the LDS image is lane-linear:
+//   bias0 [6][4][4]            acc init of tile T, lane group q, reg r  = b0[16T + 4r + q]
+//   W0    [6][K0/4][64]        lane l of tile T, k-step t: W0[chan(T, l&15)][4t + (l>>4)]
+//   bias1 [6][4][4]
+//   W1    [6][22][64]
+//   bias2 [4][4]               acc init of lane group q, reg r = b2[4q + r]
+//   W2    [22][64]             lane l, k-step t: W2[l&15][4t + (l>>4)]
+// chan(T, rho) = 16T + 4(rho&3) + (rho>>2): this row permutation makes the accumulator registers of one
+// layer line up, untouched, as the B operand of the next layer's MFMAs in natural channel order
+// (C/D layout of v_mfma_f32_16x16x4_f32: col = lane&15, row = 4(lane>>4) + reg).
+static constexpr int pack_floats(int K0) { return 96 + kMT * (K0 / 4) * 64 + 96 + kMT * kKS1 * 64 + 16 + kKS1 * 64; }
+
+template <int K0>
+struct PackOff {
+    static constexpr int bias0 = 0;
+    static constexpr int w0 = 96;
+    static constexpr int bias1 = w0 + kMT * (K0 / 4) * 64;
+    static constexpr int w1 = bias1 + 96;
+    static constexpr int bias2 = w1 + kMT * kKS1 * 64;
+    static constexpr int w2 = bias2 + 16;
+    static constexpr int total = w2 + kKS1 * 64;
+};
+
+__device__ __forceinline__ float relu(float x) { return (x > 0.0f) ? x : 0.0f; }
+
+template <int BAND>
+__global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *__restrict__ fplanes, Geom g,
+                                                                  const float *__restrict__ wpack,
+                                                                  float *__restrict__ params, long total_pos)
+{
+    constexpr int K0 = (BAND == 0) ? 48 : (BAND == 1) ? 72 : 120;
+    constexpr int NK0 = K0 / 4;
+    using PO = PackOff<K0>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int head = blockIdx.y;
+    {   // stage this head's pack (lane-linear image: a straight copy)
+        const float4 *src = reinterpret_cast<const float4 *>(wpack + (long)head * PO::total);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+        for (int i = threadIdx.x; i < PO::total / 4; i += kCnnThreads) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int q = lane >> 4;
+    const int px = lane & 15;
+    constexpr int kWaves = kCnnThreads / 64;
+
+    const int *my_taps = c_taps[BAND] + q;     // this lane's taps: k = 4t + q
+
+    const long hw = (long)g.h * g.w;
+    const long n_units = (total_pos + 16 * kNT - 1) / (16 * kNT);
+    for (long unit = (long)blockIdx.x * kWaves + wave; unit < n_units; unit += (long)gridDim.x * kWaves) {
+        // positions of this lane's pixel column in each tile
+        long gp[kNT];
+        int pi[kNT], pj[kNT];
+        const float *base[kNT];
+#pragma unroll
+        for (int n = 0; n < kNT; ++n) {
+            long p = (unit * kNT + n) * 16 + px;
+            gp[n] = p;
+            if (p > total_pos - 1) p = total_pos - 1;
+            const long img = p / hw;
+            const int rem = (int)(p - img * hw);
+            pi[n] = rem / g.w;
+            pj[n] = rem - pi[n] * g.w;
+            base[n] = fplanes + img * 3 * g.plane;
+        }
+
+        // ---- layer 0: [96 x K0] x [K0 x 16] per pixel tile, bias preloaded into the accumulators
+        f32x4 a0[kMT][kNT];
+#pragma unroll
+        for (int T = 0; T < kMT; ++T) {
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(lds + PO::bias0 + (T * 4 + q) * 4);
+#pragma unroll
+            for (int n = 0; n < kNT; ++n) a0[T][n] = bv;
+        }
+#pragma unroll
+        for (int t = 0; t < NK0; ++t) {
+            int tp = my_taps[4 * t];
+            asm volatile("" : "+v"(tp));      // keep the decoded tap fields from being hoisted out of the unit loop (VGPRs)
+            const int src = tp & 3, ci = (tp >> 2) & 3, dy = ((tp >> 4) & 15) - 2, dx = ((tp >> 8) & 15) - 2;
+            float bfrag[kNT];
+#pragma unroll
+            for (int n = 0; n < kNT; ++n) {
+                int ii = pi[n] + dy, jj = pj[n] + dx;
+                ii = max(0, min(ii, g.h - 1));
+                jj = max(0, min(jj, g.w - 1));
+                int r = 2 * ii + c_oi[src], c = 2 * jj + c_oj[src];
+                if (r >= g.Hl) r -= 2;      // replicate pad of the odd edge (LLICTI_nets.py:226-240)
+                if (c >= g.Wl) c -= 2;
+                bfrag[n] = base[n][ci * g.plane + ((long)r << g.lvl) * g.W + ((long)c << g.lvl)];
+            }
+#pragma unroll
+            for (int T = 0; T < kMT; ++T) {
+                const float a = lds[PO::w0 + (T * NK0 + t) * 64 + lane];
+#pragma unroll
+                for (int n = 0; n < kNT; ++n) a0[T][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfrag[n], a0[T][n], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the unrolled k-steps from being interleaved wholesale (VGPR pressure)
+        }
+#pragma unroll
+        for (int T = 0; T < kMT; ++T)
+#pragma unroll
+            for (int n = 0; n < kNT; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a0[T][n][r] = relu(a0[T][n][r]);
+
+        // ---- layer 1: the accumulator registers of layer 0 ARE the B fragments (k-step tt = 4T' + r)
+        f32x4 a1[kMT][kNT];
+#pragma unroll
+        for (int T = 0; T < kMT; ++T) {
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(lds + PO::bias1 + (T * 4 + q) * 4);
+#pragma unroll
+            for (int n = 0; n < kNT; ++n) a1[T][n] = bv;
+        }
+#pragma unroll
+        for (int tt = 0; tt < kKS1; ++tt) {
+#pragma unroll
+            for (int T = 0; T < kMT; ++T) {
+                const float a = lds[PO::w1 + (T * kKS1 + tt) * 64 + lane];
+#pragma unroll
+                for (int n = 0; n < kNT; ++n)
+                    a1[T][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, a0[tt >> 2][n][tt & 3], a1[T][n], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int T = 0; T < kMT; ++T)
+#pragma unroll
+            for (int n = 0; n < kNT; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a1[T][n][r] = relu(a1[T][n][r]);
+
+        // ---- layer 2: 15 outputs (+1 zero row) per head
+        f32x4 a2[kNT];
+        {
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(lds + PO::bias2 + q * 4);
+#pragma unroll
+            for (int n = 0; n < kNT; ++n) a2[n] = bv;
+        }
+#pragma unroll
+        for (int tt = 0; tt < kKS1; ++tt) {
+            const float a = lds[PO::w2 + tt * 64 + lane];
+#pragma unroll
+            for (int n = 0; n < kNT; ++n)
+                a2[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, a1[tt >> 2][n][tt & 3], a2[n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // D row 4q + r = output 4q + r of this head
+#pragma unroll
+        for (int n = 0; n < kNT; ++n) {
+            if (gp[n] < total_pos) {
+                float *dst = params + gp[n] * LLICTI_NPARAMS + head * 15 + 4 * q;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * q + r < 15) dst[r] = a2[n][r];
+            }
+        }
+    }
+}
+
+// host: canonical arrays -> fragment-ordered pack of one band (4 heads)
+static void pack_band(int K0, const float *w0, const float *b0, const float *w1, const float *b1,
+                      const float *w2, const float *b2, std::vector<float> &out)
+{
+    const int NK0 = K0 / 4;
+    const int total = pack_floats(K0);
+    out.assign((size_t)4 * total, 0.0f);
+    for (int hd = 0; hd < 4; ++hd) {
+        float *p = out.data() + (size_t)hd * total;
+        float *bias0 = p, *W0 = p + 96, *bias1 = W0 + kMT * NK0 * 64, *W1 = bias1 + 96;
+        float *bias2 = W1 + kMT * kKS1 * 64, *W2 = bias2 + 16;
+        for (int T = 0; T < kMT; ++T)
+            for (int q = 0; q < 4; ++q)
+                for (int r = 0; r < 4; ++r) {
+                    const int cl = 16 * T + 4 * r + q;
+                    bias0[(T * 4 + q) * 4 + r] = (cl < kHead) ? b0[hd * kHead + cl] : 0.0f;
+                    bias1[(T * 4 + q) * 4 + r] = (cl < kHead) ? b1[hd * kHead + cl] : 0.0f;
+                }
+        for (int T = 0; T < kMT; ++T)
+            for (int l = 0; l < 64; ++l) {
+                const int rho = l & 15, q = l >> 4;
+                const int cl = 16 * T + 4 * (rho & 3) + (rho >> 2);
+                for (int t = 0; t < NK0; ++t)
+                    W0[(T * NK0 + t) * 64 + l] = (cl < kHead) ? w0[(size_t)(hd * kHead + cl) * K0 + 4 * t + q] : 0.0f;
+                for (int t = 0; t < kKS1; ++t)
+                    W1[(T * kKS1 + t) * 64 + l] = (cl < kHead) ? w1[(size_t)(hd * kHead + cl) * kHead + 4 * t + q] : 0.0f;
+            }
+        for (int q = 0; q < 4; ++q)
+            for (int r = 0; r < 4; ++r) bias2[q * 4 + r] = (4 * q + r < 15) ? b2[hd * 15 + 4 * q + r] : 0.0f;
+        for (int l = 0; l < 64; ++l) {
+            const int o = l & 15, q = l >> 4;
+            for (int t = 0; t < kKS1; ++t) W2[t * 64 + l] = (o < 15) ? w2[(size_t)(hd * 15 + o) * kHead + 4 * t + q] : 0.0f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ CDF kernels
+struct StageGeom {      // one (level, band): band grid, coded crop, full-res addressing
+    int B, H, W, lvl, h, w, hc, wc, oi, oj;
+    long plane;
+};
+static StageGeom make_stage(const Geom &g, int band)
+{
+    static const int OI[4] = { 0, 1, 0, 1 }, OJ[4] = { 0, 1, 1, 0 };
+    StageGeom s;
+    s.B = g.B; s.H = g.H; s.W = g.W; s.lvl = g.lvl; s.h = g.h; s.w = g.w; s.plane = g.plane;
+    coded_dims(g, band, &s.hc, &s.wc);
+    s.oi = OI[band + 1]; s.oj = OJ[band + 1];
+    return s;
+}
+
+__device__ __forceinline__ void clr_range(const int32_t *mm, int clr, int &minv, int &maxv, int &shift)
+{
+    // LLICTI_nets.py:394-395, :544-547: Y uses the fixed range [-127,128], Co/Cg the image's own [min,max]
+    if (clr == 0) { minv = -127; maxv = 128; shift = 127; }
+    else { minv = mm[clr - 1]; maxv = mm[2 + clr - 1]; shift = -minv; }
+}
+
+// encoder: thread per coded position; the two entries the coder reads, for Y, Co, Cg
+__global__ __launch_bounds__(256) void cdf_pairs_kernel(const int16_t *__restrict__ planes, const float *__restrict__ params,
+                                                        const int32_t *__restrict__ minmax, StageGeom s,
+                                                        uint32_t *__restrict__ pairs)
+{
+    const int b = blockIdx.y;
+    const long nc = (long)s.hc * s.wc;
+    const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nc) return;
+    const int i = (int)(n / s.wc), j = (int)(n - (long)i * s.wc);
+    const float *par = params + ((long)b * s.h * s.w + (long)i * s.w + j) * LLICTI_NPARAMS;
+    const long off = (long)b * 3 * s.plane + ((long)(2 * i + s.oi) << s.lvl) * s.W + ((long)(2 * j + s.oj) << s.lvl);
+    const int vy = planes[off], vco = planes[off + s.plane], vcg = planes[off + 2 * s.plane];
+    const float yv = (float)vy / 255.0f, cov = (float)vco / 255.0f;
+    const int32_t *mm = minmax + 4 * b;
+#pragma unroll
+    for (int clr = 0; clr < 3; ++clr) {
+        int minv, maxv, shift;
+        clr_range(mm, clr, minv, maxv, shift);
+        const Grid gr = make_grid(minv, maxv);
+        const int v = (clr == 0) ? vy : (clr == 1) ? vco : vcg;
+        const int sym = v + shift;
+        Mix m;
+        mix_prepare(par, clr, yv, cov, m);
+        const uint32_t lo = cdf_entry(m, gr, sym);
+        const uint32_t hi = (sym == gr.Lp - 2) ? 0u : cdf_entry(m, gr, sym + 1);
+        pairs[((long)clr * s.B + b) * nc + n] = (hi << 16) | lo;
+    }
+}
+
+// decoder: one wavefront per coded position writes the whole row (entries >= Lp padded with 0xFFFF)
+__global__ __launch_bounds__(256) void cdf_table_kernel(const int16_t *__restrict__ planes, const float *__restrict__ params,
+                                                        const int32_t *__restrict__ minmax, StageGeom s, int clr,
+                                                        uint16_t *__restrict__ tables, int row_stride)
+{
+    const int b = blockIdx.y;
+    const long nc = (long)s.hc * s.wc;
+    const long n = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (n >= nc) return;
+    const int lane = threadIdx.x & 63;
+    const int i = (int)(n / s.wc), j = (int)(n - (long)i * s.wc);
+    const float *par = params + ((long)b * s.h * s.w + (long)i * s.w + j) * LLICTI_NPARAMS;
+    const long off = (long)b * 3 * s.plane + ((long)(2 * i + s.oi) << s.lvl) * s.W + ((long)(2 * j + s.oj) << s.lvl);
+    const float yv = (float)planes[off] / 255.0f, cov = (float)planes[off + s.plane] / 255.0f;
+    int minv, maxv, shift;
+    clr_range(minmax + 4 * b, clr, minv, maxv, shift);
+    const Grid gr = make_grid(minv, maxv);
+    Mix m;
+    mix_prepare(par, clr, yv, cov, m);
+    uint16_t *row = tables + ((long)b * nc + n) * row_stride;
+    for (int e = lane; e < row_stride; e += 64) row[e] = (e < gr.Lp) ? (uint16_t)cdf_entry(m, gr, e) : (uint16_t)0xFFFF;
+}
+
+// ------------------------------------------------------------------------------------------------ arithmetic coder
+// torchac 0.9.3 algorithm: 32-bit low/high, 16-bit CDFs, pending-bit carry
+// handling, MSB-first bits.  The bit-at-a-time renormalisation loop is evaluated in closed form:
+//   n1 = clz(low ^ high)                      leading bits on which low and high agree  (E1/E2 steps)
+//   n2 = min(clo(low' << 1), clz(high' << 1)) following "01.. / 10.." underflow steps   (E3 steps)
+struct BitWriter {
+    uint8_t *out; int cap; int pos; uint64_t acc; int nb; int overflow;
+    __device__ __forceinline__ void put(uint32_t bits, int k)      // k <= 32
+    {
+        acc = (acc << k) | bits; nb += k;
+        while (nb >= 8) {
+            if (pos < cap) out[pos] = (uint8_t)(acc >> (nb - 8)); else overflow = 1;
+            ++pos; nb -= 8;
+        }
+    }
+    __device__ __forceinline__ void put_run(uint32_t bit, uint32_t count)
+    {
+        while (count > 0) {
+            const int k = count > 24 ? 24 : (int)count;
+            put(bit ? ((1u << k) - 1u) : 0u, k);
+            count -= k;
+        }
+    }
+};
+
+struct AcEnc {
+    uint32_t low, high, pending;
+    __device__ __forceinline__ void init() { low = 0; high = 0xFFFFFFFFu; pending = 0; }
+    __device__ __forceinline__ void put(BitWriter &bw, uint32_t c_low, uint32_t c_high)
+    {
+        const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
+        high = (low - 1) + (uint32_t)((span * (uint64_t)c_high) >> 16);
+        low = low + (uint32_t)((span * (uint64_t)c_low) >> 16);
+        int n1 = __clz((int)(low ^ high));
+        if (n1 > 31) n1 = 31;
+        if (n1 > 0) {
+            const uint32_t b = low >> 31;
+            bw.put(b, 1);
+            bw.put_run(b ^ 1u, pending);
+            pending = 0;
+            if (n1 > 1) bw.put((low << 1) >> (33 - n1), n1 - 1);
+            low <<= n1;
+            high = (high << n1) | ((1u << n1) - 1u);
+        }
+        int n2 = min(__clz((int)~(low << 1)), __clz((int)(high << 1)));
+        if (n2 > 31) n2 = 31;
+        if (n2 > 0) {
+            pending += n2;
+            low = (low << n2) & 0x7FFFFFFFu;
+            high = ((high << n2) | ((1u << n2) - 1u)) | 0x80000000u;
+        }
+    }
+    __device__ __forceinline__ void finish(BitWriter &bw)
+    {
+        pending += 1;
+        const uint32_t b = (low < 0x40000000u) ? 0u : 1u;
+        bw.put(b, 1);
+        bw.put_run(b ^ 1u, pending);
+        if (bw.nb > 0) bw.put(0, 8 - bw.nb);
+    }
+};
+
+struct StreamDesc {     // one arithmetic-coded stream of the whole-batch encoder
+    long pair_off;      // first (c_low, c_high) pair, in uint32 units
+    long out_off;       // slot offset in bytes
+    int n;              // symbols
+    int cap;            // slot capacity in bytes
+};
+
+__global__ __launch_bounds__(64) void ac_encode_pairs_kernel(const uint32_t *__restrict__ pairs, const StreamDesc *__restrict__ desc,
+                                                             int n_streams, uint8_t *__restrict__ slots,
+                                                             int32_t *__restrict__ slot_len, int32_t *status)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_streams) return;
+    const StreamDesc d = desc[s];
+    const uint32_t *p = pairs + d.pair_off;
+    BitWriter bw = { slots + d.out_off, d.cap, 0, 0, 0, 0 };
+    AcEnc e;
+    e.init();
+    for (int i = 0; i < d.n; ++i) {
+        const uint32_t v = p[i];
+        uint32_t c_high = v >> 16;
+        if (c_high == 0) c_high = 0x10000u;
+        e.put(bw, v & 0xFFFFu, c_high);
+    }
+    e.finish(bw);
+    slot_len[s] = bw.pos;
+    if (bw.overflow) atomicExch(&status[0], LLICTI_ENOSPACE);
+}
+
+// torchac seam: explicit tables + symbols, one lane per stream
+__global__ __launch_bounds__(64) void ac_encode_tables_kernel(const uint16_t *__restrict__ cdf, int Lp, int row_stride,
+                                                              const int16_t *__restrict__ sym, int n_streams, long N,
+                                                              uint8_t *__restrict__ out, long out_stride,
+                                                              int32_t *__restrict__ len, int32_t *status)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_streams) return;
+    const uint16_t *tab = cdf + (long)s * N * row_stride;
+    const int16_t *sy = sym + (long)s * N;
+    BitWriter bw = { out + (long)s * out_stride, (int)out_stride, 0, 0, 0, 0 };
+    AcEnc e;
+    e.init();
+    const int max_symbol = Lp - 2;
+    for (long i = 0; i < N; ++i) {
+        const int v = sy[i];
+        const uint32_t c_low = tab[i * row_stride + v];
+        const uint32_t c_high = (v == max_symbol) ? 0x10000u : (uint32_t)tab[i * row_stride + v + 1];
+        e.put(bw, c_low, c_high);
+    }
+    e.finish(bw);
+    len[s] = bw.pos;
+    if (bw.overflow) atomicExch(&status[0], LLICTI_ENOSPACE);
+}
+
+// Decoder: one wavefront per stream.  The 64 lanes hold the current table row (8 entries each); the symbol
+// is the number of entries 1..max_symbol that are <= count (equal to torchac's binary search on a
+// strictly increasing row).  The next row is prefetched while the current symbol is resolved.
+// Output either to a symbol array (seam) or straight into the planes at the band's full-res positions.
+struct DecOut {
+    int16_t *sym;            // [n_streams][N] or nullptr
+    int16_t *planes;         // [B][3][H][W] or nullptr
+    float *fplanes;
+    const int32_t *minmax;   // [B][4]
+    StageGeom sg;
+    int clr;
+};
+
+__device__ __forceinline__ uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
+
+__global__ __launch_bounds__(64) void ac_decode_kernel(const uint16_t *__restrict__ cdf, int Lp_fixed, int row_stride,
+                                                       const uint8_t *__restrict__ in, long in_stride,
+                                                       const int32_t *__restrict__ len, int len_stride, long N, DecOut o)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t row_lds[520];
+    const int s = blockIdx.x;
+    const int lane = threadIdx.x;
+    const uint32_t *words = reinterpret_cast<const uint32_t *>(in + (long)s * in_stride);
+    (void)len; (void)len_stride;   // streams are zero padded: reads past the end return 0 bits like torchac's get()
+    int Lp = Lp_fixed, shift = 0;
+    if (o.planes) {
+        int minv, maxv;
+        clr_range(o.minmax + 4 * s, o.clr, minv, maxv, shift);
+        Lp = maxv - minv + 2;
+    }
+    const uint32_t max_symbol = (uint32_t)(Lp - 2);
+    const uint16_t *tab = cdf + (long)s * N * row_stride;
+    const int vec_per_row = row_stride >> 3;             // uint4 (8 entries) per row
+
+    uint32_t value = bswap32(words[0]);
+    uint64_t buf = ((uint64_t)bswap32(words[1]) << 32) | bswap32(words[2]);   // next 64 bits, MSB first
+    int have = 64;
+    long wpos = 3;
+    uint32_t low = 0, high = 0xFFFFFFFFu;
+
+    auto load_row = [&](long n) -> uint4 {
+        uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        if (lane < vec_per_row) v = reinterpret_cast<const uint4 *>(tab + n * row_stride)[lane];
+        return v;
+    };
+    uint4 cur = load_row(0);
+    for (long n = 0; n < N; ++n) {
+        const uint4 nxt = (n + 1 < N) ? load_row(n + 1) : cur;
+        const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
+        const uint32_t count = (uint32_t)(((((uint64_t)value - (uint64_t)low + 1) << 16) - 1) / span) & 0xFFFFu;
+        const uint32_t w[4] = { cur.x, cur.y, cur.z, cur.w };
+        int cnt = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t ent = (w[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
+            const uint32_t idx = (uint32_t)(8 * lane + e);
+            cnt += (idx >= 1u && idx <= max_symbol && ent <= count) ? 1 : 0;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+        const uint32_t sidx = (uint32_t)cnt;
+        reinterpret_cast<uint4 *>(row_lds)[lane] = cur;
+        __syncthreads();
+        const uint32_t c_low = row_lds[sidx];
+        const uint32_t c_high = (sidx == max_symbol) ? 0x10000u : (uint32_t)row_lds[sidx + 1];
+        __syncthreads();
+        if (lane == 0) {
+            if (o.sym) o.sym[(long)s * N + n] = (int16_t)sidx;
+            if (o.planes) {
+                const int i = (int)(n / o.sg.wc), j = (int)(n - (long)i * o.sg.wc);
+                const long off = (long)s * 3 * o.sg.plane + (long)o.clr * o.sg.plane +
+                                 ((long)(2 * i + o.sg.oi) << o.sg.lvl) * o.sg.W + ((long)(2 * j + o.sg.oj) << o.sg.lvl);
+                const int v = (int)sidx - shift;               // _convert_int16cpu_to_float32gpu, LLICTI_nets.py:559-568
+                o.planes[off] = (int16_t)v;
+                o.fplanes[off] = (float)v / 255.0f;
+            }
+        }
+        if (n == N - 1) break;
+        high = (low - 1) + (uint32_t)((span * (uint64_t)c_high) >> 16);
+        low = low + (uint32_t)((span * (uint64_t)c_low) >> 16);
+        int n1 = __clz((int)(low ^ high));
+        if (n1 > 31) n1 = 31;
+        if (n1 > 0) {
+            low <<= n1;
+            high = (high << n1) | ((1u << n1) - 1u);
+            value = (value << n1) | (uint32_t)(buf >> (64 - n1));
+            buf <<= n1; have -= n1;
+            if (have <= 32) {
+                buf |= (uint64_t)bswap32(words[wpos++]) << (32 - have);
+                have += 32;
+            }
+        }
+        int n2 = min(__clz((int)~(low << 1)), __clz((int)(high << 1)));
+        if (n2 > 31) n2 = 31;
+        if (n2 > 0) {
+            low = (low << n2) & 0x7FFFFFFFu;
+            high = ((high << n2) | ((1u << n2) - 1u)) | 0x80000000u;
+            value = ((value << n2) ^ 0x80000000u) | (uint32_t)(buf >> (64 - n2));
+            buf <<= n2; have -= n2;
+        }
+        if (have <= 32) {
+            buf |= (uint64_t)bswap32(words[wpos++]) << (32 - have);
+            have += 32;
+        }
+        cur = nxt;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ container kernels
+// encode: header segments straight into the container; seg_len[b][0..3]
+__global__ void header_write_kernel(const uint8_t *__restrict__ rgb, const int32_t *__restrict__ minmax, int H, int W,
+                                    int h4, int w4, int padint, uint8_t *__restrict__ out, long out_stride,
+                                    int32_t *__restrict__ seg_len)
+{
+    const int b = blockIdx.x;
+    uint8_t *o = out + (long)b * out_stride;
+    const long plane = (long)H * W;
+    if (threadIdx.x == 0) {
+        o[0] = LLICTI_NLEVELS; o[1] = (uint8_t)h4; o[2] = (uint8_t)w4;            // LLICTI_nets.py:347
+        const int32_t *mm = minmax + 4 * b;
+        const int16_t v[6] = { 0, (int16_t)mm[0], (int16_t)mm[1], 255, (int16_t)mm[2], (int16_t)mm[3] };   // :139, :348
+        for (int k = 0; k < 6; ++k) { o[3 + 2 * k] = (uint8_t)(v[k] & 0xFF); o[4 + 2 * k] = (uint8_t)((v[k] >> 8) & 0xFF); }
+        o[15] = (uint8_t)(padint & 0xFF); o[16] = (uint8_t)((padint >> 8) & 0xFF);                         // :349
+        int32_t *sl = seg_len + (long)b * LLICTI_NSEG;
+        sl[0] = 3; sl[1] = 12; sl[2] = 2; sl[3] = 3 * h4 * w4;
+    }
+    for (int t = threadIdx.x; t < 3 * h4 * w4; t += blockDim.x) {                                        // :248-252, :350
+        const int c = t / (h4 * w4), r = t - c * h4 * w4, i = r / w4, j = r - i * w4;
+        o[17 + t] = rgb[(long)b * 3 * plane + c * plane + (long)(32 * i) * W + 32 * j];
+    }
+}
+
+// encode: copy the 45 slots of image b behind its header, tightly; seg_len[b][4..48]
+__global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ slots, const long *__restrict__ slot_off,
+                                                   const int32_t *__restrict__ slot_len, int B, int hdr_bytes,
+                                                   uint8_t *__restrict__ out, long out_stride, int32_t *__restrict__ seg_len,
+                                                   int32_t *status)
+{
+    const int st = blockIdx.x, b = blockIdx.y;
+    // slot index: streams are stored stage-major, image-minor (see build_plan)
+    long dst = hdr_bytes;
+    for (int k = 0; k < st; ++k) dst += slot_len[(long)k * B + b];
+    const int n = slot_len[(long)st * B + b];
+    if (dst + n > out_stride) { if (threadIdx.x == 0) atomicExch(&status[0], LLICTI_ENOSPACE); return; }
+    const uint8_t *src = slots + slot_off[(long)st * B + b];
+    uint8_t *o = out + (long)b * out_stride + dst;
+    for (int t = threadIdx.x; t < n; t += blockDim.x) o[t] = src[t];
+    if (threadIdx.x == 0) seg_len[(long)b * LLICTI_NSEG + 4 + st] = n;
+}
+
+// decode: parse + validate header, min/max -> minmax[b][4], DC band -> planes at stride 32
+__global__ void header_read_kernel(const uint8_t *__restrict__ in, long in_stride, const int32_t *__restrict__ seg_len,
+                                   int H, int W, int h4, int w4, int padint, int16_t *__restrict__ planes,
+                                   float *__restrict__ fplanes, int32_t *__restrict__ minmax, int32_t *status)
+{
+    const int b = blockIdx.x;
+    const uint8_t *p = in + (long)b * in_stride;
+    const int32_t *sl = seg_len + (long)b * LLICTI_NSEG;
+    const long plane = (long)H * W;
+    __shared__ int ok;
+    if (threadIdx.x == 0) {
+        const int pad = (int)(int16_t)(p[15] | (p[16] << 8));
+        ok = (sl[0] == 3 && sl[1] == 12 && sl[2] == 2 && sl[3] == 3 * h4 * w4 &&
+              p[0] == LLICTI_NLEVELS && p[1] == h4 && p[2] == w4 && pad == padint);      // LLICTI_nets.py:423-428
+        if (!ok) atomicExch(&status[0], LLICTI_EFORMAT);
+        int16_t v[6];
+        for (int k = 0; k < 6; ++k) v[k] = (int16_t)(p[3 + 2 * k] | (p[4 + 2 * k] << 8));
+        int32_t *mm = minmax + 4 * b;
+        mm[0] = v[1]; mm[1] = v[2]; mm[2] = v[4]; mm[3] = v[5];
+        if (v[1] > v[4] || v[2] > v[5] || v[1] < -255 || v[2] < -255 || v[4] > 255 || v[5] > 255) {
+            atomicExch(&status[0], LLICTI_EFORMAT);
+            mm[0] = mm[1] = -255; mm[2] = mm[3] = 255;
+        }
+    }
+    __syncthreads();
+    if (!ok) return;
+    const uint8_t *dc = p + 17;
+    for (int t = threadIdx.x; t < h4 * w4; t += blockDim.x) {                              // :429-430, :443-444
+        const int i = t / w4, j = t - i * w4;
+        const int R = dc[t], G = dc[h4 * w4 + t], Bl = dc[2 * h4 * w4 + t];
+        const int Co = R - Bl, tt = Bl + (Co >> 1), Cg = G - tt, Y = tt + (Cg >> 1) - 127;
+        const long off = (long)b * 3 * plane + (long)(32 * i) * W + 32 * j;
+        planes[off] = (int16_t)Y; planes[off + plane] = (int16_t)Co; planes[off + 2 * plane] = (int16_t)Cg;
+        fplanes[off] = (float)Y / 255.0f; fplanes[off + plane] = (float)Co / 255.0f; fplanes[off + 2 * plane] = (float)Cg / 255.0f;
+    }
+}
+
+// decode: copy stream st of image b into its 4-byte aligned, zero padded slot
+__global__ __launch_bounds__(256) void unpack_kernel(const uint8_t *__restrict__ in, long in_stride, const int32_t *__restrict__ seg_len,
+                                                     int B, uint8_t *__restrict__ slots, const long *__restrict__ slot_off,
+                                                     const int32_t *__restrict__ slot_cap, int32_t *status)
+{
+    const int st = blockIdx.x, b = blockIdx.y;
+    const int32_t *sl = seg_len + (long)b * LLICTI_NSEG;
+    long src = 0;
+    for (int k = 0; k < 4 + st; ++k) src += sl[k];
+    int n = sl[4 + st];
+    const int cap = slot_cap[(long)st * B + b];
+    if (n < 0 || n + 16 > cap || src + n > in_stride) { if (threadIdx.x == 0) atomicExch(&status[0], LLICTI_EFORMAT); n = 0; }
+    const uint8_t *p = in + (long)b * in_stride + src;
+    uint8_t *o = slots + slot_off[(long)st * B + b];
+    for (int t = threadIdx.x; t < n; t += blockDim.x) o[t] = p[t];
+    const int padded = min(cap, ((n + 3) & ~3) + 16);
+    for (int t = n + threadIdx.x; t < padded; t += blockDim.x) o[t] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------ context
+struct Plan {                 // workspace carving for (B, H, W)
+    int B = 0, H = 0, W = 0;
+    size_t off_planes, off_fplanes, off_minmax, off_status, off_params, off_pairs, off_slots, off_slot_len, off_tables;
+    size_t total;
+    std::vector<StreamDesc> desc;       // stage-major, image-minor: index (stage * B + b)
+    std::vector<long> slot_off;
+    std::vector<int32_t> slot_cap;
+    std::vector<long> pair_base;        // per (lvl, band): first pair of [clr][B][nc]
+    size_t max_container;
+};
+
+struct llicti_ctx {
+    int device = 0;
+    float *d_pack[3] = { nullptr, nullptr, nullptr };
+    bool have[3] = { false, false, false };
+    Plan plan;
+    StreamDesc *d_desc = nullptr;
+    long *d_slot_off = nullptr;
+    int32_t *d_slot_cap = nullptr;
+    int32_t *d_status = nullptr;      // small persistent status word (for the kernel-level entry points)
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;       // pairs around band-CNN launches
+    int ev_used = 0;
+    hipEvent_t ev_call[2] = { nullptr, nullptr };
+    float last_ms[4] = { 0, 0, 0, 0 };
+    int last_launches = 0;
+    bool timing_pending = false;
+};
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static int stage_index(int lvl, int band, int clr) { return (LLICTI_NLEVELS - 1 - lvl) * 9 + band * 3 + clr; }   // scale 4..0
+
+static void build_plan(Plan &p, int B, int H, int W)
+{
+    p.B = B; p.H = H; p.W = W;
+    const size_t plane = (size_t)H * W;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+    p.off_status = take(64);
+    p.off_minmax = take((size_t)B * 4 * sizeof(int32_t));
+    p.off_planes = take((size_t)B * 3 * plane * sizeof(int16_t));
+    p.off_fplanes = take((size_t)B * 3 * plane * sizeof(float));
+    Geom g0 = make_geom(B, H, W, 0);
+    p.off_params = take((size_t)B * g0.h * g0.w * LLICTI_NPARAMS * sizeof(float));
+    // pairs + slots
+    p.desc.assign((size_t)LLICTI_NSTREAMS * B, StreamDesc{});
+    p.slot_off.assign((size_t)LLICTI_NSTREAMS * B, 0);
+    p.slot_cap.assign((size_t)LLICTI_NSTREAMS * B, 0);
+    p.pair_base.assign(LLICTI_NLEVELS * 3, 0);
+    long pair_pos = 0, slot_pos = 0;
+    size_t container = 17;
+    Geom g4 = make_geom(B, H, W, 4);
+    container += 3 * (size_t)g4.h * g4.w;
+    for (int lvl = LLICTI_NLEVELS - 1; lvl >= 0; --lvl) {
+        Geom g = make_geom(B, H, W, lvl);
+        for (int band = 0; band < 3; ++band) {
+            int hc, wc;
+            coded_dims(g, band, &hc, &wc);
+            const long nc = (long)hc * wc;
+            p.pair_base[lvl * 3 + band] = pair_pos;
+            for (int clr = 0; clr < 3; ++clr) {
+                const int st = stage_index(lvl, band, clr);
+                const int cap = (int)align_up((size_t)(2 * nc + 8 + 16), 16);   // <= 16 bits per symbol + termination + zero pad
+                for (int b = 0; b < B; ++b) {
+                    StreamDesc &d = p.desc[(size_t)st * B + b];
+                    d.pair_off = pair_pos + ((long)clr * B + b) * nc;
+                    d.out_off = slot_pos;
+                    d.n = (int)nc;
+                    d.cap = cap - 16;
+                    p.slot_off[(size_t)st * B + b] = slot_pos;
+                    p.slot_cap[(size_t)st * B + b] = cap;
+                    slot_pos += cap;
+                }
+                container += (size_t)(2 * nc + 8);
+            }
+            pair_pos += 3L * B * nc;
+        }
+    }
+    p.max_container = align_up(container, 16);
+    p.off_pairs = take((size_t)pair_pos * sizeof(uint32_t));
+    p.off_slots = take((size_t)slot_pos);
+    p.off_slot_len = take((size_t)LLICTI_NSTREAMS * B * sizeof(int32_t));
+    int hc0, wc0;
+    coded_dims(g0, 1, &hc0, &wc0);
+    p.off_tables = take((size_t)B * g0.h * g0.w * 512 * sizeof(uint16_t));
+    p.total = o;
+}
+
+extern "C" size_t llicti_workspace_bytes(int B, int H, int W, int mode)
+{
+    if (check_dims(B, H, W) || mode != 0) return 0;
+    Plan p;
+    build_plan(p, B, H, W);
+    return p.total;
+}
+extern "C" size_t llicti_max_container_bytes(int H, int W)
+{
+    if (check_dims(1, H, W)) return 0;
+    Plan p;
+    build_plan(p, 1, H, W);
+    return p.max_container;
+}
+
+extern "C" int llicti_create(llicti_ctx **out, int device)
+{
+    if (!out) return fail(LLICTI_EINVAL, "create: null ctx pointer");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(LLICTI_ENODEVICE, "no HIP device: this library has no CPU path");
+    if (device < 0 || device >= n) return fail(LLICTI_EINVAL, "create: device %d out of range (%d devices)", device, n);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(LLICTI_ENODEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    llicti_ctx *c = new llicti_ctx();
+    c->device = device;
+    int taps[3][120];
+    memset(taps, 0, sizeof taps);
+    for (int b = 0; b < 3; ++b) build_taps_host(b, taps[b]);
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_taps), taps, sizeof taps));
+    HIPCHK(hipMalloc(&c->d_status, 64));
+    HIPCHK(hipMemset(c->d_status, 0, 64));
+    HIPCHK(hipEventCreate(&c->ev_call[0]));
+    HIPCHK(hipEventCreate(&c->ev_call[1]));
+    // the band CNN stages a whole head (up to 86 KB) in LDS
+    HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, PackOff<48>::total * 4));
+    HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, PackOff<72>::total * 4));
+    HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, PackOff<120>::total * 4));
+    *out = c;
+    return LLICTI_OK;
+}
+
+extern "C" int llicti_destroy(llicti_ctx *c)
+{
+    if (!c) return LLICTI_OK;
+    for (int b = 0; b < 3; ++b) if (c->d_pack[b]) hipFree(c->d_pack[b]);
+    if (c->d_desc) hipFree(c->d_desc);
+    if (c->d_slot_off) hipFree(c->d_slot_off);
+    if (c->d_slot_cap) hipFree(c->d_slot_cap);
+    if (c->d_status) hipFree(c->d_status);
+    for (auto e : c->ev) hipEventDestroy(e);
+    for (int i = 0; i < 2; ++i) if (c->ev_call[i]) hipEventDestroy(c->ev_call[i]);
+    delete c;
+    return LLICTI_OK;
+}
+
+extern "C" int llicti_set_band_weights(llicti_ctx *c, int band, int K0, const float *w0, const float *b0,
+                                       const float *w1, const float *b1, const float *w2, const float *b2)
+{
+    if (!c || band < 0 || band > 2 || !w0 || !b0 || !w1 || !b1 || !w2 || !b2) return fail(LLICTI_EINVAL, "set_band_weights: bad argument");
+    static const int K0s[3] = { 48, 72, 120 };
+    if (K0 != K0s[band]) return fail(LLICTI_EINVAL, "set_band_weights: band %d needs K0=%d, got %d", band, K0s[band], K0);
+    std::vector<float> pk;
+    pack_band(K0, w0, b0, w1, b1, w2, b2, pk);
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->d_pack[band]) HIPCHK(hipMalloc(&c->d_pack[band], pk.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(c->d_pack[band], pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+    c->have[band] = true;
+    return LLICTI_OK;
+}
+
+extern "C" int llicti_set_profiling(llicti_ctx *c, int enable)
+{
+    if (!c) return fail(LLICTI_EINVAL, "null ctx");
+    c->profiling = enable != 0;
+    return LLICTI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ launches
+static int launch_lift(const uint8_t *d_rgb, int B, int H, int W, int16_t *planes, float *fplanes, int32_t *mm, hipStream_t s)
+{
+    const long plane = (long)H * W;
+    minmax_init_kernel<<<(B + 63) / 64, 64, 0, s>>>(mm, B);
+    const int gx = (int)std::min<long>((plane + 255) / 256, 1024);
+    lift_kernel<<<dim3(gx, B), 256, 0, s>>>(d_rgb, plane, planes, fplanes, mm);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int launch_band_params(llicti_ctx *c, const float *fplanes, const Geom &g, int band, float *params, hipStream_t s)
+{
+    if (!c->have[band]) return fail(LLICTI_ENOWEIGHTS, "band %d weights not set", band);
+    const long total = (long)g.B * g.h * g.w;
+    const long n_units = (total + 16 * kNT - 1) / (16 * kNT);
+    constexpr int kWaves = kCnnThreads / 64;
+    static const int K0s[3] = { 48, 72, 120 };
+    const int lds_bytes = pack_floats(K0s[band]) * 4;
+    const int wg_per_cu = std::max(1, std::min(4, (160 * 1024) / lds_bytes));
+    long gx = (n_units + kWaves - 1) / kWaves;
+    const long gx_cap = 256L * wg_per_cu / 4;    // 4 heads in grid.y
+    if (gx > gx_cap) gx = gx_cap;
+    if (gx < 1) gx = 1;
+    dim3 grid((unsigned)gx, 4);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->profiling) {
+        if ((int)c->ev.size() < c->ev_used + 2) {
+            hipEvent_t a, b;
+            HIPCHK(hipEventCreate(&a));
+            HIPCHK(hipEventCreate(&b));
+            c->ev.push_back(a);
+            c->ev.push_back(b);
+        }
+        e0 = c->ev[c->ev_used]; e1 = c->ev[c->ev_used + 1];
+        c->ev_used += 2;
+        HIPCHK(hipEventRecord(e0, s));
+    }
+    switch (band) {
+    case 0: band_params_kernel<0><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[0], params, total); break;
+    case 1: band_params_kernel<1><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[1], params, total); break;
+    default: band_params_kernel<2><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[2], params, total); break;
+    }
+    if (c->profiling) HIPCHK(hipEventRecord(e1, s));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int llicti_lift_u8(llicti_ctx *c, const uint8_t *d_rgb, int B, int H, int W, int16_t *d_planes,
+                              float *d_fplanes, int32_t *d_minmax, void *stream)
+{
+    if (!c || !d_rgb || !d_planes || !d_fplanes || !d_minmax) return fail(LLICTI_EINVAL, "lift: null pointer");
+    if (check_dims(B, H, W)) return LLICTI_EINVAL;
+    return launch_lift(d_rgb, B, H, W, d_planes, d_fplanes, d_minmax, (hipStream_t)stream);
+}
+
+extern "C" int llicti_unlift_u8(llicti_ctx *c, const int16_t *d_planes, int B, int H, int W, uint8_t *d_rgb, void *stream)
+{
+    if (!c || !d_planes || !d_rgb) return fail(LLICTI_EINVAL, "unlift: null pointer");
+    if (check_dims(B, H, W)) return LLICTI_EINVAL;
+    const long plane = (long)H * W;
+    const int gx = (int)std::min<long>((plane + 255) / 256, 1024);
+    unlift_kernel<<<dim3(gx, B), 256, 0, (hipStream_t)stream>>>(d_planes, plane, d_rgb);
+    HIPCHK(hipGetLastError());
+    return LLICTI_OK;
+}
+
+extern "C" int llicti_band_params_f32(llicti_ctx *c, const float *d_fplanes, int B, int H, int W, int lvl, int band,
+                                      float *d_params, void *stream)
+{
+    if (!c || !d_fplanes || !d_params) return fail(LLICTI_EINVAL, "band_params: null pointer");
+    if (check_dims(B, H, W)) return LLICTI_EINVAL;
+    if (lvl < 0 || lvl >= LLICTI_NLEVELS || band < 0 || band > 2) return fail(LLICTI_EINVAL, "band_params: bad level/band");
+    Geom g = make_geom(B, H, W, lvl);
+    return launch_band_params(c, d_fplanes, g, band, d_params, (hipStream_t)stream);
+}
+
+static int launch_cdf_pairs(const int16_t *planes, const float *params, const int32_t *mm, const Geom &g, int band,
+                            uint32_t *pairs, hipStream_t s)
+{
+    StageGeom sg = make_stage(g, band);
+    const long nc = (long)sg.hc * sg.wc;
+    cdf_pairs_kernel<<<dim3((unsigned)((nc + 255) / 256), g.B), 256, 0, s>>>(planes, params, mm, sg, pairs);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+static int launch_cdf_table(const int16_t *planes, const float *params, const int32_t *mm, const Geom &g, int band, int clr,
+                            uint16_t *tables, int row_stride, hipStream_t s)
+{
+    StageGeom sg = make_stage(g, band);
+    const long nc = (long)sg.hc * sg.wc;
+    cdf_table_kernel<<<dim3((unsigned)((nc + 3) / 4), g.B), 256, 0, s>>>(planes, params, mm, sg, clr, tables, row_stride);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int llicti_cdf_u16(llicti_ctx *c, const int16_t *d_planes, const float *d_params, const int32_t *d_minmax,
+                              int B, int H, int W, int lvl, int band, int clr, uint16_t *d_tables, int row_stride, void *stream)
+{
+    if (!c || !d_planes || !d_params || !d_minmax || !d_tables) return fail(LLICTI_EINVAL, "cdf_u16: null pointer");
+    if (check_dims(B, H, W)) return LLICTI_EINVAL;
+    if (lvl < 0 || lvl >= LLICTI_NLEVELS || band < 0 || band > 2 || clr < 0 || clr > 2) return fail(LLICTI_EINVAL, "cdf_u16: bad level/band/clr");
+    if (row_stride < 8 || row_stride > 512 || (row_stride & 7)) return fail(LLICTI_EINVAL, "cdf_u16: row_stride must be a multiple of 8 in [8,512]");
+    Geom g = make_geom(B, H, W, lvl);
+    return launch_cdf_table(d_planes, d_params, d_minmax, g, band, clr, d_tables, row_stride, (hipStream_t)stream);
+}
+
+extern "C" int llicti_cdf_pairs_u32(llicti_ctx *c, const int16_t *d_planes, const float *d_params, const int32_t *d_minmax,
+                                    int B, int H, int W, int lvl, int band, uint32_t *d_pairs, void *stream)
+{
+    if (!c || !d_planes || !d_params || !d_minmax || !d_pairs) return fail(LLICTI_EINVAL, "cdf_pairs: null pointer");
+    if (check_dims(B, H, W)) return LLICTI_EINVAL;
+    if (lvl < 0 || lvl >= LLICTI_NLEVELS || band < 0 || band > 2) return fail(LLICTI_EINVAL, "cdf_pairs: bad level/band");
+    Geom g = make_geom(B, H, W, lvl);
+    return launch_cdf_pairs(d_planes, d_params, d_minmax, g, band, d_pairs, (hipStream_t)stream);
+}
+
+extern "C" int llicti_ac_encode_u16cdf(llicti_ctx *c, const uint16_t *d_cdf, int Lp, int row_stride, const int16_t *d_sym,
+                                       int n_streams, long N, uint8_t *d_out, long out_stride, int32_t *d_len, void *stream)
+{
+    if (!c || !d_cdf || !d_sym || !d_out || !d_len) return fail(LLICTI_EINVAL, "ac_encode: null pointer");
+    if (Lp < 2 || Lp > 65536 || row_stride < Lp || n_streams < 1 || N < 1 || out_stride < 8) return fail(LLICTI_EINVAL, "ac_encode: bad argument");
+    ac_encode_tables_kernel<<<(n_streams + 63) / 64, 64, 0, (hipStream_t)stream>>>(d_cdf, Lp, row_stride, d_sym, n_streams, N, d_out,
+                                                                                  out_stride, d_len, c->d_status);
+    HIPCHK(hipGetLastError());
+    return LLICTI_OK;
+}
+
+extern "C" int llicti_ac_decode_u16cdf(llicti_ctx *c, const uint16_t *d_cdf, int Lp, int row_stride, const uint8_t *d_in,
+                                       long in_stride, const int32_t *d_len, int n_streams, long N, int16_t *d_sym, void *stream)
+{
+    if (!c || !d_cdf || !d_in || !d_len || !d_sym) return fail(LLICTI_EINVAL, "ac_decode: null pointer");
+    if (Lp < 2 || Lp > 512 || row_stride < Lp || row_stride > 512 || (row_stride & 7) || n_streams < 1 || N < 1 || (in_stride & 3) ||
+        ((uintptr_t)d_in & 3) || ((uintptr_t)d_cdf & 15))
+        return fail(LLICTI_EINVAL, "ac_decode: bad argument (Lp<=512, row_stride multiple of 8, 4-byte aligned streams, 16-byte aligned tables)");
+    DecOut o;
+    memset(&o, 0, sizeof o);
+    o.sym = d_sym;
+    ac_decode_kernel<<<n_streams, 64, 0, (hipStream_t)stream>>>(d_cdf, Lp, row_stride, d_in, in_stride, d_len, 1, N, o);
+    HIPCHK(hipGetLastError());
+    return LLICTI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ whole batch
+static int ensure_plan(llicti_ctx *c, int B, int H, int W)
+{
+    if (c->plan.B == B && c->plan.H == H && c->plan.W == W && c->d_desc) return 0;
+    build_plan(c->plan, B, H, W);
+    if (c->d_desc) { hipFree(c->d_desc); c->d_desc = nullptr; }
+    if (c->d_slot_off) { hipFree(c->d_slot_off); c->d_slot_off = nullptr; }
+    if (c->d_slot_cap) { hipFree(c->d_slot_cap); c->d_slot_cap = nullptr; }
+    const size_t n = (size_t)LLICTI_NSTREAMS * B;
+    HIPCHK(hipMalloc(&c->d_desc, n * sizeof(StreamDesc)));
+    HIPCHK(hipMalloc(&c->d_slot_off, n * sizeof(long)));
+    HIPCHK(hipMalloc(&c->d_slot_cap, n * sizeof(int32_t)));
+    HIPCHK(hipMemcpy(c->d_desc, c->plan.desc.data(), n * sizeof(StreamDesc), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_slot_off, c->plan.slot_off.data(), n * sizeof(long), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_slot_cap, c->plan.slot_cap.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+    return 0;
+}
+
+static int pad_int(int H, int W)
+{
+    int v = 0;
+    for (int l = 0; l < LLICTI_NLEVELS; ++l) {
+        Geom g = make_geom(1, H, W, l);
+        v = 4 * v + 2 * g.padH + g.padW;       // LLICTI_nets.py:230
+    }
+    return v;
+}
+
+static void begin_call(llicti_ctx *c, hipStream_t s)
+{
+    c->ev_used = 0;
+    if (c->profiling) hipEventRecord(c->ev_call[0], s);
+}
+static void end_call(llicti_ctx *c, hipStream_t s)
+{
+    if (c->profiling) { hipEventRecord(c->ev_call[1], s); c->timing_pending = true; }
+}
+
+extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, int H, int W, int mode,
+                                    void *d_workspace, size_t workspace_bytes,
+                                    uint8_t *d_out, size_t out_stride, int32_t *d_seg_len, void *stream)
+{
+    if (!c || !d_rgb || !d_workspace || !d_out || !d_seg_len) return fail(LLICTI_EINVAL, "encode_images: null pointer");
+    if (check_dims(B, H, W)) return LLICTI_EINVAL;
+    if (mode != 0) return fail(LLICTI_EINVAL, "encode_images: unknown mode %d", mode);
+    for (int b = 0; b < 3; ++b) if (!c->have[b]) return fail(LLICTI_ENOWEIGHTS, "band %d weights not set", b);
+    HIPCHK(hipSetDevice(c->device));
+    if (int rc = ensure_plan(c, B, H, W)) return rc;
+    const Plan &p = c->plan;
+    if (workspace_bytes < p.total) return fail(LLICTI_ENOSPACE, "encode_images: workspace %zu < %zu", workspace_bytes, p.total);
+    if (out_stride < p.max_container) return fail(LLICTI_ENOSPACE, "encode_images: out_stride %zu < %zu", out_stride, p.max_container);
+    hipStream_t s = (hipStream_t)stream;
+    uint8_t *ws = (uint8_t *)d_workspace;
+    int16_t *planes = (int16_t *)(ws + p.off_planes);
+    float *fplanes = (float *)(ws + p.off_fplanes);
+    int32_t *mm = (int32_t *)(ws + p.off_minmax);
+    int32_t *status = (int32_t *)(ws + p.off_status);
+    float *params = (float *)(ws + p.off_params);
+    uint32_t *pairs = (uint32_t *)(ws + p.off_pairs);
+    uint8_t *slots = ws + p.off_slots;
+    int32_t *slot_len = (int32_t *)(ws + p.off_slot_len);
+
+    begin_call(c, s);
+    HIPCHK(hipMemsetAsync(status, 0, 64, s));
+    if (int rc = launch_lift(d_rgb, B, H, W, planes, fplanes, mm, s)) return rc;
+    Geom g4 = make_geom(B, H, W, 4);
+    header_write_kernel<<<B, 256, 0, s>>>(d_rgb, mm, H, W, g4.h, g4.w, pad_int(H, W), d_out, (long)out_stride, d_seg_len);
+    // the encoder has no dependency between stages: every (level, band) reads only original pixels
+    for (int lvl = LLICTI_NLEVELS - 1; lvl >= 0; --lvl) {
+        Geom g = make_geom(B, H, W, lvl);
+        for (int band = 0; band < 3; ++band) {
+            if (int rc = launch_band_params(c, fplanes, g, band, params, s)) return rc;
+            if (int rc = launch_cdf_pairs(planes, params, mm, g, band, pairs + p.pair_base[lvl * 3 + band], s)) return rc;
+        }
+    }
+    const int n_streams = LLICTI_NSTREAMS * B;
+    ac_encode_pairs_kernel<<<(n_streams + 63) / 64, 64, 0, s>>>(pairs, c->d_desc, n_streams, slots, slot_len, status);
+    const int hdr_bytes = 17 + 3 * g4.h * g4.w;
+    pack_kernel<<<dim3(LLICTI_NSTREAMS, B), 256, 0, s>>>(slots, c->d_slot_off, slot_len, B, hdr_bytes, d_out, (long)out_stride, d_seg_len, status);
+    HIPCHK(hipMemcpyAsync(c->d_status, status, 4, hipMemcpyDeviceToDevice, s));   // latch
+    HIPCHK(hipGetLastError());
+    end_call(c, s);
+    return LLICTI_OK;
+}
+
+extern "C" int llicti_decode_images(llicti_ctx *c, const uint8_t *d_in, size_t in_stride, const int32_t *d_seg_len,
+                                    int B, int H, int W, int mode, void *d_workspace, size_t workspace_bytes,
+                                    uint8_t *d_rgb, void *stream)
+{
+    if (!c || !d_in || !d_seg_len || !d_workspace || !d_rgb) return fail(LLICTI_EINVAL, "decode_images: null pointer");
+    if (check_dims(B, H, W)) return LLICTI_EINVAL;
+    if (mode != 0) return fail(LLICTI_EINVAL, "decode_images: unknown mode %d", mode);
+    for (int b = 0; b < 3; ++b) if (!c->have[b]) return fail(LLICTI_ENOWEIGHTS, "band %d weights not set", b);
+    HIPCHK(hipSetDevice(c->device));
+    if (int rc = ensure_plan(c, B, H, W)) return rc;
+    const Plan &p = c->plan;
+    if (workspace_bytes < p.total) return fail(LLICTI_ENOSPACE, "decode_images: workspace %zu < %zu", workspace_bytes, p.total);
+    hipStream_t s = (hipStream_t)stream;
+    uint8_t *ws = (uint8_t *)d_workspace;
+    int16_t *planes = (int16_t *)(ws + p.off_planes);
+    float *fplanes = (float *)(ws + p.off_fplanes);
+    int32_t *mm = (int32_t *)(ws + p.off_minmax);
+    int32_t *status = (int32_t *)(ws + p.off_status);
+    float *params = (float *)(ws + p.off_params);
+    uint8_t *slots = ws + p.off_slots;
+    uint16_t *tables = (uint16_t *)(ws + p.off_tables);
+
+    begin_call(c, s);
+    HIPCHK(hipMemsetAsync(status, 0, 64, s));
+    Geom g4 = make_geom(B, H, W, 4);
+    header_read_kernel<<<B, 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, H, W, g4.h, g4.w, pad_int(H, W), planes, fplanes, mm, status);
+    unpack_kernel<<<dim3(LLICTI_NSTREAMS, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, B, slots, c->d_slot_off, c->d_slot_cap, status);
+    // 45 dependent stages (LLICTI_nets.py:440-498): CNN of band b needs bands < b of this level, Co needs Y, Cg needs Y, Co
+    for (int lvl = LLICTI_NLEVELS - 1; lvl >= 0; --lvl) {
+        Geom g = make_geom(B, H, W, lvl);
+        for (int band = 0; band < 3; ++band) {
+            if (int rc = launch_band_params(c, fplanes, g, band, params, s)) return rc;
+            StageGeom sg = make_stage(g, band);
+            const long nc = (long)sg.hc * sg.wc;
+            for (int clr = 0; clr < 3; ++clr) {
+                const int row_stride = (clr == 0) ? 264 : 512;      // Y: Lp = 257; Co/Cg: Lp <= 512
+                if (int rc = launch_cdf_table(planes, params, mm, g, band, clr, tables, row_stride, s)) return rc;
+                const int st = stage_index(lvl, band, clr);
+                DecOut o;
+                memset(&o, 0, sizeof o);
+                o.planes = planes; o.fplanes = fplanes; o.minmax = mm; o.sg = sg; o.clr = clr;
+                // the B streams of one stage sit in consecutive slots of equal capacity
+                const long in_stride_slots = p.slot_cap[(size_t)st * B];
+                ac_decode_kernel<<<B, 64, 0, s>>>(tables, 0, row_stride, slots + p.slot_off[(size_t)st * B], in_stride_slots,
+                                                  nullptr, 0, nc, o);
+            }
+        }
+    }
+    const long plane = (long)H * W;
+    const int gx = (int)std::min<long>((plane + 255) / 256, 1024);
+    unlift_kernel<<<dim3(gx, B), 256, 0, s>>>(planes, plane, d_rgb);
+    HIPCHK(hipMemcpyAsync(c->d_status, status, 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipGetLastError());
+    end_call(c, s);
+    return LLICTI_OK;
+}
+
+extern "C" int llicti_check_status(llicti_ctx *c, void *stream)
+{
+    if (!c) return fail(LLICTI_EINVAL, "null ctx");
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    int32_t st = 0;
+    HIPCHK(hipMemcpy(&st, c->d_status, 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(c->d_status, 0, 4));
+    if (st == LLICTI_EFORMAT) return fail(LLICTI_EFORMAT, "malformed container (header does not match the requested shape, or a stream is too long)");
+    if (st == LLICTI_ENOSPACE) return fail(LLICTI_ENOSPACE, "output buffer too small for the encoded streams");
+    if (st != 0) return fail(st, "device-side status %d", st);
+    return LLICTI_OK;
+}
+
+extern "C" int llicti_header_dims(const uint8_t *h, int *H, int *W)
+{
+    if (!h || !H || !W) return fail(LLICTI_EINVAL, "header_dims: null pointer");
+    if (h[0] != LLICTI_NLEVELS) return fail(LLICTI_EFORMAT, "header: %d scales, expected %d", h[0], LLICTI_NLEVELS);
+    int Hc = h[1], Wc = h[2];
+    int pad = (int)(int16_t)(h[15] | (h[16] << 8));
+    for (int l = LLICTI_NLEVELS - 1; l >= 0; --l) {     // _get_padHW_lev_list, LLICTI_nets.py:533-542
+        const int padW = pad & 1; pad >>= 1;
+        const int padH = pad & 1; pad >>= 1;
+        Hc = 2 * Hc - padH;
+        Wc = 2 * Wc - padW;
+    }
+    *H = Hc; *W = Wc;
+    return LLICTI_OK;
+}
+
+extern "C" int llicti_last_timing(llicti_ctx *c, float ms[4], int *n_launch)
+{
+    if (!c || !ms) return fail(LLICTI_EINVAL, "last_timing: null pointer");
+    if (c->timing_pending) {
+        HIPCHK(hipEventSynchronize(c->ev_call[1]));
+        float t = 0;
+        HIPCHK(hipEventElapsedTime(&t, c->ev_call[0], c->ev_call[1]));
+        c->last_ms[0] = t;
+        float sum = 0;
+        for (int i = 0; i + 1 < c->ev_used; i += 2) {
+            float k = 0;
+            HIPCHK(hipEventElapsedTime(&k, c->ev[i], c->ev[i + 1]));
+            sum += k;
+        }
+        c->last_ms[1] = sum;
+        c->last_launches = c->ev_used / 2;
+        c->timing_pending = false;
+    }
+    for (int i = 0; i < 4; ++i) ms[i] = c->last_ms[i];
+    if (n_launch) *n_launch = c->last_launches;
+    return LLICTI_OK;
+}

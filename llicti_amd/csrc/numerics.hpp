@@ -1,0 +1,141 @@
+// numerics.hpp -- device side of the "LLICTI-MI355X numerics spec v1" (DESIGN.md section 4).
+//
+// Every fp32 operation, its order and its rounding are fixed by the spec so that the gfx950 kernels,
+// run in any launch shape, produce the same 16-bit CDF tables (hence the same bitstreams) as any other
+// conforming implementation.  Build with -ffp-contract=off: the only fused operations are the
+// explicit __builtin_fmaf calls below; '/' is IEEE division (hipcc default for HIP).
+//
+// What it restates (reference file:line):
+//   entropy_layer_nets.py:197-203   sigma/weight lower bounds, weight normalisation, mixture CDF
+//   LLICTI_nets.py:385-392          cross-channel mean update
+//   LLICTI_nets.py:941-942          sample grid, ends pushed out by 20 grey levels
+//   LLICTI_nets.py:955-983          round(cdf * (65536-(Lp-1))) -> 16-bit wrap -> + index
+//   compressai GaussianConditional._standardized_cumulative: 0.5 * erfc(-(2**-0.5) * x)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace llicti {
+
+// polynomial coefficients: tools/gen_numerics_coeffs.py
+__device__ __forceinline__ float exp_spec(float y)          // y in [-49, 0]
+{
+    const float j = __builtin_rintf(y * 0x1.715476p+0f);
+    float f = __builtin_fmaf(j, -0x1.62e4p-1f, y);
+    f = __builtin_fmaf(j, -0x1.7f7d1cp-20f, f);
+    float q = 0x1.6d4328p-10f;
+    q = __builtin_fmaf(q, f, 0x1.120b74p-7f);
+    q = __builtin_fmaf(q, f, 0x1.5554eap-5f);
+    q = __builtin_fmaf(q, f, 0x1.5554dcp-3f);
+    q = __builtin_fmaf(q, f, 0x1.0p-1f);
+    const float f2 = f * f;
+    q = __builtin_fmaf(q, f2, f);
+    q = q + 1.0f;
+    const int ji = (int)j;
+    return __int_as_float(__float_as_int(q) + (ji << 23));
+}
+
+__device__ __forceinline__ float erfc_pos(float x)          // x >= 0;  := 0 for x >= 7 (and NaN)
+{
+    if (!(x < 7.0f)) return 0.0f;
+    const float r = 1.0f / (x + 2.0f);
+    const float t = (x - 2.0f) * r;
+    float p = 0x1.73901ap-15f;
+    p = __builtin_fmaf(p, t, -0x1.d399c2p-18f);
+    p = __builtin_fmaf(p, t, -0x1.3ddc9cp-11f);
+    p = __builtin_fmaf(p, t, -0x1.a18b0cp-11f);
+    p = __builtin_fmaf(p, t, 0x1.93b74ap-9f);
+    p = __builtin_fmaf(p, t, 0x1.a7e3c6p-8f);
+    p = __builtin_fmaf(p, t, -0x1.606bd2p-6f);
+    p = __builtin_fmaf(p, t, -0x1.2a869p-5f);
+    p = __builtin_fmaf(p, t, 0x1.1e2deep-2f);
+    p = __builtin_fmaf(p, t, -0x1.5fd388p-1f);
+    p = __builtin_fmaf(p, t, 0x1.058672p+0f);
+    const float s = x * x;
+    const float e = __builtin_fmaf(x, x, -s);
+    float ex = exp_spec(-s);
+    ex = __builtin_fmaf(-e, ex, ex);
+    return (p * ex) * r;
+}
+
+__device__ __forceinline__ float erfc_spec(float x)
+{
+    const float v = erfc_pos(__builtin_fabsf(x));
+    return (x < 0.0f) ? 2.0f - v : v;
+}
+
+constexpr float kScaleBound = (float)(0.11 / 255.0);
+constexpr float kWeightBound = 1e-6f;
+constexpr float kNegRsqrt2 = (float)(-0.70710678118654752440);
+
+struct Mix { float sig[5], mu[5], wn[5]; };
+
+// par: the 60 raw CNN outputs of one position (sigma 0..14 | mu 15..29 | weight 30..44 | a | b | d)
+__device__ __forceinline__ void mix_prepare(const float *par, int clr, float yv, float cov, Mix &m)
+{
+    float w[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const float sg = par[5 * clr + k];
+        float mu = par[15 + 5 * clr + k];
+        const float wk = par[30 + 5 * clr + k];
+        if (clr == 1) {
+            const float t = par[45 + k] * yv;
+            mu = mu + t;
+        } else if (clr == 2) {
+            const float t1 = par[50 + k] * yv;
+            const float t2 = par[55 + k] * cov;
+            const float t = t1 + t2;
+            mu = mu + t;
+        }
+        m.sig[k] = (sg > kScaleBound) ? sg : kScaleBound;
+        m.mu[k] = mu;
+        w[k] = (wk > kWeightBound) ? wk : kWeightBound;
+    }
+    const float s = (((w[0] + w[1]) + w[2]) + w[3]) + w[4];
+    const float den = 1e-9f + s;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) m.wn[k] = w[k] / den;
+}
+
+__device__ __forceinline__ float mix_cdf(const Mix &m, float pt)
+{
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const float z = (pt - m.mu[k]) / m.sig[k];
+        const float c = 0.5f * erfc_spec(kNegRsqrt2 * z);
+        const float t = m.wn[k] * c;
+        acc = (k == 0) ? t : acc + t;
+    }
+    return acc;
+}
+
+// per-stream constants of the sample grid
+struct Grid {
+    int minv, Lp;
+    float p_first, p_last, scale;
+};
+__device__ __forceinline__ Grid make_grid(int minv, int maxv)
+{
+    Grid g;
+    g.minv = minv;
+    g.Lp = maxv - minv + 2;
+    g.p_first = (float)(((double)minv - 0.5 - 20.0) / 255.0);   // Python-double scalars in the reference
+    g.p_last = (float)(((double)maxv + 0.5 + 20.0) / 255.0);
+    g.scale = (float)(65536 - (g.Lp - 1));
+    return g;
+}
+__device__ __forceinline__ float sample_pt(const Grid &g, int i)
+{
+    if (i == 0) return g.p_first;
+    if (i == g.Lp - 1) return g.p_last;
+    return ((float)g.minv - 0.5f + (float)i) / 255.0f;
+}
+__device__ __forceinline__ uint32_t cdf_entry(const Mix &m, const Grid &g, int i)
+{
+    const float q = __builtin_rintf(mix_cdf(m, sample_pt(g, i)) * g.scale);
+    return (uint32_t)((int)q + i) & 0xFFFFu;
+}
+
+}  // namespace llicti

@@ -1,0 +1,190 @@
+"""Drop-in for the reference's `graphs.models.LLICTI_nets.LLICTI` on the encode/decode path.
+
+Same constructor, `nn.Module` surface (33 `state_dict` entries with the reference's key names, so
+`load_state_dict(ckpt['state_dict'])` works -- agents/base.py:51-76), `compress(x)` and `decompres(...)`
+(sic: the missing "s" is part of the reference API, LLICTI_nets.py:161) with the reference's
+`bytestream_list` container.  All computation is done by the gfx950 HIP library through
+`llicti_amd.codec.HipCodec`; the torch modules below only hold parameters.  There is no CPU path:
+calling compress/decompres without a GPU raises.
+
+Differences from the reference, by design:
+  * fp32 arithmetic follows the numerics spec (same bits on every launch shape / device), so
+    decode(encode(x)) == x by construction, where the reference relies on PyTorch determinism;
+  * `compress` accepts B >= 1 only through `compress_batch` (the reference's decoder assumes B == 1,
+    LLICTI_nets.py:429, :443); `compress` itself keeps the B == 1 contract.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch import nn
+
+from ...codec import HipCodec, bytestream_list_to_container, container_to_bytestream_list, header_dims
+from ...config import check_supported
+
+
+class _LowerBound(nn.Module):
+    """Parameter-less stand-in that only carries compressai's `bound` buffer name (state_dict parity)."""
+
+    def __init__(self, bound):
+        super().__init__()
+        self.register_buffer("bound", torch.Tensor([float(bound)]))
+
+
+class _CondProbModel(nn.Module):
+    """Buffer names of GaussianConditionalLosslessGMM (entropy_layer_nets.py:145-158)."""
+
+    def __init__(self):
+        super().__init__()
+        self.likelihood_lower_bound = _LowerBound(1e-9)
+        self.lower_bound_scale = _LowerBound(0.11 / 255.0)
+        self.lower_bound_weights = _LowerBound(1e-6)
+
+
+class LLICTIEntropyModel4(nn.Module):
+    """Parameter container of one band interpolator (LLICTI_nets.py:585-712, config A branch).
+    Construction order matches the reference so a seeded default init gives the same weights."""
+
+    def __init__(self, scale, band, config, Ev, Od, Ch, Ly):
+        super().__init__()
+        self.band = band
+        self.num_mixtures = config.num_mixtures
+        self.conditional_prob_model = _CondProbModel()
+        grps = 4
+        Ch = grps * Ch
+        Co = (3 * self.num_mixtures) * 3 + (1 + 2) * self.num_mixtures
+        c = 3
+        if band == 0:
+            self.layer0_00_11 = nn.Conv2d(c, Ch, kernel_size=(Ev, Ev))
+        if band == 1:
+            self.layer0_00_01 = nn.Conv2d(c, Ch, kernel_size=(Od, Ev))
+            self.layer0_11_01 = nn.Conv2d(c, Ch, kernel_size=(Ev, Od))
+        if band == 2:
+            self.layer0_00_10 = nn.Conv2d(c, Ch, kernel_size=(Ev, Od))
+            self.layer0_11_10 = nn.Conv2d(c, Ch, kernel_size=(Od, Ev))
+            self.layer0_01_10 = nn.Conv2d(c, Ch, kernel_size=(Ev, Ev))
+        layers = []
+        for _ in range((Ly - 1) - 1):
+            layers.append(nn.Conv2d(Ch, Ch, kernel_size=1, groups=grps))
+            layers.append(nn.ReLU(inplace=True))
+        layers.append(nn.Conv2d(Ch, Co, kernel_size=1, groups=grps))
+        self.layers1toL = nn.Sequential(*layers)
+
+
+class LLICTIEntropyLayer(nn.Module):
+    """LLICTI_nets.py:255-316 with useprevlevNN=[F,T,T,T,T]: one scale entry of three band models,
+    shared by all five levels."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.list_scales = config.dwtlevels
+        self.num_scales = len(self.list_scales)
+        bands = nn.ModuleList()
+        for b in range(3):
+            bands.append(LLICTIEntropyModel4(scale=0, band=b, config=config, Ev=config.Evens[0], Od=config.Odds[0],
+                                             Ch=config.chs[0], Ly=config.conv_layers))
+        self.entmdls_scale_band = nn.ModuleList([bands])
+
+
+class LLICTI(nn.Module):
+    """(L)earned (L)ossless (I)mage (C)ompression (T)hrough (I)nterpolation -- MI355X hot path."""
+
+    def __init__(self, config):
+        super().__init__()
+        check_supported(config)
+        self.config = config
+        self.ycocg = config.ycocg
+        self.clrchs = config.clrchs
+        self.clrjnt = config.clr_joint_mode
+        self.list_scales = config.dwtlevels
+        self.num_scales = len(self.list_scales)
+        self.entropymodel = LLICTIEntropyLayer(config)
+        self._codec = None
+        self._weights_version = None
+
+    # ------------------------------------------------------------------ plumbing
+    def _weights_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def codec(self, device=None) -> HipCodec:
+        if self._codec is None:
+            dev = device
+            if dev is None:
+                p = next(self.parameters())
+                dev = p.device if p.is_cuda else None
+            self._codec = HipCodec(dev)
+        key = self._weights_key()
+        if key != self._weights_version:
+            self._codec.load_state_dict({k: v for k, v in self.state_dict().items()})
+            self._weights_version = key
+        return self._codec
+
+    def forward(self, x):
+        raise NotImplementedError("LLICTI.forward (training likelihood, LLICTI_nets.py:101-123) is outside the encode/decode "
+                                  "hot path this package accelerates (SURVEY.md section 8f)")
+
+    @staticmethod
+    def _to_u8(x):
+        # dataloader tensors are uint8/255 as float32 (image_dl.py ToTensor); round(x*255) is the
+        # reference's own first step (LLICTI_nets.py:65)
+        if x.dtype == torch.uint8:
+            return x
+        return (x * 255).round().clamp_(0, 255).to(torch.uint8)
+
+    # ------------------------------------------------------------------ reference API
+    @torch.no_grad()
+    def compress(self, x):
+        """x: float32 [1,3,H,W] in {k/255} (or uint8) -> (bytestream_list, x_ycocg)  (LLICTI_nets.py:125-159)."""
+        assert x.dim() == 4 and x.shape[1] == 3     # ensure x has 3 colour channels (LLICTI_nets.py:63)
+        if x.shape[0] != 1:
+            raise ValueError("compress() codes one image (the reference's decoder assumes B == 1); use compress_batch()")
+        lists, x_ycocg = self.compress_batch(x)
+        return lists[0], x_ycocg
+
+    @torch.no_grad()
+    def compress_batch(self, x):
+        codec = self.codec(x.device if x.is_cuda else None)
+        rgb = self._to_u8(x).to(codec.device).contiguous()
+        cont, seg = codec.encode(rgb)
+        _, fplanes, _ = codec.lift(rgb)               # x_ycocg = (YCoCg - [127,0,0]) / 255 (LLICTI_nets.py:143-144)
+        codec.check()
+        cont_h, seg_h = cont.cpu().numpy(), seg.cpu().numpy()
+        lists = [container_to_bytestream_list(cont_h[b], seg_h[b]) for b in range(rgb.shape[0])]
+        return lists, fplanes
+
+    @torch.no_grad()
+    def decompres(self, bytestream_list, devc=None, xorg=None):
+        """bytestream_list -> float32 [1,3,H,W] (LLICTI_nets.py:161-179)."""
+        out = self.decompres_batch([bytestream_list], devc)
+        return out
+
+    @torch.no_grad()
+    def decompres_batch(self, lists, devc=None):
+        codec = self.codec(devc if (devc is not None and torch.device(devc).type == "cuda") else None)
+        dims = None
+        bufs, segs = [], []
+        for bl in lists:
+            hdr = bytes(bl[0][0]) + bytes(bl[0][1]) + bytes(bl[0][2])
+            if len(bl[0][0]) != 3 or len(bl[0][1]) != 12 or len(bl[0][2]) != 2:
+                raise ValueError("malformed header streams")
+            assert hdr[0] == self.num_scales            # LLICTI_nets.py:424
+            d = header_dims(hdr)
+            if dims is None:
+                dims = d
+            elif d != dims:
+                raise ValueError("all images of one decompres_batch call must have the same size")
+            b, s = bytestream_list_to_container(bl)
+            bufs.append(b)
+            segs.append(s)
+        H, W = dims
+        stride = codec.max_container_bytes(H, W)
+        cont = np.zeros((len(lists), stride), np.uint8)
+        for i, b in enumerate(bufs):
+            if b.size > stride:
+                raise ValueError("container larger than any valid stream set for this image size")
+            cont[i, :b.size] = b
+        cont_d = torch.from_numpy(cont).to(codec.device)
+        seg_d = torch.from_numpy(np.stack(segs)).to(codec.device)
+        rgb = codec.decode(cont_d, seg_d, H, W)
+        codec.check()
+        return rgb.to(torch.float32) / 255           # LLICTI_nets.py:87

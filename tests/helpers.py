@@ -1,0 +1,23 @@
+"""Shared test helpers (synthetic inputs; no reference code)."""
+import numpy as np
+
+
+def make_image(kind, H, W, seed):
+    """Same generators as tests/golden/make_fixtures.py: i.i.d. uniform RGB, or low-pass 'smooth' RGB."""
+    rng = np.random.default_rng(seed)
+    if kind == "noise":
+        return rng.integers(0, 256, size=(3, H, W), dtype=np.uint8)
+    base = rng.standard_normal((3, H + 16, W + 16))
+    k = np.ones(9) / 9.0
+    for _ in range(2):
+        base = np.apply_along_axis(lambda r: np.convolve(r, k, mode="same"), 1, base)
+        base = np.apply_along_axis(lambda r: np.convolve(r, k, mode="same"), 2, base)
+    base = base[:, 8:8 + H, 8:8 + W]
+    lum = base[0:1] * 220.0
+    img = 128 + lum + base * 60.0 + np.linspace(-40, 40, W)[None, None, :]
+    img = img + rng.standard_normal(img.shape) * 2.0
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def make_batch(kind, B, H, W, seed0=0):
+    return np.stack([make_image(kind, H, W, seed0 + i) for i in range(B)])

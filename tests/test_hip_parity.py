@@ -1,0 +1,297 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI, against the
+CPU oracle on the same seeded inputs and against the golden fixtures.  Integer / byte / index work and --
+because the numerics spec fixes every fp32 rounding -- the CNN outputs, the 16-bit tables and the
+bitstreams are required to be BIT-EXACT."""
+import numpy as np
+import pytest
+
+from conftest import CASES, load_case, load_state_dict
+from helpers import make_batch, make_image
+
+pytestmark = pytest.mark.gpu
+
+PARAM_TOL = 1e-5      # vs the reference's PyTorch numbers (north_star); vs the oracle the bar is equality
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def codecs(torch_mod):
+    from llicti_amd.codec import HipCodec
+    cache = {}
+
+    def get(wname):
+        if wname not in cache:
+            c = HipCodec("cuda:0")
+            c.load_state_dict(load_state_dict(wname))
+            cache[wname] = c
+        return cache[wname]
+    yield get
+    for c in cache.values():
+        c.close()
+
+
+def _dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+@pytest.mark.parametrize("shape", [(32, 32), (67, 93), (128, 80), (33, 250)])
+def test_lift_unlift_exact(torch_mod, codecs, shape):
+    from oracle import oracle as orc
+    torch = torch_mod
+    c = codecs("rand1337")
+    H, W = shape
+    rgb = make_batch("noise", 3, H, W, seed0=10)
+    planes, fplanes, mm = c.lift(_dev(torch, rgb))
+    for b in range(3):
+        p_ref, mm_ref = orc.lift(rgb[b])
+        assert np.array_equal(planes[b].cpu().numpy(), p_ref)
+        assert np.array_equal(mm[b].cpu().numpy(), [mm_ref[1], mm_ref[2], mm_ref[4], mm_ref[5]])
+        assert np.array_equal(fplanes[b].cpu().numpy(), p_ref.astype(np.float32) / np.float32(255))
+    assert np.array_equal(c.unlift(planes).cpu().numpy(), rgb)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_band_params_bitexact_and_golden(torch_mod, codecs, golden_index, oracle_weights, case):
+    """MFMA CNN == oracle's k-ordered fmaf chains bit for bit, and within 1e-5 of the reference's PyTorch."""
+    from oracle import oracle as orc
+    torch = torch_mod
+    info = golden_index[case]
+    c = codecs(info["weights"])
+    W_o = oracle_weights(info["weights"])
+    g = load_case(case)
+    rgb = g["rgb"]
+    planes, fplanes, mm = c.lift(_dev(torch, rgb[None]))
+    p_host = planes[0].cpu().numpy()
+    for lvl in range(5):
+        for band in range(3):
+            got = c.band_params(fplanes, lvl, band)[0].cpu().numpy()
+            ref = orc.band_params(p_host, lvl, band, W_o)
+            assert got.shape == ref.shape
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (lvl, band, np.abs(got - ref).max())
+            key = f"params_s{lvl}_b{band}"
+            if key in g.files:
+                assert np.abs(got - np.transpose(g[key], (1, 2, 0))).max() < PARAM_TOL
+
+
+@pytest.mark.parametrize("case", ["smooth_67x93_tl", "noise_33x64_tl", "noise_32x32_rand"])
+def test_cdf_tables_and_pairs_bitexact(torch_mod, codecs, golden_index, oracle_weights, case):
+    from oracle import oracle as orc
+    torch = torch_mod
+    info = golden_index[case]
+    c = codecs(info["weights"])
+    W_o = oracle_weights(info["weights"])
+    rgb = load_case(case)["rgb"]
+    H, W = rgb.shape[1:]
+    planes, fplanes, mm = c.lift(_dev(torch, rgb[None]))
+    p_host, mm_ref = orc.lift(rgb)
+    offs = {0: (1, 1), 1: (0, 1), 2: (1, 0)}
+    for lvl in range(5):
+        for band in range(3):
+            params = c.band_params(fplanes, lvl, band)
+            par_ref = orc.band_params(p_host, lvl, band, W_o)
+            pairs = c.cdf_pairs(planes, params, mm, lvl, band).cpu().numpy().view(np.uint32)
+            for clr in range(3):
+                clow, chigh, sym = orc.stream_pairs(p_host, mm_ref, lvl, band, clr, par_ref)
+                got = pairs[clr, 0]
+                assert np.array_equal(got & 0xFFFF, clow), (lvl, band, clr)
+                assert np.array_equal(got >> 16, chigh & 0xFFFF), (lvl, band, clr)
+                minv = -127 if clr == 0 else int(mm_ref[clr])
+                maxv = 128 if clr == 0 else int(mm_ref[3 + clr])
+                Lp = maxv - minv + 2
+                stride = 264 if clr == 0 else 512
+                tab = c.cdf_tables(planes, params, mm, lvl, band, clr, row_stride=stride)[0].cpu().numpy().view(np.uint16)
+                *_, hc, wc = __import__("llicti_amd._lib", fromlist=["level_geom"]).level_geom(H, W, lvl, band)
+                assert tab.shape == (hc * wc, stride)
+                oi, oj = offs[band]
+                idx = np.unique(np.linspace(0, hc * wc - 1, 12).astype(int))
+                for n in idx:
+                    i, j = divmod(int(n), wc)
+                    R, Cc = (2 * i + oi) << lvl, (2 * j + oj) << lvl
+                    row = orc.cdf_row(par_ref[i, j], clr, np.float32(p_host[0, R, Cc]) / np.float32(255),
+                                      np.float32(p_host[1, R, Cc]) / np.float32(255), minv, maxv)
+                    assert np.array_equal(tab[n, :Lp], row), (lvl, band, clr, n)
+                    assert (tab[n, Lp:] == 0xFFFF).all()
+
+
+def test_ac_seam_matches_oracle(torch_mod, codecs):
+    """torchac seam: explicit tables + symbols -> bytes equal to the oracle coder; decode inverts."""
+    from oracle import oracle as orc
+    torch = torch_mod
+    c = codecs("rand1337")
+    rng = np.random.default_rng(5)
+    for Lp, N, S in [(257, 700, 3), (12, 1000, 2), (512, 300, 4), (2, 50, 1), (3, 64, 2)]:
+        stride = (Lp + 7) // 8 * 8
+        cdfs = np.full((S, N, stride), 0xFFFF, np.uint16)
+        syms = np.zeros((S, N), np.int16)
+        for s in range(S):
+            # random strictly increasing rows in the reference's format: q + arange, last entry wraps to 0
+            pm = rng.random((N, Lp - 1)) ** 4 + 1e-4
+            cum = np.concatenate([np.zeros((N, 1)), np.cumsum(pm, 1)], 1)
+            cum /= cum[:, -1:]
+            q = np.rint(cum * (65536 - (Lp - 1))).astype(np.int64) + np.arange(Lp)
+            cdfs[s, :, :Lp] = (q & 0xFFFF).astype(np.uint16)
+            syms[s] = rng.integers(0, Lp - 1, N)
+        out, ln = c.ac_encode(_dev(torch, cdfs.view(np.int16)), _dev(torch, syms), Lp)
+        out_h, ln_h = out.cpu().numpy(), ln.cpu().numpy()
+        streams = []
+        for s in range(S):
+            ref = orc.ac_encode_tables(cdfs[s, :, :Lp].copy(), syms[s])
+            assert bytes(out_h[s, :ln_h[s]]) == ref, (Lp, s)
+            streams.append(ref)
+        # decode through the seam: 4-byte aligned, zero padded streams
+        in_stride = (max(len(x) for x in streams) + 3) // 4 * 4 + 16
+        buf = np.zeros((S, in_stride), np.uint8)
+        for s, x in enumerate(streams):
+            buf[s, :len(x)] = np.frombuffer(x, np.uint8)
+        dec = c.ac_decode(_dev(torch, cdfs.view(np.int16)), Lp, _dev(torch, buf), _dev(torch, ln_h.astype(np.int32)), N)
+        assert np.array_equal(dec.cpu().numpy(), syms)
+        for s in range(S):
+            assert np.array_equal(orc.ac_decode_tables(cdfs[s, :, :Lp].copy(), streams[s]), syms[s])
+
+
+def _encode_to_lists(c, torch, rgb_batch):
+    from llicti_amd.codec import container_to_bytestream_list
+    cont, seg = c.encode(_dev(torch, rgb_batch))
+    c.check()
+    cont_h, seg_h = cont.cpu().numpy(), seg.cpu().numpy()
+    return [container_to_bytestream_list(cont_h[b], seg_h[b]) for b in range(rgb_batch.shape[0])], cont, seg
+
+
+@pytest.mark.parametrize("kind,H,W,wname", [("noise", 32, 32, "rand1337"), ("smooth", 64, 48, "trainedlike"),
+                                            ("smooth", 67, 93, "trainedlike"), ("noise", 33, 64, "trainedlike"),
+                                            ("smooth", 100, 131, "trainedlike"), ("noise", 95, 40, "rand1337")])
+def test_whole_image_bitstream_bitexact(torch_mod, codecs, oracle_weights, kind, H, W, wname):
+    """HIP container == oracle container byte for byte; both decoders accept both; lossless."""
+    from oracle import oracle as orc
+    from llicti_amd.codec import bytestream_list_to_container
+    torch = torch_mod
+    c = codecs(wname)
+    W_o = oracle_weights(wname)
+    rgb = make_batch(kind, 2, H, W, seed0=20)
+    lists, cont, seg = _encode_to_lists(c, torch, rgb)
+    for b in range(2):
+        ref = orc.encode_image(rgb[b], W_o)
+        assert lists[b] == ref, [(i, j) for i in range(6) for j in range(9) if lists[b][i][j] != ref[i][j]][:5]
+        assert np.array_equal(orc.decode_image(lists[b], W_o), rgb[b])      # oracle decodes the GPU stream
+    rec = c.decode(cont, seg, H, W)
+    c.check()
+    assert np.array_equal(rec.cpu().numpy(), rgb)                           # GPU decodes the GPU stream
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_golden_headers_and_pixels(torch_mod, codecs, golden_index, case):
+    torch = torch_mod
+    info = golden_index[case]
+    c = codecs(info["weights"])
+    g = load_case(case)
+    lists, cont, seg = _encode_to_lists(c, torch, g["rgb"][None])
+    bl = lists[0]
+    assert bl[0][0] == g["hdr0"].tobytes() and bl[0][1] == g["hdr_minmax"].tobytes()
+    assert bl[0][2] == g["hdr_pad"].tobytes() and bl[0][3] == g["hdr_dc"].tobytes()
+    H, W = g["rgb"].shape[1:]
+    rec = c.decode(cont, seg, H, W).cpu().numpy()[0]
+    assert np.array_equal(rec, g["reco_rgb"])
+    # rate: total bytes within 0.001 bpp... of the ideal code length of the REFERENCE's own tables
+    bits_ref = 0.0
+    for s in range(5):
+        for b in range(3):
+            for cl in range(3):
+                lo = g[f"clow_s{s}_b{b}_c{cl}"].astype(np.int64)
+                hi = g[f"chigh_s{s}_b{b}_c{cl}"].astype(np.int64)
+                bits_ref += -np.log2((hi - lo) / 65536.0).sum()
+    coded_bits = 8 * sum(len(x) for row in bl[1:] for x in row)
+    # 45 streams x <= 2 bytes of arithmetic-coder termination is the only overhead over the ideal length
+    assert coded_bits - bits_ref < 45 * 16 + 0.001 * H * W
+    assert coded_bits - bits_ref > -0.001 * H * W - 16
+
+
+def test_kodak_shape_properties(torch_mod, codecs):
+    """BASELINE.json full size (768x512): round trip, batch independence, idempotence."""
+    torch = torch_mod
+    c = codecs("trainedlike")
+    rgb = np.concatenate([make_batch("smooth", 2, 512, 768, seed0=40), make_batch("noise", 1, 512, 768, seed0=41)])
+    lists, cont, seg = _encode_to_lists(c, torch, rgb)
+    rec = c.decode(cont, seg, 512, 768)
+    c.check()
+    assert np.array_equal(rec.cpu().numpy(), rgb)
+    # coding an image alone gives the same bytes as coding it inside a batch
+    l1, _, _ = _encode_to_lists(c, torch, rgb[1:2])
+    assert l1[0] == lists[1]
+    # encode(decode(encode(x))) == encode(x)
+    l2, _, _ = _encode_to_lists(c, torch, rec.cpu().numpy())
+    assert l2 == lists
+    # sizes: smooth images compress, noise does not (sanity of the model, not a reference number)
+    bpp = [8 * sum(len(x) for row in l for x in row) / (512 * 768) for l in lists]
+    assert bpp[0] < 20 and bpp[1] < 20 and bpp[2] > 20
+
+
+def test_large_odd_image_roundtrip(torch_mod, codecs):
+    torch = torch_mod
+    c = codecs("trainedlike")
+    rgb = make_batch("smooth", 1, 1080 // 2 + 1, 1920 // 2 + 3, seed0=50)
+    lists, cont, seg = _encode_to_lists(c, torch, rgb)
+    rec = c.decode(cont, seg, rgb.shape[2], rgb.shape[3])
+    c.check()
+    assert np.array_equal(rec.cpu().numpy(), rgb)
+
+
+def test_malformed_container_rejected(torch_mod, codecs):
+    from llicti_amd._lib import LlictiError, EFORMAT
+    torch = torch_mod
+    c = codecs("trainedlike")
+    rgb = make_batch("smooth", 1, 64, 64, seed0=60)
+    cont, seg = c.encode(_dev(torch, rgb))
+    c.check()
+    bad = cont.clone()
+    bad[0, 0] = 4                               # wrong number of scales (assert at LLICTI_nets.py:424)
+    c.decode(bad, seg, 64, 64)
+    with pytest.raises(LlictiError) as e:
+        c.check()
+    assert e.value.code == EFORMAT
+    with pytest.raises(LlictiError):
+        c.decode(cont, seg, 64, 96)             # header says 64x64
+        c.check()
+    rec = c.decode(cont, seg, 64, 64)           # context still usable afterwards
+    c.check()
+    assert np.array_equal(rec.cpu().numpy(), rgb)
+
+
+def test_reference_api_roundtrip(torch_mod):
+    """graphs.models.LLICTI_nets.LLICTI: compress / decompres with the reference's container and seeded init."""
+    torch = torch_mod
+    from llicti_amd.config import default_config
+    from llicti_amd.graphs.models.LLICTI_nets import LLICTI
+    from oracle import oracle as orc
+    from llicti_amd.weights import pack_state_dict
+    torch.manual_seed(1337)
+    model = LLICTI(default_config()).to("cuda:0").eval()
+    rgb = make_image("noise", 67, 93, 1)
+    x = torch.from_numpy(rgb.astype(np.float32) / np.float32(255)).unsqueeze(0).to("cuda:0")
+    bl, x_ycocg = model.compress(x)
+    assert len(bl) == 6 and all(len(r) == 9 for r in bl)
+    g = load_case("noise_67x93_rand")           # same image, same seeded weights as the fixture
+    assert bl[0][1] == g["hdr_minmax"].tobytes() and bl[0][3] == g["hdr_dc"].tobytes()
+    assert np.array_equal(x_ycocg.cpu().numpy()[0], g["x_ycocg_f32"])
+    x_reco = model.decompres(bl, torch.device("cuda:0"))
+    assert float(((x - x_reco) * 255).abs().max()) == 0.0
+    W_o = orc.Weights(pack_state_dict(model.state_dict()))
+    assert orc.encode_image(rgb, W_o) == bl
+
+
+def test_agent_eval_model(torch_mod, caplog):
+    import logging
+    from llicti_amd.agents.llicti_agent import LLICTIAgent
+    from llicti_amd.config import default_config
+    caplog.set_level(logging.INFO)
+    agent = LLICTIAgent(default_config(test_data="synthetic:48x80x2"))
+    res = agent.run()
+    agent.finalize()
+    assert len(res) == 2 and all(r["max_abs_err"] == 0.0 for r in res)
+    assert sum("Check: Decoded img matches original" in r.message for r in caplog.records) == 2
+    assert all(len(r["rates"]) == 6 and all(len(row) == 9 for row in r["rates"]) for r in res)

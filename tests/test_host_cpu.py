@@ -1,0 +1,120 @@
+"""CPU-side tests of the product's host logic: the C-ABI library loads and exports every symbol the
+header declares (no compute call without a GPU), geometry helpers, weight packing, config checks,
+container plumbing, and the loud failure when no GPU is present."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_state_dict
+
+
+def test_library_exports_every_header_symbol():
+    from llicti_amd import _lib
+    _lib.build()
+    hdr = open(os.path.join(ROOT, "include", "llicti_hip.h")).read()
+    declared = set(re.findall(r"\b(llicti_[a-z0-9_]+)\s*\(", hdr))
+    declared.discard("llicti_ctx")
+    L = C.CDLL(_lib.SO_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert declared == set(_lib.EXPORTS)
+    assert b"gfx950" in _lib.lib().llicti_version()
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from llicti_amd import _lib
+    from llicti_amd.codec import HipCodec
+    ctx = C.c_void_p()
+    rc = _lib.lib().llicti_create(C.byref(ctx), 0)
+    assert rc == _lib.ENODEVICE and b"no CPU path" in _lib.lib().llicti_last_error()
+    with pytest.raises(_lib.LlictiError):
+        HipCodec()
+    from llicti_amd.config import default_config
+    from llicti_amd.graphs.models.LLICTI_nets import LLICTI
+    with pytest.raises(_lib.LlictiError):
+        LLICTI(default_config()).compress(torch.zeros(1, 3, 32, 32))
+
+
+@pytest.mark.parametrize("H,W", [(32, 32), (67, 93), (512, 768), (2160, 3840), (33, 250)])
+def test_level_geometry_matches_oracle(H, W):
+    from llicti_amd import _lib
+    from oracle import oracle as orc
+    for lvl in range(5):
+        for band in range(3):
+            Hl, Wl, h, w, padH, padW, hc, wc = _lib.level_geom(H, W, lvl, band)
+            assert (Hl, Wl, h, w, padH, padW) == orc.level_geom(H, W, lvl)
+            assert hc == (h - padH if band in (0, 2) else h) and wc == (w - padW if band in (0, 1) else w)
+    # position / symbol counts
+    if (H, W) == (512, 768):
+        assert sum(_lib.level_geom(H, W, l)[2] * _lib.level_geom(H, W, l)[3] for l in range(5)) == 130944
+    if (H, W) == (2160, 3840):
+        assert _lib.level_geom(H, W, 4)[2:6] == (68, 120, 1, 0)
+
+
+def test_workspace_and_container_bounds():
+    from llicti_amd import _lib
+    L = _lib.lib()
+    assert L.llicti_workspace_bytes(1, 16, 16, 0) == 0          # too small
+    assert L.llicti_workspace_bytes(1, 9000, 64, 0) == 0        # header stores h4 as uint8
+    n1 = L.llicti_workspace_bytes(1, 512, 768, 0)
+    n24 = L.llicti_workspace_bytes(24, 512, 768, 0)
+    assert 0 < n1 < n24 < 8 * 2 ** 30
+    # worst case of a 16-bit-precision coder: 2 bytes per symbol + termination, 1,178,496 symbols
+    assert 2 * 1178496 < L.llicti_max_container_bytes(512, 768) < 2 * 1178496 + 4096
+
+
+def test_weight_packing_and_state_dict_names():
+    import torch
+    from llicti_amd.config import default_config
+    from llicti_amd.graphs.models.LLICTI_nets import LLICTI
+    from llicti_amd.weights import expected_keys, pack_state_dict
+    torch.manual_seed(1337)
+    m = LLICTI(default_config())
+    sd = m.state_dict()
+    ref = load_state_dict("rand1337")       # captured from the reference with the same seed (base.py:28)
+    assert set(sd) == set(ref) and len(sd) == 33
+    assert all(np.array_equal(sd[k].numpy(), ref[k]) for k in ref)
+    assert sum(p.numel() for p in m.parameters()) == 196596      # exp_debug.log:101 (0.750 MB)
+    assert set(expected_keys()) <= set(sd)
+    packed = pack_state_dict(sd)
+    assert [packed[b]["K0"] for b in range(3)] == [48, 72, 120]
+    assert packed[2]["w0"].shape == (352, 120)
+    w = ref["entropymodel.entmdls_scale_band.0.2.layer0_11_10.weight"]
+    assert np.array_equal(packed[2]["w0"][:, 36:72], w.reshape(352, -1))
+    # a real checkpoint carries extra compressai buffers: they must be ignorable
+    sd2 = dict(ref)
+    sd2["entropymodel.entmdls_scale_band.0.0.conditional_prob_model._offset"] = np.zeros(1)
+    assert np.array_equal(pack_state_dict(sd2)[0]["w0"], packed[0]["w0"])
+
+
+def test_config_rejects_unsupported_variants():
+    from llicti_amd.config import check_supported, default_config
+    check_supported(default_config())
+    for k, v in [("num_mixtures", 3), ("clr_joint_mode", 0), ("ycocg", False), ("activfun", "LeakyReLU"),
+                 ("dwtlevels", [0, 1, 2, 3]), ("mwsa_joint", True)]:
+        with pytest.raises(NotImplementedError):
+            check_supported(default_config(**{k: v}))
+
+
+def test_container_list_roundtrip():
+    from llicti_amd.codec import bytestream_list_to_container, container_to_bytestream_list, header_dims
+    rng = np.random.default_rng(0)
+    segs = [bytes([5, 3, 4]), bytes(12), bytes([0x6A, 0x03]), bytes(rng.integers(0, 256, 36, dtype=np.uint8))]
+    segs += [bytes(rng.integers(0, 256, int(n), dtype=np.uint8)) for n in rng.integers(0, 40, 45)]
+    buf = np.frombuffer(b"".join(segs), np.uint8)
+    seg_len = np.array([len(s) for s in segs], np.int32)
+    bl = container_to_bytestream_list(buf, seg_len)
+    assert len(bl) == 6 and all(len(r) == 9 for r in bl) and bl[0][4:] == [b""] * 5
+    b2, s2 = bytestream_list_to_container(bl)
+    assert np.array_equal(b2, buf) and np.array_equal(s2, seg_len)
+    with pytest.raises(ValueError):
+        bytestream_list_to_container(bl[:5])
+    # header -> image size: h4=3, w4=4, pad flags 0x036A = 874 is the fixture value of a 67x93 image
+    assert header_dims(bytes([5, 3, 3]) + bytes(12) + bytes([0x6A, 0x03])) == (67, 93)
+    assert header_dims(bytes([5, 16, 24]) + bytes(12) + bytes([0, 0])) == (512, 768)
