@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- LLICTI encode+decode throughput on MI355X (BASELINE.json metric: MPix/s encode+decode).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path over one batch of synthetic input on every rank: encode the batch
+(uint8 RGB already resident in HBM -> containers in HBM) and decode it again (containers in HBM -> uint8
+RGB in HBM).  Workload: 24 x 768x512 RGB per GPU (BASELINE.json configs[2], the shape the north-star
+target is quoted on; --batch 1 gives configs[1]'s single image), i.i.d. uniform noise, seeds 0..B-1 per
+rank, weights = seed-1337 default init (the reference does the same when its
+checkpoint is missing).  Images shard across ranks with no data-path collective ("weak" scaling): the
+only collectives are the timing barrier and a MAX / SUM of scalars at the end.
+
+One JSON line is printed by rank 0.  `value` = pixels of all ranks x K / max-over-ranks time of the K
+steps.  `roofline` is for the dominant kernel (the fp32-MFMA interpolator CNN): algorithmic FLOPs of the
+launches in one encode+decode / their summed HIP-event durations, measured live in extra profiled steps
+after the timed region.  `cpu_baseline` times the CPU oracle in the reference's structure (materialised
+Lp-entry tables, single-thread coder) on the host cores, on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MAC_PER_POSITION = 193248            # 84,480 layer-0 + 92,928 mid + 15,840 out
+PEAK_FP32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def positions_per_image(H, W):
+    n = 0
+    for lvl in range(5):
+        st = 1 << lvl
+        Hl, Wl = (H + st - 1) // st, (W + st - 1) // st
+        n += ((Hl + 1) // 2) * ((Wl + 1) // 2)
+    return n
+
+
+def make_batch(B, H, W, seed0):
+    return np.stack([np.random.default_rng(seed0 + i).integers(0, 256, size=(3, H, W), dtype=np.uint8) for i in range(B)])
+
+
+def cpu_baseline(H, W):
+    """Oracle ("port"), reference structure, on a bounded sample: ONE H x W image of the same workload."""
+    from llicti_amd.config import default_config
+    from llicti_amd.graphs.models.LLICTI_nets import LLICTI
+    from llicti_amd.weights import pack_state_dict
+    from oracle import oracle as orc
+    import torch
+    torch.manual_seed(1337)
+    sd = LLICTI(default_config()).state_dict()
+    Wt = orc.Weights(pack_state_dict(sd))
+    cores = os.cpu_count() or 1
+    orc.set_threads(cores)
+    rgb = make_batch(1, H, W, 0)[0]
+    t0 = time.time()
+    bl = orc.encode_image(rgb, Wt, full_tables=True)
+    t1 = time.time()
+    rec = orc.decode_image(bl, Wt, full_tables=True)
+    t2 = time.time()
+    assert np.array_equal(rec, rgb)
+    return {"value": round(H * W / 1e6 / (t2 - t0), 5), "unit": "MPix/s", "cores": cores, "kind": "port",
+            "sample": f"1 image {W}x{H} uniform-noise RGB, encode {t1 - t0:.2f}s + decode {t2 - t1:.2f}s, "
+                      "materialised Lp-entry tables (OpenMP) + single-thread range coder",
+            "enc_s": round(t1 - t0, 3), "dec_s": round(t2 - t1, 3)}, bl
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=24, help="images per GPU per step")
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=768)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI; used for the barrier + scalars only
+
+    from llicti_amd.codec import HipCodec, container_to_bytestream_list
+    from llicti_amd.config import default_config
+    from llicti_amd.graphs.models.LLICTI_nets import LLICTI
+
+    B, H, W = args.batch, args.height, args.width
+    torch.manual_seed(1337)
+    sd = LLICTI(default_config()).state_dict()                # seed-1337 default init, identical on every rank
+    codec = HipCodec(dev)
+    codec.load_state_dict(sd)
+
+    rgb_h = make_batch(B, H, W, seed0=rank * B)
+    rgb = torch.from_numpy(rgb_h).to(dev)
+    stride = codec.max_container_bytes(H, W)
+    cont = torch.empty((B, stride), dtype=torch.uint8, device=dev)
+    seg = torch.zeros((B, 49), dtype=torch.int32, device=dev)
+    rec = torch.empty_like(rgb)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def step():
+        codec.encode(rgb, out=cont, seg_len=seg)
+        codec.decode(cont, seg, H, W, out=rec)
+
+    # correctness outside the timed region: lossless, and rank 0's first image bit-exact to the CPU oracle
+    step()
+    codec.check()
+    assert torch.equal(rec, rgb), "decode(encode(x)) != x"
+    seg_h = seg.cpu().numpy()
+    total_bytes = int(seg_h.sum())
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    # separate encode / decode timings (informational)
+    def timed(fn, n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+    t_enc = timed(lambda: codec.encode(rgb, out=cont, seg_len=seg), max(1, min(3, args.steps)))
+    t_dec = timed(lambda: codec.decode(cont, seg, H, W, out=rec), max(1, min(3, args.steps)))
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    codec.check()
+
+    # dominant-kernel timing with HIP events on the launch stream, in extra (untimed) profiled steps
+    codec.set_profiling(True)
+    cnn_ms, cnn_launches, call_ms = 0.0, 0, 0.0
+    for fn in (lambda: codec.encode(rgb, out=cont, seg_len=seg), lambda: codec.decode(cont, seg, H, W, out=rec)):
+        fn()
+        torch.cuda.synchronize()
+        ms, n = codec.last_timing()
+        cnn_ms += ms[1]
+        cnn_launches += n
+        call_ms += ms[0]
+    codec.set_profiling(False)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    byt = torch.tensor([float(total_bytes)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(byt, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        pix = float(world) * B * H * W
+        value = pix * args.steps / elapsed / 1e6
+        flops = 2.0 * MAC_PER_POSITION * positions_per_image(H, W) * B * 2      # encode + decode passes
+        achieved = flops / (cnn_ms * 1e-3) / 1e12 if cnn_ms > 0 else 0.0
+        out = {
+            "metric": "MPix/s encode+decode", "value": round(value, 3), "unit": "MPix/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{B}x{W}x{H} uniform-noise RGB per GPU, AC container (torchac-compatible), "
+                                   "seed-1337 weights; BASELINE.json configs[2]" if B == 24 else
+                                   f"{B}x{W}x{H} uniform-noise RGB per GPU, AC container, seed-1337 weights",
+                       "batch_per_gpu": B, "height": H, "width": W, "mode": "ac", "sharding": f"images/{world}gpu"},
+            "enc_mpix_s": round(B * H * W / t_enc / 1e6, 3), "dec_mpix_s": round(B * H * W / t_dec / 1e6, 3),
+            "bpp": round(8.0 * float(byt.item()) / pix, 4),
+            "roofline": {"bound": "mfma", "kernel": "band_params_kernel<0|1|2> (fp32 MFMA 16x16x4)",
+                         "achieved": round(achieved, 3), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": None,
+                         "launches": cnn_launches, "kernel_ms_per_step": round(cnn_ms, 3),
+                         "call_ms_profiled": round(call_ms, 3),
+                         "flop_per_step": flops},
+        }
+        if not args.no_cpu_baseline:
+            cb, bl = cpu_baseline(H, W)
+            # the same image through the HIP path must give the oracle's bytes
+            got = container_to_bytestream_list(cont[0].cpu().numpy(), seg_h[0])
+            cb["bitexact_vs_hip"] = bool(got == bl)
+            out["cpu_baseline"] = cb
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

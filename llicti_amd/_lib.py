@@ -70,6 +70,10 @@ def lib():
     """Load the shared library (raises if it has not been built)."""
     global _lib
     if _lib is None:
+        # PyTorch-ROCm ships its own libamdhip64; import it first so that this library binds to the HIP
+        # runtime already in the process (same SONAME) instead of pulling a second copy from /opt/rocm --
+        # two runtimes in one process do not share devices, streams or allocations.
+        import torch  # noqa: F401
         if not os.path.exists(SO_PATH):
             raise LlictiError(ENODEVICE, f"{SO_PATH} is missing: run __graft_entry__.build() (hipcc); "
                                          "there is no CPU fallback for the LLICTI hot path")

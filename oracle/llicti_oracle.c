@@ -634,15 +634,27 @@ int orc_decode_image(const uint8_t *in, const int32_t seg_len[49], const orc_wei
                 const uint16_t max_symbol = (uint16_t)(Lp - 2);
                 acdec_t d;
                 acdec_init(&d, in + pos, seg_len[si]);
-                uint16_t *row = (uint16_t *)malloc(sizeof(uint16_t) * Lp);
+                uint16_t *tab = NULL;
+                if (full_tables) {
+                    /* reference structure: the whole [N][Lp] table of the stage is materialised first
+                     * (get_cdfs, LLICTI_nets.py:489), then the stream is decoded from it (:492) */
+                    tab = (uint16_t *)malloc(sizeof(uint16_t) * n * Lp);
+#pragma omp parallel for schedule(static) num_threads(nthreads())
+                    for (long q = 0; q < n; ++q) {
+                        int i = (int)(q / wc), j = (int)(q % wc);
+                        long off = ((long)(2 * i + BAND_OI[src]) << lvl) * W + ((long)(2 * j + BAND_OJ[src]) << lvl);
+                        orc_cdf_row(params + ((long)i * w + j) * ORC_NPAR, clr, (float)planes[off] / 255.0f,
+                                    (float)planes[plane_sz + off] / 255.0f, minv, maxv, tab + q * Lp);
+                    }
+                }
                 for (long q = 0; q < n; ++q) {
                     int i = (int)(q / wc), j = (int)(q % wc);
                     long off = ((long)(2 * i + BAND_OI[src]) << lvl) * W + ((long)(2 * j + BAND_OJ[src]) << lvl);
                     mix_t m;
-                    mix_prepare(params + ((long)i * w + j) * ORC_NPAR, clr, (float)planes[off] / 255.0f,
-                                (float)planes[plane_sz + off] / 255.0f, &m);
-                    if (full_tables)
-                        for (int e = 0; e < Lp; ++e) row[e] = cdf_entry(&m, e, Lp, minv, maxv);
+                    const uint16_t *row = full_tables ? tab + q * Lp : NULL;
+                    if (!full_tables)
+                        mix_prepare(params + ((long)i * w + j) * ORC_NPAR, clr, (float)planes[off] / 255.0f,
+                                    (float)planes[plane_sz + off] / 255.0f, &m);
                     const uint16_t count = acdec_count(&d);
                     /* torchac binsearch, entries evaluated on demand (same values as the table's) */
                     uint16_t left = 0, right = (uint16_t)(max_symbol + 1);
@@ -660,7 +672,7 @@ int orc_decode_image(const uint8_t *in, const int32_t seg_len[49], const orc_wei
                                     : (full_tables ? row[s + 1] : cdf_entry(&m, s + 1, Lp, minv, maxv));
                     acdec_update(&d, c_low, c_high);
                 }
-                free(row);
+                free(tab);
                 pos += seg_len[si++];
             }
         }
