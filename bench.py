@@ -6,10 +6,11 @@
 
 A "step" is one pass of the hot path over one batch of synthetic input on every rank: encode the batch
 (uint8 RGB already resident in HBM -> containers in HBM) and decode it again (containers in HBM -> uint8
-RGB in HBM).  Workload: 24 x 768x512 RGB per GPU (BASELINE.json configs[2], the shape the north-star
-target is quoted on; --batch 1 gives configs[1]'s single image), i.i.d. uniform noise, seeds 0..B-1 per
-rank, weights = seed-1337 default init (the reference does the same when its
-checkpoint is missing).  Images shard across ranks with no data-path collective ("weak" scaling): the
+RGB in HBM).  Workload: 24 x 768x512 RGB per GPU in the rANS container (BASELINE.json configs[2]: "Batch
+of 24x 768x512 RGB, HIP rANS replacing torchac end-to-end", the shape the north-star target is quoted on;
+--batch 1 gives configs[1]'s single image, --container ac the torchac-compatible container), i.i.d.
+uniform noise, seeds 0..B-1 per rank, weights = seed-1337 default init (the
+reference does the same when its checkpoint is missing).  Images shard across ranks with no data-path collective ("weak" scaling): the
 only collectives are the timing barrier and a MAX / SUM of scalars at the end.
 
 One JSON line is printed by rank 0.  `value` = pixels of all ranks x K / max-over-ranks time of the K
@@ -82,6 +83,7 @@ def main():
     ap.add_argument("--batch", type=int, default=24, help="images per GPU per step")
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=768)
+    ap.add_argument("--container", default="rans16", help="rans<M> (M streams per image) or ac (torchac-compatible)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -97,11 +99,12 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI; used for the barrier + scalars only
 
-    from llicti_amd.codec import HipCodec, container_to_bytestream_list
+    from llicti_amd.codec import MODE_AC, MODE_RANS, HipCodec, container_to_bytestream_list
     from llicti_amd.config import default_config
     from llicti_amd.graphs.models.LLICTI_nets import LLICTI
 
     B, H, W = args.batch, args.height, args.width
+    mode = MODE_AC if args.container == "ac" else MODE_RANS(int(args.container[4:]))
     torch.manual_seed(1337)
     sd = LLICTI(default_config()).state_dict()                # seed-1337 default init, identical on every rank
     codec = HipCodec(dev)
@@ -118,9 +121,15 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def enc(m=mode, c=None, s_=None):
+        return codec.encode(rgb, mode=m, out=cont if c is None else c, seg_len=seg if s_ is None else s_)
+
+    def dec(m=mode, c=None, s_=None):
+        return codec.decode(cont if c is None else c, seg if s_ is None else s_, H, W, mode=m, out=rec)
+
     def step():
-        codec.encode(rgb, out=cont, seg_len=seg)
-        codec.decode(cont, seg, H, W, out=rec)
+        enc()
+        dec()
 
     # correctness outside the timed region: lossless, and rank 0's first image bit-exact to the CPU oracle
     step()
@@ -140,8 +149,8 @@ def main():
             fn()
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n
-    t_enc = timed(lambda: codec.encode(rgb, out=cont, seg_len=seg), max(1, min(3, args.steps)))
-    t_dec = timed(lambda: codec.decode(cont, seg, H, W, out=rec), max(1, min(3, args.steps)))
+    t_enc = timed(enc, max(1, min(3, args.steps)))
+    t_dec = timed(dec, max(1, min(3, args.steps)))
 
     barrier()
     torch.cuda.synchronize()
@@ -156,7 +165,7 @@ def main():
     # dominant-kernel timing with HIP events on the launch stream, in extra (untimed) profiled steps
     codec.set_profiling(True)
     cnn_ms, cnn_launches, call_ms = 0.0, 0, 0.0
-    for fn in (lambda: codec.encode(rgb, out=cont, seg_len=seg), lambda: codec.decode(cont, seg, H, W, out=rec)):
+    for fn in (enc, dec):
         fn()
         torch.cuda.synchronize()
         ms, n = codec.last_timing()
@@ -164,6 +173,28 @@ def main():
         cnn_launches += n
         call_ms += ms[0]
     codec.set_profiling(False)
+
+    # the other container on the same batch (untimed region; informational): the torchac-compatible AC
+    # container is what bit-exactness with the reference's format is claimed on
+    other = {}
+    if mode != MODE_AC:
+        cont2 = torch.empty_like(cont)
+        seg2 = torch.zeros_like(seg)
+        enc(MODE_AC, cont2, seg2)
+        dec(MODE_AC, cont2, seg2)
+        codec.check()
+        assert torch.equal(rec, rgb)
+        ta = timed(lambda: enc(MODE_AC, cont2, seg2), 1)
+        tb = timed(lambda: dec(MODE_AC, cont2, seg2), 1)
+        ac_bytes = int(seg2.sum().item())
+        other = {"ac_container": {"enc_mpix_s": round(B * H * W / ta / 1e6, 3), "dec_mpix_s": round(B * H * W / tb / 1e6, 3),
+                                  "encdec_mpix_s": round(B * H * W / (ta + tb) / 1e6, 3),
+                                  "bpp": round(8.0 * ac_bytes / (B * H * W), 4),
+                                  "bpp_delta_rans_minus_ac": round(8.0 * (total_bytes - ac_bytes) / (B * H * W), 4)}}
+        seg_ac_h = seg2.cpu().numpy()
+        cont_ac0 = cont2[0].cpu().numpy()
+    else:
+        seg_ac_h, cont_ac0 = seg_h, cont[0].cpu().numpy()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     byt = torch.tensor([float(total_bytes)], dtype=torch.float64, device=dev)
@@ -181,10 +212,10 @@ def main():
             "metric": "MPix/s encode+decode", "value": round(value, 3), "unit": "MPix/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{B}x{W}x{H} uniform-noise RGB per GPU, AC container (torchac-compatible), "
-                                   "seed-1337 weights; BASELINE.json configs[2]" if B == 24 else
-                                   f"{B}x{W}x{H} uniform-noise RGB per GPU, AC container, seed-1337 weights",
-                       "batch_per_gpu": B, "height": H, "width": W, "mode": "ac", "sharding": f"images/{world}gpu"},
+            "config": {"workload": f"{B}x{W}x{H} uniform-noise RGB per GPU, container {args.container}, seed-1337 weights"
+                                   + ("; BASELINE.json configs[2]" if (B == 24 and mode != MODE_AC) else ""),
+                       "batch_per_gpu": B, "height": H, "width": W, "container": args.container,
+                       "sharding": f"images/{world}gpu"},
             "enc_mpix_s": round(B * H * W / t_enc / 1e6, 3), "dec_mpix_s": round(B * H * W / t_dec / 1e6, 3),
             "bpp": round(8.0 * float(byt.item()) / pix, 4),
             "roofline": {"bound": "mfma", "kernel": "band_params_kernel<0|1|2> (fp32 MFMA 16x16x4)",
@@ -194,10 +225,11 @@ def main():
                          "call_ms_profiled": round(call_ms, 3),
                          "flop_per_step": flops},
         }
+        out.update(other)
         if not args.no_cpu_baseline:
             cb, bl = cpu_baseline(H, W)
-            # the same image through the HIP path must give the oracle's bytes
-            got = container_to_bytestream_list(cont[0].cpu().numpy(), seg_h[0])
+            # the same image through the HIP path (AC container) must give the oracle's bytes
+            got = container_to_bytestream_list(cont_ac0, seg_ac_h[0])
             cb["bitexact_vs_hip"] = bool(got == bl)
             out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)

@@ -122,7 +122,15 @@ int llicti_ac_decode_u16cdf(llicti_ctx *ctx, const uint16_t *d_cdf, int Lp, int 
  * synchronise; device-side failures (malformed header, stream overflow) are latched in the context
  * and reported by llicti_check_status. */
 
-/* Bytes of device workspace the two calls below need for B images of H x W (mode 0 = AC container). */
+/* mode: LLICTI_MODE_AC = the reference's container (45 torchac-algorithm streams per image, bit-exact
+ * to the oracle / reference format); LLICTI_MODE_RANS(M) = "LLICTI-rANS v1", a NEW container of this
+ * build: header byte 0 = 0x80 | lg2(M) << 4 | 5, then M independent 64-way interleaved rANS streams per
+ * image (segments 4 .. 4+M-1, the other stream segments empty), same CDFs and symbols, decodable
+ * 64*M symbols at a time.  Cost: about 190 bytes per stream over the AC container. */
+#define LLICTI_MODE_AC        0
+#define LLICTI_MODE_RANS(M)  (0x100 | (M))      /* M in {1, 2, 4, 8, 16, 32} */
+
+/* Bytes of device workspace the two calls below need for B images of H x W in `mode`. */
 size_t llicti_workspace_bytes(int B, int H, int W, int mode);
 /* Upper bound of the container size of ONE image: the minimum out_stride / in_stride. */
 size_t llicti_max_container_bytes(int H, int W);

@@ -18,7 +18,20 @@ from . import _lib
 from .weights import pack_state_dict
 
 NSEG = 49
-MODE_AC = 0
+MODE_AC = 0                      # the reference's container: 45 torchac-algorithm streams per image
+
+
+def MODE_RANS(M=8):
+    """"LLICTI-rANS v1" container: M independent 64-way interleaved rANS streams per image (include/llicti_hip.h)."""
+    return 0x100 | int(M)
+
+
+def mode_of_header(byte0: int) -> int:
+    if byte0 == 5:
+        return MODE_AC
+    if (byte0 & 0x8F) == 0x85:
+        return MODE_RANS(1 << ((byte0 >> 4) & 7))
+    raise ValueError(f"unknown container tag 0x{byte0:02x}")
 
 
 def _ptr(t):

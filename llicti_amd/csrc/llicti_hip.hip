@@ -679,17 +679,178 @@ __global__ __launch_bounds__(64) void ac_decode_kernel(const uint16_t *__restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------ rANS container
+// "LLICTI-rANS v1" (new format of this build; BASELINE.json north_star: "torchac replaced by a HIP rANS
+// coder").  Same CDFs and symbols as the AC container; each image has M independent streams, each a
+// 64-way interleaved rANS coder (32-bit states, 16-bit words, 16-bit probabilities) driven by ONE
+// wavefront: lane l of stream m codes symbol n = 64c + l of every chunk c = m (mod M) of every stage.
+// Words are shared by the 64 lanes in lane order (ballot + mbcnt prefix), so a whole stage decodes in
+// ceil(nc / 64M) wave steps instead of nc serial symbols.
+__device__ __forceinline__ int lanes_below(uint64_t mask)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+__global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restrict__ pairs, const StreamDesc *__restrict__ desc,
+                                                         int B, int M, uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
+                                                         int rslot_cap, int32_t *__restrict__ rinfo, int32_t *status)
+{
+    const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M, lane = threadIdx.x;
+    uint16_t *w16 = reinterpret_cast<uint16_t *>(slots + rslot_off[sidx]);
+    long p = rslot_cap / 2;                         // word cursor, moving backwards from the end of the slot
+    uint32_t x = 1u << 16;
+    int bad = 0;
+    for (int st = LLICTI_NSTREAMS - 1; st >= 0; --st) {      // rANS is LIFO: last decoded symbol first
+        const StreamDesc d = desc[(long)st * B + b];
+        const int nchunks = (d.n + 63) >> 6;
+        if (nchunks <= m) continue;
+        const int K = (nchunks - m + M - 1) / M;
+        const uint32_t *pp = pairs + d.pair_off;
+        for (int k = K - 1; k >= 0; --k) {
+            const int n = 64 * (m + k * M) + lane;
+            const bool active = n < d.n;
+            const uint32_t v = active ? pp[n] : 0x00010000u;
+            const uint32_t lo = v & 0xFFFFu;
+            uint32_t hi = v >> 16;
+            if (hi == 0) hi = 0x10000u;
+            uint32_t freq = hi - lo;
+            if (active && (freq == 0 || hi < lo)) { bad = 1; freq = 1; }
+            const bool emit = active && ((uint64_t)x >= ((uint64_t)freq << 16));
+            const uint64_t E = __ballot(emit);
+            p -= __builtin_popcountll(E);
+            if (p < 128) { bad = 2; p = 128; }
+            if (emit) { w16[p + lanes_below(E)] = (uint16_t)(x & 0xFFFFu); x >>= 16; }
+            if (active) {
+                const uint32_t q = x / freq;
+                x = (q << 16) + (x - q * freq) + lo;
+            }
+        }
+    }
+    p -= 128;                                       // 64 final states, little-endian uint32, lane order
+    w16[p + 2 * lane] = (uint16_t)(x & 0xFFFFu);
+    w16[p + 2 * lane + 1] = (uint16_t)(x >> 16);
+    if (lane == 0) { rinfo[2 * sidx] = (int32_t)(2 * p); rinfo[2 * sidx + 1] = (int32_t)(rslot_cap - 2 * p); }
+    if (bad) atomicExch(&status[0], bad == 1 ? LLICTI_EFORMAT : LLICTI_ENOSPACE);
+}
+
+__global__ __launch_bounds__(64) void rans_init_kernel(const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
+                                                       uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos)
+{
+    const int sidx = blockIdx.x, lane = threadIdx.x;
+    rstate[(long)sidx * 64 + lane] = reinterpret_cast<const uint32_t *>(slots + rslot_off[sidx])[lane];
+    if (lane == 0) rpos[sidx] = 0;
+}
+
+// one stage (level, band, colour channel) of all images: the mixture CDF is evaluated on the fly inside a
+// per-lane binary search (no table in HBM): ceil(log2 Lp) probes x 5 erfc.
+__global__ __launch_bounds__(64) void rans_decode_stage_kernel(const float *__restrict__ params, StageGeom sg, int clr, int M,
+                                                               const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
+                                                               int rslot_cap, uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos,
+                                                               int16_t *__restrict__ planes, float *__restrict__ fplanes,
+                                                               const int32_t *__restrict__ minmax)
+{
+    const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M, lane = threadIdx.x;
+    const int nc = sg.hc * sg.wc;
+    const int nchunks = (nc + 63) >> 6;
+    if (nchunks <= m) return;
+    const int K = (nchunks - m + M - 1) / M;
+    uint32_t x = rstate[(long)sidx * 64 + lane];
+    uint32_t pos = rpos[sidx];
+    const uint16_t *words = reinterpret_cast<const uint16_t *>(slots + rslot_off[sidx] + 256);
+    const uint32_t max_words = (uint32_t)((rslot_cap - 256) / 2);
+    int minv, maxv, shift;
+    clr_range(minmax + 4 * b, clr, minv, maxv, shift);
+    const Grid gr = make_grid(minv, maxv);
+    const int max_symbol = gr.Lp - 2;
+    const long img = (long)b * 3 * sg.plane;
+    for (int k = 0; k < K; ++k) {
+        const int n = 64 * (m + k * M) + lane;
+        const bool active = n < nc;
+        if (active) {
+            const int i = n / sg.wc, j = n - i * sg.wc;
+            const float *par = params + ((long)b * sg.h * sg.w + (long)i * sg.w + j) * LLICTI_NPARAMS;
+            const long off = img + ((long)(2 * i + sg.oi) << sg.lvl) * sg.W + ((long)(2 * j + sg.oj) << sg.lvl);
+            Mix mx;
+            mix_prepare(par, clr, fplanes[off], fplanes[off + sg.plane], mx);
+            const uint32_t slot = x & 0xFFFFu;
+            int lo = 0, hi = max_symbol + 1;
+            uint32_t vlo = 0, vhi = 0x10000u;
+            bool have_lo = false;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                const uint32_t e = cdf_entry(mx, gr, mid);
+                if (e <= slot) { lo = mid; vlo = e; have_lo = true; } else { hi = mid; vhi = e; }
+            }
+            if (!have_lo) vlo = cdf_entry(mx, gr, 0);
+            x = (vhi - vlo) * (x >> 16) + slot - vlo;
+            const int v = lo - shift;
+            planes[off + (long)clr * sg.plane] = (int16_t)v;
+            fplanes[off + (long)clr * sg.plane] = (float)v / 255.0f;
+        }
+        const bool need = active && x < 0x10000u;
+        const uint64_t E = __ballot(need);
+        if (need) {
+            const uint32_t idx = pos + (uint32_t)lanes_below(E);
+            const uint32_t wv = (idx < max_words) ? words[idx] : 0u;
+            x = (x << 16) | wv;
+        }
+        pos += (uint32_t)__builtin_popcountll(E);
+    }
+    rstate[(long)sidx * 64 + lane] = x;
+    if (lane == 0) rpos[sidx] = pos;
+}
+
+__global__ __launch_bounds__(256) void rans_pack_kernel(const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
+                                                        const int32_t *__restrict__ rinfo, int M, int hdr_bytes,
+                                                        uint8_t *__restrict__ out, long out_stride, int32_t *__restrict__ seg_len, int32_t *status)
+{
+    const int m = blockIdx.x, b = blockIdx.y;
+    long dst = hdr_bytes;
+    for (int k = 0; k < m; ++k) dst += rinfo[2 * (b * M + k) + 1];
+    const int n = rinfo[2 * (b * M + m) + 1];
+    if (dst + n > out_stride) { if (threadIdx.x == 0) atomicExch(&status[0], LLICTI_ENOSPACE); return; }
+    const uint8_t *src = slots + rslot_off[b * M + m] + rinfo[2 * (b * M + m)];
+    uint8_t *o = out + (long)b * out_stride + dst;
+    for (int t = threadIdx.x; t < n; t += blockDim.x) o[t] = src[t];
+    if (threadIdx.x == 0) {
+        seg_len[(long)b * LLICTI_NSEG + 4 + m] = n;
+        if (m == 0) for (int k = 4 + M; k < LLICTI_NSEG; ++k) seg_len[(long)b * LLICTI_NSEG + k] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void rans_unpack_kernel(const uint8_t *__restrict__ in, long in_stride, const int32_t *__restrict__ seg_len,
+                                                          int M, uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
+                                                          int rslot_cap, int32_t *status)
+{
+    const int m = blockIdx.x, b = blockIdx.y;
+    const int32_t *sl = seg_len + (long)b * LLICTI_NSEG;
+    long src = 0;
+    for (int k = 0; k < 4 + m; ++k) src += sl[k];
+    int n = sl[4 + m];
+    uint8_t *o = slots + rslot_off[b * M + m];
+    if (n < 256 || n > rslot_cap || src + n > in_stride) {
+        if (threadIdx.x == 0) atomicExch(&status[0], LLICTI_EFORMAT);
+        for (int t = threadIdx.x; t < 256; t += blockDim.x) o[t] = (t & 3) == 2 ? 1 : 0;     // states = 1 << 16: harmless
+        n = 256;
+    } else {
+        const uint8_t *p = in + (long)b * in_stride + src;
+        for (int t = threadIdx.x; t < n; t += blockDim.x) o[t] = p[t];
+    }
+    const int padded = min(rslot_cap, n + 64);
+    for (int t = n + threadIdx.x; t < padded; t += blockDim.x) o[t] = 0;
+}
+
 // ------------------------------------------------------------------------------------------------ container kernels
 // encode: header segments straight into the container; seg_len[b][0..3]
 __global__ void header_write_kernel(const uint8_t *__restrict__ rgb, const int32_t *__restrict__ minmax, int H, int W,
-                                    int h4, int w4, int padint, uint8_t *__restrict__ out, long out_stride,
+                                    int h4, int w4, int padint, int byte0, uint8_t *__restrict__ out, long out_stride,
                                     int32_t *__restrict__ seg_len)
 {
     const int b = blockIdx.x;
     uint8_t *o = out + (long)b * out_stride;
     const long plane = (long)H * W;
     if (threadIdx.x == 0) {
-        o[0] = LLICTI_NLEVELS; o[1] = (uint8_t)h4; o[2] = (uint8_t)w4;            // LLICTI_nets.py:347
+        o[0] = (uint8_t)byte0; o[1] = (uint8_t)h4; o[2] = (uint8_t)w4;          // LLICTI_nets.py:347 (AC: number of scales)
         const int32_t *mm = minmax + 4 * b;
         const int16_t v[6] = { 0, (int16_t)mm[0], (int16_t)mm[1], 255, (int16_t)mm[2], (int16_t)mm[3] };   // :139, :348
         for (int k = 0; k < 6; ++k) { o[3 + 2 * k] = (uint8_t)(v[k] & 0xFF); o[4 + 2 * k] = (uint8_t)((v[k] >> 8) & 0xFF); }
@@ -723,7 +884,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ s
 
 // decode: parse + validate header, min/max -> minmax[b][4], DC band -> planes at stride 32
 __global__ void header_read_kernel(const uint8_t *__restrict__ in, long in_stride, const int32_t *__restrict__ seg_len,
-                                   int H, int W, int h4, int w4, int padint, int16_t *__restrict__ planes,
+                                   int H, int W, int h4, int w4, int padint, int byte0, int16_t *__restrict__ planes,
                                    float *__restrict__ fplanes, int32_t *__restrict__ minmax, int32_t *status)
 {
     const int b = blockIdx.x;
@@ -734,7 +895,7 @@ __global__ void header_read_kernel(const uint8_t *__restrict__ in, long in_strid
     if (threadIdx.x == 0) {
         const int pad = (int)(int16_t)(p[15] | (p[16] << 8));
         ok = (sl[0] == 3 && sl[1] == 12 && sl[2] == 2 && sl[3] == 3 * h4 * w4 &&
-              p[0] == LLICTI_NLEVELS && p[1] == h4 && p[2] == w4 && pad == padint);      // LLICTI_nets.py:423-428
+              p[0] == byte0 && p[1] == h4 && p[2] == w4 && pad == padint);               // LLICTI_nets.py:423-428
         if (!ok) atomicExch(&status[0], LLICTI_EFORMAT);
         int16_t v[6];
         for (int k = 0; k < 6; ++k) v[k] = (int16_t)(p[3 + 2 * k] | (p[4 + 2 * k] << 8));
@@ -787,6 +948,10 @@ struct Plan {                 // workspace carving for (B, H, W)
     std::vector<int32_t> slot_cap;
     std::vector<long> pair_base;        // per (lvl, band): first pair of [clr][B][nc]
     size_t max_container;
+    int M = 0;                          // rANS streams per image (0: AC container only)
+    int rslot_cap = 0;
+    std::vector<long> rslot_off;        // [B*M] byte offsets into the slots region
+    size_t off_rinfo, off_rstate, off_rpos;
 };
 
 struct llicti_ctx {
@@ -797,6 +962,7 @@ struct llicti_ctx {
     StreamDesc *d_desc = nullptr;
     long *d_slot_off = nullptr;
     int32_t *d_slot_cap = nullptr;
+    long *d_rslot_off = nullptr;
     int32_t *d_status = nullptr;      // small persistent status word (for the kernel-level entry points)
     bool profiling = false;
     std::vector<hipEvent_t> ev;       // pairs around band-CNN launches
@@ -811,9 +977,9 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static int stage_index(int lvl, int band, int clr) { return (LLICTI_NLEVELS - 1 - lvl) * 9 + band * 3 + clr; }   // scale 4..0
 
-static void build_plan(Plan &p, int B, int H, int W)
+static void build_plan(Plan &p, int B, int H, int W, int M)
 {
-    p.B = B; p.H = H; p.W = W;
+    p.B = B; p.H = H; p.W = W; p.M = M;
     const size_t plane = (size_t)H * W;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
@@ -857,9 +1023,26 @@ static void build_plan(Plan &p, int B, int H, int W)
             pair_pos += 3L * B * nc;
         }
     }
-    p.max_container = align_up(container, 16);
+    p.max_container = align_up(container + 64 * 45, 16);
     p.off_pairs = take((size_t)pair_pos * sizeof(uint32_t));
+    if (M > 0) {
+        // worst case of one stream: every symbol emits a 16-bit word; chunks are dealt round-robin, so a
+        // stream gets at most ceil(nchunks / M) chunks of every stage
+        long syms = 0;
+        for (int st = 0; st < LLICTI_NSTREAMS; ++st) {
+            const long nchunks = (p.desc[(size_t)st * B].n + 63) / 64;
+            syms += (nchunks + M - 1) / M * 64;
+        }
+        p.rslot_cap = (int)align_up((size_t)(2 * syms + 256 + 64), 64);
+        p.rslot_off.assign((size_t)B * M, 0);
+        for (long i = 0; i < (long)B * M; ++i) p.rslot_off[i] = (long)i * p.rslot_cap;
+        slot_pos = std::max<long>(slot_pos, (long)B * M * p.rslot_cap);
+        p.max_container = std::max(p.max_container, align_up((size_t)(17 + 3 * g4.h * g4.w) + (size_t)M * p.rslot_cap, 16));
+    }
     p.off_slots = take((size_t)slot_pos);
+    p.off_rinfo = take((size_t)B * 32 * 2 * sizeof(int32_t));
+    p.off_rstate = take((size_t)B * 32 * 64 * sizeof(uint32_t));
+    p.off_rpos = take((size_t)B * 32 * sizeof(uint32_t));
     p.off_slot_len = take((size_t)LLICTI_NSTREAMS * B * sizeof(int32_t));
     int hc0, wc0;
     coded_dims(g0, 1, &hc0, &wc0);
@@ -867,18 +1050,31 @@ static void build_plan(Plan &p, int B, int H, int W)
     p.total = o;
 }
 
+// mode: 0 = AC container (torchac-compatible, the reference's format); 0x100 | M = rANS container with M
+// streams per image, M in {1,2,4,8,16,32}
+static int mode_streams(int mode)
+{
+    if (mode == 0) return 0;
+    if ((mode & ~0xFF) != 0x100) return -1;
+    const int M = mode & 0xFF;
+    if (M < 1 || M > 32 || (M & (M - 1))) return -1;
+    return M;
+}
+static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
 extern "C" size_t llicti_workspace_bytes(int B, int H, int W, int mode)
 {
-    if (check_dims(B, H, W) || mode != 0) return 0;
+    const int M = mode_streams(mode);
+    if (check_dims(B, H, W) || M < 0) return 0;
     Plan p;
-    build_plan(p, B, H, W);
+    build_plan(p, B, H, W, M);
     return p.total;
 }
 extern "C" size_t llicti_max_container_bytes(int H, int W)
 {
     if (check_dims(1, H, W)) return 0;
     Plan p;
-    build_plan(p, 1, H, W);
+    build_plan(p, 1, H, W, 32);     // covers every mode
     return p.max_container;
 }
 
@@ -917,6 +1113,7 @@ extern "C" int llicti_destroy(llicti_ctx *c)
     if (c->d_desc) hipFree(c->d_desc);
     if (c->d_slot_off) hipFree(c->d_slot_off);
     if (c->d_slot_cap) hipFree(c->d_slot_cap);
+    if (c->d_rslot_off) hipFree(c->d_rslot_off);
     if (c->d_status) hipFree(c->d_status);
     for (auto e : c->ev) hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) if (c->ev_call[i]) hipEventDestroy(c->ev_call[i]);
@@ -1090,10 +1287,15 @@ extern "C" int llicti_ac_decode_u16cdf(llicti_ctx *c, const uint16_t *d_cdf, int
 }
 
 // ------------------------------------------------------------------------------------------------ whole batch
-static int ensure_plan(llicti_ctx *c, int B, int H, int W)
+static int ensure_plan(llicti_ctx *c, int B, int H, int W, int M)
 {
-    if (c->plan.B == B && c->plan.H == H && c->plan.W == W && c->d_desc) return 0;
-    build_plan(c->plan, B, H, W);
+    if (c->plan.B == B && c->plan.H == H && c->plan.W == W && c->plan.M == M && c->d_desc) return 0;
+    build_plan(c->plan, B, H, W, M);
+    if (c->d_rslot_off) { hipFree(c->d_rslot_off); c->d_rslot_off = nullptr; }
+    if (M > 0) {
+        HIPCHK(hipMalloc(&c->d_rslot_off, (size_t)B * M * sizeof(long)));
+        HIPCHK(hipMemcpy(c->d_rslot_off, c->plan.rslot_off.data(), (size_t)B * M * sizeof(long), hipMemcpyHostToDevice));
+    }
     if (c->d_desc) { hipFree(c->d_desc); c->d_desc = nullptr; }
     if (c->d_slot_off) { hipFree(c->d_slot_off); c->d_slot_off = nullptr; }
     if (c->d_slot_cap) { hipFree(c->d_slot_cap); c->d_slot_cap = nullptr; }
@@ -1133,10 +1335,11 @@ extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, 
 {
     if (!c || !d_rgb || !d_workspace || !d_out || !d_seg_len) return fail(LLICTI_EINVAL, "encode_images: null pointer");
     if (check_dims(B, H, W)) return LLICTI_EINVAL;
-    if (mode != 0) return fail(LLICTI_EINVAL, "encode_images: unknown mode %d", mode);
+    const int M = mode_streams(mode);
+    if (M < 0) return fail(LLICTI_EINVAL, "encode_images: unknown mode 0x%x", mode);
     for (int b = 0; b < 3; ++b) if (!c->have[b]) return fail(LLICTI_ENOWEIGHTS, "band %d weights not set", b);
     HIPCHK(hipSetDevice(c->device));
-    if (int rc = ensure_plan(c, B, H, W)) return rc;
+    if (int rc = ensure_plan(c, B, H, W, M)) return rc;
     const Plan &p = c->plan;
     if (workspace_bytes < p.total) return fail(LLICTI_ENOSPACE, "encode_images: workspace %zu < %zu", workspace_bytes, p.total);
     if (out_stride < p.max_container) return fail(LLICTI_ENOSPACE, "encode_images: out_stride %zu < %zu", out_stride, p.max_container);
@@ -1155,7 +1358,8 @@ extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, 
     HIPCHK(hipMemsetAsync(status, 0, 64, s));
     if (int rc = launch_lift(d_rgb, B, H, W, planes, fplanes, mm, s)) return rc;
     Geom g4 = make_geom(B, H, W, 4);
-    header_write_kernel<<<B, 256, 0, s>>>(d_rgb, mm, H, W, g4.h, g4.w, pad_int(H, W), d_out, (long)out_stride, d_seg_len);
+    const int byte0 = M ? (0x80 | (ilog2(M) << 4) | LLICTI_NLEVELS) : LLICTI_NLEVELS;
+    header_write_kernel<<<B, 256, 0, s>>>(d_rgb, mm, H, W, g4.h, g4.w, pad_int(H, W), byte0, d_out, (long)out_stride, d_seg_len);
     // the encoder has no dependency between stages: every (level, band) reads only original pixels
     for (int lvl = LLICTI_NLEVELS - 1; lvl >= 0; --lvl) {
         Geom g = make_geom(B, H, W, lvl);
@@ -1164,10 +1368,16 @@ extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, 
             if (int rc = launch_cdf_pairs(planes, params, mm, g, band, pairs + p.pair_base[lvl * 3 + band], s)) return rc;
         }
     }
-    const int n_streams = LLICTI_NSTREAMS * B;
-    ac_encode_pairs_kernel<<<(n_streams + 63) / 64, 64, 0, s>>>(pairs, c->d_desc, n_streams, slots, slot_len, status);
     const int hdr_bytes = 17 + 3 * g4.h * g4.w;
-    pack_kernel<<<dim3(LLICTI_NSTREAMS, B), 256, 0, s>>>(slots, c->d_slot_off, slot_len, B, hdr_bytes, d_out, (long)out_stride, d_seg_len, status);
+    if (M == 0) {
+        const int n_streams = LLICTI_NSTREAMS * B;
+        ac_encode_pairs_kernel<<<(n_streams + 63) / 64, 64, 0, s>>>(pairs, c->d_desc, n_streams, slots, slot_len, status);
+        pack_kernel<<<dim3(LLICTI_NSTREAMS, B), 256, 0, s>>>(slots, c->d_slot_off, slot_len, B, hdr_bytes, d_out, (long)out_stride, d_seg_len, status);
+    } else {
+        int32_t *rinfo = (int32_t *)(ws + p.off_rinfo);
+        rans_encode_kernel<<<B * M, 64, 0, s>>>(pairs, c->d_desc, B, M, slots, c->d_rslot_off, p.rslot_cap, rinfo, status);
+        rans_pack_kernel<<<dim3(M, B), 256, 0, s>>>(slots, c->d_rslot_off, rinfo, M, hdr_bytes, d_out, (long)out_stride, d_seg_len, status);
+    }
     HIPCHK(hipMemcpyAsync(c->d_status, status, 4, hipMemcpyDeviceToDevice, s));   // latch
     HIPCHK(hipGetLastError());
     end_call(c, s);
@@ -1180,10 +1390,11 @@ extern "C" int llicti_decode_images(llicti_ctx *c, const uint8_t *d_in, size_t i
 {
     if (!c || !d_in || !d_seg_len || !d_workspace || !d_rgb) return fail(LLICTI_EINVAL, "decode_images: null pointer");
     if (check_dims(B, H, W)) return LLICTI_EINVAL;
-    if (mode != 0) return fail(LLICTI_EINVAL, "decode_images: unknown mode %d", mode);
+    const int M = mode_streams(mode);
+    if (M < 0) return fail(LLICTI_EINVAL, "decode_images: unknown mode 0x%x", mode);
     for (int b = 0; b < 3; ++b) if (!c->have[b]) return fail(LLICTI_ENOWEIGHTS, "band %d weights not set", b);
     HIPCHK(hipSetDevice(c->device));
-    if (int rc = ensure_plan(c, B, H, W)) return rc;
+    if (int rc = ensure_plan(c, B, H, W, M)) return rc;
     const Plan &p = c->plan;
     if (workspace_bytes < p.total) return fail(LLICTI_ENOSPACE, "decode_images: workspace %zu < %zu", workspace_bytes, p.total);
     hipStream_t s = (hipStream_t)stream;
@@ -1199,8 +1410,16 @@ extern "C" int llicti_decode_images(llicti_ctx *c, const uint8_t *d_in, size_t i
     begin_call(c, s);
     HIPCHK(hipMemsetAsync(status, 0, 64, s));
     Geom g4 = make_geom(B, H, W, 4);
-    header_read_kernel<<<B, 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, H, W, g4.h, g4.w, pad_int(H, W), planes, fplanes, mm, status);
-    unpack_kernel<<<dim3(LLICTI_NSTREAMS, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, B, slots, c->d_slot_off, c->d_slot_cap, status);
+    const int byte0 = M ? (0x80 | (ilog2(M) << 4) | LLICTI_NLEVELS) : LLICTI_NLEVELS;
+    header_read_kernel<<<B, 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, H, W, g4.h, g4.w, pad_int(H, W), byte0, planes, fplanes, mm, status);
+    uint32_t *rstate = (uint32_t *)(ws + p.off_rstate);
+    uint32_t *rpos = (uint32_t *)(ws + p.off_rpos);
+    if (M == 0) {
+        unpack_kernel<<<dim3(LLICTI_NSTREAMS, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, B, slots, c->d_slot_off, c->d_slot_cap, status);
+    } else {
+        rans_unpack_kernel<<<dim3(M, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, M, slots, c->d_rslot_off, p.rslot_cap, status);
+        rans_init_kernel<<<B * M, 64, 0, s>>>(slots, c->d_rslot_off, rstate, rpos);
+    }
     // 45 dependent stages (LLICTI_nets.py:440-498): CNN of band b needs bands < b of this level, Co needs Y, Cg needs Y, Co
     for (int lvl = LLICTI_NLEVELS - 1; lvl >= 0; --lvl) {
         Geom g = make_geom(B, H, W, lvl);
@@ -1208,7 +1427,10 @@ extern "C" int llicti_decode_images(llicti_ctx *c, const uint8_t *d_in, size_t i
             if (int rc = launch_band_params(c, fplanes, g, band, params, s)) return rc;
             StageGeom sg = make_stage(g, band);
             const long nc = (long)sg.hc * sg.wc;
-            for (int clr = 0; clr < 3; ++clr) {
+            for (int clr = 0; clr < 3 && M > 0; ++clr)
+                rans_decode_stage_kernel<<<B * M, 64, 0, s>>>(params, sg, clr, M, slots, c->d_rslot_off, p.rslot_cap, rstate, rpos,
+                                                              planes, fplanes, mm);
+            for (int clr = 0; clr < 3 && M == 0; ++clr) {
                 const int row_stride = (clr == 0) ? 264 : 512;      // Y: Lp = 257; Co/Cg: Lp <= 512
                 if (int rc = launch_cdf_table(planes, params, mm, g, band, clr, tables, row_stride, s)) return rc;
                 const int st = stage_index(lvl, band, clr);
@@ -1247,7 +1469,8 @@ extern "C" int llicti_check_status(llicti_ctx *c, void *stream)
 extern "C" int llicti_header_dims(const uint8_t *h, int *H, int *W)
 {
     if (!h || !H || !W) return fail(LLICTI_EINVAL, "header_dims: null pointer");
-    if (h[0] != LLICTI_NLEVELS) return fail(LLICTI_EFORMAT, "header: %d scales, expected %d", h[0], LLICTI_NLEVELS);
+    if (h[0] != LLICTI_NLEVELS && (h[0] & 0x8F) != (0x80 | LLICTI_NLEVELS))
+        return fail(LLICTI_EFORMAT, "header: byte 0 = 0x%02x is neither %d scales (AC container) nor a rANS container tag", h[0], LLICTI_NLEVELS);
     int Hc = h[1], Wc = h[2];
     int pad = (int)(int16_t)(h[15] | (h[16] << 8));
     for (int l = LLICTI_NLEVELS - 1; l >= 0; --l) {     // _get_padHW_lev_list, LLICTI_nets.py:533-542

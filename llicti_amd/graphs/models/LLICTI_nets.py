@@ -19,7 +19,8 @@ import numpy as np
 import torch
 from torch import nn
 
-from ...codec import HipCodec, bytestream_list_to_container, container_to_bytestream_list, header_dims
+from ...codec import (MODE_AC, MODE_RANS, HipCodec, bytestream_list_to_container, container_to_bytestream_list,
+                      header_dims, mode_of_header)
 from ...config import check_supported
 
 
@@ -101,6 +102,10 @@ class LLICTI(nn.Module):
         self.entropymodel = LLICTIEntropyLayer(config)
         self._codec = None
         self._weights_version = None
+        # container written by compress(): the reference's (torchac-compatible) one unless the config asks
+        # for the throughput container, e.g. config.container = "rans8"
+        cont = config["container"] if "container" in config else "ac"
+        self.mode = MODE_AC if cont == "ac" else MODE_RANS(int(cont[4:] or 8))
 
     # ------------------------------------------------------------------ plumbing
     def _weights_key(self):
@@ -145,7 +150,7 @@ class LLICTI(nn.Module):
     def compress_batch(self, x):
         codec = self.codec(x.device if x.is_cuda else None)
         rgb = self._to_u8(x).to(codec.device).contiguous()
-        cont, seg = codec.encode(rgb)
+        cont, seg = codec.encode(rgb, mode=self.mode)
         _, fplanes, _ = codec.lift(rgb)               # x_ycocg = (YCoCg - [127,0,0]) / 255 (LLICTI_nets.py:143-144)
         codec.check()
         cont_h, seg_h = cont.cpu().numpy(), seg.cpu().numpy()
@@ -167,16 +172,16 @@ class LLICTI(nn.Module):
             hdr = bytes(bl[0][0]) + bytes(bl[0][1]) + bytes(bl[0][2])
             if len(bl[0][0]) != 3 or len(bl[0][1]) != 12 or len(bl[0][2]) != 2:
                 raise ValueError("malformed header streams")
-            assert hdr[0] == self.num_scales            # LLICTI_nets.py:424
-            d = header_dims(hdr)
+            mode = mode_of_header(hdr[0])               # AC container: hdr[0] == num_scales (LLICTI_nets.py:424)
+            d = header_dims(hdr) + (mode,)
             if dims is None:
                 dims = d
             elif d != dims:
-                raise ValueError("all images of one decompres_batch call must have the same size")
+                raise ValueError("all images of one decompres_batch call must have the same size and container")
             b, s = bytestream_list_to_container(bl)
             bufs.append(b)
             segs.append(s)
-        H, W = dims
+        H, W, mode = dims
         stride = codec.max_container_bytes(H, W)
         cont = np.zeros((len(lists), stride), np.uint8)
         for i, b in enumerate(bufs):
@@ -185,6 +190,6 @@ class LLICTI(nn.Module):
             cont[i, :b.size] = b
         cont_d = torch.from_numpy(cont).to(codec.device)
         seg_d = torch.from_numpy(np.stack(segs)).to(codec.device)
-        rgb = codec.decode(cont_d, seg_d, H, W)
+        rgb = codec.decode(cont_d, seg_d, H, W, mode=mode)
         codec.check()
         return rgb.to(torch.float32) / 255           # LLICTI_nets.py:87

@@ -573,7 +573,7 @@ long orc_encode_image(const uint8_t *rgb, int H, int W, const orc_weights *wts, 
 void orc_header_dims(const uint8_t *in, const int32_t seg_len[49], int *H_out, int *W_out)
 {
     (void)seg_len;
-    int h4 = in[1], w4 = in[2];
+    int h4 = in[1], w4 = in[2];   /* byte 0: number of scales (AC container) or 0x80|lgM<<4|5 (rANS container) */
     int16_t padi16;
     memcpy(&padi16, in + 15, 2);
     int padint = padi16;
@@ -680,5 +680,198 @@ int orc_decode_image(const uint8_t *in, const int32_t seg_len[49], const orc_wei
     }
     orc_unlift(planes, H, W, rgb);
     free(planes);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ rANS container (new format, see header) */
+typedef struct { long n; uint32_t *clow, *chigh; } stage_syms_t;
+
+long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *wts, int M,
+                           uint8_t *out, long cap, int32_t seg_len[49])
+{
+    if (H < 32 || W < 32 || H > 8160 || W > 8160) return -2;
+    int lgM = 0;
+    while ((1 << lgM) < M) ++lgM;
+    if ((1 << lgM) != M || M > 32) return -2;
+    const long plane_sz = (long)H * W;
+    int16_t *planes = (int16_t *)malloc(sizeof(int16_t) * 3 * plane_sz);
+    int16_t minmax[6];
+    orc_lift(rgb, H, W, planes, minmax);
+    int Hl, Wl, h, w, padH, padW;
+    long pos = 0;
+    orc_level_geom(H, W, 4, &Hl, &Wl, &h, &w, &padH, &padW);
+    const int h4 = h, w4 = w;
+    if (cap < 17 + 3L * h4 * w4) { free(planes); return -1; }
+    for (int i = 0; i < 49; ++i) seg_len[i] = 0;
+    out[pos++] = (uint8_t)(0x80 | (lgM << 4) | ORC_NLEV); out[pos++] = (uint8_t)h4; out[pos++] = (uint8_t)w4;
+    seg_len[0] = 3;
+    memcpy(out + pos, minmax, 12); pos += 12; seg_len[1] = 12;
+    int padint = 0;
+    for (int l = 0; l < ORC_NLEV; ++l) {
+        orc_level_geom(H, W, l, &Hl, &Wl, &h, &w, &padH, &padW);
+        padint = 4 * padint + 2 * padH + padW;
+    }
+    int16_t padi16 = (int16_t)padint;
+    memcpy(out + pos, &padi16, 2); pos += 2; seg_len[2] = 2;
+    for (int c = 0; c < 3; ++c)
+        for (int i = 0; i < h4; ++i)
+            for (int j = 0; j < w4; ++j) out[pos++] = rgb[c * plane_sz + (long)(32 * i) * W + 32 * j];
+    seg_len[3] = 3 * h4 * w4;
+
+    /* all 45 stages' (c_low, c_high), in decode order */
+    stage_syms_t st[ORC_NSTREAM];
+    int si = 0;
+    long total = 0;
+    for (int lvl = ORC_NLEV - 1; lvl >= 0; --lvl) {
+        orc_level_geom(H, W, lvl, &Hl, &Wl, &h, &w, &padH, &padW);
+        float *params = (float *)malloc(sizeof(float) * (long)h * w * ORC_NPAR);
+        int16_t *sym = (int16_t *)malloc(sizeof(int16_t) * (long)h * w);
+        for (int band = 0; band < 3; ++band) {
+            orc_band_params(planes, H, W, lvl, band, &wts->band[band], params);
+            for (int clr = 0; clr < 3; ++clr) {
+                st[si].clow = (uint32_t *)malloc(sizeof(uint32_t) * (long)h * w);
+                st[si].chigh = (uint32_t *)malloc(sizeof(uint32_t) * (long)h * w);
+                st[si].n = orc_stream_pairs(planes, H, W, minmax, lvl, band, clr, params, st[si].clow, st[si].chigh, sym);
+                total += st[si].n;
+                ++si;
+            }
+        }
+        free(params); free(sym);
+    }
+    free(planes);
+    long rc = 0;
+    uint16_t *wbuf = (uint16_t *)malloc(sizeof(uint16_t) * (total + 64));
+    for (int m = 0; m < M && rc >= 0; ++m) {
+        uint32_t x[64];
+        for (int l = 0; l < 64; ++l) x[l] = 1u << 16;
+        long p = total + 64;                     /* words are written backwards from the end */
+        for (int s = ORC_NSTREAM - 1; s >= 0; --s) {
+            const long nchunks = (st[s].n + 63) / 64;
+            if (nchunks <= m) continue;
+            const long K = (nchunks - m + M - 1) / M;
+            for (long k = K - 1; k >= 0; --k) {
+                const long c = m + k * M;
+                for (int l = 63; l >= 0; --l) {  /* highest lane first: the decoder reads lane-ascending */
+                    const long n = 64 * c + l;
+                    if (n >= st[s].n) continue;
+                    const uint32_t lo = st[s].clow[n], freq = st[s].chigh[n] - lo;
+                    if (freq == 0) { rc = -5; break; }
+                    if ((uint64_t)x[l] >= ((uint64_t)freq << 16)) { wbuf[--p] = (uint16_t)(x[l] & 0xFFFF); x[l] >>= 16; }
+                }
+                for (int l = 0; l < 64; ++l) {
+                    const long n = 64 * c + l;
+                    if (n >= st[s].n) continue;
+                    const uint32_t lo = st[s].clow[n], freq = st[s].chigh[n] - lo;
+                    if (freq == 0) break;
+                    x[l] = ((x[l] / freq) << 16) + (x[l] % freq) + lo;
+                }
+            }
+        }
+        const long nwords = total + 64 - p;
+        const long bytes = 256 + 2 * nwords;
+        if (pos + bytes > cap) { rc = -1; break; }
+        for (int l = 0; l < 64; ++l) { memcpy(out + pos, &x[l], 4); pos += 4; }
+        memcpy(out + pos, wbuf + p, 2 * nwords); pos += 2 * nwords;
+        seg_len[4 + m] = (int32_t)bytes;
+    }
+    free(wbuf);
+    for (int s = 0; s < ORC_NSTREAM; ++s) { free(st[s].clow); free(st[s].chigh); }
+    return rc < 0 ? rc : pos;
+}
+
+int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const orc_weights *wts,
+                          uint8_t *rgb, long rgb_cap, int *H_out, int *W_out)
+{
+    if (seg_len[0] != 3 || seg_len[1] != 12 || seg_len[2] != 2) return -3;
+    if ((in[0] & 0x8F) != (0x80 | ORC_NLEV)) return -4;
+    const int M = 1 << ((in[0] >> 4) & 7);
+    int H, W;
+    orc_header_dims(in, seg_len, &H, &W);
+    *H_out = H; *W_out = W;
+    const long plane_sz = (long)H * W;
+    if (rgb_cap < 3 * plane_sz) return -1;
+    int16_t minmax[6];
+    memcpy(minmax, in + 3, 12);
+    const int h4 = in[1], w4 = in[2];
+    if (seg_len[3] != 3 * h4 * w4) return -3;
+    int16_t *planes = (int16_t *)calloc(3 * plane_sz, sizeof(int16_t));
+    const uint8_t *dc = in + 17;
+    for (int i = 0; i < h4; ++i)
+        for (int j = 0; j < w4; ++j) {
+            int R = dc[i * w4 + j], G = dc[h4 * w4 + i * w4 + j], B = dc[2 * h4 * w4 + i * w4 + j];
+            int Co = R - B, t = B + fdiv2(Co), Cg = G - t, Y = t + fdiv2(Cg);
+            long off = (long)(32 * i) * W + 32 * j;
+            planes[off] = (int16_t)(Y - 127);
+            planes[plane_sz + off] = (int16_t)Co;
+            planes[2 * plane_sz + off] = (int16_t)Cg;
+        }
+    /* stream states and word cursors */
+    uint32_t (*x)[64] = (uint32_t (*)[64])malloc(sizeof(uint32_t) * 64 * M);
+    const uint8_t **words = (const uint8_t **)malloc(sizeof(uint8_t *) * M);
+    long *wpos = (long *)calloc(M, sizeof(long)), *wcnt = (long *)calloc(M, sizeof(long));
+    long pos = 17 + seg_len[3];
+    for (int m = 0; m < M; ++m) {
+        if (seg_len[4 + m] < 256) { free(planes); free(x); free(words); free(wpos); free(wcnt); return -3; }
+        for (int l = 0; l < 64; ++l) memcpy(&x[m][l], in + pos + 4 * l, 4);
+        words[m] = in + pos + 256;
+        wcnt[m] = (seg_len[4 + m] - 256) / 2;
+        pos += seg_len[4 + m];
+    }
+    int Hl, Wl, h, w, padH, padW;
+    for (int lvl = ORC_NLEV - 1; lvl >= 0; --lvl) {
+        orc_level_geom(H, W, lvl, &Hl, &Wl, &h, &w, &padH, &padW);
+        float *params = (float *)malloc(sizeof(float) * (long)h * w * ORC_NPAR);
+        for (int band = 0; band < 3; ++band) {
+            orc_band_params(planes, H, W, lvl, band, &wts->band[band], params);
+            const int src = band + 1;
+            int hc, wc;
+            stream_dims(h, w, padH, padW, band, &hc, &wc);
+            const long n_sym = (long)hc * wc;
+            const long nchunks = (n_sym + 63) / 64;
+            for (int clr = 0; clr < 3; ++clr) {
+                const int minv = (clr == 0) ? -127 : minmax[clr];
+                const int maxv = (clr == 0) ? 128 : minmax[3 + clr];
+                const int shift = (clr == 0) ? 127 : -minmax[clr];
+                const int Lp = maxv - minv + 2;
+                const int max_symbol = Lp - 2;
+                for (long c = 0; c < nchunks; ++c) {
+                    const int m = (int)(c % M);
+                    for (int l = 0; l < 64; ++l) {
+                        const long q = 64 * c + l;
+                        if (q >= n_sym) break;
+                        int i = (int)(q / wc), j = (int)(q % wc);
+                        long off = ((long)(2 * i + BAND_OI[src]) << lvl) * W + ((long)(2 * j + BAND_OJ[src]) << lvl);
+                        mix_t mx;
+                        mix_prepare(params + ((long)i * w + j) * ORC_NPAR, clr, (float)planes[off] / 255.0f,
+                                    (float)planes[plane_sz + off] / 255.0f, &mx);
+                        const uint32_t slot = x[m][l] & 0xFFFF;
+                        /* largest idx in [0, max_symbol] whose entry is <= slot (idx 0 always qualifies) */
+                        int lo = 0, hi = max_symbol + 1;
+                        while (hi - lo > 1) {
+                            int mid = (lo + hi) >> 1;
+                            if (cdf_entry(&mx, mid, Lp, minv, maxv) <= slot) lo = mid; else hi = mid;
+                        }
+                        const uint32_t c_low = cdf_entry(&mx, lo, Lp, minv, maxv);
+                        const uint32_t c_high = (lo == max_symbol) ? 0x10000u : cdf_entry(&mx, lo + 1, Lp, minv, maxv);
+                        x[m][l] = (c_high - c_low) * (x[m][l] >> 16) + slot - c_low;
+                        planes[clr * plane_sz + off] = (int16_t)(lo - shift);
+                    }
+                    for (int l = 0; l < 64; ++l) {       /* renormalise lane-ascending */
+                        const long q = 64 * c + l;
+                        if (q >= n_sym) break;
+                        if (x[m][l] < (1u << 16)) {
+                            uint16_t wv = 0;
+                            if (wpos[m] < wcnt[m]) memcpy(&wv, words[m] + 2 * wpos[m], 2);
+                            wpos[m]++;
+                            x[m][l] = (x[m][l] << 16) | wv;
+                        }
+                    }
+                }
+            }
+        }
+        free(params);
+    }
+    orc_unlift(planes, H, W, rgb);
+    free(planes); free(x); free(words); free(wpos); free(wcnt);
     return 0;
 }

@@ -101,6 +101,18 @@ long orc_stream_pairs(const int16_t *planes, int H, int W, const int16_t minmax[
                       const float *params /* [h*w][60] from orc_band_params */,
                       uint32_t *clow, uint32_t *chigh, int16_t *sym);
 
+/* ---- rANS container ("LLICTI-rANS v1", a NEW format of this build: the reference has only torchac) ----
+ * Same header segments (byte 0 = 0x80 | lg2(M) << 4 | 5), same CDFs, same symbols; the 45 torchac streams
+ * are replaced by M independent 64-way interleaved rANS streams per image (32-bit states, 16-bit words,
+ * 16-bit probabilities).  Stage st (decode order) has nc symbols in cropped raster order; symbol n sits in
+ * chunk n/64, lane n%64; chunk c belongs to stream c % M and is that stream's step c / M of the stage.
+ * A stream = 64 little-endian uint32 final encoder states followed by the 16-bit words in decode order.
+ * seg_len[0..3] header, seg_len[4..4+M-1] streams, rest 0.  Returns total bytes or <0. */
+long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *wts, int M,
+                           uint8_t *out, long cap, int32_t seg_len[49]);
+int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const orc_weights *wts,
+                          uint8_t *rgb, long rgb_cap, int *H_out, int *W_out);
+
 void orc_set_threads(int n);
 
 #ifdef __cplusplus

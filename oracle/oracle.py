@@ -40,6 +40,7 @@ def lib():
         build()
         L = C.CDLL(_SO)
         L.orc_encode_image.restype = C.c_long
+        L.orc_encode_image_rans.restype = C.c_long
         L.orc_ac_encode_tables.restype = C.c_long
         L.orc_ac_encode_pairs.restype = C.c_long
         L.orc_stream_pairs.restype = C.c_long
@@ -192,6 +193,30 @@ def _list_to_segments(bl):
         segs += list(bl[s])
     seg_len = np.array([len(s) for s in segs], dtype=np.int32)
     return np.frombuffer(b"".join(segs), dtype=np.uint8).copy(), seg_len
+
+
+def encode_image_rans(rgb, weights: "Weights", M=8):
+    """uint8 [3,H,W] -> bytestream_list holding the rANS container (M streams in the first M stream slots)."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    _, H, W = rgb.shape
+    cap = 8 * H * W + 4096 + 512 * M
+    out = np.empty(cap, np.uint8)
+    seg = np.zeros(49, np.int32)
+    n = lib().orc_encode_image_rans(_p(rgb), H, W, C.byref(weights.c), int(M), _p(out), C.c_long(cap), _p(seg))
+    if n < 0:
+        raise RuntimeError(f"orc_encode_image_rans failed: {n}")
+    return _segments_to_list(out[:n], seg)
+
+
+def decode_image_rans(bl, weights: "Weights"):
+    buf, seg = _list_to_segments(bl)
+    H, W = C.c_int(), C.c_int()
+    lib().orc_header_dims(_p(buf), _p(seg), C.byref(H), C.byref(W))
+    rgb = np.empty((3, H.value, W.value), np.uint8)
+    rc = lib().orc_decode_image_rans(_p(buf), _p(seg), C.byref(weights.c), _p(rgb), C.c_long(rgb.size), C.byref(H), C.byref(W))
+    if rc != 0:
+        raise RuntimeError(f"orc_decode_image_rans failed: {rc}")
+    return rgb
 
 
 def encode_image(rgb, weights: Weights, full_tables=False):

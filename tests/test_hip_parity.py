@@ -211,6 +211,51 @@ def test_golden_headers_and_pixels(torch_mod, codecs, golden_index, case):
     assert coded_bits - bits_ref > -0.001 * H * W - 16
 
 
+@pytest.mark.parametrize("kind,H,W,wname,M", [("smooth", 67, 93, "trainedlike", 1), ("noise", 64, 48, "rand1337", 4),
+                                              ("smooth", 100, 131, "trainedlike", 8), ("noise", 33, 250, "trainedlike", 16),
+                                              ("smooth", 256, 256, "trainedlike", 32)])
+def test_rans_container_bitexact(torch_mod, codecs, oracle_weights, kind, H, W, wname, M):
+    """The throughput container: HIP bytes == oracle bytes, both decoders invert it, and it costs about
+    190 bytes per stream over the AC container (same CDFs, same symbols)."""
+    from oracle import oracle as orc
+    from llicti_amd.codec import MODE_RANS, container_to_bytestream_list
+    torch = torch_mod
+    c = codecs(wname)
+    W_o = oracle_weights(wname)
+    rgb = make_batch(kind, 2, H, W, seed0=70)
+    cont, seg = c.encode(_dev(torch, rgb), mode=MODE_RANS(M))
+    c.check()
+    cont_h, seg_h = cont.cpu().numpy(), seg.cpu().numpy()
+    for b in range(2):
+        bl = container_to_bytestream_list(cont_h[b], seg_h[b])
+        ref = orc.encode_image_rans(rgb[b], W_o, M)
+        assert bl == ref
+        assert np.array_equal(orc.decode_image_rans(bl, W_o), rgb[b])
+        n_ac = sum(len(x) for row in orc.encode_image(rgb[b], W_o) for x in row)
+        n_rans = sum(len(x) for row in bl for x in row)
+        assert -64 <= n_rans - n_ac <= 260 * M + 64
+    rec = c.decode(cont, seg, H, W, mode=MODE_RANS(M))
+    c.check()
+    assert np.array_equal(rec.cpu().numpy(), rgb)
+
+
+def test_rans_kodak_batch_roundtrip(torch_mod, codecs):
+    from llicti_amd.codec import MODE_RANS
+    torch = torch_mod
+    c = codecs("rand1337")
+    rgb = make_batch("noise", 3, 512, 768, seed0=80)
+    for M in (8, 16):
+        cont, seg = c.encode(_dev(torch, rgb), mode=MODE_RANS(M))
+        rec = c.decode(cont, seg, 512, 768, mode=MODE_RANS(M))
+        c.check()
+        assert np.array_equal(rec.cpu().numpy(), rgb)
+    # a container is only accepted in the mode its header names
+    from llicti_amd._lib import LlictiError
+    c.decode(cont, seg, 512, 768, mode=MODE_RANS(8))
+    with pytest.raises(LlictiError):
+        c.check()
+
+
 def test_kodak_shape_properties(torch_mod, codecs):
     """BASELINE.json full size (768x512): round trip, batch independence, idempotence."""
     torch = torch_mod
@@ -283,6 +328,13 @@ def test_reference_api_roundtrip(torch_mod):
     assert np.array_equal((x_reco * 255).round().to(torch.uint8).cpu().numpy()[0], rgb)   # and exact as integers
     W_o = orc.Weights(pack_state_dict(model.state_dict()))
     assert orc.encode_image(rgb, W_o) == bl
+    # the throughput container through the same API
+    m2 = LLICTI(default_config(container="rans4")).to("cuda:0").eval()
+    m2.load_state_dict(model.state_dict())
+    bl2, _ = m2.compress(x)
+    assert bl2 == orc.encode_image_rans(rgb, W_o, 4)
+    x2 = model.decompres(bl2, torch.device("cuda:0"))          # any model instance decodes either container
+    assert np.array_equal((x2 * 255).round().to(torch.uint8).cpu().numpy()[0], rgb)
 
 
 def test_agent_eval_model(torch_mod, caplog):

@@ -65,8 +65,11 @@ def test_workspace_and_container_bounds():
     n1 = L.llicti_workspace_bytes(1, 512, 768, 0)
     n24 = L.llicti_workspace_bytes(24, 512, 768, 0)
     assert 0 < n1 < n24 < 8 * 2 ** 30
-    # worst case of a 16-bit-precision coder: 2 bytes per symbol + termination, 1,178,496 symbols
-    assert 2 * 1178496 < L.llicti_max_container_bytes(512, 768) < 2 * 1178496 + 4096
+    # worst case of a 16-bit-precision coder: 2 bytes per symbol + termination / stream flush, 1,178,496 symbols
+    assert 2 * 1178496 < L.llicti_max_container_bytes(512, 768) < 2 * 1178496 + 256 * 1024
+    assert L.llicti_workspace_bytes(1, 512, 768, 0x100 | 8) > 0
+    assert L.llicti_workspace_bytes(1, 512, 768, 0x100 | 3) == 0     # M must be a power of two <= 32
+    assert L.llicti_workspace_bytes(1, 512, 768, 7) == 0
 
 
 def test_weight_packing_and_state_dict_names():

@@ -130,3 +130,17 @@ def test_full_tables_equals_lazy(golden_index, oracle_weights):
     b = orc.encode_image(c["rgb"], W, full_tables=True)
     assert a == b
     assert np.array_equal(orc.decode_image(a, W, full_tables=True), c["rgb"])
+
+
+@pytest.mark.parametrize("M", [1, 4, 32])
+def test_rans_container_oracle_roundtrip(M, oracle_weights):
+    """The build's throughput container (no reference counterpart): lossless, header tag, size overhead."""
+    c = load_case("smooth_67x93_tl")
+    W = oracle_weights("trainedlike")
+    bl = orc.encode_image_rans(c["rgb"], W, M)
+    assert bl[0][0][0] == (0x80 | ({1: 0, 4: 2, 32: 5}[M] << 4) | 5)
+    assert bl[0][1] == c["hdr_minmax"].tobytes() and bl[0][3] == c["hdr_dc"].tobytes()
+    assert np.array_equal(orc.decode_image_rans(bl, W), c["rgb"])
+    n_ac = sum(len(x) for row in orc.encode_image(c["rgb"], W) for x in row)
+    n_r = sum(len(x) for row in bl for x in row)
+    assert -64 <= n_r - n_ac <= 260 * M + 64
