@@ -24,7 +24,8 @@
  *                                 strided views of these planes: band (oi,oj) of level l, pixel (i,j)
  *                                 is planes[.., (2i+oi)<<l, (2j+oj)<<l]  (lazyDWT, LLICTI_nets.py:218-225)
  *   fplanes float  [B][3][H][W]   planes / 255 (one IEEE division, LLICTI_nets.py:143-144)
- *   params  float  [B][h*w][60]   raw CNN outputs on the band grid of one (level, band)
+ *   params  float  [B][h*w][64]   raw CNN outputs on the band grid of one (level, band): 4 heads x 16
+ *                                 (15 used), reference channel o at (o/15)*16 + o%15
  *   tables  uint16 [B][hc*wc][stride]  integer CDF rows of one stream (stride = Lp rounded up to 8)
  */
 #ifndef LLICTI_HIP_H
@@ -47,7 +48,8 @@ extern "C" {
 #define LLICTI_NLEVELS   5
 #define LLICTI_NSTREAMS 45      /* 5 levels x 3 bands x 3 colour channels per image */
 #define LLICTI_NSEG     49      /* 4 header segments + 45 streams (the reference's bytestream_list) */
-#define LLICTI_NPARAMS  60
+#define LLICTI_NPARAMS  60      /* mixture parameters per position: 15 sigma | 15 mu | 15 weight | 5 a | 5 b | 5 d */
+#define LLICTI_PARAM_STRIDE 64  /* floats per position in HBM: 4 heads x 16 (15 used): reference channel o at (o/15)*16 + o%15 */
 
 typedef struct llicti_ctx llicti_ctx;
 
@@ -83,7 +85,7 @@ int llicti_lift_u8(llicti_ctx *ctx, const uint8_t *d_rgb, int B, int H, int W,
 int llicti_unlift_u8(llicti_ctx *ctx, const int16_t *d_planes, int B, int H, int W, uint8_t *d_rgb, void *stream);
 
 /* K4+K5: interpolator CNN of one (level, band) for every position of the h x w band grid of every
- * image -> d_params [B][h*w][60].  fp32 MFMA, k-ordered accumulation (bit-exact to the numerics spec).
+ * image -> d_params [B][h*w][64] (LLICTI_PARAM_STRIDE).  fp32 MFMA, k-ordered accumulation (bit-exact to the numerics spec).
  * Replaces LLICTIEntropyModel4.get_params (LLICTI_nets.py:721-753, :822-825). */
 int llicti_band_params_f32(llicti_ctx *ctx, const float *d_fplanes, int B, int H, int W, int lvl, int band,
                            float *d_params, void *stream);

@@ -104,9 +104,14 @@ class HipCodec:
     def band_params(self, fplanes, lvl, band):
         B, _, H, W = fplanes.shape
         _, _, h, w, _, _, _, _ = _lib.level_geom(H, W, lvl, band)
-        out = torch.empty((B, h * w, 60), dtype=torch.float32, device=self.device)
+        out = torch.empty((B, h * w, 64), dtype=torch.float32, device=self.device)
         _lib.check(self.L.llicti_band_params_f32(self.ctx, _ptr(fplanes), B, H, W, lvl, band, _ptr(out), _stream_ptr(self.device)))
-        return out.view(B, h, w, 60)
+        return out.view(B, h, w, 64)           # 4 heads x 16 (15 used); params60() gives the reference's 60 channels
+
+    @staticmethod
+    def params60(p64):
+        """[.., 64] device layout -> [.., 60] in the reference's channel order (LLICTI_nets.py:381-387)."""
+        return p64.reshape(*p64.shape[:-1], 4, 16)[..., :15].reshape(*p64.shape[:-1], 60)
 
     def cdf_tables(self, planes, params, mm, lvl, band, clr, row_stride=512):
         B, _, H, W = planes.shape

@@ -18,6 +18,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../../include/llicti_hip.h"
@@ -149,37 +151,59 @@ __global__ __launch_bounds__(256) void unlift_kernel(const int16_t *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------------ band CNN
-// Layer-0 taps of band b: k -> (src, ci, dy, dx), k ordered conv by conv (sources x00, x11, x01), each
-// conv flattened (ci, ky, kx) row-major: the K order of the canonical packed w0 (llicti_amd/weights.py).
-// kernel sizes / pads: LLICTI_nets.py:651-675.  packed: src | ci<<2 | (dy+2)<<4 | (dx+2)<<8
+// Layer-0 convolutions of band b (LLICTI_nets.py:651-675): source sub-band, kernel size, top / left pad.
 struct ConvDef { int src, kh, kw, pt, pl; };
-static const ConvDef kConvs[3][3] = {
+constexpr ConvDef kConvs[3][3] = {
     { { 0, 4, 4, 1, 1 }, { -1, 0, 0, 0, 0 }, { -1, 0, 0, 0, 0 } },
     { { 0, 3, 4, 1, 1 }, { 1, 4, 3, 2, 1 }, { -1, 0, 0, 0, 0 } },
     { { 0, 4, 3, 1, 1 }, { 1, 3, 4, 1, 2 }, { 2, 4, 4, 1, 2 } },
 };
-__device__ __constant__ int c_taps[3][120];
-static int build_taps_host(int band, int *taps)
-{
-    int k = 0;
-    for (int c = 0; c < 3; ++c) {
-        const ConvDef &cv = kConvs[band][c];
-        if (cv.src < 0) break;
-        for (int ci = 0; ci < 3; ++ci)
-            for (int ky = 0; ky < cv.kh; ++ky)
-                for (int kx = 0; kx < cv.kw; ++kx)
-                    taps[k++] = cv.src | (ci << 2) | ((ky - cv.pt + 2) << 4) | ((kx - cv.pl + 2) << 8);
-    }
-    return k;
-}
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kHead = 88;          // channels per head (configs/llicti_A.json chs[0])
 constexpr int kMT = 6;             // 16-row MFMA tiles per head (88 -> 96, rows >= 88 are zero)
 constexpr int kKS1 = 22;           // k-steps of the 88-deep layers (88 / 4)
-constexpr int kNT = 2;             // pixel tiles (16 positions each) per wavefront work unit
+constexpr int kNT = 4;             // pixel tiles (16 positions each) per wavefront
 constexpr int kCnnThreads = 512;   // 8 wavefronts: 2 per SIMD
+constexpr int kTileH = 16;         // band-grid positions per workgroup tile: 16 rows x 32 columns,
+constexpr int kTileW = 32;         //   wave w owns rows 2w, 2w+1 (two 16-column pixel tiles each)
+constexpr int kInRows = kTileH + 4;    // taps reach rows i-2 .. i+2 and columns j-2 .. j+2
+constexpr int kInCols = kTileW + 4;
+constexpr int kInPitch = 48;       // = 16 (mod 32): B-fragment reads that stride by one row stay bank-conflict free
+constexpr int kInPlane = kInRows * kInPitch;
+constexpr int kParamStride = LLICTI_PARAM_STRIDE;
+
+// One MFMA k-step consumes 4 consecutive k of the canonical K order (llicti_amd/weights.py): the kernel's
+// length-4 axis.  Lane (q = lane>>4, px = lane&15) therefore reads the staged input tile at
+// U + q*S + pixel offset with U, S compile-time constants of the k-step.
+struct KStep { int U, S; };
+struct KTab { KStep s[30]; int n; };
+constexpr KTab make_ktab(int band)
+{
+    KTab t{};
+    int k = 0;
+    for (int c = 0; c < 3; ++c) {
+        const ConvDef cv = kConvs[band][c];
+        if (cv.src < 0) break;
+        for (int ci = 0; ci < 3; ++ci) {
+            const int plane = (cv.src * 3 + ci) * kInPlane;
+            if (cv.kw == 4) {
+                for (int ky = 0; ky < cv.kh; ++ky) { t.s[k].U = plane + (ky - cv.pt + 2) * kInPitch + (2 - cv.pl); t.s[k].S = 1; ++k; }
+            } else {
+                for (int kx = 0; kx < cv.kw; ++kx) { t.s[k].U = plane + (2 - cv.pt) * kInPitch + (kx - cv.pl + 2); t.s[k].S = kInPitch; ++k; }
+            }
+        }
+    }
+    t.n = k;
+    return t;
+}
+template <int BAND> inline constexpr KTab kKTab = make_ktab(BAND);
+
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // Per (band, head) weight pack, in MFMA-fragment order so that the LDS image is lane-linear:
 //   bias0 [6][4][4]            acc init of tile T, lane group q, reg r  = b0[16T + 4r + q]
@@ -203,18 +227,28 @@ struct PackOff {
     static constexpr int w2 = bias2 + 16;
     static constexpr int total = w2 + kKS1 * 64;
 };
+static constexpr int cnn_lds_bytes(int band)
+{
+    const int K0 = band == 0 ? 48 : band == 1 ? 72 : 120;
+    return (pack_floats(K0) + 3 * (band + 1) * kInPlane) * 4;
+}
 
 __device__ __forceinline__ float relu(float x) { return (x > 0.0f) ? x : 0.0f; }
+__device__ __forceinline__ f32x4 relu4(f32x4 v) { v[0] = relu(v[0]); v[1] = relu(v[1]); v[2] = relu(v[2]); v[3] = relu(v[3]); return v; }
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 template <int BAND>
 __global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *__restrict__ fplanes, Geom g,
                                                                   const float *__restrict__ wpack,
-                                                                  float *__restrict__ params, long total_pos)
+                                                                  float *__restrict__ params, int tiles_x, int tiles_y, int n_tiles)
 {
     constexpr int K0 = (BAND == 0) ? 48 : (BAND == 1) ? 72 : 120;
     constexpr int NK0 = K0 / 4;
+    constexpr int NPL = 3 * (BAND + 1);          // staged input planes: (x00 | x11 | x01) x (Y, Co, Cg)
     using PO = PackOff<K0>;
+    static_assert(kKTab<BAND>.n == NK0, "k-step table");
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *lds_in = lds + PO::total;
 
     const int head = blockIdx.y;
     {   // stage this head's pack (lane-linear image: a straight copy)
@@ -222,36 +256,37 @@ __global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *_
         float4 *dst = reinterpret_cast<float4 *>(lds);
         for (int i = threadIdx.x; i < PO::total / 4; i += kCnnThreads) dst[i] = src[i];
     }
-    __syncthreads();
-
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int q = lane >> 4;
     const int px = lane & 15;
-    constexpr int kWaves = kCnnThreads / 64;
+    const int q_row = q * kInPitch;
+    const int pix0 = (2 * wave) * kInPitch + px;      // + (n>>1)*pitch + 16*(n&1) for pixel tile n
 
-    const int *my_taps = c_taps[BAND] + q;     // this lane's taps: k = 4t + q
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int img = tile / (tiles_x * tiles_y);
+        const int trem = tile - img * (tiles_x * tiles_y);
+        const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+        const int i0 = ty * kTileH, j0 = tx * kTileW;
+        const float *base = fplanes + (long)img * 3 * g.plane;
 
-    const long hw = (long)g.h * g.w;
-    const long n_units = (total_pos + 16 * kNT - 1) / (16 * kNT);
-    for (long unit = (long)blockIdx.x * kWaves + wave; unit < n_units; unit += (long)gridDim.x * kWaves) {
-        // positions of this lane's pixel column in each tile
-        long gp[kNT];
-        int pi[kNT], pj[kNT];
-        const float *base[kNT];
-#pragma unroll
-        for (int n = 0; n < kNT; ++n) {
-            long p = (unit * kNT + n) * 16 + px;
-            gp[n] = p;
-            if (p > total_pos - 1) p = total_pos - 1;
-            const long img = p / hw;
-            const int rem = (int)(p - img * hw);
-            pi[n] = rem / g.w;
-            pj[n] = rem - pi[n] * g.w;
-            base[n] = fplanes + img * 3 * g.plane;
+        __syncthreads();                               // previous tile's fragment reads (and the pack copy) are done
+        for (int e = threadIdx.x; e < NPL * kInRows * kInCols; e += kCnnThreads) {
+            const int pl = e / (kInRows * kInCols);
+            const int rc = e - pl * (kInRows * kInCols);
+            const int r = rc / kInCols, cidx = rc - r * kInCols;
+            const int src = pl / 3, ci = pl - 3 * src;
+            int bi = i0 + r - 2, bj = j0 + cidx - 2;
+            bi = max(0, min(bi, g.h - 1));             // the conv's replicate padding, in band coordinates
+            bj = max(0, min(bj, g.w - 1));
+            int rr = 2 * bi + c_oi[src], cc = 2 * bj + c_oj[src];
+            if (rr >= g.Hl) rr -= 2;                   // lazyDWT's replicate pad of the odd edge (LLICTI_nets.py:226-240)
+            if (cc >= g.Wl) cc -= 2;
+            lds_in[pl * kInPlane + r * kInPitch + cidx] = base[ci * g.plane + ((long)rr << g.lvl) * g.W + ((long)cc << g.lvl)];
         }
+        __syncthreads();
 
-        // ---- layer 0: [96 x K0] x [K0 x 16] per pixel tile, bias preloaded into the accumulators
+        // ---- layer 0: [96 x K0] x [K0 x 64 pixels]; bias preloaded into the accumulators
         f32x4 a0[kMT][kNT];
 #pragma unroll
         for (int T = 0; T < kMT; ++T) {
@@ -259,87 +294,68 @@ __global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *_
 #pragma unroll
             for (int n = 0; n < kNT; ++n) a0[T][n] = bv;
         }
+        static_for<NK0>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int U = kKTab<BAND>.s[t].U, S = kKTab<BAND>.s[t].S;
+            const float *bp = lds_in + U + pix0 + (S == 1 ? q : q_row);
+            float bf[kNT];
 #pragma unroll
-        for (int t = 0; t < NK0; ++t) {
-            int tp = my_taps[4 * t];
-            asm volatile("" : "+v"(tp));      // keep the decoded tap fields from being hoisted out of the unit loop (VGPRs)
-            const int src = tp & 3, ci = (tp >> 2) & 3, dy = ((tp >> 4) & 15) - 2, dx = ((tp >> 8) & 15) - 2;
-            float bfrag[kNT];
-#pragma unroll
-            for (int n = 0; n < kNT; ++n) {
-                int ii = pi[n] + dy, jj = pj[n] + dx;
-                ii = max(0, min(ii, g.h - 1));
-                jj = max(0, min(jj, g.w - 1));
-                int r = 2 * ii + c_oi[src], c = 2 * jj + c_oj[src];
-                if (r >= g.Hl) r -= 2;      // replicate pad of the odd edge (LLICTI_nets.py:226-240)
-                if (c >= g.Wl) c -= 2;
-                bfrag[n] = base[n][ci * g.plane + ((long)r << g.lvl) * g.W + ((long)c << g.lvl)];
-            }
+            for (int n = 0; n < kNT; ++n) bf[n] = bp[(n >> 1) * kInPitch + 16 * (n & 1)];
 #pragma unroll
             for (int T = 0; T < kMT; ++T) {
                 const float a = lds[PO::w0 + (T * NK0 + t) * 64 + lane];
 #pragma unroll
-                for (int n = 0; n < kNT; ++n) a0[T][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfrag[n], a0[T][n], 0, 0, 0);
+                for (int n = 0; n < kNT; ++n) a0[T][n] = MFMA4(a, bf[n], a0[T][n]);
             }
-            __builtin_amdgcn_sched_barrier(0);   // keep the unrolled k-steps from being interleaved wholesale (VGPR pressure)
-        }
+            __builtin_amdgcn_sched_barrier(0);     // one k-step per scheduling region (bounds VGPR pressure)
+        });
 #pragma unroll
         for (int T = 0; T < kMT; ++T)
 #pragma unroll
-            for (int n = 0; n < kNT; ++n)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) a0[T][n][r] = relu(a0[T][n][r]);
+            for (int n = 0; n < kNT; ++n) a0[T][n] = relu4(a0[T][n]);
 
-        // ---- layer 1: the accumulator registers of layer 0 ARE the B fragments (k-step tt = 4T' + r)
-        f32x4 a1[kMT][kNT];
-#pragma unroll
-        for (int T = 0; T < kMT; ++T) {
-            const f32x4 bv = *reinterpret_cast<const f32x4 *>(lds + PO::bias1 + (T * 4 + q) * 4);
-#pragma unroll
-            for (int n = 0; n < kNT; ++n) a1[T][n] = bv;
-        }
-#pragma unroll
-        for (int tt = 0; tt < kKS1; ++tt) {
-#pragma unroll
-            for (int T = 0; T < kMT; ++T) {
-                const float a = lds[PO::w1 + (T * kKS1 + tt) * 64 + lane];
-#pragma unroll
-                for (int n = 0; n < kNT; ++n)
-                    a1[T][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, a0[tt >> 2][n][tt & 3], a1[T][n], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int T = 0; T < kMT; ++T)
-#pragma unroll
-            for (int n = 0; n < kNT; ++n)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) a1[T][n][r] = relu(a1[T][n][r]);
-
-        // ---- layer 2: 15 outputs (+1 zero row) per head
+        // ---- layers 1 and 2, interleaved per 16-channel tile: the accumulator registers of one layer ARE
+        //      the B fragments of the next (k-step tt of the consumer = tile tt>>2, register tt&3)
         f32x4 a2[kNT];
         {
             const f32x4 bv = *reinterpret_cast<const f32x4 *>(lds + PO::bias2 + q * 4);
 #pragma unroll
             for (int n = 0; n < kNT; ++n) a2[n] = bv;
         }
+        static_for<kMT>([&](auto Tc) {
+            constexpr int T = decltype(Tc)::value;
+            f32x4 a1[kNT];
+            {
+                const f32x4 bv = *reinterpret_cast<const f32x4 *>(lds + PO::bias1 + (T * 4 + q) * 4);
 #pragma unroll
-        for (int tt = 0; tt < kKS1; ++tt) {
-            const float a = lds[PO::w2 + tt * 64 + lane];
+                for (int n = 0; n < kNT; ++n) a1[n] = bv;
+            }
+            static_for<kKS1>([&](auto ttc) {
+                constexpr int tt = decltype(ttc)::value;
+                const float a = lds[PO::w1 + (T * kKS1 + tt) * 64 + lane];
 #pragma unroll
-            for (int n = 0; n < kNT; ++n)
-                a2[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, a1[tt >> 2][n][tt & 3], a2[n], 0, 0, 0);
+                for (int n = 0; n < kNT; ++n) a1[n] = MFMA4(a, a0[tt >> 2][n][tt & 3], a1[n]);
+                if constexpr ((tt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            });
+#pragma unroll
+            for (int n = 0; n < kNT; ++n) a1[n] = relu4(a1[n]);
+            static_for<4>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                if constexpr (4 * T + r < kKS1) {
+                    const float a = lds[PO::w2 + (4 * T + r) * 64 + lane];
+#pragma unroll
+                    for (int n = 0; n < kNT; ++n) a2[n] = MFMA4(a, a1[n][r], a2[n]);
+                }
+            });
             __builtin_amdgcn_sched_barrier(0);
-        }
-        // D row 4q + r = output 4q + r of this head
+        });
+
+        // D row 4q + r = output 4q + r of this head; params[pos][head][16]
 #pragma unroll
         for (int n = 0; n < kNT; ++n) {
-            if (gp[n] < total_pos) {
-                float *dst = params + gp[n] * LLICTI_NPARAMS + head * 15 + 4 * q;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (4 * q + r < 15) dst[r] = a2[n][r];
-            }
+            const int i = i0 + 2 * wave + (n >> 1), j = j0 + 16 * (n & 1) + px;
+            if (i < g.h && j < g.w)
+                *reinterpret_cast<f32x4 *>(params + (((long)img * g.h + i) * g.w + j) * kParamStride + head * 16 + 4 * q) = a2[n];
         }
     }
 }
@@ -412,7 +428,7 @@ __global__ __launch_bounds__(256) void cdf_pairs_kernel(const int16_t *__restric
     const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= nc) return;
     const int i = (int)(n / s.wc), j = (int)(n - (long)i * s.wc);
-    const float *par = params + ((long)b * s.h * s.w + (long)i * s.w + j) * LLICTI_NPARAMS;
+    const float *par = params + ((long)b * s.h * s.w + (long)i * s.w + j) * LLICTI_PARAM_STRIDE;
     const long off = (long)b * 3 * s.plane + ((long)(2 * i + s.oi) << s.lvl) * s.W + ((long)(2 * j + s.oj) << s.lvl);
     const int vy = planes[off], vco = planes[off + s.plane], vcg = planes[off + 2 * s.plane];
     const float yv = (float)vy / 255.0f, cov = (float)vco / 255.0f;
@@ -443,7 +459,7 @@ __global__ __launch_bounds__(256) void cdf_table_kernel(const int16_t *__restric
     if (n >= nc) return;
     const int lane = threadIdx.x & 63;
     const int i = (int)(n / s.wc), j = (int)(n - (long)i * s.wc);
-    const float *par = params + ((long)b * s.h * s.w + (long)i * s.w + j) * LLICTI_NPARAMS;
+    const float *par = params + ((long)b * s.h * s.w + (long)i * s.w + j) * LLICTI_PARAM_STRIDE;
     const long off = (long)b * 3 * s.plane + ((long)(2 * i + s.oi) << s.lvl) * s.W + ((long)(2 * j + s.oj) << s.lvl);
     const float yv = (float)planes[off] / 255.0f, cov = (float)planes[off + s.plane] / 255.0f;
     int minv, maxv, shift;
@@ -768,7 +784,7 @@ __global__ __launch_bounds__(64) void rans_decode_stage_kernel(const float *__re
         const bool active = n < nc;
         if (active) {
             const int i = n / sg.wc, j = n - i * sg.wc;
-            const float *par = params + ((long)b * sg.h * sg.w + (long)i * sg.w + j) * LLICTI_NPARAMS;
+            const float *par = params + ((long)b * sg.h * sg.w + (long)i * sg.w + j) * LLICTI_PARAM_STRIDE;
             const long off = img + ((long)(2 * i + sg.oi) << sg.lvl) * sg.W + ((long)(2 * j + sg.oj) << sg.lvl);
             Mix mx;
             mix_prepare(par, clr, fplanes[off], fplanes[off + sg.plane], mx);
@@ -988,7 +1004,7 @@ static void build_plan(Plan &p, int B, int H, int W, int M)
     p.off_planes = take((size_t)B * 3 * plane * sizeof(int16_t));
     p.off_fplanes = take((size_t)B * 3 * plane * sizeof(float));
     Geom g0 = make_geom(B, H, W, 0);
-    p.off_params = take((size_t)B * g0.h * g0.w * LLICTI_NPARAMS * sizeof(float));
+    p.off_params = take((size_t)B * g0.h * g0.w * LLICTI_PARAM_STRIDE * sizeof(float));
     // pairs + slots
     p.desc.assign((size_t)LLICTI_NSTREAMS * B, StreamDesc{});
     p.slot_off.assign((size_t)LLICTI_NSTREAMS * B, 0);
@@ -1090,18 +1106,14 @@ extern "C" int llicti_create(llicti_ctx **out, int device)
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(LLICTI_ENODEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
     llicti_ctx *c = new llicti_ctx();
     c->device = device;
-    int taps[3][120];
-    memset(taps, 0, sizeof taps);
-    for (int b = 0; b < 3; ++b) build_taps_host(b, taps[b]);
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_taps), taps, sizeof taps));
     HIPCHK(hipMalloc(&c->d_status, 64));
     HIPCHK(hipMemset(c->d_status, 0, 64));
     HIPCHK(hipEventCreate(&c->ev_call[0]));
     HIPCHK(hipEventCreate(&c->ev_call[1]));
     // the band CNN stages a whole head (up to 86 KB) in LDS
-    HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, PackOff<48>::total * 4));
-    HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, PackOff<72>::total * 4));
-    HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, PackOff<120>::total * 4));
+    HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(0)));
+    HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(1)));
+    HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(2)));
     *out = c;
     return LLICTI_OK;
 }
@@ -1157,15 +1169,13 @@ static int launch_lift(const uint8_t *d_rgb, int B, int H, int W, int16_t *plane
 static int launch_band_params(llicti_ctx *c, const float *fplanes, const Geom &g, int band, float *params, hipStream_t s)
 {
     if (!c->have[band]) return fail(LLICTI_ENOWEIGHTS, "band %d weights not set", band);
-    const long total = (long)g.B * g.h * g.w;
-    const long n_units = (total + 16 * kNT - 1) / (16 * kNT);
-    constexpr int kWaves = kCnnThreads / 64;
-    static const int K0s[3] = { 48, 72, 120 };
-    const int lds_bytes = pack_floats(K0s[band]) * 4;
+    const int tiles_x = (g.w + kTileW - 1) / kTileW, tiles_y = (g.h + kTileH - 1) / kTileH;
+    const long n_tiles_l = (long)g.B * tiles_x * tiles_y;
+    if (n_tiles_l > 0x7FFFFFFFL) return fail(LLICTI_EINVAL, "band_params: too many tiles");
+    const int n_tiles = (int)n_tiles_l;
+    const int lds_bytes = cnn_lds_bytes(band);
     const int wg_per_cu = std::max(1, std::min(4, (160 * 1024) / lds_bytes));
-    long gx = (n_units + kWaves - 1) / kWaves;
-    const long gx_cap = 256L * wg_per_cu / 4;    // 4 heads in grid.y
-    if (gx > gx_cap) gx = gx_cap;
+    int gx = std::min(n_tiles, 256 * wg_per_cu / 4);    // 4 heads in grid.y; persistent loop over tiles
     if (gx < 1) gx = 1;
     dim3 grid((unsigned)gx, 4);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1182,9 +1192,9 @@ static int launch_band_params(llicti_ctx *c, const float *fplanes, const Geom &g
         HIPCHK(hipEventRecord(e0, s));
     }
     switch (band) {
-    case 0: band_params_kernel<0><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[0], params, total); break;
-    case 1: band_params_kernel<1><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[1], params, total); break;
-    default: band_params_kernel<2><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[2], params, total); break;
+    case 0: band_params_kernel<0><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[0], params, tiles_x, tiles_y, n_tiles); break;
+    case 1: band_params_kernel<1><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[1], params, tiles_x, tiles_y, n_tiles); break;
+    default: band_params_kernel<2><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[2], params, tiles_x, tiles_y, n_tiles); break;
     }
     if (c->profiling) HIPCHK(hipEventRecord(e1, s));
     HIPCHK(hipGetLastError());

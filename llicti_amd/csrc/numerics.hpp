@@ -70,21 +70,23 @@ constexpr float kNegRsqrt2 = (float)(-0.70710678118654752440);
 
 struct Mix { float sig[5], mu[5], wn[5]; };
 
-// par: the 60 raw CNN outputs of one position (sigma 0..14 | mu 15..29 | weight 30..44 | a | b | d)
+// par: the raw CNN outputs of one position, one 16-float row per head (15 used):
+//   head 0 sigma | head 1 mu | head 2 weight (each Y, Co, Cg x 5 mixtures) | head 3 a, b, d x 5
+// i.e. reference channel o (LLICTI_nets.py:381-387) sits at par[(o / 15) * 16 + o % 15].
 __device__ __forceinline__ void mix_prepare(const float *par, int clr, float yv, float cov, Mix &m)
 {
     float w[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
         const float sg = par[5 * clr + k];
-        float mu = par[15 + 5 * clr + k];
-        const float wk = par[30 + 5 * clr + k];
+        float mu = par[16 + 5 * clr + k];
+        const float wk = par[32 + 5 * clr + k];
         if (clr == 1) {
-            const float t = par[45 + k] * yv;
+            const float t = par[48 + k] * yv;
             mu = mu + t;
         } else if (clr == 2) {
-            const float t1 = par[50 + k] * yv;
-            const float t2 = par[55 + k] * cov;
+            const float t1 = par[48 + 5 + k] * yv;
+            const float t2 = par[48 + 10 + k] * cov;
             const float t = t1 + t2;
             mu = mu + t;
         }

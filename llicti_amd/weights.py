@@ -4,8 +4,11 @@ Maps the reference's `state_dict` (33 entries, key names as in /root/reference
 graphs/models/LLICTI_nets.py:651-675, :697, :711) to the per-band arrays the
 numerics spec is written in:
 
-    w0 [352][K0]  concatenation along K of the band's layer-0 conv weights, each flattened
-                  (ci, ky, kx) row-major, sources in lazyDWT order x00, x11, x01   (K0 = 48/72/120)
+    w0 [352][K0]  concatenation along K of the band's layer-0 conv weights, sources in lazyDWT order
+                  x00, x11, x01 (K0 = 48/72/120).  A conv with a 4-wide kernel (4x4, 3x4) is flattened
+                  (ci, ky, kx); a conv with a 4-high, 3-wide kernel (4x3) is flattened (ci, kx, ky).  Either
+                  way four consecutive k walk the kernel's length-4 axis, which is what one fp32 MFMA
+                  k-step (k = 4) consumes.  The K order is the order of the fmaf chain, i.e. part of the spec.
     b0 [352]      fp32 sum of those convs' biases, left to right
     w1 [352][88], b1 [352]    grouped 1x1 (4 heads of 88)
     w2 [60][88],  b2 [60]     grouped 1x1 (4 heads of 15 outputs)
@@ -44,6 +47,11 @@ def pack_state_dict(sd) -> dict:
         for name in LAYER0[b]:
             w = _np(sd[p + name + ".weight"])
             assert w.shape[0] == NCH and w.shape[1] == 3, w.shape
+            if w.shape[3] == 3:                      # (kh, kw) = (4, 3): walk ky fastest
+                assert w.shape[2] == 4
+                w = np.ascontiguousarray(w.transpose(0, 1, 3, 2))
+            else:
+                assert w.shape[3] == 4
             ws.append(w.reshape(NCH, -1))
             bs.append(_np(sd[p + name + ".bias"]))
         w0 = np.ascontiguousarray(np.concatenate(ws, axis=1))

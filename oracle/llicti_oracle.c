@@ -240,13 +240,24 @@ static int build_taps(int band, tap_t *taps)
     for (int c = 0; c < 3; ++c) {
         const conv_t *cv = &CONVS[band][c];
         if (cv->src < 0) break;
-        for (int ci = 0; ci < 3; ++ci)
-            for (int ky = 0; ky < cv->kh; ++ky)
-                for (int kx = 0; kx < cv->kw; ++kx) {
-                    taps[k].src = cv->src; taps[k].ci = ci;
-                    taps[k].dy = ky - cv->pt; taps[k].dx = kx - cv->pl;
-                    ++k;
-                }
+        /* K order of the spec: the kernel's length-4 axis runs fastest (kw == 4: kx; 4x3 kernels: ky) */
+        for (int ci = 0; ci < 3; ++ci) {
+            if (cv->kw == 4) {
+                for (int ky = 0; ky < cv->kh; ++ky)
+                    for (int kx = 0; kx < 4; ++kx) {
+                        taps[k].src = cv->src; taps[k].ci = ci;
+                        taps[k].dy = ky - cv->pt; taps[k].dx = kx - cv->pl;
+                        ++k;
+                    }
+            } else {
+                for (int kx = 0; kx < cv->kw; ++kx)
+                    for (int ky = 0; ky < 4; ++ky) {
+                        taps[k].src = cv->src; taps[k].ci = ci;
+                        taps[k].dy = ky - cv->pt; taps[k].dx = kx - cv->pl;
+                        ++k;
+                    }
+            }
+        }
     }
     return k;
 }

@@ -42,9 +42,10 @@ extern "C" {
 #define ORC_NSTREAM 45         /* 5 levels x 3 bands x 3 colour channels */
 
 /* Canonical packed weights of one band network (band 0: x00->x11, 1: x00,x11->x01, 2: x00,x11,x01->x10).
- * w0 is the concatenation along K of the band's layer-0 conv weights, each flattened (ci, ky, kx)
- * row-major, in source order x00, x11, x01  (K0 = 48 / 72 / 120); b0 is the fp32 sum of their biases
- * taken left to right. */
+ * w0 is the concatenation along K of the band's layer-0 conv weights in source order x00, x11, x01
+ * (K0 = 48 / 72 / 120); a conv with a 4-wide kernel is flattened (ci, ky, kx), a 4x3 conv (ci, kx, ky),
+ * so that four consecutive k walk the kernel's length-4 axis (llicti_amd/weights.py); b0 is the fp32
+ * sum of their biases taken left to right. */
 typedef struct {
     int K0;
     const float *w0;   /* [352][K0] */

@@ -70,7 +70,7 @@ def test_band_params_bitexact_and_golden(torch_mod, codecs, golden_index, oracle
     p_host = planes[0].cpu().numpy()
     for lvl in range(5):
         for band in range(3):
-            got = c.band_params(fplanes, lvl, band)[0].cpu().numpy()
+            got = np.ascontiguousarray(c.params60(c.band_params(fplanes, lvl, band))[0].cpu().numpy())
             ref = orc.band_params(p_host, lvl, band, W_o)
             assert got.shape == ref.shape
             assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (lvl, band, np.abs(got - ref).max())
