@@ -106,7 +106,8 @@ int llicti_cdf_pairs_u32(llicti_ctx *ctx, const int16_t *d_planes, const float *
 /* K10: torchac-compatible arithmetic ENCODER on explicit tables -- the reference's third-party seam
  * torchac.encode_int16_normalized_cdf(cdf, sym) (LLICTI_nets.py:406-407).  n_streams independent
  * streams of N symbols; d_cdf [n_streams][N][row_stride] uint16 (Lp valid entries), d_sym [n_streams][N]
- * int16; bytes of stream s go to d_out + s*out_stride, its length to d_len[s]. */
+ * int16; bytes of stream s go to d_out + s*out_stride (4-byte aligned, out_stride a multiple of 4 and
+ * >= 2N + 8), its length to d_len[s]. */
 int llicti_ac_encode_u16cdf(llicti_ctx *ctx, const uint16_t *d_cdf, int Lp, int row_stride, const int16_t *d_sym,
                             int n_streams, long N, uint8_t *d_out, long out_stride, int32_t *d_len, void *stream);
 

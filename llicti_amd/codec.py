@@ -132,7 +132,7 @@ class HipCodec:
     def ac_encode_tables(self, cdf, sym):
         """cdf int16/uint16 [S, N, stride] (Lp = stride valid entries unless Lp given), sym int16 [S, N]."""
         S, N, stride = cdf.shape
-        out_stride = 2 * N + 32
+        out_stride = (2 * N + 32 + 3) // 4 * 4      # slots are written 32 bits at a time
         out = torch.zeros((S, out_stride), dtype=torch.uint8, device=self.device)
         ln = torch.zeros((S,), dtype=torch.int32, device=self.device)
         _lib.check(self.L.llicti_ac_encode_u16cdf(self.ctx, _ptr(cdf), self._lp, stride, _ptr(sym), S, N, _ptr(out), out_stride,

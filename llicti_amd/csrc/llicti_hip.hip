@@ -107,6 +107,8 @@ __global__ void minmax_init_kernel(int32_t *mm, int B)
     if (i < B) { mm[4 * i + 0] = 32767; mm[4 * i + 1] = 32767; mm[4 * i + 2] = -32768; mm[4 * i + 3] = -32768; }
 }
 
+// 4 pixels per thread when the plane size allows 4-byte aligned uchar4 / short4 / float4 accesses
+template <int VEC>
 __global__ __launch_bounds__(256) void lift_kernel(const uint8_t *__restrict__ rgb, long plane, int16_t *__restrict__ planes,
                                                    float *__restrict__ fplanes, int32_t *__restrict__ mm)
 {
@@ -115,15 +117,42 @@ __global__ __launch_bounds__(256) void lift_kernel(const uint8_t *__restrict__ r
     int16_t *dst = planes + (long)b * 3 * plane;
     float *fdst = fplanes + (long)b * 3 * plane;
     int mnCo = 32767, mnCg = 32767, mxCo = -32768, mxCg = -32768;
-    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < plane; p += (long)gridDim.x * blockDim.x) {
-        const int R = src[p], G = src[plane + p], Bl = src[2 * plane + p];
-        const int Co = R - Bl;
-        const int t = Bl + (Co >> 1);        // floor division (torch >= 1.13 '//'; JVT YCoCg-R '>> 1')
-        const int Cg = G - t;
-        const int Y = t + (Cg >> 1) - 127;
-        dst[p] = (int16_t)Y; dst[plane + p] = (int16_t)Co; dst[2 * plane + p] = (int16_t)Cg;
-        fdst[p] = (float)Y / 255.0f; fdst[plane + p] = (float)Co / 255.0f; fdst[2 * plane + p] = (float)Cg / 255.0f;
-        mnCo = min(mnCo, Co); mxCo = max(mxCo, Co); mnCg = min(mnCg, Cg); mxCg = max(mxCg, Cg);
+    for (long p = ((long)blockIdx.x * blockDim.x + threadIdx.x) * VEC; p < plane; p += (long)gridDim.x * blockDim.x * VEC) {
+        uint8_t r[VEC], gch[VEC], bl[VEC];
+        if constexpr (VEC == 4) {
+            const uchar4 a = *reinterpret_cast<const uchar4 *>(src + p);
+            const uchar4 c = *reinterpret_cast<const uchar4 *>(src + plane + p);
+            const uchar4 d = *reinterpret_cast<const uchar4 *>(src + 2 * plane + p);
+            r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w;
+            gch[0] = c.x; gch[1] = c.y; gch[2] = c.z; gch[3] = c.w;
+            bl[0] = d.x; bl[1] = d.y; bl[2] = d.z; bl[3] = d.w;
+        } else {
+            r[0] = src[p]; gch[0] = src[plane + p]; bl[0] = src[2 * plane + p];
+        }
+        short y[VEC], co[VEC], cg[VEC];
+        float fy[VEC], fco[VEC], fcg[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const int R = r[k], G = gch[k], Bl = bl[k];
+            const int Co = R - Bl;
+            const int t = Bl + (Co >> 1);        // floor division (torch >= 1.13 '//'; JVT YCoCg-R '>> 1')
+            const int Cg = G - t;
+            const int Y = t + (Cg >> 1) - 127;
+            y[k] = (short)Y; co[k] = (short)Co; cg[k] = (short)Cg;
+            fy[k] = (float)Y / 255.0f; fco[k] = (float)Co / 255.0f; fcg[k] = (float)Cg / 255.0f;
+            mnCo = min(mnCo, Co); mxCo = max(mxCo, Co); mnCg = min(mnCg, Cg); mxCg = max(mxCg, Cg);
+        }
+        if constexpr (VEC == 4) {
+            *reinterpret_cast<short4 *>(dst + p) = make_short4(y[0], y[1], y[2], y[3]);
+            *reinterpret_cast<short4 *>(dst + plane + p) = make_short4(co[0], co[1], co[2], co[3]);
+            *reinterpret_cast<short4 *>(dst + 2 * plane + p) = make_short4(cg[0], cg[1], cg[2], cg[3]);
+            *reinterpret_cast<float4 *>(fdst + p) = make_float4(fy[0], fy[1], fy[2], fy[3]);
+            *reinterpret_cast<float4 *>(fdst + plane + p) = make_float4(fco[0], fco[1], fco[2], fco[3]);
+            *reinterpret_cast<float4 *>(fdst + 2 * plane + p) = make_float4(fcg[0], fcg[1], fcg[2], fcg[3]);
+        } else {
+            dst[p] = y[0]; dst[plane + p] = co[0]; dst[2 * plane + p] = cg[0];
+            fdst[p] = fy[0]; fdst[plane + p] = fco[0]; fdst[2 * plane + p] = fcg[0];
+        }
     }
     for (int o = 32; o > 0; o >>= 1) {
         mnCo = min(mnCo, __shfl_xor(mnCo, o)); mxCo = max(mxCo, __shfl_xor(mxCo, o));
@@ -448,7 +477,28 @@ __global__ __launch_bounds__(256) void cdf_pairs_kernel(const int16_t *__restric
     }
 }
 
-// decoder: one wavefront per coded position writes the whole row (entries >= Lp padded with 0xFFFF)
+// decoder: one wavefront per coded position writes the whole row (entries >= Lp padded with 0xFFFF).
+// 64 consecutive sample points per wave-iteration: when a mixture is saturated (|x| >= 7: erfc_spec is
+// exactly 0 or 2) for all 64 of them -- the common case away from the mean -- its polynomial is skipped
+// wave-uniformly; the value produced is bit-identical to erfc_spec's.
+__device__ __forceinline__ uint32_t cdf_entry_wave(const Mix &m, const Grid &g, int i)
+{
+    const float pt = sample_pt(g, i);
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const float z = (pt - m.mu[k]) * m.rsig[k];
+        const float x = kNegRsqrt2 * z;
+        float e;
+        if (__all(!(__builtin_fabsf(x) < 7.0f))) e = (x < 0.0f) ? 2.0f : 0.0f;
+        else e = erfc_spec(x);
+        const float t = m.wn[k] * (0.5f * e);
+        acc = (k == 0) ? t : acc + t;
+    }
+    const float q = __builtin_rintf(acc * g.scale);
+    return (uint32_t)((int)q + i) & 0xFFFFu;
+}
+
 __global__ __launch_bounds__(256) void cdf_table_kernel(const int16_t *__restrict__ planes, const float *__restrict__ params,
                                                         const int32_t *__restrict__ minmax, StageGeom s, int clr,
                                                         uint16_t *__restrict__ tables, int row_stride)
@@ -468,7 +518,15 @@ __global__ __launch_bounds__(256) void cdf_table_kernel(const int16_t *__restric
     Mix m;
     mix_prepare(par, clr, yv, cov, m);
     uint16_t *row = tables + ((long)b * nc + n) * row_stride;
-    for (int e = lane; e < row_stride; e += 64) row[e] = (e < gr.Lp) ? (uint16_t)cdf_entry(m, gr, e) : (uint16_t)0xFFFF;
+    // two entries per lane and iteration -> one 32-bit store (row_stride is a multiple of 8)
+    for (int e0 = 0; e0 < row_stride; e0 += 128) {
+        const int e = e0 + 2 * lane;
+        const int ec0 = min(e, gr.Lp - 1), ec1 = min(e + 1, gr.Lp - 1);    // clamp: keeps the loop wave-uniform
+        const uint32_t v0 = cdf_entry_wave(m, gr, ec0);
+        const uint32_t v1 = cdf_entry_wave(m, gr, ec1);
+        if (e < row_stride)
+            *reinterpret_cast<uint32_t *>(row + e) = ((e + 1 < gr.Lp) ? v1 : 0xFFFFu) << 16 | ((e < gr.Lp) ? v0 : 0xFFFFu);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ arithmetic coder
@@ -476,14 +534,15 @@ __global__ __launch_bounds__(256) void cdf_table_kernel(const int16_t *__restric
 // handling, MSB-first bits.  The bit-at-a-time renormalisation loop is evaluated in closed form:
 //   n1 = clz(low ^ high)                      leading bits on which low and high agree  (E1/E2 steps)
 //   n2 = min(clo(low' << 1), clz(high' << 1)) following "01.. / 10.." underflow steps   (E3 steps)
-struct BitWriter {
-    uint8_t *out; int cap; int pos; uint64_t acc; int nb; int overflow;
-    __device__ __forceinline__ void put(uint32_t bits, int k)      // k <= 32
+struct BitWriter {          // MSB-first bit stream, flushed 32 bits at a time into a 4-byte aligned slot
+    uint32_t *out; int cap_words; int pos; uint64_t acc; int nb; int overflow;
+    __device__ __forceinline__ void put(uint32_t bits, int k)      // k <= 32, nb < 32 on entry
     {
         acc = (acc << k) | bits; nb += k;
-        while (nb >= 8) {
-            if (pos < cap) out[pos] = (uint8_t)(acc >> (nb - 8)); else overflow = 1;
-            ++pos; nb -= 8;
+        if (nb >= 32) {
+            const uint32_t w = (uint32_t)(acc >> (nb - 32));
+            if (pos < cap_words) out[pos] = __builtin_bswap32(w); else overflow = 1;
+            ++pos; nb -= 32;
         }
     }
     __device__ __forceinline__ void put_run(uint32_t bit, uint32_t count)
@@ -494,16 +553,34 @@ struct BitWriter {
             count -= k;
         }
     }
+    // pad with zero bits to a byte boundary; returns the stream length in bytes
+    __device__ __forceinline__ int finish()
+    {
+        const int nbytes = (nb + 7) >> 3;
+        if (nbytes > 0) {
+            const uint32_t w = (uint32_t)(acc << (32 - nb));       // left-aligned remaining bits, zero padded
+            if (pos < cap_words) out[pos] = __builtin_bswap32(w); else overflow = 1;
+        }
+        return 4 * pos + nbytes;
+    }
 };
+
+// (span * c) >> 16 (mod 2^32) with span = r + 1 (r = high - low, possibly 0xFFFFFFFF) and c <= 0x10000,
+// on full-rate 24-bit multiplies: r = rh * 2^16 + rl  =>  rh*c + ((rl*c + c) >> 16); no term overflows for c < 2^16
+__device__ __forceinline__ uint32_t scale16(uint32_t r, uint32_t c)
+{
+    if (c == 0x10000u) return r + 1u;
+    return __umul24(r >> 16, c) + ((__umul24(r & 0xFFFFu, c) + c) >> 16);
+}
 
 struct AcEnc {
     uint32_t low, high, pending;
     __device__ __forceinline__ void init() { low = 0; high = 0xFFFFFFFFu; pending = 0; }
     __device__ __forceinline__ void put(BitWriter &bw, uint32_t c_low, uint32_t c_high)
     {
-        const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
-        high = (low - 1) + (uint32_t)((span * (uint64_t)c_high) >> 16);
-        low = low + (uint32_t)((span * (uint64_t)c_low) >> 16);
+        const uint32_t r = high - low;
+        high = (low - 1) + scale16(r, c_high);
+        low = low + scale16(r, c_low);
         int n1 = __clz((int)(low ^ high));
         if (n1 > 31) n1 = 31;
         if (n1 > 0) {
@@ -529,7 +606,6 @@ struct AcEnc {
         const uint32_t b = (low < 0x40000000u) ? 0u : 1u;
         bw.put(b, 1);
         bw.put_run(b ^ 1u, pending);
-        if (bw.nb > 0) bw.put(0, 8 - bw.nb);
     }
 };
 
@@ -548,17 +624,29 @@ __global__ __launch_bounds__(64) void ac_encode_pairs_kernel(const uint32_t *__r
     if (s >= n_streams) return;
     const StreamDesc d = desc[s];
     const uint32_t *p = pairs + d.pair_off;
-    BitWriter bw = { slots + d.out_off, d.cap, 0, 0, 0, 0 };
+    BitWriter bw = { reinterpret_cast<uint32_t *>(slots + d.out_off), d.cap / 4, 0, 0, 0, 0 };
     AcEnc e;
     e.init();
-    for (int i = 0; i < d.n; ++i) {
+    int i = 0;
+    for (; i + 8 <= d.n; i += 8) {              // 8 pairs in flight: the loads do not depend on the coder state
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = p[i + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint32_t c_high = v[k] >> 16;
+            if (c_high == 0) c_high = 0x10000u;
+            e.put(bw, v[k] & 0xFFFFu, c_high);
+        }
+    }
+    for (; i < d.n; ++i) {
         const uint32_t v = p[i];
         uint32_t c_high = v >> 16;
         if (c_high == 0) c_high = 0x10000u;
         e.put(bw, v & 0xFFFFu, c_high);
     }
     e.finish(bw);
-    slot_len[s] = bw.pos;
+    slot_len[s] = bw.finish();
     if (bw.overflow) atomicExch(&status[0], LLICTI_ENOSPACE);
 }
 
@@ -572,7 +660,7 @@ __global__ __launch_bounds__(64) void ac_encode_tables_kernel(const uint16_t *__
     if (s >= n_streams) return;
     const uint16_t *tab = cdf + (long)s * N * row_stride;
     const int16_t *sy = sym + (long)s * N;
-    BitWriter bw = { out + (long)s * out_stride, (int)out_stride, 0, 0, 0, 0 };
+    BitWriter bw = { reinterpret_cast<uint32_t *>(out + (long)s * out_stride), (int)(out_stride / 4), 0, 0, 0, 0 };
     AcEnc e;
     e.init();
     const int max_symbol = Lp - 2;
@@ -583,14 +671,16 @@ __global__ __launch_bounds__(64) void ac_encode_tables_kernel(const uint16_t *__
         e.put(bw, c_low, c_high);
     }
     e.finish(bw);
-    len[s] = bw.pos;
+    len[s] = bw.finish();
     if (bw.overflow) atomicExch(&status[0], LLICTI_ENOSPACE);
 }
 
-// Decoder: one wavefront per stream.  The 64 lanes hold the current table row (8 entries each); the symbol
-// is the number of entries 1..max_symbol that are <= count (equal to torchac's binary search on a
-// strictly increasing row).  The next row is prefetched while the current symbol is resolved.
-// Output either to a symbol array (seam) or straight into the planes at the band's full-res positions.
+// Decoder: one wavefront per stream; everything below is wave-uniform except the table row, of which each
+// lane holds 8 entries.  torchac decodes  count = ((value-low+1)*65536 - 1) / span  and binary-searches the
+// row for it; since  entry <= count  <=>  (span*entry >> 16) <= value-low  (integers), the 64-bit division is
+// replaced by one multiply-compare per candidate: round 1 tests every lane's first entry (ballot -> the
+// lane L holding the symbol), round 2 the 8 entries of lane L (readlane + ballot).  On a strictly
+// increasing row this is the index torchac's search returns.  8 rows are kept in flight in registers.
 struct DecOut {
     int16_t *sym;            // [n_streams][N] or nullptr
     int16_t *planes;         // [B][3][H][W] or nullptr
@@ -601,12 +691,18 @@ struct DecOut {
 };
 
 __device__ __forceinline__ uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
+__device__ __forceinline__ uint32_t pick16(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, int e)   // entry e of 8 packed in 4 words
+{
+    const uint32_t w = (e & 4) ? ((e & 2) ? w3 : w2) : ((e & 2) ? w1 : w0);
+    return (e & 1) ? (w >> 16) : (w & 0xFFFFu);
+}
+
+constexpr int kDecRing = 8;
 
 __global__ __launch_bounds__(64) void ac_decode_kernel(const uint16_t *__restrict__ cdf, int Lp_fixed, int row_stride,
                                                        const uint8_t *__restrict__ in, long in_stride,
                                                        const int32_t *__restrict__ len, int len_stride, long N, DecOut o)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t row_lds[520];
     const int s = blockIdx.x;
     const int lane = threadIdx.x;
     const uint32_t *words = reinterpret_cast<const uint32_t *>(in + (long)s * in_stride);
@@ -629,70 +725,85 @@ __global__ __launch_bounds__(64) void ac_decode_kernel(const uint16_t *__restric
 
     auto load_row = [&](long n) -> uint4 {
         uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-        if (lane < vec_per_row) v = reinterpret_cast<const uint4 *>(tab + n * row_stride)[lane];
+        if (lane < vec_per_row) v = reinterpret_cast<const uint4 *>(tab + (n < N ? n : N - 1) * row_stride)[lane];
         return v;
     };
-    uint4 cur = load_row(0);
-    for (long n = 0; n < N; ++n) {
-        const uint4 nxt = (n + 1 < N) ? load_row(n + 1) : cur;
-        const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
-        const uint32_t count = (uint32_t)(((((uint64_t)value - (uint64_t)low + 1) << 16) - 1) / span) & 0xFFFFu;
-        const uint32_t w[4] = { cur.x, cur.y, cur.z, cur.w };
-        int cnt = 0;
+    uint4 ring[kDecRing];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const uint32_t ent = (w[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
-            const uint32_t idx = (uint32_t)(8 * lane + e);
-            cnt += (idx >= 1u && idx <= max_symbol && ent <= count) ? 1 : 0;
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
-        const uint32_t sidx = (uint32_t)cnt;
-        reinterpret_cast<uint4 *>(row_lds)[lane] = cur;
-        __syncthreads();
-        const uint32_t c_low = row_lds[sidx];
-        const uint32_t c_high = (sidx == max_symbol) ? 0x10000u : (uint32_t)row_lds[sidx + 1];
-        __syncthreads();
-        if (lane == 0) {
-            if (o.sym) o.sym[(long)s * N + n] = (int16_t)sidx;
+    for (int k = 0; k < kDecRing; ++k) ring[k] = load_row(k);
+
+    // decoded symbols are parked one per lane and written out every 64 symbols (one store wave instead of 64)
+    int mysym = 0;
+    auto flush = [&](long n_first, int count) {
+        if (lane < count) {
+            const long n = n_first + lane;
+            if (o.sym) o.sym[(long)s * N + n] = (int16_t)mysym;
             if (o.planes) {
                 const int i = (int)(n / o.sg.wc), j = (int)(n - (long)i * o.sg.wc);
                 const long off = (long)s * 3 * o.sg.plane + (long)o.clr * o.sg.plane +
                                  ((long)(2 * i + o.sg.oi) << o.sg.lvl) * o.sg.W + ((long)(2 * j + o.sg.oj) << o.sg.lvl);
-                const int v = (int)sidx - shift;               // _convert_int16cpu_to_float32gpu, LLICTI_nets.py:559-568
+                const int v = mysym - shift;                       // _convert_int16cpu_to_float32gpu, LLICTI_nets.py:559-568
                 o.planes[off] = (int16_t)v;
                 o.fplanes[off] = (float)v / 255.0f;
             }
         }
-        if (n == N - 1) break;
-        high = (low - 1) + (uint32_t)((span * (uint64_t)c_high) >> 16);
-        low = low + (uint32_t)((span * (uint64_t)c_low) >> 16);
-        int n1 = __clz((int)(low ^ high));
-        if (n1 > 31) n1 = 31;
-        if (n1 > 0) {
-            low <<= n1;
-            high = (high << n1) | ((1u << n1) - 1u);
-            value = (value << n1) | (uint32_t)(buf >> (64 - n1));
-            buf <<= n1; have -= n1;
-            if (have <= 32) {
-                buf |= (uint64_t)bswap32(words[wpos++]) << (32 - have);
-                have += 32;
+    };
+
+    for (long n0 = 0; n0 < N; n0 += kDecRing) {
+#pragma unroll
+        for (int k = 0; k < kDecRing; ++k) {
+            const long n = n0 + k;
+            if (n >= N) break;
+            const uint4 cur = ring[k];
+            ring[k] = load_row(n + kDecRing);
+            const uint32_t r = high - low, T = value - low;
+            // round 1: first entry of every lane (entry 0 always qualifies: torchac's search starts at left = 0)
+            const uint32_t idx0 = 8u * (uint32_t)lane;
+            const bool p1 = (lane == 0) || (idx0 <= max_symbol && scale16(r, cur.x & 0xFFFFu) <= T);
+            const int L = __builtin_popcountll(__ballot(p1)) - 1;
+            const uint32_t w0 = __builtin_amdgcn_readlane(cur.x, L), w1 = __builtin_amdgcn_readlane(cur.y, L);
+            const uint32_t w2 = __builtin_amdgcn_readlane(cur.z, L), w3 = __builtin_amdgcn_readlane(cur.w, L);
+            const uint32_t nxt_first = __builtin_amdgcn_readlane(cur.x, (L + 1) & 63) & 0xFFFFu;
+            // round 2: the 8 entries of lane L
+            const int e = lane & 7;
+            const uint32_t idx = 8u * (uint32_t)L + (uint32_t)e;
+            const bool p2 = (e == 0) || (idx <= max_symbol && scale16(r, pick16(w0, w1, w2, w3, e)) <= T);
+            const int es = __builtin_popcount((uint32_t)__ballot(p2) & 0xFFu) - 1;
+            const uint32_t sidx = 8u * (uint32_t)L + (uint32_t)es;
+            const uint32_t c_low = pick16(w0, w1, w2, w3, es);
+            const uint32_t c_high = (sidx == max_symbol) ? 0x10000u : (es == 7 ? nxt_first : pick16(w0, w1, w2, w3, es + 1));
+            if (lane == (int)(n & 63)) mysym = (int)sidx;
+            if ((n & 63) == 63) flush(n - 63, 64);
+            if (n == N - 1) break;
+            high = (low - 1) + scale16(r, c_high);
+            low = low + scale16(r, c_low);
+            int n1 = __clz((int)(low ^ high));
+            if (n1 > 31) n1 = 31;
+            if (n1 > 0) {
+                low <<= n1;
+                high = (high << n1) | ((1u << n1) - 1u);
+                value = (value << n1) | (uint32_t)(buf >> (64 - n1));
+                buf <<= n1; have -= n1;
+                if (have <= 32) {
+                    buf |= (uint64_t)bswap32(words[wpos++]) << (32 - have);
+                    have += 32;
+                }
+            }
+            int n2 = min(__clz((int)~(low << 1)), __clz((int)(high << 1)));
+            if (n2 > 31) n2 = 31;
+            if (n2 > 0) {
+                low = (low << n2) & 0x7FFFFFFFu;
+                high = ((high << n2) | ((1u << n2) - 1u)) | 0x80000000u;
+                value = ((value << n2) ^ 0x80000000u) | (uint32_t)(buf >> (64 - n2));
+                buf <<= n2; have -= n2;
+                if (have <= 32) {
+                    buf |= (uint64_t)bswap32(words[wpos++]) << (32 - have);
+                    have += 32;
+                }
             }
         }
-        int n2 = min(__clz((int)~(low << 1)), __clz((int)(high << 1)));
-        if (n2 > 31) n2 = 31;
-        if (n2 > 0) {
-            low = (low << n2) & 0x7FFFFFFFu;
-            high = ((high << n2) | ((1u << n2) - 1u)) | 0x80000000u;
-            value = ((value << n2) ^ 0x80000000u) | (uint32_t)(buf >> (64 - n2));
-            buf <<= n2; have -= n2;
-        }
-        if (have <= 32) {
-            buf |= (uint64_t)bswap32(words[wpos++]) << (32 - have);
-            have += 32;
-        }
-        cur = nxt;
     }
+    if (N & 63) flush(N & ~63L, (int)(N & 63));
 }
 
 // ------------------------------------------------------------------------------------------------ rANS container
@@ -1160,8 +1271,14 @@ static int launch_lift(const uint8_t *d_rgb, int B, int H, int W, int16_t *plane
 {
     const long plane = (long)H * W;
     minmax_init_kernel<<<(B + 63) / 64, 64, 0, s>>>(mm, B);
-    const int gx = (int)std::min<long>((plane + 255) / 256, 1024);
-    lift_kernel<<<dim3(gx, B), 256, 0, s>>>(d_rgb, plane, planes, fplanes, mm);
+    const bool vec = (plane % 4 == 0) && (((uintptr_t)d_rgb | (uintptr_t)planes | (uintptr_t)fplanes) % 16 == 0);
+    if (vec) {
+        const int gx = (int)std::min<long>((plane / 4 + 255) / 256, 2048);
+        lift_kernel<4><<<dim3(gx, B), 256, 0, s>>>(d_rgb, plane, planes, fplanes, mm);
+    } else {
+        const int gx = (int)std::min<long>((plane + 255) / 256, 2048);
+        lift_kernel<1><<<dim3(gx, B), 256, 0, s>>>(d_rgb, plane, planes, fplanes, mm);
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1274,7 +1391,8 @@ extern "C" int llicti_ac_encode_u16cdf(llicti_ctx *c, const uint16_t *d_cdf, int
                                        int n_streams, long N, uint8_t *d_out, long out_stride, int32_t *d_len, void *stream)
 {
     if (!c || !d_cdf || !d_sym || !d_out || !d_len) return fail(LLICTI_EINVAL, "ac_encode: null pointer");
-    if (Lp < 2 || Lp > 65536 || row_stride < Lp || n_streams < 1 || N < 1 || out_stride < 8) return fail(LLICTI_EINVAL, "ac_encode: bad argument");
+    if (Lp < 2 || Lp > 65536 || row_stride < Lp || n_streams < 1 || N < 1 || out_stride < 8 || (out_stride & 3) || ((uintptr_t)d_out & 3))
+        return fail(LLICTI_EINVAL, "ac_encode: bad argument (out_stride and d_out must be multiples of 4)");
     ac_encode_tables_kernel<<<(n_streams + 63) / 64, 64, 0, (hipStream_t)stream>>>(d_cdf, Lp, row_stride, d_sym, n_streams, N, d_out,
                                                                                   out_stride, d_len, c->d_status);
     HIPCHK(hipGetLastError());

@@ -68,7 +68,7 @@ constexpr float kScaleBound = (float)(0.11 / 255.0);
 constexpr float kWeightBound = 1e-6f;
 constexpr float kNegRsqrt2 = (float)(-0.70710678118654752440);
 
-struct Mix { float sig[5], mu[5], wn[5]; };
+struct Mix { float rsig[5], mu[5], wn[5]; };     // rsig = 1 / max(sigma, bound): one IEEE division per mixture
 
 // par: the raw CNN outputs of one position, one 16-float row per head (15 used):
 //   head 0 sigma | head 1 mu | head 2 weight (each Y, Co, Cg x 5 mixtures) | head 3 a, b, d x 5
@@ -90,7 +90,7 @@ __device__ __forceinline__ void mix_prepare(const float *par, int clr, float yv,
             const float t = t1 + t2;
             mu = mu + t;
         }
-        m.sig[k] = (sg > kScaleBound) ? sg : kScaleBound;
+        m.rsig[k] = 1.0f / ((sg > kScaleBound) ? sg : kScaleBound);
         m.mu[k] = mu;
         w[k] = (wk > kWeightBound) ? wk : kWeightBound;
     }
@@ -105,7 +105,7 @@ __device__ __forceinline__ float mix_cdf(const Mix &m, float pt)
     float acc = 0.0f;
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
-        const float z = (pt - m.mu[k]) / m.sig[k];
+        const float z = (pt - m.mu[k]) * m.rsig[k];
         const float c = 0.5f * erfc_spec(kNegRsqrt2 * z);
         const float t = m.wn[k] * c;
         acc = (k == 0) ? t : acc + t;

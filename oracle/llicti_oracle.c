@@ -82,7 +82,7 @@ float orc_erfc(float x) { return erfc_spec(x); }
 #define WEIGHT_BOUND (1e-6f)
 #define NEG_RSQRT2 ((float)(-0.70710678118654752440))
 
-typedef struct { float sig[5], mu[5], wn[5]; } mix_t;
+typedef struct { float rsig[5], mu[5], wn[5]; } mix_t;   /* rsig = 1 / max(sigma, bound), one IEEE division */
 
 /* entropy_layer_nets.py:197-200 + LLICTI_nets.py:385-392: slice, cross-channel mean update, bounds, normalise */
 static inline void mix_prepare(const float *par, int clr, float yv, float cov, mix_t *m)
@@ -101,7 +101,7 @@ static inline void mix_prepare(const float *par, int clr, float yv, float cov, m
             float t = t1 + t2;
             mu = mu + t;
         }
-        m->sig[k] = (sg > SCALE_BOUND) ? sg : SCALE_BOUND;
+        m->rsig[k] = 1.0f / ((sg > SCALE_BOUND) ? sg : SCALE_BOUND);
         m->mu[k] = mu;
         w[k] = (wk > WEIGHT_BOUND) ? wk : WEIGHT_BOUND;
     }
@@ -114,7 +114,7 @@ static inline float mix_cdf(const mix_t *m, float pt)
 {
     float acc = 0.0f;
     for (int k = 0; k < 5; ++k) {
-        float z = (pt - m->mu[k]) / m->sig[k];
+        float z = (pt - m->mu[k]) * m->rsig[k];     /* spec: reciprocal once per mixture, then multiply */
         float c = 0.5f * erfc_spec(NEG_RSQRT2 * z);
         float t = m->wn[k] * c;
         acc = (k == 0) ? t : acc + t;
