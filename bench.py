@@ -60,7 +60,8 @@ def cpu_baseline(H, W):
     torch.manual_seed(1337)
     sd = LLICTI(default_config()).state_dict()
     Wt = orc.Weights(pack_state_dict(sd))
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, 64)        # the oracle's OpenMP loops stop scaling well before that
     orc.set_threads(cores)
     rgb = make_batch(1, H, W, 0)[0]
     t0 = time.time()
@@ -117,9 +118,8 @@ def main():
     seg = torch.zeros((B, 49), dtype=torch.int32, device=dev)
     rec = torch.empty_like(rgb)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    from llicti_amd import shard
+    barrier = shard.barrier
 
     def enc(m=mode, c=None, s_=None):
         return codec.encode(rgb, mode=m, out=cont if c is None else c, seg_len=seg if s_ is None else s_)
@@ -196,17 +196,14 @@ def main():
     else:
         seg_ac_h, cont_ac0 = seg_h, cont[0].cpu().numpy()
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    byt = torch.tensor([float(total_bytes)], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(byt, op=dist.ReduceOp.SUM)
-    elapsed = float(t.item())
+    # whole job: time = MAX over ranks, bytes / pixels = SUM over ranks (the only collectives of the run)
+    agg = shard.aggregate(elapsed, total_bytes, B * H * W, device=dev)
+    elapsed = agg["elapsed_s"]
 
     if rank == 0:
-        pix = float(world) * B * H * W
+        pix = agg["pixels"]
         value = pix * args.steps / elapsed / 1e6
-        flops = 2.0 * MAC_PER_POSITION * positions_per_image(H, W) * B * 2      # encode + decode passes
+        flops = 2.0 * MAC_PER_POSITION * positions_per_image(H, W) * B * 2      # rank 0's launches: encode + decode pass
         achieved = flops / (cnn_ms * 1e-3) / 1e12 if cnn_ms > 0 else 0.0
         out = {
             "metric": "MPix/s encode+decode", "value": round(value, 3), "unit": "MPix/s", "n_gpus": world,
@@ -217,7 +214,7 @@ def main():
                        "batch_per_gpu": B, "height": H, "width": W, "container": args.container,
                        "sharding": f"images/{world}gpu"},
             "enc_mpix_s": round(B * H * W / t_enc / 1e6, 3), "dec_mpix_s": round(B * H * W / t_dec / 1e6, 3),
-            "bpp": round(8.0 * float(byt.item()) / pix, 4),
+            "bpp": round(agg["bpp"], 4),
             "roofline": {"bound": "mfma", "kernel": "band_params_kernel<0|1|2> (fp32 MFMA 16x16x4)",
                          "achieved": round(achieved, 3), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": None,
