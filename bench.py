@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--width", type=int, default=768)
     ap.add_argument("--container", default="rans16", help="rans<M> (M streams per image) or ac (torchac-compatible)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     args = ap.parse_args()
 
     import torch
@@ -95,10 +96,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    local_dev = local_rank % max(1, torch.cuda.device_count())   # identity on a full node
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI; used for the barrier + scalars only
+        # RCCL over xGMI; used for the barrier + two scalar all-reduces only (no data-path collective)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from llicti_amd.codec import MODE_AC, MODE_RANS, HipCodec, container_to_bytestream_list
     from llicti_amd.config import default_config
@@ -197,7 +203,7 @@ def main():
         seg_ac_h, cont_ac0 = seg_h, cont[0].cpu().numpy()
 
     # whole job: time = MAX over ranks, bytes / pixels = SUM over ranks (the only collectives of the run)
-    agg = shard.aggregate(elapsed, total_bytes, B * H * W, device=dev)
+    agg = shard.aggregate(elapsed, total_bytes, B * H * W, device=dev if (world == 1 or args.backend == "nccl") else "cpu")
     elapsed = agg["elapsed_s"]
 
     if rank == 0:
