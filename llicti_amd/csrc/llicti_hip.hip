@@ -17,7 +17,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <map>
 #include <string>
+#include <tuple>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -868,21 +870,61 @@ __global__ __launch_bounds__(64) void rans_init_kernel(const uint8_t *__restrict
     if (lane == 0) rpos[sidx] = 0;
 }
 
-// one stage (level, band, colour channel) of all images: the mixture CDF is evaluated on the fly inside a
-// per-lane binary search (no table in HBM): ceil(log2 Lp) probes x 5 erfc.
-__global__ __launch_bounds__(64) void rans_decode_stage_kernel(const float *__restrict__ params, StageGeom sg, int clr, int M,
+// One stage (level, band, colour channel) of all images.  One workgroup of 8 wavefronts per stream: wave 0
+// owns the 64 rANS states; for every step it publishes the 64 slot values (x & 0xFFFF) in LDS, then all 8
+// waves resolve 8 symbols each with 8 lanes per symbol -- lane m < 5 evaluates mixture component m of the
+// probed table entry and the five terms are summed in the spec's order over DPP row shifts -- inside a
+// binary search (ceil(log2 Lp) probes, no table in HBM); wave 0 then updates and renormalises the states.
+// Bit-identical to evaluating cdf_entry() in one lane; ~4x shorter per step.
+constexpr int kRansWaves = 8;
+
+__device__ __forceinline__ float dpp_row_shl(float v, int n)   // lane i <- lane i+n within a 16-lane row (n = 1..4)
+{
+    int r;
+    const int iv = __float_as_int(v);
+    switch (n) {
+    case 1: r = __builtin_amdgcn_update_dpp(0, iv, 0x101, 0xF, 0xF, true); break;
+    case 2: r = __builtin_amdgcn_update_dpp(0, iv, 0x102, 0xF, 0xF, true); break;
+    case 3: r = __builtin_amdgcn_update_dpp(0, iv, 0x103, 0xF, 0xF, true); break;
+    default: r = __builtin_amdgcn_update_dpp(0, iv, 0x104, 0xF, 0xF, true); break;
+    }
+    return __int_as_float(r);
+}
+__device__ __forceinline__ uint32_t group8_lane0(uint32_t v)   // broadcast lane (l & ~7) to the 8 lanes of its group
+{
+    return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x0018);   // bit-mask mode: and 0x18, or 0, xor 0
+}
+
+// table entry i of the symbol handled by this 8-lane group; valid in every lane of the group
+__device__ __forceinline__ uint32_t group_cdf_entry(float mu, float rsig, float wn, const Grid &g, int i)
+{
+    const float pt = sample_pt(g, i);
+    const float z = (pt - mu) * rsig;
+    const float t = wn * (0.5f * erfc_spec(kNegRsqrt2 * z));
+    float acc = t + dpp_row_shl(t, 1);          // (((t0 + t1) + t2) + t3) + t4, meaningful in group lane 0
+    acc = acc + dpp_row_shl(t, 2);
+    acc = acc + dpp_row_shl(t, 3);
+    acc = acc + dpp_row_shl(t, 4);
+    const float q = __builtin_rintf(acc * g.scale);
+    return group8_lane0((uint32_t)((int)q + i) & 0xFFFFu);
+}
+
+__global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(const float *__restrict__ params, StageGeom sg, int clr, int M,
                                                                const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
                                                                int rslot_cap, uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos,
                                                                int16_t *__restrict__ planes, float *__restrict__ fplanes,
                                                                const int32_t *__restrict__ minmax)
 {
-    const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M, lane = threadIdx.x;
+    __shared__ uint32_t sh_slot[64];
+    __shared__ uint32_t sh_res[64][2];           // [0] = symbol | c_low << 16, [1] = c_high
+    const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nc = sg.hc * sg.wc;
     const int nchunks = (nc + 63) >> 6;
-    if (nchunks <= m) return;
+    if (nchunks <= m) return;                    // whole workgroup
     const int K = (nchunks - m + M - 1) / M;
-    uint32_t x = rstate[(long)sidx * 64 + lane];
-    uint32_t pos = rpos[sidx];
+    uint32_t x = 0, pos = 0;
+    if (wave == 0) { x = rstate[(long)sidx * 64 + lane]; pos = rpos[sidx]; }
     const uint16_t *words = reinterpret_cast<const uint16_t *>(slots + rslot_off[sidx] + 256);
     const uint32_t max_words = (uint32_t)((rslot_cap - 256) / 2);
     int minv, maxv, shift;
@@ -890,41 +932,81 @@ __global__ __launch_bounds__(64) void rans_decode_stage_kernel(const float *__re
     const Grid gr = make_grid(minv, maxv);
     const int max_symbol = gr.Lp - 2;
     const long img = (long)b * 3 * sg.plane;
+    const int gsym = 8 * wave + (lane >> 3);     // symbol (lane of the stream) this 8-lane group resolves
+    const int mi = min(lane & 7, 4);             // mixture component of this lane (lanes 5..7 mirror component 4)
     for (int k = 0; k < K; ++k) {
-        const int n = 64 * (m + k * M) + lane;
-        const bool active = n < nc;
-        if (active) {
-            const int i = n / sg.wc, j = n - i * sg.wc;
-            const float *par = params + ((long)b * sg.h * sg.w + (long)i * sg.w + j) * LLICTI_PARAM_STRIDE;
-            const long off = img + ((long)(2 * i + sg.oi) << sg.lvl) * sg.W + ((long)(2 * j + sg.oj) << sg.lvl);
-            Mix mx;
-            mix_prepare(par, clr, fplanes[off], fplanes[off + sg.plane], mx);
-            const uint32_t slot = x & 0xFFFFu;
-            int lo = 0, hi = max_symbol + 1;
-            uint32_t vlo = 0, vhi = 0x10000u;
-            bool have_lo = false;
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                const uint32_t e = cdf_entry(mx, gr, mid);
-                if (e <= slot) { lo = mid; vlo = e; have_lo = true; } else { hi = mid; vhi = e; }
+        const int chunk0 = 64 * (m + k * M);
+        if (wave == 0) sh_slot[lane] = x & 0xFFFFu;
+        __syncthreads();
+        {
+            const int n = chunk0 + gsym;
+            if (n < nc) {                        // uniform within the 8-lane group
+                const int i = n / sg.wc, j = n - i * sg.wc;
+                const float *par = params + ((long)b * sg.h * sg.w + (long)i * sg.w + j) * LLICTI_PARAM_STRIDE;
+                const long off = img + ((long)(2 * i + sg.oi) << sg.lvl) * sg.W + ((long)(2 * j + sg.oj) << sg.lvl);
+                // this lane's component, prepared exactly as mix_prepare() does
+                const float sgm = par[5 * clr + mi];
+                float mu = par[16 + 5 * clr + mi];
+                const float wk = par[32 + 5 * clr + mi];
+                if (clr == 1) {
+                    const float t = par[48 + mi] * fplanes[off];
+                    mu = mu + t;
+                } else if (clr == 2) {
+                    const float t1 = par[48 + 5 + mi] * fplanes[off];
+                    const float t2 = par[48 + 10 + mi] * fplanes[off + sg.plane];
+                    const float t = t1 + t2;
+                    mu = mu + t;
+                }
+                const float rsig = 1.0f / ((sgm > kScaleBound) ? sgm : kScaleBound);
+                const float w = (wk > kWeightBound) ? wk : kWeightBound;
+                float ssum = w + dpp_row_shl(w, 1);                  // (((w0 + w1) + w2) + w3) + w4 in group lane 0
+                ssum = ssum + dpp_row_shl(w, 2);
+                ssum = ssum + dpp_row_shl(w, 3);
+                ssum = ssum + dpp_row_shl(w, 4);
+                ssum = __int_as_float((int)group8_lane0((uint32_t)__float_as_int(ssum)));
+                const float wn = w / (1e-9f + ssum);
+
+                const uint32_t slot = sh_slot[gsym];
+                int lo = 0, hi = max_symbol + 1;
+                uint32_t vlo = 0, vhi = 0x10000u;
+                bool have_lo = false;
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    const uint32_t e = group_cdf_entry(mu, rsig, wn, gr, mid);
+                    if (e <= slot) { lo = mid; vlo = e; have_lo = true; } else { hi = mid; vhi = e; }
+                }
+                if (!have_lo) vlo = group_cdf_entry(mu, rsig, wn, gr, 0);
+                if ((lane & 7) == 0) {
+                    sh_res[gsym][0] = (uint32_t)lo | (vlo << 16);
+                    sh_res[gsym][1] = vhi;
+                    const int v = lo - shift;
+                    planes[off + (long)clr * sg.plane] = (int16_t)v;
+                    fplanes[off + (long)clr * sg.plane] = (float)v / 255.0f;
+                }
             }
-            if (!have_lo) vlo = cdf_entry(mx, gr, 0);
-            x = (vhi - vlo) * (x >> 16) + slot - vlo;
-            const int v = lo - shift;
-            planes[off + (long)clr * sg.plane] = (int16_t)v;
-            fplanes[off + (long)clr * sg.plane] = (float)v / 255.0f;
         }
-        const bool need = active && x < 0x10000u;
-        const uint64_t E = __ballot(need);
-        if (need) {
-            const uint32_t idx = pos + (uint32_t)lanes_below(E);
-            const uint32_t wv = (idx < max_words) ? words[idx] : 0u;
-            x = (x << 16) | wv;
+        __syncthreads();
+        if (wave == 0) {
+            const bool active = chunk0 + lane < nc;
+            if (active) {
+                const uint32_t r0 = sh_res[lane][0], vhi = sh_res[lane][1];
+                const uint32_t vlo = r0 >> 16;
+                x = (vhi - vlo) * (x >> 16) + (x & 0xFFFFu) - vlo;
+            }
+            const bool need = active && x < 0x10000u;
+            const uint64_t E = __ballot(need);
+            if (need) {
+                const uint32_t idx = pos + (uint32_t)lanes_below(E);
+                const uint32_t wv = (idx < max_words) ? words[idx] : 0u;
+                x = (x << 16) | wv;
+            }
+            pos += (uint32_t)__builtin_popcountll(E);
         }
-        pos += (uint32_t)__builtin_popcountll(E);
     }
-    rstate[(long)sidx * 64 + lane] = x;
-    if (lane == 0) rpos[sidx] = pos;
+    if (wave == 0) {
+        rstate[(long)sidx * 64 + lane] = x;
+        if (lane == 0) rpos[sidx] = pos;
+    }
 }
 
 __global__ __launch_bounds__(256) void rans_pack_kernel(const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
@@ -1081,15 +1163,23 @@ struct Plan {                 // workspace carving for (B, H, W)
     size_t off_rinfo, off_rstate, off_rpos;
 };
 
-struct llicti_ctx {
-    int device = 0;
-    float *d_pack[3] = { nullptr, nullptr, nullptr };
-    bool have[3] = { false, false, false };
-    Plan plan;
+constexpr int kMaxSub = 4;
+struct PlanDev {
+    Plan p;
     StreamDesc *d_desc = nullptr;
     long *d_slot_off = nullptr;
     int32_t *d_slot_cap = nullptr;
     long *d_rslot_off = nullptr;
+};
+
+struct llicti_ctx {
+    int device = 0;
+    float *d_pack[3] = { nullptr, nullptr, nullptr };
+    bool have[3] = { false, false, false };
+    std::map<std::tuple<int, int, int, int>, struct PlanDev *> plans;   // (B, H, W, M) -> plan + its device arrays
+    hipStream_t sub[kMaxSub] = { nullptr, nullptr, nullptr, nullptr };    // sub-batch pipelining (decode)
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxSub] = { nullptr, nullptr, nullptr, nullptr };
+    bool pipeline = false;     // sub-batch pipelining of decode: measured neutral (co-resident CNN and rANS waves share VALU issue)
     int32_t *d_status = nullptr;      // small persistent status word (for the kernel-level entry points)
     bool profiling = false;
     std::vector<hipEvent_t> ev;       // pairs around band-CNN launches
@@ -1189,13 +1279,28 @@ static int mode_streams(int mode)
 }
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
+static int sub_batches_max(int B, int M)
+{
+    if (M == 0) return 1;
+    if (B % 4 == 0 && B >= 8) return 4;
+    if (B % 2 == 0 && B >= 4) return 2;
+    return 1;
+}
+
 extern "C" size_t llicti_workspace_bytes(int B, int H, int W, int mode)
 {
     const int M = mode_streams(mode);
     if (check_dims(B, H, W) || M < 0) return 0;
     Plan p;
     build_plan(p, B, H, W, M);
-    return p.total;
+    size_t need = p.total;
+    const int S = sub_batches_max(B, M);
+    if (S > 1) {
+        Plan q;
+        build_plan(q, B / S, H, W, M);
+        need = std::max(need, (size_t)S * align_up(q.total, 256));
+    }
+    return need;
 }
 extern "C" size_t llicti_max_container_bytes(int H, int W)
 {
@@ -1221,6 +1326,11 @@ extern "C" int llicti_create(llicti_ctx **out, int device)
     HIPCHK(hipMemset(c->d_status, 0, 64));
     HIPCHK(hipEventCreate(&c->ev_call[0]));
     HIPCHK(hipEventCreate(&c->ev_call[1]));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    for (int i = 1; i < kMaxSub; ++i) {
+        HIPCHK(hipStreamCreateWithFlags(&c->sub[i], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+    }
     // the band CNN stages a whole head (up to 86 KB) in LDS
     HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(0)));
     HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(1)));
@@ -1233,10 +1343,19 @@ extern "C" int llicti_destroy(llicti_ctx *c)
 {
     if (!c) return LLICTI_OK;
     for (int b = 0; b < 3; ++b) if (c->d_pack[b]) hipFree(c->d_pack[b]);
-    if (c->d_desc) hipFree(c->d_desc);
-    if (c->d_slot_off) hipFree(c->d_slot_off);
-    if (c->d_slot_cap) hipFree(c->d_slot_cap);
-    if (c->d_rslot_off) hipFree(c->d_rslot_off);
+    for (auto &kv : c->plans) {
+        PlanDev *pd = kv.second;
+        if (pd->d_desc) hipFree(pd->d_desc);
+        if (pd->d_slot_off) hipFree(pd->d_slot_off);
+        if (pd->d_slot_cap) hipFree(pd->d_slot_cap);
+        if (pd->d_rslot_off) hipFree(pd->d_rslot_off);
+        delete pd;
+    }
+    for (int i = 0; i < kMaxSub; ++i) {
+        if (c->sub[i]) hipStreamDestroy(c->sub[i]);
+        if (c->ev_join[i]) hipEventDestroy(c->ev_join[i]);
+    }
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->d_status) hipFree(c->d_status);
     for (auto e : c->ev) hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) if (c->ev_call[i]) hipEventDestroy(c->ev_call[i]);
@@ -1415,26 +1534,52 @@ extern "C" int llicti_ac_decode_u16cdf(llicti_ctx *c, const uint16_t *d_cdf, int
 }
 
 // ------------------------------------------------------------------------------------------------ whole batch
-static int ensure_plan(llicti_ctx *c, int B, int H, int W, int M)
+static int get_plan(llicti_ctx *c, int B, int H, int W, int M, PlanDev **out)
 {
-    if (c->plan.B == B && c->plan.H == H && c->plan.W == W && c->plan.M == M && c->d_desc) return 0;
-    build_plan(c->plan, B, H, W, M);
-    if (c->d_rslot_off) { hipFree(c->d_rslot_off); c->d_rslot_off = nullptr; }
-    if (M > 0) {
-        HIPCHK(hipMalloc(&c->d_rslot_off, (size_t)B * M * sizeof(long)));
-        HIPCHK(hipMemcpy(c->d_rslot_off, c->plan.rslot_off.data(), (size_t)B * M * sizeof(long), hipMemcpyHostToDevice));
+    auto key = std::make_tuple(B, H, W, M);
+    auto it = c->plans.find(key);
+    if (it != c->plans.end()) { *out = it->second; return 0; }
+    if (c->plans.size() >= 16) {      // bounded cache: drop everything (plans are cheap to rebuild)
+        HIPCHK(hipDeviceSynchronize());
+        for (auto &kv : c->plans) {
+            PlanDev *pd = kv.second;
+            hipFree(pd->d_desc); hipFree(pd->d_slot_off); hipFree(pd->d_slot_cap);
+            if (pd->d_rslot_off) hipFree(pd->d_rslot_off);
+            delete pd;
+        }
+        c->plans.clear();
     }
-    if (c->d_desc) { hipFree(c->d_desc); c->d_desc = nullptr; }
-    if (c->d_slot_off) { hipFree(c->d_slot_off); c->d_slot_off = nullptr; }
-    if (c->d_slot_cap) { hipFree(c->d_slot_cap); c->d_slot_cap = nullptr; }
+    PlanDev *pd = new PlanDev();
+    build_plan(pd->p, B, H, W, M);
+    if (M > 0) {
+        HIPCHK(hipMalloc(&pd->d_rslot_off, (size_t)B * M * sizeof(long)));
+        HIPCHK(hipMemcpy(pd->d_rslot_off, pd->p.rslot_off.data(), (size_t)B * M * sizeof(long), hipMemcpyHostToDevice));
+    }
     const size_t n = (size_t)LLICTI_NSTREAMS * B;
-    HIPCHK(hipMalloc(&c->d_desc, n * sizeof(StreamDesc)));
-    HIPCHK(hipMalloc(&c->d_slot_off, n * sizeof(long)));
-    HIPCHK(hipMalloc(&c->d_slot_cap, n * sizeof(int32_t)));
-    HIPCHK(hipMemcpy(c->d_desc, c->plan.desc.data(), n * sizeof(StreamDesc), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(c->d_slot_off, c->plan.slot_off.data(), n * sizeof(long), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(c->d_slot_cap, c->plan.slot_cap.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&pd->d_desc, n * sizeof(StreamDesc)));
+    HIPCHK(hipMalloc(&pd->d_slot_off, n * sizeof(long)));
+    HIPCHK(hipMalloc(&pd->d_slot_cap, n * sizeof(int32_t)));
+    HIPCHK(hipMemcpy(pd->d_desc, pd->p.desc.data(), n * sizeof(StreamDesc), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(pd->d_slot_off, pd->p.slot_off.data(), n * sizeof(long), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(pd->d_slot_cap, pd->p.slot_cap.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+    c->plans[key] = pd;
+    *out = pd;
     return 0;
+}
+
+// decode runs as S sub-batches on S streams: the rANS stage kernels are latency bound and occupy a few per
+// cent of the GPU, so one sub-batch's stages overlap another's CNN launches (images are independent)
+static int sub_batches(const llicti_ctx *c, int B, int M)
+{
+    if (!c->pipeline || c->profiling || M == 0) return 1;
+    if (B % 4 == 0 && B >= 8) return 4;
+    if (B % 2 == 0 && B >= 4) return 2;
+    return 1;
+}
+
+__global__ void latch_status_kernel(const int32_t *status, int32_t *latched)
+{
+    if (*status != 0) *latched = *status;
 }
 
 static int pad_int(int H, int W)
@@ -1467,8 +1612,9 @@ extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, 
     if (M < 0) return fail(LLICTI_EINVAL, "encode_images: unknown mode 0x%x", mode);
     for (int b = 0; b < 3; ++b) if (!c->have[b]) return fail(LLICTI_ENOWEIGHTS, "band %d weights not set", b);
     HIPCHK(hipSetDevice(c->device));
-    if (int rc = ensure_plan(c, B, H, W, M)) return rc;
-    const Plan &p = c->plan;
+    PlanDev *pd = nullptr;
+    if (int rc = get_plan(c, B, H, W, M, &pd)) return rc;
+    const Plan &p = pd->p;
     if (workspace_bytes < p.total) return fail(LLICTI_ENOSPACE, "encode_images: workspace %zu < %zu", workspace_bytes, p.total);
     if (out_stride < p.max_container) return fail(LLICTI_ENOSPACE, "encode_images: out_stride %zu < %zu", out_stride, p.max_container);
     hipStream_t s = (hipStream_t)stream;
@@ -1499,34 +1645,23 @@ extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, 
     const int hdr_bytes = 17 + 3 * g4.h * g4.w;
     if (M == 0) {
         const int n_streams = LLICTI_NSTREAMS * B;
-        ac_encode_pairs_kernel<<<(n_streams + 63) / 64, 64, 0, s>>>(pairs, c->d_desc, n_streams, slots, slot_len, status);
-        pack_kernel<<<dim3(LLICTI_NSTREAMS, B), 256, 0, s>>>(slots, c->d_slot_off, slot_len, B, hdr_bytes, d_out, (long)out_stride, d_seg_len, status);
+        ac_encode_pairs_kernel<<<(n_streams + 63) / 64, 64, 0, s>>>(pairs, pd->d_desc, n_streams, slots, slot_len, status);
+        pack_kernel<<<dim3(LLICTI_NSTREAMS, B), 256, 0, s>>>(slots, pd->d_slot_off, slot_len, B, hdr_bytes, d_out, (long)out_stride, d_seg_len, status);
     } else {
         int32_t *rinfo = (int32_t *)(ws + p.off_rinfo);
-        rans_encode_kernel<<<B * M, 64, 0, s>>>(pairs, c->d_desc, B, M, slots, c->d_rslot_off, p.rslot_cap, rinfo, status);
-        rans_pack_kernel<<<dim3(M, B), 256, 0, s>>>(slots, c->d_rslot_off, rinfo, M, hdr_bytes, d_out, (long)out_stride, d_seg_len, status);
+        rans_encode_kernel<<<B * M, 64, 0, s>>>(pairs, pd->d_desc, B, M, slots, pd->d_rslot_off, p.rslot_cap, rinfo, status);
+        rans_pack_kernel<<<dim3(M, B), 256, 0, s>>>(slots, pd->d_rslot_off, rinfo, M, hdr_bytes, d_out, (long)out_stride, d_seg_len, status);
     }
-    HIPCHK(hipMemcpyAsync(c->d_status, status, 4, hipMemcpyDeviceToDevice, s));   // latch
+    latch_status_kernel<<<1, 1, 0, s>>>(status, c->d_status);
     HIPCHK(hipGetLastError());
     end_call(c, s);
     return LLICTI_OK;
 }
 
-extern "C" int llicti_decode_images(llicti_ctx *c, const uint8_t *d_in, size_t in_stride, const int32_t *d_seg_len,
-                                    int B, int H, int W, int mode, void *d_workspace, size_t workspace_bytes,
-                                    uint8_t *d_rgb, void *stream)
+static int decode_sub(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in_stride, const int32_t *d_seg_len,
+                      int B, int H, int W, int M, uint8_t *ws, uint8_t *d_rgb, hipStream_t s)
 {
-    if (!c || !d_in || !d_seg_len || !d_workspace || !d_rgb) return fail(LLICTI_EINVAL, "decode_images: null pointer");
-    if (check_dims(B, H, W)) return LLICTI_EINVAL;
-    const int M = mode_streams(mode);
-    if (M < 0) return fail(LLICTI_EINVAL, "decode_images: unknown mode 0x%x", mode);
-    for (int b = 0; b < 3; ++b) if (!c->have[b]) return fail(LLICTI_ENOWEIGHTS, "band %d weights not set", b);
-    HIPCHK(hipSetDevice(c->device));
-    if (int rc = ensure_plan(c, B, H, W, M)) return rc;
-    const Plan &p = c->plan;
-    if (workspace_bytes < p.total) return fail(LLICTI_ENOSPACE, "decode_images: workspace %zu < %zu", workspace_bytes, p.total);
-    hipStream_t s = (hipStream_t)stream;
-    uint8_t *ws = (uint8_t *)d_workspace;
+    const Plan &p = pd->p;
     int16_t *planes = (int16_t *)(ws + p.off_planes);
     float *fplanes = (float *)(ws + p.off_fplanes);
     int32_t *mm = (int32_t *)(ws + p.off_minmax);
@@ -1535,7 +1670,6 @@ extern "C" int llicti_decode_images(llicti_ctx *c, const uint8_t *d_in, size_t i
     uint8_t *slots = ws + p.off_slots;
     uint16_t *tables = (uint16_t *)(ws + p.off_tables);
 
-    begin_call(c, s);
     HIPCHK(hipMemsetAsync(status, 0, 64, s));
     Geom g4 = make_geom(B, H, W, 4);
     const int byte0 = M ? (0x80 | (ilog2(M) << 4) | LLICTI_NLEVELS) : LLICTI_NLEVELS;
@@ -1543,10 +1677,10 @@ extern "C" int llicti_decode_images(llicti_ctx *c, const uint8_t *d_in, size_t i
     uint32_t *rstate = (uint32_t *)(ws + p.off_rstate);
     uint32_t *rpos = (uint32_t *)(ws + p.off_rpos);
     if (M == 0) {
-        unpack_kernel<<<dim3(LLICTI_NSTREAMS, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, B, slots, c->d_slot_off, c->d_slot_cap, status);
+        unpack_kernel<<<dim3(LLICTI_NSTREAMS, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, B, slots, pd->d_slot_off, pd->d_slot_cap, status);
     } else {
-        rans_unpack_kernel<<<dim3(M, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, M, slots, c->d_rslot_off, p.rslot_cap, status);
-        rans_init_kernel<<<B * M, 64, 0, s>>>(slots, c->d_rslot_off, rstate, rpos);
+        rans_unpack_kernel<<<dim3(M, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, M, slots, pd->d_rslot_off, p.rslot_cap, status);
+        rans_init_kernel<<<B * M, 64, 0, s>>>(slots, pd->d_rslot_off, rstate, rpos);
     }
     // 45 dependent stages (LLICTI_nets.py:440-498): CNN of band b needs bands < b of this level, Co needs Y, Cg needs Y, Co
     for (int lvl = LLICTI_NLEVELS - 1; lvl >= 0; --lvl) {
@@ -1556,7 +1690,7 @@ extern "C" int llicti_decode_images(llicti_ctx *c, const uint8_t *d_in, size_t i
             StageGeom sg = make_stage(g, band);
             const long nc = (long)sg.hc * sg.wc;
             for (int clr = 0; clr < 3 && M > 0; ++clr)
-                rans_decode_stage_kernel<<<B * M, 64, 0, s>>>(params, sg, clr, M, slots, c->d_rslot_off, p.rslot_cap, rstate, rpos,
+                rans_decode_stage_kernel<<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, clr, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos,
                                                               planes, fplanes, mm);
             for (int clr = 0; clr < 3 && M == 0; ++clr) {
                 const int row_stride = (clr == 0) ? 264 : 512;      // Y: Lp = 257; Co/Cg: Lp <= 512
@@ -1575,8 +1709,43 @@ extern "C" int llicti_decode_images(llicti_ctx *c, const uint8_t *d_in, size_t i
     const long plane = (long)H * W;
     const int gx = (int)std::min<long>((plane + 255) / 256, 1024);
     unlift_kernel<<<dim3(gx, B), 256, 0, s>>>(planes, plane, d_rgb);
-    HIPCHK(hipMemcpyAsync(c->d_status, status, 4, hipMemcpyDeviceToDevice, s));
+    latch_status_kernel<<<1, 1, 0, s>>>(status, c->d_status);
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int llicti_decode_images(llicti_ctx *c, const uint8_t *d_in, size_t in_stride, const int32_t *d_seg_len,
+                                    int B, int H, int W, int mode, void *d_workspace, size_t workspace_bytes,
+                                    uint8_t *d_rgb, void *stream)
+{
+    if (!c || !d_in || !d_seg_len || !d_workspace || !d_rgb) return fail(LLICTI_EINVAL, "decode_images: null pointer");
+    if (check_dims(B, H, W)) return LLICTI_EINVAL;
+    const int M = mode_streams(mode);
+    if (M < 0) return fail(LLICTI_EINVAL, "decode_images: unknown mode 0x%x", mode);
+    for (int b = 0; b < 3; ++b) if (!c->have[b]) return fail(LLICTI_ENOWEIGHTS, "band %d weights not set", b);
+    HIPCHK(hipSetDevice(c->device));
+    const int S = sub_batches(c, B, M);
+    const int Bs = B / S;
+    PlanDev *pd = nullptr;
+    if (int rc = get_plan(c, Bs, H, W, M, &pd)) return rc;
+    const size_t sub_total = align_up(pd->p.total, 256);
+    if (workspace_bytes < (size_t)S * sub_total)
+        return fail(LLICTI_ENOSPACE, "decode_images: workspace %zu < %zu", workspace_bytes, (size_t)S * sub_total);
+    hipStream_t s = (hipStream_t)stream;
+    uint8_t *ws = (uint8_t *)d_workspace;
+    const size_t plane3 = (size_t)3 * H * W;
+
+    begin_call(c, s);
+    if (S > 1) HIPCHK(hipEventRecord(c->ev_fork, s));
+    for (int k = 0; k < S; ++k) {
+        hipStream_t sk = (k == 0) ? s : c->sub[k];
+        if (k > 0) HIPCHK(hipStreamWaitEvent(sk, c->ev_fork, 0));
+        if (int rc = decode_sub(c, pd, d_in + (size_t)k * Bs * in_stride, in_stride, d_seg_len + (size_t)k * Bs * LLICTI_NSEG,
+                                Bs, H, W, M, ws + (size_t)k * sub_total, d_rgb + (size_t)k * Bs * plane3, sk))
+            return rc;
+        if (k > 0) HIPCHK(hipEventRecord(c->ev_join[k], sk));
+    }
+    for (int k = 1; k < S; ++k) HIPCHK(hipStreamWaitEvent(s, c->ev_join[k], 0));
     end_call(c, s);
     return LLICTI_OK;
 }
