@@ -195,8 +195,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kHead = 88;          // channels per head (configs/llicti_A.json chs[0])
 constexpr int kMT = 6;             // 16-row MFMA tiles per head (88 -> 96, rows >= 88 are zero)
 constexpr int kKS1 = 22;           // k-steps of the 88-deep layers (88 / 4)
-constexpr int kNT = 4;             // pixel tiles (16 positions each) per wavefront
-constexpr int kCnnThreads = 512;   // 8 wavefronts: 2 per SIMD
+#ifndef CNN_NT
+#define CNN_NT 2
+#endif
+constexpr int kNT = CNN_NT;                    // pixel tiles (16 positions each) per wavefront
+constexpr int kCnnThreads = 64 * (32 / CNN_NT);    // NT=4: 8 wavefronts (2 per SIMD); NT=2: 16 wavefronts (4 per SIMD)
 constexpr int kTileH = 16;         // band-grid positions per workgroup tile: 16 rows x 32 columns,
 constexpr int kTileW = 32;         //   wave w owns rows 2w, 2w+1 (two 16-column pixel tiles each)
 constexpr int kInRows = kTileH + 4;    // taps reach rows i-2 .. i+2 and columns j-2 .. j+2
@@ -204,6 +207,15 @@ constexpr int kInCols = kTileW + 4;
 constexpr int kInPitch = 48;       // = 16 (mod 32): B-fragment reads that stride by one row stay bank-conflict free
 constexpr int kInPlane = kInRows * kInPitch;
 constexpr int kParamStride = LLICTI_PARAM_STRIDE;
+#ifndef CNN_PREFETCH_L0
+#define CNN_PREFETCH_L0 1      // software-pipeline the layer-0 fragments one k-step ahead
+#endif
+#ifndef CNN_FENCE_L1
+#define CNN_FENCE_L1 4         // scheduler fence every N k-steps of layer 1 (0 = none)
+#endif
+#ifndef CNN_STAGGER
+#define CNN_STAGGER 0          // delay waves 4-7 before the first tile (decorrelates the two waves of a SIMD)
+#endif
 
 // One MFMA k-step consumes 4 consecutive k of the canonical K order (llicti_amd/weights.py): the kernel's
 // length-4 axis.  Lane (q = lane>>4, px = lane&15) therefore reads the staged input tile at
@@ -261,7 +273,7 @@ struct PackOff {
 static constexpr int cnn_lds_bytes(int band)
 {
     const int K0 = band == 0 ? 48 : band == 1 ? 72 : 120;
-    return (pack_floats(K0) + 3 * (band + 1) * kInPlane) * 4;
+    return (pack_floats(K0) + 2 * 3 * (band + 1) * kInPlane) * 4;     // weights + double-buffered input tile
 }
 
 __device__ __forceinline__ float relu(float x) { return (x > 0.0f) ? x : 0.0f; }
@@ -292,20 +304,24 @@ __global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *_
     const int q = lane >> 4;
     const int px = lane & 15;
     const int q_row = q * kInPitch;
-    const int pix0 = (2 * wave) * kInPitch + px;      // + (n>>1)*pitch + 16*(n&1) for pixel tile n
+    const int pix0 = ((wave * kNT) >> 1) * kInPitch + px;      // + (n>>1)*pitch + 16*(n&1) for pixel tile n
 
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // Input tile: LDS-DMA (global_load_lds), double buffered.  One wave-instruction fills 64 consecutive LDS
+    // floats, so the tile image [plane][20 rows][pitch 48] is cut into NPL*15 such pieces (the 12 pad columns
+    // of a row are filled with a duplicate of column 35); each lane computes its own clamped source address.
+    auto stage = [&](int tile, float *dst) {
         const int img = tile / (tiles_x * tiles_y);
         const int trem = tile - img * (tiles_x * tiles_y);
         const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
         const int i0 = ty * kTileH, j0 = tx * kTileW;
         const float *base = fplanes + (long)img * 3 * g.plane;
-
-        __syncthreads();                               // previous tile's fragment reads (and the pack copy) are done
-        for (int e = threadIdx.x; e < NPL * kInRows * kInCols; e += kCnnThreads) {
-            const int pl = e / (kInRows * kInCols);
-            const int rc = e - pl * (kInRows * kInCols);
-            const int r = rc / kInCols, cidx = rc - r * kInCols;
+        for (int u = wave; u < NPL * (kInPlane / 64); u += kCnnThreads / 64) {
+            const int e = u * 64 + lane;
+            const int pl = e / kInPlane;
+            const int rc = e - pl * kInPlane;
+            const int r = rc / kInPitch;
+            int cidx = rc - r * kInPitch;
+            cidx = min(cidx, kInCols - 1);
             const int src = pl / 3, ci = pl - 3 * src;
             int bi = i0 + r - 2, bj = j0 + cidx - 2;
             bi = max(0, min(bi, g.h - 1));             // the conv's replicate padding, in band coordinates
@@ -313,9 +329,29 @@ __global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *_
             int rr = 2 * bi + c_oi[src], cc = 2 * bj + c_oj[src];
             if (rr >= g.Hl) rr -= 2;                   // lazyDWT's replicate pad of the odd edge (LLICTI_nets.py:226-240)
             if (cc >= g.Wl) cc -= 2;
-            lds_in[pl * kInPlane + r * kInPitch + cidx] = base[ci * g.plane + ((long)rr << g.lvl) * g.W + ((long)cc << g.lvl)];
+            const float *gp = base + ci * g.plane + ((long)rr << g.lvl) * g.W + ((long)cc << g.lvl);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gp,
+                                             (__attribute__((address_space(3))) void *)(dst + u * 64), 4, 0, 0);
         }
+    };
+    static_assert(kInPlane % 64 == 0, "tile plane must be a whole number of 64-float pieces");
+
+    int cur = 0;
+    if ((int)blockIdx.x < n_tiles) stage(blockIdx.x, lds_in);
+#if CNN_STAGGER
+    if (__builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_sleep(CNN_STAGGER);
+#endif
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int img = tile / (tiles_x * tiles_y);
+        const int trem = tile - img * (tiles_x * tiles_y);
+        const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+        const int i0 = ty * kTileH, j0 = tx * kTileW;
+        float *lds_cur = lds_in + cur * (NPL * kInPlane);
+
+        // this tile's pieces have landed (each wave drains its own DMA, then the barrier), and every wave has
+        // finished reading the other buffer (previous tile) -- which the next tile's DMA may now overwrite
         __syncthreads();
+        if (tile + (int)gridDim.x < n_tiles) stage(tile + gridDim.x, lds_in + (cur ^ 1) * (NPL * kInPlane));
 
         // ---- layer 0: [96 x K0] x [K0 x 64 pixels]; bias preloaded into the accumulators
         f32x4 a0[kMT][kNT];
@@ -325,10 +361,46 @@ __global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *_
 #pragma unroll
             for (int n = 0; n < kNT; ++n) a0[T][n] = bv;
         }
+#if CNN_PREFETCH_L0
+        {
+            float a_c[kMT], b_c[kNT];
+            {
+                constexpr int U = kKTab<BAND>.s[0].U, S = kKTab<BAND>.s[0].S;
+                const float *bp = lds_cur + U + pix0 + (S == 1 ? q : q_row);
+#pragma unroll
+                for (int n = 0; n < kNT; ++n) b_c[n] = bp[(n >> 1) * kInPitch + 16 * (n & 1)];
+#pragma unroll
+                for (int T = 0; T < kMT; ++T) a_c[T] = lds[PO::w0 + (T * NK0 + 0) * 64 + lane];
+            }
+            static_for<NK0>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                float a_n[kMT], b_n[kNT];
+                if constexpr (t + 1 < NK0) {       // next k-step's fragments are in flight while this one's MFMAs run
+                    constexpr int U = kKTab<BAND>.s[t + 1].U, S = kKTab<BAND>.s[t + 1].S;
+                    const float *bp = lds_cur + U + pix0 + (S == 1 ? q : q_row);
+#pragma unroll
+                    for (int n = 0; n < kNT; ++n) b_n[n] = bp[(n >> 1) * kInPitch + 16 * (n & 1)];
+#pragma unroll
+                    for (int T = 0; T < kMT; ++T) a_n[T] = lds[PO::w0 + (T * NK0 + t + 1) * 64 + lane];
+                }
+#pragma unroll
+                for (int T = 0; T < kMT; ++T)
+#pragma unroll
+                    for (int n = 0; n < kNT; ++n) a0[T][n] = MFMA4(a_c[T], b_c[n], a0[T][n]);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (t + 1 < NK0) {
+#pragma unroll
+                    for (int T = 0; T < kMT; ++T) a_c[T] = a_n[T];
+#pragma unroll
+                    for (int n = 0; n < kNT; ++n) b_c[n] = b_n[n];
+                }
+            });
+        }
+#else
         static_for<NK0>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
             constexpr int U = kKTab<BAND>.s[t].U, S = kKTab<BAND>.s[t].S;
-            const float *bp = lds_in + U + pix0 + (S == 1 ? q : q_row);
+            const float *bp = lds_cur + U + pix0 + (S == 1 ? q : q_row);
             float bf[kNT];
 #pragma unroll
             for (int n = 0; n < kNT; ++n) bf[n] = bp[(n >> 1) * kInPitch + 16 * (n & 1)];
@@ -340,6 +412,7 @@ __global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *_
             }
             __builtin_amdgcn_sched_barrier(0);     // one k-step per scheduling region (bounds VGPR pressure)
         });
+#endif
 #pragma unroll
         for (int T = 0; T < kMT; ++T)
 #pragma unroll
@@ -366,7 +439,9 @@ __global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *_
                 const float a = lds[PO::w1 + (T * kKS1 + tt) * 64 + lane];
 #pragma unroll
                 for (int n = 0; n < kNT; ++n) a1[n] = MFMA4(a, a0[tt >> 2][n][tt & 3], a1[n]);
-                if constexpr ((tt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+#if CNN_FENCE_L1 > 0
+                if constexpr ((tt % CNN_FENCE_L1) == CNN_FENCE_L1 - 1) __builtin_amdgcn_sched_barrier(0);
+#endif
             });
 #pragma unroll
             for (int n = 0; n < kNT; ++n) a1[n] = relu4(a1[n]);
@@ -384,10 +459,11 @@ __global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *_
         // D row 4q + r = output 4q + r of this head; params[pos][head][16]
 #pragma unroll
         for (int n = 0; n < kNT; ++n) {
-            const int i = i0 + 2 * wave + (n >> 1), j = j0 + 16 * (n & 1) + px;
+            const int i = i0 + ((wave * kNT) >> 1) + (n >> 1), j = j0 + 16 * (n & 1) + px;
             if (i < g.h && j < g.w)
                 *reinterpret_cast<f32x4 *>(params + (((long)img * g.h + i) * g.w + j) * kParamStride + head * 16 + 4 * q) = a2[n];
         }
+        cur ^= 1;
     }
 }
 
