@@ -99,8 +99,10 @@ static int check_dims(int B, int H, int W)
 }
 
 // source sub-bands in lazyDWT cat order x00, x11, x01, x10 (LLICTI_nets.py:241); band b predicts source b+1
-__device__ __constant__ int c_oi[4] = { 0, 1, 0, 1 };
-__device__ __constant__ int c_oj[4] = { 0, 1, 1, 0 };
+// (row, column) phase of source s: (0,0), (1,1), (0,1), (1,0) -- computed, not looked up: a table load inside
+// the CNN's staging loop would put an s_waitcnt vmcnt(0) between consecutive LDS-DMA pieces
+__device__ __forceinline__ int src_oi(int s) { return s & 1; }
+__device__ __forceinline__ int src_oj(int s) { return ((s + 1) >> 1) & 1; }
 
 // ------------------------------------------------------------------------------------------------ lift
 __global__ void minmax_init_kernel(int32_t *mm, int B)
@@ -160,9 +162,22 @@ __global__ __launch_bounds__(256) void lift_kernel(const uint8_t *__restrict__ r
         mnCo = min(mnCo, __shfl_xor(mnCo, o)); mxCo = max(mxCo, __shfl_xor(mxCo, o));
         mnCg = min(mnCg, __shfl_xor(mnCg, o)); mxCg = max(mxCg, __shfl_xor(mxCg, o));
     }
+    // one set of atomics per workgroup, and only where it would change the running value (a stale read can
+    // only be larger than the true minimum / smaller than the true maximum, i.e. conservative): thousands
+    // of waves hitting the same 16 bytes otherwise serialise at the memory side
+    __shared__ int red[4][4];
     if ((threadIdx.x & 63) == 0) {
-        atomicMin(&mm[4 * b + 0], mnCo); atomicMin(&mm[4 * b + 1], mnCg);
-        atomicMax(&mm[4 * b + 2], mxCo); atomicMax(&mm[4 * b + 3], mxCg);
+        const int wv = threadIdx.x >> 6;
+        red[wv][0] = mnCo; red[wv][1] = mnCg; red[wv][2] = mxCo; red[wv][3] = mxCg;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int k = threadIdx.x;
+        int v = red[0][k];
+        for (int wv = 1; wv < 4; ++wv) v = (k < 2) ? min(v, red[wv][k]) : max(v, red[wv][k]);
+        const int cur = __hip_atomic_load(&mm[4 * b + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (k < 2) { if (v < cur) atomicMin(&mm[4 * b + k], v); }
+        else { if (v > cur) atomicMax(&mm[4 * b + k], v); }
     }
 }
 
@@ -326,7 +341,7 @@ __global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *_
             int bi = i0 + r - 2, bj = j0 + cidx - 2;
             bi = max(0, min(bi, g.h - 1));             // the conv's replicate padding, in band coordinates
             bj = max(0, min(bj, g.w - 1));
-            int rr = 2 * bi + c_oi[src], cc = 2 * bj + c_oj[src];
+            int rr = 2 * bi + src_oi(src), cc = 2 * bj + src_oj(src);
             if (rr >= g.Hl) rr -= 2;                   // lazyDWT's replicate pad of the odd edge (LLICTI_nets.py:226-240)
             if (cc >= g.Wl) cc -= 2;
             const float *gp = base + ci * g.plane + ((long)rr << g.lvl) * g.W + ((long)cc << g.lvl);
@@ -503,6 +518,19 @@ static void pack_band(int K0, const float *w0, const float *b0, const float *w1,
     }
 }
 
+__device__ __forceinline__ float dpp_row_shl(float v, int n)   // lane i <- lane i+n within a 16-lane row (n = 1..4)
+{
+    int r;
+    const int iv = __float_as_int(v);
+    switch (n) {
+    case 1: r = __builtin_amdgcn_update_dpp(0, iv, 0x101, 0xF, 0xF, true); break;
+    case 2: r = __builtin_amdgcn_update_dpp(0, iv, 0x102, 0xF, 0xF, true); break;
+    case 3: r = __builtin_amdgcn_update_dpp(0, iv, 0x103, 0xF, 0xF, true); break;
+    default: r = __builtin_amdgcn_update_dpp(0, iv, 0x104, 0xF, 0xF, true); break;
+    }
+    return __int_as_float(r);
+}
+
 // ------------------------------------------------------------------------------------------------ CDF kernels
 struct StageGeom {      // one (level, band): band grid, coded crop, full-res addressing
     int B, H, W, lvl, h, w, hc, wc, oi, oj;
@@ -555,55 +583,103 @@ __global__ __launch_bounds__(256) void cdf_pairs_kernel(const int16_t *__restric
     }
 }
 
-// decoder: one wavefront per coded position writes the whole row (entries >= Lp padded with 0xFFFF).
-// 64 consecutive sample points per wave-iteration: when a mixture is saturated (|x| >= 7: erfc_spec is
-// exactly 0 or 2) for all 64 of them -- the common case away from the mean -- its polynomial is skipped
-// wave-uniformly; the value produced is bit-identical to erfc_spec's.
-__device__ __forceinline__ uint32_t cdf_entry_wave(const Mix &m, const Grid &g, int i)
-{
-    const float pt = sample_pt(g, i);
-    float acc = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const float z = (pt - m.mu[k]) * m.rsig[k];
-        const float x = kNegRsqrt2 * z;
-        float e;
-        if (__all(!(__builtin_fabsf(x) < 7.0f))) e = (x < 0.0f) ? 2.0f : 0.0f;
-        else e = erfc_spec(x);
-        const float t = m.wn[k] * (0.5f * e);
-        acc = (k == 0) ? t : acc + t;
-    }
-    const float q = __builtin_rintf(acc * g.scale);
-    return (uint32_t)((int)q + i) & 0xFFFFu;
-}
+// decoder / seam export: full Lp-entry rows (entries >= Lp padded with 0xFFFF).  Persistent wavefronts, one
+// row per wave iteration, lane l owns entry 64k + l of block k.  Per row the wave derives, for every mixture
+// component, a conservative index interval outside which erfc_spec is exactly 0 (below) or 2 (above):
+// x = -(p - mu) * rsig / sqrt2 is monotone in the sample index, |x| >= 7 saturates, and the interval is widened
+// by 2 entries against rounding.  A (block, component) pair outside the interval contributes the constant 0
+// or wn (bit-identical to evaluating erfc_spec there); only pairs that overlap it run the polynomial.
+constexpr int kTabWaves = 4;
 
-__global__ __launch_bounds__(256) void cdf_table_kernel(const int16_t *__restrict__ planes, const float *__restrict__ params,
-                                                        const int32_t *__restrict__ minmax, StageGeom s, int clr,
-                                                        uint16_t *__restrict__ tables, int row_stride)
+__global__ __launch_bounds__(64 * kTabWaves) void cdf_table_kernel(const int16_t *__restrict__ planes, const float *__restrict__ params,
+                                                                   const int32_t *__restrict__ minmax, StageGeom s, int clr,
+                                                                   uint16_t *__restrict__ tables, int row_stride)
 {
     const int b = blockIdx.y;
-    const long nc = (long)s.hc * s.wc;
-    const long n = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (n >= nc) return;
+    const int nc = s.hc * s.wc;
     const int lane = threadIdx.x & 63;
-    const int i = (int)(n / s.wc), j = (int)(n - (long)i * s.wc);
-    const float *par = params + ((long)b * s.h * s.w + (long)i * s.w + j) * LLICTI_PARAM_STRIDE;
-    const long off = (long)b * 3 * s.plane + ((long)(2 * i + s.oi) << s.lvl) * s.W + ((long)(2 * j + s.oj) << s.lvl);
-    const float yv = (float)planes[off] / 255.0f, cov = (float)planes[off + s.plane] / 255.0f;
+    const int wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * kTabWaves + (threadIdx.x >> 6)));
+    const int nwaves = gridDim.x * kTabWaves;
     int minv, maxv, shift;
     clr_range(minmax + 4 * b, clr, minv, maxv, shift);
     const Grid gr = make_grid(minv, maxv);
-    Mix m;
-    mix_prepare(par, clr, yv, cov, m);
-    uint16_t *row = tables + ((long)b * nc + n) * row_stride;
-    // two entries per lane and iteration -> one 32-bit store (row_stride is a multiple of 8)
-    for (int e0 = 0; e0 < row_stride; e0 += 128) {
-        const int e = e0 + 2 * lane;
-        const int ec0 = min(e, gr.Lp - 1), ec1 = min(e + 1, gr.Lp - 1);    // clamp: keeps the loop wave-uniform
-        const uint32_t v0 = cdf_entry_wave(m, gr, ec0);
-        const uint32_t v1 = cdf_entry_wave(m, gr, ec1);
-        if (e < row_stride)
-            *reinterpret_cast<uint32_t *>(row + e) = ((e + 1 < gr.Lp) ? v1 : 0xFFFFu) << 16 | ((e < gr.Lp) ? v0 : 0xFFFFu);
+    const int nblk = (row_stride + 63) >> 6;             // <= 8
+    float pt[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pt[k] = sample_pt(gr, min(64 * k + lane, gr.Lp - 1));
+    const float fmin = (float)minv;
+    const long img = (long)b * 3 * s.plane;
+    const int mi = min(lane, 4);                         // lanes 0..4 prepare one mixture component each
+
+    for (int n = wave0; n < nc; n += nwaves) {
+        const int i = n / s.wc, j = n - i * s.wc;
+        const float *par = params + ((long)b * s.h * s.w + (long)i * s.w + j) * LLICTI_PARAM_STRIDE;
+        const long off = img + ((long)(2 * i + s.oi) << s.lvl) * s.W + ((long)(2 * j + s.oj) << s.lvl);
+        // component mi, prepared exactly as mix_prepare() does
+        const float sgm = par[5 * clr + mi];
+        float mu = par[16 + 5 * clr + mi];
+        const float wk = par[32 + 5 * clr + mi];
+        if (clr == 1) {
+            const float t = par[48 + mi] * ((float)planes[off] / 255.0f);
+            mu = mu + t;
+        } else if (clr == 2) {
+            const float t1 = par[48 + 5 + mi] * ((float)planes[off] / 255.0f);
+            const float t2 = par[48 + 10 + mi] * ((float)planes[off + s.plane] / 255.0f);
+            const float t = t1 + t2;
+            mu = mu + t;
+        }
+        const float sg = (sgm > kScaleBound) ? sgm : kScaleBound;
+        const float rsig = 1.0f / sg;
+        const float w = (wk > kWeightBound) ? wk : kWeightBound;
+        float ssum = w + dpp_row_shl(w, 1);              // (((w0 + w1) + w2) + w3) + w4 in lane 0
+        ssum = ssum + dpp_row_shl(w, 2);
+        ssum = ssum + dpp_row_shl(w, 3);
+        ssum = ssum + dpp_row_shl(w, 4);
+        ssum = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ssum)));
+        const float wn = w / (1e-9f + ssum);
+        // saturation interval in entry coordinates: entry i samples (minv - 0.5 + i) / 255 (the two pushed-out
+        // end points are further out on their own side, hence at least as saturated as this says)
+        const float c = mu * 255.0f - fmin + 0.5f, hw = 9.8994949f * 255.0f * sg + 2.0f;    // 7 * sqrt2
+        int lo = -1, hi = 1 << 20;                       // entries <= lo: erfc = 0;  entries >= hi: erfc = 2
+        if (c - hw > -1.0f && c - hw < 1e6f) lo = (int)(c - hw);
+        if (c + hw > -1e6f && c + hw < 1e6f) hi = (int)(c + hw) + 1;
+        if (!(c == c) || !(hw == hw)) { lo = -1; hi = 1 << 20; }
+        float mu_[5], rs_[5], wn_[5];
+        int lo_[5], hi_[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            mu_[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mu), k));
+            rs_[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rsig), k));
+            wn_[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wn), k));
+            lo_[k] = __builtin_amdgcn_readlane(lo, k);
+            hi_[k] = __builtin_amdgcn_readlane(hi, k);
+        }
+        uint16_t *row = tables + ((long)b * nc + n) * row_stride;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k < nblk) {
+                const int e = 64 * k + lane;
+                const int ec = min(e, gr.Lp - 1);
+                // index span of the block's sample points; entries 0 and Lp-1 sit 20 grey levels further out
+                const int bmin = (k == 0) ? -20 : 64 * k;
+                const int bmax = (64 * k + 63 >= gr.Lp - 1) ? gr.Lp + 19 : 64 * k + 63;
+                float acc = 0.0f;
+#pragma unroll
+                for (int m = 0; m < 5; ++m) {
+                    float t;
+                    if (bmax <= lo_[m]) t = 0.0f;                        // wn * (0.5 * 0)
+                    else if (bmin >= hi_[m]) t = wn_[m];                 // wn * (0.5 * 2)
+                    else {
+                        const float z = (pt[k] - mu_[m]) * rs_[m];
+                        t = wn_[m] * (0.5f * erfc_spec(kNegRsqrt2 * z));
+                    }
+                    acc = (m == 0) ? t : acc + t;
+                }
+                const float q = __builtin_rintf(acc * gr.scale);
+                const uint32_t v = (uint32_t)((int)q + ec) & 0xFFFFu;
+                if (e < row_stride) row[e] = (uint16_t)((e < gr.Lp) ? v : 0xFFFFu);
+            }
+        }
     }
 }
 
@@ -775,14 +851,33 @@ __device__ __forceinline__ uint32_t pick16(uint32_t w0, uint32_t w1, uint32_t w2
     return (e & 1) ? (w >> 16) : (w & 0xFFFFu);
 }
 
-constexpr int kDecRing = 8;
+constexpr int kDecRing = 8;            // table rows in flight per stream (LDS ring, 1 KB each)
+
+#define VMCNT_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// LDS read the compiler cannot see: in front of a visible ds_read of memory an LDS-DMA may have written it
+// inserts s_waitcnt vmcnt(0) (all transfers), which would defeat the ring; the explicit counts above order
+// this read after the one transfer it needs.
+__device__ __forceinline__ u32x4 lds_read_b128_hidden(const void *p)
+{
+    u32x4 v;
+    const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+    return v;
+}
 
 __global__ __launch_bounds__(64) void ac_decode_kernel(const uint16_t *__restrict__ cdf, int Lp_fixed, int row_stride,
                                                        const uint8_t *__restrict__ in, long in_stride,
-                                                       const int32_t *__restrict__ len, int len_stride, long N, DecOut o)
+                                                       const int32_t *__restrict__ len, int len_stride, long N_, DecOut o)
 {
+    // Table rows reach the wave through an LDS ring filled by LDS-DMA (global_load_lds_dwordx4: one
+    // instruction moves a whole 1 KB row), waited for with explicit vmcnt counts: rows held in registers
+    // made the compiler copy them around behind an s_waitcnt vmcnt(0), i.e. one full memory latency per symbol.
+    __shared__ uint4 ring[kDecRing][64];
     const int s = blockIdx.x;
     const int lane = threadIdx.x;
+    const int N = (int)N_;
     const uint32_t *words = reinterpret_cast<const uint32_t *>(in + (long)s * in_stride);
     (void)len; (void)len_stride;   // streams are zero padded: reads past the end return 0 bits like torchac's get()
     int Lp = Lp_fixed, shift = 0;
@@ -794,30 +889,48 @@ __global__ __launch_bounds__(64) void ac_decode_kernel(const uint16_t *__restric
     const uint32_t max_symbol = (uint32_t)(Lp - 2);
     const uint16_t *tab = cdf + (long)s * N * row_stride;
     const int vec_per_row = row_stride >> 3;             // uint4 (8 entries) per row
-
-    uint32_t value = bswap32(words[0]);
-    uint64_t buf = ((uint64_t)bswap32(words[1]) << 32) | bswap32(words[2]);   // next 64 bits, MSB first
-    int have = 64;
-    long wpos = 3;
-    uint32_t low = 0, high = 0xFFFFFFFFu;
-
-    auto load_row = [&](long n) -> uint4 {
-        uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-        if (lane < vec_per_row) v = reinterpret_cast<const uint4 *>(tab + (n < N ? n : N - 1) * row_stride)[lane];
-        return v;
+    // every lane transfers (lanes past the row re-read its last vector; their entries fail idx <= max_symbol)
+    const int lane_vec = min(lane, vec_per_row - 1);
+    auto dma_row = [&](int n, int slot) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(tab + (long)min(n, N - 1) * row_stride) + lane_vec;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)&ring[slot][0], 16, 0, 0);
     };
-    uint4 ring[kDecRing];
+
+    // Bitstream window: lane l holds word (wbase + l) of the stream; the coder pulls its next 32 bits with one
+    // readlane.  Every 64 words (~150 symbols) the window is reloaded synchronously: one memory latency per
+    // 150 symbols, and no register with a load in flight across loop iterations (those make the compiler
+    // emit s_waitcnt vmcnt(0) at every merge point, which would drain the row ring as well).
+    const int in_words = (int)(in_stride >> 2);
+    auto load_win = [&](int w0) -> uint32_t { return words[min(w0 + lane, in_words - 1)]; };
+    uint32_t win_cur = load_win(0);
+    asm volatile("" : "+v"(win_cur));
+    int wpos = 3;                                       // next word to pull (wave-uniform)
+    auto next_word = [&]() -> uint32_t {
+        uint32_t w = bswap32((uint32_t)__builtin_amdgcn_readlane((int)win_cur, wpos & 63));
+        if (wpos >= in_words) w = 0;                    // reads past the slot return 0 bits
+        ++wpos;
+        if ((wpos & 63) == 0) { win_cur = load_win(wpos); asm volatile("" : "+v"(win_cur)); }   // wait for it here, not at every later pull
+        return w;
+    };
 #pragma unroll
-    for (int k = 0; k < kDecRing; ++k) ring[k] = load_row(k);
+    for (int k = 0; k < kDecRing; ++k) dma_row(k, k);
+    uint32_t value = bswap32((uint32_t)__builtin_amdgcn_readlane((int)win_cur, 0));
+    const uint32_t w1_ = bswap32((uint32_t)__builtin_amdgcn_readlane((int)win_cur, 1)), w2_ = bswap32((uint32_t)__builtin_amdgcn_readlane((int)win_cur, 2));
+    uint64_t buf = ((uint64_t)w1_ << 32) | w2_;        // next 64 bits, MSB first (readlane returns a signed int: no sign extension here)
+    int have = 64;
+    uint32_t low = 0, high = 0xFFFFFFFFu;
+    const bool lane_ok = 8u * (uint32_t)lane <= max_symbol;      // this lane's first entry is a real table entry
+    const int e = lane & 7;
 
     // decoded symbols are parked one per lane and written out every 64 symbols (one store wave instead of 64)
     int mysym = 0;
-    auto flush = [&](long n_first, int count) {
+    auto flush = [&](int n_first, int count) {
         if (lane < count) {
-            const long n = n_first + lane;
+            const int n = n_first + lane;
             if (o.sym) o.sym[(long)s * N + n] = (int16_t)mysym;
             if (o.planes) {
-                const int i = (int)(n / o.sg.wc), j = (int)(n - (long)i * o.sg.wc);
+                const int i = n / o.sg.wc, j = n - i * o.sg.wc;
                 const long off = (long)s * 3 * o.sg.plane + (long)o.clr * o.sg.plane +
                                  ((long)(2 * i + o.sg.oi) << o.sg.lvl) * o.sg.W + ((long)(2 * j + o.sg.oj) << o.sg.lvl);
                 const int v = mysym - shift;                       // _convert_int16cpu_to_float32gpu, LLICTI_nets.py:559-568
@@ -827,61 +940,69 @@ __global__ __launch_bounds__(64) void ac_decode_kernel(const uint16_t *__restric
         }
     };
 
-    for (long n0 = 0; n0 < N; n0 += kDecRing) {
-#pragma unroll
-        for (int k = 0; k < kDecRing; ++k) {
-            const long n = n0 + k;
-            if (n >= N) break;
-            const uint4 cur = ring[k];
-            ring[k] = load_row(n + kDecRing);
-            const uint32_t r = high - low, T = value - low;
-            // round 1: first entry of every lane (entry 0 always qualifies: torchac's search starts at left = 0)
-            const uint32_t idx0 = 8u * (uint32_t)lane;
-            const bool p1 = (lane == 0) || (idx0 <= max_symbol && scale16(r, cur.x & 0xFFFFu) <= T);
-            const int L = __builtin_popcountll(__ballot(p1)) - 1;
-            const uint32_t w0 = __builtin_amdgcn_readlane(cur.x, L), w1 = __builtin_amdgcn_readlane(cur.y, L);
-            const uint32_t w2 = __builtin_amdgcn_readlane(cur.z, L), w3 = __builtin_amdgcn_readlane(cur.w, L);
-            const uint32_t nxt_first = __builtin_amdgcn_readlane(cur.x, (L + 1) & 63) & 0xFFFFu;
-            // round 2: the 8 entries of lane L
-            const int e = lane & 7;
-            const uint32_t idx = 8u * (uint32_t)L + (uint32_t)e;
-            const bool p2 = (e == 0) || (idx <= max_symbol && scale16(r, pick16(w0, w1, w2, w3, e)) <= T);
-            const int es = __builtin_popcount((uint32_t)__ballot(p2) & 0xFFu) - 1;
-            const uint32_t sidx = 8u * (uint32_t)L + (uint32_t)es;
-            const uint32_t c_low = pick16(w0, w1, w2, w3, es);
-            const uint32_t c_high = (sidx == max_symbol) ? 0x10000u : (es == 7 ? nxt_first : pick16(w0, w1, w2, w3, es + 1));
-            if (lane == (int)(n & 63)) mysym = (int)sidx;
-            if ((n & 63) == 63) flush(n - 63, 64);
-            if (n == N - 1) break;
-            high = (low - 1) + scale16(r, c_high);
-            low = low + scale16(r, c_low);
-            int n1 = __clz((int)(low ^ high));
-            if (n1 > 31) n1 = 31;
-            if (n1 > 0) {
-                low <<= n1;
-                high = (high << n1) | ((1u << n1) - 1u);
-                value = (value << n1) | (uint32_t)(buf >> (64 - n1));
-                buf <<= n1; have -= n1;
-                if (have <= 32) {
-                    buf |= (uint64_t)bswap32(words[wpos++]) << (32 - have);
-                    have += 32;
-                }
+    VMCNT_WAIT(7);                                      // row 0 has landed (kDecRing - 1 younger transfers)
+    u32x4 cur = lds_read_b128_hidden(&ring[0][lane]);
+    for (int n = 0; n < N; ++n) {
+        const int slot = n & (kDecRing - 1);
+        VMCNT_WAIT(6);                                  // row n + 1 has landed (kDecRing - 2 younger transfers, or more waited for)
+        const u32x4 nxt = lds_read_b128_hidden(&ring[(n + 1) & (kDecRing - 1)][lane]);
+        const uint32_t r = high - low, T = value - low;
+        const uint32_t rh = r >> 16, rl = r & 0xFFFFu;
+        // (span * c) >> 16 for a table entry c < 2^16 (see scale16); the scaled values double as the interval
+        // update below: low += scaled(c_low), high = low - 1 + scaled(c_high)
+        // round 1: first entry of every lane (entry 0 always qualifies: torchac's search starts at left = 0)
+        const uint32_t c1 = cur.x & 0xFFFFu;
+        const uint32_t sc1 = __umul24(rh, c1) + ((__umul24(rl, c1) + c1) >> 16);
+        const bool p1 = (lane == 0) || (lane_ok && sc1 <= T);
+        const int L = __builtin_popcountll(__ballot(p1)) - 1;
+        const uint32_t w0 = __builtin_amdgcn_readlane(cur.x, L), w1 = __builtin_amdgcn_readlane(cur.y, L);
+        const uint32_t w2 = __builtin_amdgcn_readlane(cur.z, L), w3 = __builtin_amdgcn_readlane(cur.w, L);
+        // round 2: the 8 entries of lane L, one per lane e = lane & 7
+        const uint32_t c2 = pick16(w0, w1, w2, w3, e);
+        const uint32_t sc2 = __umul24(rh, c2) + ((__umul24(rl, c2) + c2) >> 16);
+        const uint32_t idx = 8u * (uint32_t)L + (uint32_t)e;
+        const bool p2 = (e == 0) || (idx <= max_symbol && sc2 <= T);
+        const int es = __builtin_popcount((uint32_t)__ballot(p2) & 0xFFu) - 1;
+        const uint32_t sidx = 8u * (uint32_t)L + (uint32_t)es;
+        const uint32_t low_add = __builtin_amdgcn_readlane(sc2, es);
+        const uint32_t hi_in = __builtin_amdgcn_readlane(sc2, (es + 1) & 7);      // entry sidx + 1 when es < 7
+        const uint32_t hi_nx = __builtin_amdgcn_readlane(sc1, (L + 1) & 63);     // ... when it is the next lane's first entry
+        const uint32_t high_add = (sidx == max_symbol) ? r + 1u : (es == 7 ? hi_nx : hi_in);   // top symbol: c_high = 0x10000
+        if (lane == (n & 63)) mysym = (int)sidx;
+        if ((n & 63) == 63) flush(n - 63, 64);
+        // slot's row sits in `cur` (read one iteration ago): refill it with row n + kDecRing
+        dma_row(n + kDecRing, slot);
+        cur = nxt;
+        if (n == N - 1) break;
+        high = (low - 1) + high_add;
+        low = low + low_add;
+        int n1 = __clz((int)(low ^ high));
+        if (n1 > 31) n1 = 31;
+        if (n1 > 0) {
+            low <<= n1;
+            high = (high << n1) | ((1u << n1) - 1u);
+            value = (value << n1) | (uint32_t)(buf >> (64 - n1));
+            buf <<= n1; have -= n1;
+            if (have <= 32) {
+                buf |= (uint64_t)next_word() << (32 - have);
+                have += 32;
             }
-            int n2 = min(__clz((int)~(low << 1)), __clz((int)(high << 1)));
-            if (n2 > 31) n2 = 31;
-            if (n2 > 0) {
-                low = (low << n2) & 0x7FFFFFFFu;
-                high = ((high << n2) | ((1u << n2) - 1u)) | 0x80000000u;
-                value = ((value << n2) ^ 0x80000000u) | (uint32_t)(buf >> (64 - n2));
-                buf <<= n2; have -= n2;
-                if (have <= 32) {
-                    buf |= (uint64_t)bswap32(words[wpos++]) << (32 - have);
-                    have += 32;
-                }
+        }
+        int n2 = min(__clz((int)~(low << 1)), __clz((int)(high << 1)));
+        if (n2 > 31) n2 = 31;
+        if (n2 > 0) {
+            low = (low << n2) & 0x7FFFFFFFu;
+            high = ((high << n2) | ((1u << n2) - 1u)) | 0x80000000u;
+            value = ((value << n2) ^ 0x80000000u) | (uint32_t)(buf >> (64 - n2));
+            buf <<= n2; have -= n2;
+            if (have <= 32) {
+                buf |= (uint64_t)next_word() << (32 - have);
+                have += 32;
             }
         }
     }
-    if (N & 63) flush(N & ~63L, (int)(N & 63));
+    if (N & 63) flush(N & ~63, N & 63);
+    VMCNT_WAIT(0);                                      // no transfer may still target this workgroup's LDS at exit
 }
 
 // ------------------------------------------------------------------------------------------------ rANS container
@@ -911,10 +1032,16 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restr
         if (nchunks <= m) continue;
         const int K = (nchunks - m + M - 1) / M;
         const uint32_t *pp = pairs + d.pair_off;
+        // the pair loads do not depend on the coder state: keep three steps in flight.  The loads are
+        // unconditional (clamped address) and the raw value is masked only where it is consumed: a select
+        // next to the load would make the compiler wait for it on the spot
+        auto fetch = [&](int k) -> uint32_t { return pp[min(64 * (m + max(k, 0) * M) + lane, d.n - 1)]; };
+        uint32_t r0 = fetch(K - 1), r1 = fetch(K - 2), r2 = fetch(K - 3);
         for (int k = K - 1; k >= 0; --k) {
             const int n = 64 * (m + k * M) + lane;
             const bool active = n < d.n;
-            const uint32_t v = active ? pp[n] : 0x00010000u;
+            const uint32_t v = active ? r0 : 0x00010000u;
+            r0 = r1; r1 = r2; r2 = fetch(k - 3);
             const uint32_t lo = v & 0xFFFFu;
             uint32_t hi = v >> 16;
             if (hi == 0) hi = 0x10000u;
@@ -946,32 +1073,17 @@ __global__ __launch_bounds__(64) void rans_init_kernel(const uint8_t *__restrict
     if (lane == 0) rpos[sidx] = 0;
 }
 
-// One stage (level, band, colour channel) of all images.  One workgroup of 8 wavefronts per stream: wave 0
-// owns the 64 rANS states; for every step it publishes the 64 slot values (x & 0xFFFF) in LDS, then all 8
-// waves resolve 8 symbols each with 8 lanes per symbol -- lane m < 5 evaluates mixture component m of the
-// probed table entry and the five terms are summed in the spec's order over DPP row shifts -- inside a
-// binary search (ceil(log2 Lp) probes, no table in HBM); wave 0 then updates and renormalises the states.
-// Bit-identical to evaluating cdf_entry() in one lane; ~4x shorter per step.
+// One stage (level, band, colour channel) of all images.  One workgroup of 8 wavefronts per stream.  Every
+// wave keeps its own copy of the 64 rANS states (the update is cheap and identical in all of them), so a
+// step needs ONE barrier: each wave resolves 8 of the step's 64 symbols with 8 lanes per symbol -- lane
+// m < 5 evaluates mixture component m of the probed table entry, the five terms are summed in the spec's
+// order over DPP row shifts, and a ballot hands the comparison to the group's lanes -- inside a binary
+// search (ceil(log2 Lp) probes, no table in HBM); the 64 (c_low, c_high) pairs meet in a ping-pong LDS
+// buffer, after which every wave updates and renormalises its state copy.  Bit-identical to evaluating
+// cdf_entry() in one lane.
 constexpr int kRansWaves = 8;
 
-__device__ __forceinline__ float dpp_row_shl(float v, int n)   // lane i <- lane i+n within a 16-lane row (n = 1..4)
-{
-    int r;
-    const int iv = __float_as_int(v);
-    switch (n) {
-    case 1: r = __builtin_amdgcn_update_dpp(0, iv, 0x101, 0xF, 0xF, true); break;
-    case 2: r = __builtin_amdgcn_update_dpp(0, iv, 0x102, 0xF, 0xF, true); break;
-    case 3: r = __builtin_amdgcn_update_dpp(0, iv, 0x103, 0xF, 0xF, true); break;
-    default: r = __builtin_amdgcn_update_dpp(0, iv, 0x104, 0xF, 0xF, true); break;
-    }
-    return __int_as_float(r);
-}
-__device__ __forceinline__ uint32_t group8_lane0(uint32_t v)   // broadcast lane (l & ~7) to the 8 lanes of its group
-{
-    return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x0018);   // bit-mask mode: and 0x18, or 0, xor 0
-}
-
-// table entry i of the symbol handled by this 8-lane group; valid in every lane of the group
+// table entry i of the symbol handled by this 8-lane group; valid in the group's lane 0
 __device__ __forceinline__ uint32_t group_cdf_entry(float mu, float rsig, float wn, const Grid &g, int i)
 {
     const float pt = sample_pt(g, i);
@@ -982,7 +1094,7 @@ __device__ __forceinline__ uint32_t group_cdf_entry(float mu, float rsig, float 
     acc = acc + dpp_row_shl(t, 3);
     acc = acc + dpp_row_shl(t, 4);
     const float q = __builtin_rintf(acc * g.scale);
-    return group8_lane0((uint32_t)((int)q + i) & 0xFFFFu);
+    return (uint32_t)((int)q + i) & 0xFFFFu;
 }
 
 __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(const float *__restrict__ params, StageGeom sg, int clr, int M,
@@ -991,16 +1103,14 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
                                                                int16_t *__restrict__ planes, float *__restrict__ fplanes,
                                                                const int32_t *__restrict__ minmax)
 {
-    __shared__ uint32_t sh_slot[64];
-    __shared__ uint32_t sh_res[64][2];           // [0] = symbol | c_low << 16, [1] = c_high
+    __shared__ uint32_t sh_res[2][64][2];        // ping-pong by step parity: [0] = c_low, [1] = c_high
     const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nc = sg.hc * sg.wc;
     const int nchunks = (nc + 63) >> 6;
     if (nchunks <= m) return;                    // whole workgroup
     const int K = (nchunks - m + M - 1) / M;
-    uint32_t x = 0, pos = 0;
-    if (wave == 0) { x = rstate[(long)sidx * 64 + lane]; pos = rpos[sidx]; }
+    uint32_t x = rstate[(long)sidx * 64 + lane], pos = rpos[sidx];      // every wave: its own copy
     const uint16_t *words = reinterpret_cast<const uint16_t *>(slots + rslot_off[sidx] + 256);
     const uint32_t max_words = (uint32_t)((rslot_cap - 256) / 2);
     int minv, maxv, shift;
@@ -1010,10 +1120,11 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
     const long img = (long)b * 3 * sg.plane;
     const int gsym = 8 * wave + (lane >> 3);     // symbol (lane of the stream) this 8-lane group resolves
     const int mi = min(lane & 7, 4);             // mixture component of this lane (lanes 5..7 mirror component 4)
+    const int gbit = lane & ~7;                  // ballot bit of the group's lane 0
     for (int k = 0; k < K; ++k) {
         const int chunk0 = 64 * (m + k * M);
-        if (wave == 0) sh_slot[lane] = x & 0xFFFFu;
-        __syncthreads();
+        // slot of this group's symbol = low half of the state in lane gsym of this wave's copy
+        const uint32_t slot = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * gsym, (int)x) & 0xFFFFu;
         {
             const int n = chunk0 + gsym;
             if (n < nc) {                        // uniform within the 8-lane group
@@ -1039,34 +1150,37 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
                 ssum = ssum + dpp_row_shl(w, 2);
                 ssum = ssum + dpp_row_shl(w, 3);
                 ssum = ssum + dpp_row_shl(w, 4);
-                ssum = __int_as_float((int)group8_lane0((uint32_t)__float_as_int(ssum)));
+                ssum = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(ssum), 0x0018));   // group lane 0 -> its 8 lanes
                 const float wn = w / (1e-9f + ssum);
 
-                const uint32_t slot = sh_slot[gsym];
                 int lo = 0, hi = max_symbol + 1;
-                uint32_t vlo = 0, vhi = 0x10000u;
+                uint32_t vlo = 0, vhi = 0x10000u;                    // meaningful in group lane 0 only
                 bool have_lo = false;
                 while (hi - lo > 1) {
                     const int mid = (lo + hi) >> 1;
                     const uint32_t e = group_cdf_entry(mu, rsig, wn, gr, mid);
-                    if (e <= slot) { lo = mid; vlo = e; have_lo = true; } else { hi = mid; vhi = e; }
+                    // group lane 0 holds the entry; its verdict reaches the group through the ballot mask
+                    const uint64_t bal = __ballot(e <= slot);
+                    const bool le = ((bal >> gbit) & 1ull) != 0;
+                    if (le) { lo = mid; vlo = e; have_lo = true; } else { hi = mid; vhi = e; }
                 }
                 if (!have_lo) vlo = group_cdf_entry(mu, rsig, wn, gr, 0);
                 if ((lane & 7) == 0) {
-                    sh_res[gsym][0] = (uint32_t)lo | (vlo << 16);
-                    sh_res[gsym][1] = vhi;
-                    const int v = lo - shift;
-                    planes[off + (long)clr * sg.plane] = (int16_t)v;
-                    fplanes[off + (long)clr * sg.plane] = (float)v / 255.0f;
+                    sh_res[k & 1][gsym][0] = vlo;
+                    sh_res[k & 1][gsym][1] = vhi;
+                    if (true) {
+                        const int v = lo - shift;
+                        planes[off + (long)clr * sg.plane] = (int16_t)v;
+                        fplanes[off + (long)clr * sg.plane] = (float)v / 255.0f;
+                    }
                 }
             }
         }
         __syncthreads();
-        if (wave == 0) {
+        {
             const bool active = chunk0 + lane < nc;
             if (active) {
-                const uint32_t r0 = sh_res[lane][0], vhi = sh_res[lane][1];
-                const uint32_t vlo = r0 >> 16;
+                const uint32_t vlo = sh_res[k & 1][lane][0], vhi = sh_res[k & 1][lane][1];
                 x = (vhi - vlo) * (x >> 16) + (x & 0xFFFFu) - vlo;
             }
             const bool need = active && x < 0x10000u;
@@ -1468,10 +1582,10 @@ static int launch_lift(const uint8_t *d_rgb, int B, int H, int W, int16_t *plane
     minmax_init_kernel<<<(B + 63) / 64, 64, 0, s>>>(mm, B);
     const bool vec = (plane % 4 == 0) && (((uintptr_t)d_rgb | (uintptr_t)planes | (uintptr_t)fplanes) % 16 == 0);
     if (vec) {
-        const int gx = (int)std::min<long>((plane / 4 + 255) / 256, 2048);
+        const int gx = (int)std::min<long>((plane / 4 + 255) / 256, std::max(8, 4096 / B));
         lift_kernel<4><<<dim3(gx, B), 256, 0, s>>>(d_rgb, plane, planes, fplanes, mm);
     } else {
-        const int gx = (int)std::min<long>((plane + 255) / 256, 2048);
+        const int gx = (int)std::min<long>((plane + 255) / 256, std::max(8, 4096 / B));
         lift_kernel<1><<<dim3(gx, B), 256, 0, s>>>(d_rgb, plane, planes, fplanes, mm);
     }
     HIPCHK(hipGetLastError());
@@ -1556,7 +1670,9 @@ static int launch_cdf_table(const int16_t *planes, const float *params, const in
 {
     StageGeom sg = make_stage(g, band);
     const long nc = (long)sg.hc * sg.wc;
-    cdf_table_kernel<<<dim3((unsigned)((nc + 3) / 4), g.B), 256, 0, s>>>(planes, params, mm, sg, clr, tables, row_stride);
+    const long want = (nc + kTabWaves - 1) / kTabWaves;                     // one row per wave ...
+    const long cap = std::max<long>(1, (256L * 8 * 2) / std::max(1, g.B));   // ... up to ~16 waves per SIMD-quad in flight per image set
+    cdf_table_kernel<<<dim3((unsigned)std::min(want, cap), g.B), 64 * kTabWaves, 0, s>>>(planes, params, mm, sg, clr, tables, row_stride);
     HIPCHK(hipGetLastError());
     return 0;
 }

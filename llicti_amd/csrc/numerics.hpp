@@ -128,11 +128,21 @@ __device__ __forceinline__ Grid make_grid(int minv, int maxv)
     g.scale = (float)(65536 - (g.Lp - 1));
     return g;
 }
+// x / 255.0f for half-integers |x| <= 350 (every regular sample point), in three operations instead of the
+// ~10 of an IEEE division: q = x * RN(1/255), one fma residual, one fma correction.  Bit-identical to the
+// division on that whole domain (exhaustive check: tests/test_host_cpu.py::test_div255_shortcut_is_exact).
+__device__ __forceinline__ float div255_exact(float x)
+{
+    const float r = 0x1.010102p-8f;
+    const float q = x * r;
+    const float rem = __builtin_fmaf(-q, 255.0f, x);
+    return __builtin_fmaf(rem, r, q);
+}
 __device__ __forceinline__ float sample_pt(const Grid &g, int i)
 {
     if (i == 0) return g.p_first;
     if (i == g.Lp - 1) return g.p_last;
-    return ((float)g.minv - 0.5f + (float)i) / 255.0f;
+    return div255_exact((float)g.minv - 0.5f + (float)i);
 }
 __device__ __forceinline__ uint32_t cdf_entry(const Mix &m, const Grid &g, int i)
 {
