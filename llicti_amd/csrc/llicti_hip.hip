@@ -228,6 +228,9 @@ constexpr int kParamStride = LLICTI_PARAM_STRIDE;
 #ifndef CNN_FENCE_L1
 #define CNN_FENCE_L1 4         // scheduler fence every N k-steps of layer 1 (0 = none)
 #endif
+#ifndef CNN_STAGE_SITES
+#define CNN_STAGE_SITES 4     // points of the tile at which the wave groups request the next tile's DMA (1, 2 or 4)
+#endif
 #ifndef CNN_STAGGER
 #define CNN_STAGGER 0          // delay waves 4-7 before the first tile (decorrelates the two waves of a SIMD)
 #endif
@@ -324,33 +327,39 @@ __global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *_
     // Input tile: LDS-DMA (global_load_lds), double buffered.  One wave-instruction fills 64 consecutive LDS
     // floats, so the tile image [plane][20 rows][pitch 48] is cut into NPL*15 such pieces (the 12 pad columns
     // of a row are filled with a duplicate of column 35); each lane computes its own clamped source address.
+    // Pitch 48 makes four tile rows exactly three 64-float pieces, so a piece's plane, row group and phase are
+    // functions of the wave-uniform piece index (scalar arithmetic) and only ~20 vector operations per piece
+    // depend on the lane: piece phase t covers row 4q+t from column 16t (lanes below 48-16t) and the head
+    // of row 4q+t+1 (the others).
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     auto stage = [&](int tile, float *dst) {
         const int img = tile / (tiles_x * tiles_y);
         const int trem = tile - img * (tiles_x * tiles_y);
         const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
-        const int i0 = ty * kTileH, j0 = tx * kTileW;
+        const int i0 = ty * kTileH - 2, j0 = tx * kTileW - 2;
         const float *base = fplanes + (long)img * 3 * g.plane;
-        for (int u = wave; u < NPL * (kInPlane / 64); u += kCnnThreads / 64) {
-            const int e = u * 64 + lane;
-            const int pl = e / kInPlane;
-            const int rc = e - pl * kInPlane;
-            const int r = rc / kInPitch;
-            int cidx = rc - r * kInPitch;
-            cidx = min(cidx, kInCols - 1);
+        for (int u = wave_u; u < NPL * (kInPlane / 64); u += kCnnThreads / 64) {
+            const int pl = u / 15, v = u - 15 * pl, q4 = v / 3, t = v - 3 * q4;       // wave-uniform
             const int src = pl / 3, ci = pl - 3 * src;
-            int bi = i0 + r - 2, bj = j0 + cidx - 2;
-            bi = max(0, min(bi, g.h - 1));             // the conv's replicate padding, in band coordinates
-            bj = max(0, min(bj, g.w - 1));
+            const int thr = 48 - 16 * t;
+            const bool up = lane >= thr;
+            const int cidx = min(up ? lane - thr : lane + 16 * t, kInCols - 1);
+            const int r = 4 * q4 + t + (up ? 1 : 0);
+            const int bi = max(0, min(i0 + r, g.h - 1));            // the conv's replicate padding, in band coordinates
+            const int bj = max(0, min(j0 + cidx, g.w - 1));
             int rr = 2 * bi + src_oi(src), cc = 2 * bj + src_oj(src);
             if (rr >= g.Hl) rr -= 2;                   // lazyDWT's replicate pad of the odd edge (LLICTI_nets.py:226-240)
             if (cc >= g.Wl) cc -= 2;
-            const float *gp = base + ci * g.plane + ((long)rr << g.lvl) * g.W + ((long)cc << g.lvl);
+            const unsigned off = (unsigned)(rr * g.W + cc) << g.lvl;   // < H * W
+            const float *gp = base + (long)ci * g.plane + off;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gp,
                                              (__attribute__((address_space(3))) void *)(dst + u * 64), 4, 0, 0);
         }
     };
+    static_assert(kInPitch == 48 && kInRows % 4 == 0 && kInPlane / 64 == 15, "piece decomposition assumes pitch 48, 20 rows");
     static_assert(kInPlane % 64 == 0, "tile plane must be a whole number of 64-float pieces");
 
+    const int stage_site = (__builtin_amdgcn_readfirstlane(wave) / (kCnnThreads / 256)) % CNN_STAGE_SITES;
     int cur = 0;
     if ((int)blockIdx.x < n_tiles) stage(blockIdx.x, lds_in);
 #if CNN_STAGGER
@@ -366,7 +375,15 @@ __global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *_
         // this tile's pieces have landed (each wave drains its own DMA, then the barrier), and every wave has
         // finished reading the other buffer (previous tile) -- which the next tile's DMA may now overwrite
         __syncthreads();
-        if (tile + (int)gridDim.x < n_tiles) stage(tile + gridDim.x, lds_in + (cur ^ 1) * (NPL * kInPlane));
+        // The next tile's DMA (address arithmetic + issue: pure VALU / VMEM work) is requested at four
+        // different points of the tile, one per wave group: a SIMD hosts one wave of each group, so while
+        // one of its waves stages, the other three keep the matrix pipe busy.  (All 16 waves staging right
+        // after the barrier left the pipe idle for ~9 % of the tile.)
+        const bool more = tile + (int)gridDim.x < n_tiles;
+        auto stage_next = [&](int site) {
+            if (more && stage_site == site % CNN_STAGE_SITES) stage(tile + gridDim.x, lds_in + (cur ^ 1) * (NPL * kInPlane));
+        };
+        stage_next(0);
 
         // ---- layer 0: [96 x K0] x [K0 x 64 pixels]; bias preloaded into the accumulators
         f32x4 a0[kMT][kNT];
@@ -428,6 +445,7 @@ __global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *_
             __builtin_amdgcn_sched_barrier(0);     // one k-step per scheduling region (bounds VGPR pressure)
         });
 #endif
+        if constexpr (CNN_STAGE_SITES > 1) stage_next(1);
 #pragma unroll
         for (int T = 0; T < kMT; ++T)
 #pragma unroll
@@ -443,6 +461,8 @@ __global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *_
         }
         static_for<kMT>([&](auto Tc) {
             constexpr int T = decltype(Tc)::value;
+            if constexpr (T == 2 && CNN_STAGE_SITES > 2) stage_next(2);
+            if constexpr (T == 4 && CNN_STAGE_SITES > 2) stage_next(3);
             f32x4 a1[kNT];
             {
                 const f32x4 bv = *reinterpret_cast<const f32x4 *>(lds + PO::bias1 + (T * 4 + q) * 4);
