@@ -1093,28 +1093,53 @@ __global__ __launch_bounds__(64) void rans_init_kernel(const uint8_t *__restrict
     if (lane == 0) rpos[sidx] = 0;
 }
 
-// One stage (level, band, colour channel) of all images.  One workgroup of 8 wavefronts per stream.  Every
+// One stage (level, band, colour channel) of all images.  One workgroup of 6 wavefronts per stream.  Every
 // wave keeps its own copy of the 64 rANS states (the update is cheap and identical in all of them), so a
-// step needs ONE barrier: each wave resolves 8 of the step's 64 symbols with 8 lanes per symbol -- lane
-// m < 5 evaluates mixture component m of the probed table entry, the five terms are summed in the spec's
-// order over DPP row shifts, and a ballot hands the comparison to the group's lanes -- inside a binary
-// search (ceil(log2 Lp) probes, no table in HBM); the 64 (c_low, c_high) pairs meet in a ping-pong LDS
-// buffer, after which every wave updates and renormalises its state copy.  Bit-identical to evaluating
-// cdf_entry() in one lane.
-constexpr int kRansWaves = 8;
+// step needs ONE barrier.  A wave resolves 12 of the step's 64 symbols, 5 lanes per symbol (three groups per
+// 16-lane DPP row, lane 15 idle): lane m of a group evaluates mixture component m of the probed table entry,
+// the five terms are summed in the spec's order over DPP row shifts, and a ballot hands the comparison to the
+// group's lanes.  The symbol is first located with a CHEAP approximate CDF (Abramowitz-Stegun 7.1.26 erfc on
+// v_rcp / v_exp, ~0.01 table counts of error) by bisection, then PROVEN with the exact spec arithmetic:
+// entry[s] <= slot < entry[s+1] is checked with cdf_entry()'s operations, and if the guess is off the exact
+// search gallops away from it and bisects -- so the result is bit-identical to an exact search whatever the
+// approximation does.  The 64 (c_low, c_high) pairs meet in a ping-pong LDS buffer, after which every wave
+// updates and renormalises its state copy.  No table in HBM.
+constexpr int kRansWaves = 6;
 
-// table entry i of the symbol handled by this 8-lane group; valid in the group's lane 0
+__device__ __forceinline__ float dpp_sum5(float t)      // (((t0 + t1) + t2) + t3) + t4 of lanes l .. l+4, in lane l
+{
+    float acc = t + dpp_row_shl(t, 1);
+    acc = acc + dpp_row_shl(t, 2);
+    acc = acc + dpp_row_shl(t, 3);
+    acc = acc + dpp_row_shl(t, 4);
+    return acc;
+}
+
+// exact table entry i (numerics spec); valid in the group's first lane
 __device__ __forceinline__ uint32_t group_cdf_entry(float mu, float rsig, float wn, const Grid &g, int i)
 {
     const float pt = sample_pt(g, i);
     const float z = (pt - mu) * rsig;
     const float t = wn * (0.5f * erfc_spec(kNegRsqrt2 * z));
-    float acc = t + dpp_row_shl(t, 1);          // (((t0 + t1) + t2) + t3) + t4, meaningful in group lane 0
-    acc = acc + dpp_row_shl(t, 2);
-    acc = acc + dpp_row_shl(t, 3);
-    acc = acc + dpp_row_shl(t, 4);
-    const float q = __builtin_rintf(acc * g.scale);
+    const float q = __builtin_rintf(dpp_sum5(t) * g.scale);
     return (uint32_t)((int)q + i) & 0xFFFFu;
+}
+
+// approximate table entry i, 0 < i < Lp - 1 (search hint only -- never used as a result)
+__device__ __forceinline__ int group_cdf_entry_fast(float mu, float rsig, float wn, float fbase, float scale, int i)
+{
+    const float pt = div255_exact(fbase + (float)i);     // the exact sample point: near a narrow component the CDF moves by counts per ulp of pt
+    const float x = kNegRsqrt2 * ((pt - mu) * rsig);
+    const float a = __builtin_fabsf(x);
+    const float u = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, a, 1.0f));
+    float p = __builtin_fmaf(1.061405429f, u, -1.453152027f);
+    p = __builtin_fmaf(p, u, 1.421413741f);
+    p = __builtin_fmaf(p, u, -0.284496736f);
+    p = __builtin_fmaf(p, u, 0.254829592f);
+    const float E = (p * u) * __builtin_amdgcn_exp2f((a * a) * -1.4426950409f);
+    const float er = (x < 0.0f) ? 2.0f - E : E;
+    const float t = wn * (0.5f * er);
+    return (int)__builtin_rintf(dpp_sum5(t) * scale) + i;
 }
 
 __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(const float *__restrict__ params, StageGeom sg, int clr, int M,
@@ -1137,62 +1162,92 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
     clr_range(minmax + 4 * b, clr, minv, maxv, shift);
     const Grid gr = make_grid(minv, maxv);
     const int max_symbol = gr.Lp - 2;
+    const float fbase = (float)minv - 0.5f;
     const long img = (long)b * 3 * sg.plane;
-    const int gsym = 8 * wave + (lane >> 3);     // symbol (lane of the stream) this 8-lane group resolves
-    const int mi = min(lane & 7, 4);             // mixture component of this lane (lanes 5..7 mirror component 4)
-    const int gbit = lane & ~7;                  // ballot bit of the group's lane 0
+    const int l16 = lane & 15, g3 = min(l16 / 5, 2);                    // lane 15 shadows the last lane of group 2 (its values are never read)
+    const int mi = min(l16 - 5 * g3, 4);                                // mixture component of this lane
+    const int gsym = 12 * wave + 3 * (lane >> 4) + g3;                  // symbol (lane of the stream) this group resolves
+    const int gbit = (lane & 48) + 5 * g3;                              // ballot bit of the group's first lane
+    const bool head = (l16 == 5 * g3);
+    // Raw CNN outputs / prior-channel pixels of this group's symbol in step k: requested one step ahead, so the
+    // memory round trip runs under the previous step's search instead of in front of this one's.
+    struct Raw { float sgm, mu, wk, a0, a1, y, co; long off; bool on; };
+    auto fetch = [&](int k) -> Raw {
+        Raw r;
+        const int n = min(64 * (m + k * M) + gsym, nc - 1);          // clamped: the loads are unconditional
+        const int i = n / sg.wc, j = n - i * sg.wc;
+        const float *par = params + ((long)b * sg.h * sg.w + (long)i * sg.w + j) * LLICTI_PARAM_STRIDE;
+        r.off = img + ((long)(2 * i + sg.oi) << sg.lvl) * sg.W + ((long)(2 * j + sg.oj) << sg.lvl);
+        r.sgm = par[5 * clr + mi];
+        r.mu = par[16 + 5 * clr + mi];
+        r.wk = par[32 + 5 * clr + mi];
+        r.a0 = r.a1 = r.y = r.co = 0.0f;
+        if (clr == 1) { r.a0 = par[48 + mi]; r.y = fplanes[r.off]; }
+        else if (clr == 2) { r.a0 = par[48 + 5 + mi]; r.a1 = par[48 + 10 + mi]; r.y = fplanes[r.off]; r.co = fplanes[r.off + sg.plane]; }
+        r.on = (k < K) && gsym < 64 && (64 * (m + k * M) + gsym) < nc;
+        return r;
+    };
+    // Stream words: lane l holds word wbase + l, a second register the 64 after them; a step consumes at most
+    // 64 words, pulled with ds_bpermute instead of a dependent global load.
+    uint32_t wbase = pos & ~63u;
+    auto load_words = [&](uint32_t w0) -> uint32_t { return words[min(w0 + (uint32_t)lane, max_words - 1)]; };
+    uint32_t win0 = load_words(wbase), win1 = load_words(wbase + 64);
+    Raw cur = fetch(0);
     for (int k = 0; k < K; ++k) {
         const int chunk0 = 64 * (m + k * M);
+        const Raw nxt = fetch(min(k + 1, K - 1));
         // slot of this group's symbol = low half of the state in lane gsym of this wave's copy
-        const uint32_t slot = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * gsym, (int)x) & 0xFFFFu;
+        const uint32_t slot = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (gsym & 63), (int)x) & 0xFFFFu;
         {
-            const int n = chunk0 + gsym;
-            if (n < nc) {                        // uniform within the 8-lane group
-                const int i = n / sg.wc, j = n - i * sg.wc;
-                const float *par = params + ((long)b * sg.h * sg.w + (long)i * sg.w + j) * LLICTI_PARAM_STRIDE;
-                const long off = img + ((long)(2 * i + sg.oi) << sg.lvl) * sg.W + ((long)(2 * j + sg.oj) << sg.lvl);
+            if (cur.on) {                        // uniform within the group
+                const long off = cur.off;
                 // this lane's component, prepared exactly as mix_prepare() does
-                const float sgm = par[5 * clr + mi];
-                float mu = par[16 + 5 * clr + mi];
-                const float wk = par[32 + 5 * clr + mi];
+                const float sgm = cur.sgm;
+                float mu = cur.mu;
+                const float wk = cur.wk;
                 if (clr == 1) {
-                    const float t = par[48 + mi] * fplanes[off];
+                    const float t = cur.a0 * cur.y;
                     mu = mu + t;
                 } else if (clr == 2) {
-                    const float t1 = par[48 + 5 + mi] * fplanes[off];
-                    const float t2 = par[48 + 10 + mi] * fplanes[off + sg.plane];
+                    const float t1 = cur.a0 * cur.y;
+                    const float t2 = cur.a1 * cur.co;
                     const float t = t1 + t2;
                     mu = mu + t;
                 }
                 const float rsig = 1.0f / ((sgm > kScaleBound) ? sgm : kScaleBound);
                 const float w = (wk > kWeightBound) ? wk : kWeightBound;
-                float ssum = w + dpp_row_shl(w, 1);                  // (((w0 + w1) + w2) + w3) + w4 in group lane 0
-                ssum = ssum + dpp_row_shl(w, 2);
-                ssum = ssum + dpp_row_shl(w, 3);
-                ssum = ssum + dpp_row_shl(w, 4);
-                ssum = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(ssum), 0x0018));   // group lane 0 -> its 8 lanes
+                float ssum = dpp_sum5(w);                            // (((w0 + w1) + w2) + w3) + w4 in the group's first lane
+                ssum = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * gbit, __float_as_int(ssum)));
                 const float wn = w / (1e-9f + ssum);
 
+                // 1. hint: bisection on the approximate table
+                int glo = 0, ghi = max_symbol + 1;
+                while (ghi - glo > 1) {
+                    const int mid = (glo + ghi) >> 1;
+                    const int e = group_cdf_entry_fast(mu, rsig, wn, fbase, gr.scale, mid);
+                    const uint64_t bal = __ballot(e <= (int)slot);
+                    if ((bal >> gbit) & 1ull) glo = mid; else ghi = mid;
+                }
+                // 2. proof: exact entries around the hint; gallop away from it, then bisect, if it is off
                 int lo = 0, hi = max_symbol + 1;
-                uint32_t vlo = 0, vhi = 0x10000u;                    // meaningful in group lane 0 only
-                bool have_lo = false;
+                uint32_t vlo = 0, vhi = 0x10000u;                    // meaningful in the group's first lane only
+                bool have_lo = false, have_hi = false;
+                int probe = max(1, min(glo, max_symbol)), step = 1;
                 while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    const uint32_t e = group_cdf_entry(mu, rsig, wn, gr, mid);
-                    // group lane 0 holds the entry; its verdict reaches the group through the ballot mask
+                    const uint32_t e = group_cdf_entry(mu, rsig, wn, gr, probe);
                     const uint64_t bal = __ballot(e <= slot);
-                    const bool le = ((bal >> gbit) & 1ull) != 0;
-                    if (le) { lo = mid; vlo = e; have_lo = true; } else { hi = mid; vhi = e; }
+                    if ((bal >> gbit) & 1ull) { lo = probe; vlo = e; have_lo = true; } else { hi = probe; vhi = e; have_hi = true; }
+                    if (have_lo && have_hi) probe = (lo + hi) >> 1;
+                    else if (have_lo) { probe = min(lo + step, hi - 1); step <<= 1; }
+                    else { probe = max(hi - step, lo + 1); step <<= 1; }
                 }
                 if (!have_lo) vlo = group_cdf_entry(mu, rsig, wn, gr, 0);
-                if ((lane & 7) == 0) {
+                if (head) {
                     sh_res[k & 1][gsym][0] = vlo;
                     sh_res[k & 1][gsym][1] = vhi;
-                    if (true) {
-                        const int v = lo - shift;
-                        planes[off + (long)clr * sg.plane] = (int16_t)v;
-                        fplanes[off + (long)clr * sg.plane] = (float)v / 255.0f;
-                    }
+                    const int v = lo - shift;
+                    planes[off + (long)clr * sg.plane] = (int16_t)v;
+                    fplanes[off + (long)clr * sg.plane] = (float)v / 255.0f;
                 }
             }
         }
@@ -1205,13 +1260,18 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
             }
             const bool need = active && x < 0x10000u;
             const uint64_t E = __ballot(need);
+            const uint32_t idx = pos + (uint32_t)lanes_below(E);
+            const uint32_t rel = idx - wbase;                                   // < 128
+            const uint32_t wa = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (int)(rel & 63u), (int)win0);
+            const uint32_t wb = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (int)(rel & 63u), (int)win1);
             if (need) {
-                const uint32_t idx = pos + (uint32_t)lanes_below(E);
-                const uint32_t wv = (idx < max_words) ? words[idx] : 0u;
+                const uint32_t wv = (idx < max_words) ? ((rel < 64u) ? wa : wb) : 0u;
                 x = (x << 16) | wv;
             }
             pos += (uint32_t)__builtin_popcountll(E);
+            if (pos - wbase >= 64u) { wbase += 64u; win0 = win1; win1 = load_words(wbase + 64); }
         }
+        cur = nxt;
     }
     if (wave == 0) {
         rstate[(long)sidx * 64 + lane] = x;
