@@ -119,6 +119,53 @@ def test_cdf_tables_and_pairs_bitexact(torch_mod, codecs, golden_index, oracle_w
                     assert (tab[n, Lp:] == 0xFFFF).all()
 
 
+def test_cdf_table_kernel_adversarial_params(torch_mod, codecs):
+    """Every row of the full-table kernel against the oracle for hand-made CNN outputs: very narrow and very
+    wide components, means far outside / on the edges of the range, saturating weights -- the cases the
+    kernel's constant-fill intervals (entries it does not evaluate) must get exactly right."""
+    from oracle import oracle as orc
+    torch = torch_mod
+    c = codecs("rand1337")
+    H = W = 32
+    rng = np.random.default_rng(7)
+    rgb = make_batch("noise", 1, H, W, seed0=3)
+    planes, fplanes, mm = c.lift(_dev(torch, rgb))
+    p_host, _ = orc.lift(rgb[0])
+    h = w = 16
+    n = h * w
+    par60 = np.zeros((n, 60), np.float32)
+    kinds = rng.integers(0, 6, size=n)
+    for r in range(n):
+        k = kinds[r]
+        sig = {0: rng.uniform(1e-5, 1e-3, 15), 1: rng.uniform(0.003, 0.05, 15), 2: rng.uniform(0.2, 3.0, 15),
+               3: rng.uniform(-1, 1, 15), 4: 10.0 ** rng.uniform(-6, 3, 15), 5: rng.uniform(0.0004, 0.01, 15)}[k]
+        mu = {0: rng.uniform(-1.0, 1.0, 15), 1: rng.uniform(-1.2, 1.2, 15), 2: rng.uniform(-0.5, 0.5, 15),
+              3: rng.uniform(-5, 5, 15), 4: rng.choice([-1.0, -0.5, 0.0, 0.5, 1.0, 127.5 / 255, -127.5 / 255], 15),
+              5: (rng.integers(-255, 256, 15) + rng.choice([0.0, 0.5, -0.5], 15)) / 255.0}[k]
+        wt = {0: rng.uniform(0, 1, 15), 1: rng.uniform(-0.5, 1, 15), 2: 10.0 ** rng.uniform(-8, 2, 15),
+              3: rng.uniform(0, 1, 15), 4: rng.uniform(0, 1, 15), 5: rng.uniform(0, 1, 15)}[k]
+        par60[r, 0:15], par60[r, 15:30], par60[r, 30:45] = sig, mu, wt
+        par60[r, 45:60] = rng.uniform(-1, 1, 15)
+    par64 = np.zeros((1, n, 4, 16), np.float32)
+    par64[0, :, :, :15] = par60.reshape(n, 4, 15)
+    params = _dev(torch, par64.reshape(1, n, 64))
+    for (mnco, mncg, mxco, mxcg) in ((-255, -255, 255, 255), (-3, -40, 5, 61), (0, -1, 0, 0)):
+        mm2 = _dev(torch, np.array([[mnco, mncg, mxco, mxcg]], np.int32))
+        for clr in range(3):
+            minv = -127 if clr == 0 else (mnco, mncg)[clr - 1]
+            maxv = 128 if clr == 0 else (mxco, mxcg)[clr - 1]
+            Lp = maxv - minv + 2
+            for stride in ((264,) if clr == 0 else (512, max(8, (Lp + 7) // 8 * 8))):
+                tab = c.cdf_tables(planes, params, mm2, 0, 0, clr, row_stride=stride)[0].cpu().numpy().view(np.uint16)
+                for r in range(n):
+                    i, j = divmod(r, w)
+                    R, Cc = 2 * i + 1, 2 * j + 1
+                    row = orc.cdf_row(par60[r], clr, np.float32(p_host[0, R, Cc]) / np.float32(255),
+                                      np.float32(p_host[1, R, Cc]) / np.float32(255), minv, maxv)
+                    assert np.array_equal(tab[r, :Lp], row), (clr, r, int(kinds[r]), stride)
+                    assert (tab[r, Lp:] == 0xFFFF).all()
+
+
 def test_ac_seam_matches_oracle(torch_mod, codecs):
     """torchac seam: explicit tables + symbols -> bytes equal to the oracle coder; decode inverts."""
     from oracle import oracle as orc
@@ -284,6 +331,85 @@ def test_large_odd_image_roundtrip(torch_mod, codecs):
     rec = c.decode(cont, seg, rgb.shape[2], rgb.shape[3])
     c.check()
     assert np.array_equal(rec.cpu().numpy(), rgb)
+
+
+def _wild_state_dict(scale, seed):
+    """Seed-1337 architecture with weights blown up: wide, overlapping, far-off-range mixtures (stress for the
+    decoders' search: an approximate hint that is often wrong must still end in the exact symbol)."""
+    sd = {k: np.array(v) for k, v in load_state_dict("rand1337").items()}
+    rng = np.random.default_rng(seed)
+    for k in sd:
+        if k.endswith("layers1toL.2.weight") or k.endswith("layers1toL.2.bias"):
+            sd[k] = (sd[k] * scale + rng.standard_normal(sd[k].shape) * 0.05 * scale).astype(np.float32)
+    return sd
+
+
+@pytest.mark.parametrize("scale,kind", [(6.0, "noise"), (25.0, "smooth"), (120.0, "noise")])
+def test_wild_weights_bitexact_both_containers(torch_mod, scale, kind):
+    from llicti_amd.codec import HipCodec, MODE_RANS, container_to_bytestream_list
+    from llicti_amd.weights import pack_state_dict
+    from oracle import oracle as orc
+    torch = torch_mod
+    sd = _wild_state_dict(scale, int(scale))
+    c = HipCodec("cuda:0")
+    c.load_state_dict(sd)
+    W_o = orc.Weights(pack_state_dict(sd))
+    rgb = make_batch(kind, 2, 48, 80, seed0=int(scale))
+    try:
+        lists, cont, seg = _encode_to_lists(c, torch, rgb)
+        for b in range(2):
+            assert lists[b] == orc.encode_image(rgb[b], W_o), b
+        rec = c.decode(cont, seg, 48, 80)
+        c.check()
+        assert np.array_equal(rec.cpu().numpy(), rgb)
+        cont, seg = c.encode(_dev(torch, rgb), mode=MODE_RANS(4))
+        c.check()
+        seg_h, cont_h = seg.cpu().numpy(), cont.cpu().numpy()
+        for b in range(2):
+            assert container_to_bytestream_list(cont_h[b], seg_h[b]) == orc.encode_image_rans(rgb[b], W_o, 4), b
+        rec = c.decode(cont, seg, 48, 80, mode=MODE_RANS(4))
+        c.check()
+        assert np.array_equal(rec.cpu().numpy(), rgb)
+    finally:
+        c.close()
+
+
+def test_4k_image_roundtrip_rans(torch_mod, codecs):
+    """BASELINE.json configs[3] shape: one 3840x2160 image (level 4 is 68x120 with padH = 1)."""
+    from llicti_amd.codec import MODE_RANS
+    torch = torch_mod
+    c = codecs("trainedlike")
+    rng = np.random.default_rng(99)
+    small = make_batch("smooth", 1, 270, 480, seed0=70)[0]
+    rgb = np.repeat(np.repeat(small, 8, axis=1), 8, axis=2)             # 2160 x 3840, smooth ...
+    rgb = (rgb.astype(np.int16) + rng.integers(-3, 4, size=rgb.shape)).clip(0, 255).astype(np.uint8)[None]   # ... plus fine noise
+    cont, seg = c.encode(_dev(torch, rgb), mode=MODE_RANS(16))
+    c.check()
+    rec = c.decode(cont, seg, 2160, 3840, mode=MODE_RANS(16))
+    c.check()
+    assert np.array_equal(rec.cpu().numpy(), rgb)
+    hdr = cont[0, :17].cpu().numpy()
+    assert hdr[1] == 68 and hdr[2] == 120 and int(hdr[15]) | (int(hdr[16]) << 8) == 2      # pad flags: level 4 rows only
+    bpp = 8.0 * float(seg.sum().item()) / (2160 * 3840)
+    assert 0.5 < bpp < 24.0
+
+
+@pytest.mark.parametrize("H,W", [(8160, 32), (32, 8160), (1055, 2049)])
+def test_extreme_shapes_roundtrip(torch_mod, codecs, H, W):
+    """The format's maximum dimension (h4, w4 are uint8: H, W <= 8160) at minimum width, and an odd mid-size
+    image through the reference (AC) container."""
+    from llicti_amd.codec import MODE_RANS
+    torch = torch_mod
+    c = codecs("trainedlike")
+    rgb = make_batch("smooth", 1, min(H, 1055), min(W, 2049), seed0=71)
+    if rgb.shape[2] != H or rgb.shape[3] != W:
+        rgb = np.ascontiguousarray(np.resize(rgb, (1, 3, H, W)))
+    for mode in ((0, MODE_RANS(2)) if H * W < 3_000_000 else (MODE_RANS(2),)):
+        cont, seg = c.encode(_dev(torch, rgb), mode=mode)
+        c.check()
+        rec = c.decode(cont, seg, H, W, mode=mode)
+        c.check()
+        assert np.array_equal(rec.cpu().numpy(), rgb), (H, W, mode)
 
 
 def test_malformed_container_rejected(torch_mod, codecs):
