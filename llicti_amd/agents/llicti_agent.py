@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 from ..graphs.models.LLICTI_nets import LLICTI
+from ..loggers.rate import RateLogger
 
 
 class CompressionRLossList:
@@ -35,11 +36,11 @@ def _iter_test_images(config, device):
             rgb = np.random.default_rng(i).integers(0, 256, size=(3, H, W), dtype=np.uint8)
             yield torch.from_numpy(rgb.astype(np.float32) / np.float32(255)).unsqueeze(0).to(device)
         return
-    from PIL import Image
-    names = sorted(f for f in os.listdir(src) if f.lower().endswith((".png", ".jpg")))
+    from ..fileio import read_image
+    names = sorted(f for f in os.listdir(src) if f.lower().endswith((".png", ".jpg", ".ppm")))
     for f in names:
-        rgb = np.asarray(Image.open(os.path.join(src, f)).convert("RGB"), dtype=np.uint8).transpose(2, 0, 1)
-        yield torch.from_numpy(np.ascontiguousarray(rgb).astype(np.float32) / np.float32(255)).unsqueeze(0).to(device)
+        rgb = read_image(os.path.join(src, f))
+        yield torch.from_numpy(rgb.astype(np.float32) / np.float32(255)).unsqueeze(0).to(device)
 
 
 class LLICTIAgent:
@@ -55,6 +56,7 @@ class LLICTIAgent:
         assert config.wtr_type in ("lazydwt", "x")
         self.model = LLICTI(config).to(self.device)
         self.compr_loss = CompressionRLossList()
+        self.test_logger = RateLogger()                # llicti_agent.py:40
         self.results = []
         if config.mode in ("test", "validate", "debug", "eval_model"):
             self.load_checkpoint("model_best.pth.tar")
@@ -89,6 +91,7 @@ class LLICTIAgent:
             torch.cuda.synchronize()
             enc_time = time.time() - t0
             rate1_list = self.compr_loss.forward(torch.numel(x), bytestream_list)
+            self.test_logger(rate1_list)               # llicti_agent.py:140
             total = sum(len(s) * 8 for row in bytestream_list for s in row)
             t0 = time.time()
             x_reco = self.model.decompres(bytestream_list, self.device)
@@ -105,6 +108,8 @@ class LLICTIAgent:
                                  "(Check: Decoded img matches original)".format(bpsp, enc_time, dec_time))
             self.results.append({"idx": batch_idx, "H": int(x.shape[2]), "W": int(x.shape[3]), "bpsp": bpsp,
                                  "enc_s": enc_time, "dec_s": dec_time, "max_abs_err": maxx_abserr, "rates": rate1_list})
+        if self.results:
+            self.test_logger.display(lr=0.0, typ="te")     # mean scale x band x channel table (llicti_agent.py:164)
         return self.results
 
     def finalize(self):

@@ -474,3 +474,19 @@ def test_agent_eval_model(torch_mod, caplog):
     assert len(res) == 2 and all(r["max_abs_err"] < 1e-3 for r in res)   # float32 uint8/255 on host vs device division
     assert sum("Check: Decoded img matches original" in r.message for r in caplog.records) == 2
     assert all(len(r["rates"]) == 6 and all(len(row) == 9 for row in r["rates"]) for r in res)
+
+
+def test_cli_file_roundtrip(torch_mod, tmp_path, capsys):
+    """image file -> .llic -> image file through the command-line front end, both containers."""
+    from llicti_amd import cli, fileio
+    rgb = make_image("smooth", 75, 131, 90)
+    src = tmp_path / "in.ppm"
+    fileio.write_image(src, rgb)
+    for container in ("ac", "rans4"):
+        mid, dst = tmp_path / f"x_{container}.llic", tmp_path / f"out_{container}.png"
+        assert cli.main(["encode", str(src), str(mid), "--container", container]) == 0
+        assert cli.main(["info", str(mid)]) == 0
+        assert cli.main(["decode", str(mid), str(dst)]) == 0
+        assert np.array_equal(fileio.read_image(dst), rgb)
+    out = capsys.readouterr().out
+    assert "131x75" in out and "container rans4" in out

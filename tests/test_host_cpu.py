@@ -121,3 +121,65 @@ def test_container_list_roundtrip():
     # header -> image size: h4=3, w4=4, pad flags 0x036A = 874 is the fixture value of a 67x93 image
     assert header_dims(bytes([5, 3, 3]) + bytes(12) + bytes([0x6A, 0x03])) == (67, 93)
     assert header_dims(bytes([5, 16, 24]) + bytes(12) + bytes([0, 0])) == (512, 768)
+
+
+def test_rate_logger_matches_reference_text():
+    """loggers/rate.py:120-168: the table text the reference's own RateLogger printed for this input
+    (tests/golden/rate_table.json, generated by tests/golden/make_fixtures_f.py from the reference module)."""
+    import json
+    import logging
+    from llicti_amd.agents.llicti_agent import CompressionRLossList
+    from llicti_amd.loggers.rate import RateLogger
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "rate_table.json")))
+    bl = [[bytes(n) for n in row] for row in g["stream_lengths"]]
+    rates = CompressionRLossList().forward(g["numel"], bl)               # graphs/losses/rate_dist.py:130-135
+    assert np.allclose(rates, g["rates"], rtol=0, atol=0)
+    lines = []
+
+    class Grab(logging.Handler):
+        def emit(self, record):
+            lines.append(record.getMessage())
+    lg = logging.getLogger("Rate Loss")
+    h = Grab()
+    lg.addHandler(h)
+    lg.setLevel(logging.INFO)
+    try:
+        rl = RateLogger()
+        rl._get_time_now_str = lambda: "12:34:56"
+        rl(rates)
+        rl(g["rates2"])
+        tot, zero = rl.display(typ="te")
+        assert lines[-1] == g["text"]["te"]
+        assert abs(float(tot) - g["display_sum"]) < 1e-12 and zero == 0.0
+        rl(rates)
+        rl.display(lr=0.0001, typ="va")
+        assert lines[-1] == g["text"]["va"]
+        with pytest.raises(AssertionError):
+            rl([[0.0] * 8] * 6)
+            rl.display(typ="te")
+    finally:
+        lg.removeHandler(h)
+
+
+def test_llic_file_and_ppm_roundtrip(tmp_path):
+    from llicti_amd import fileio
+    rng = np.random.default_rng(0)
+    bl = [[bytes([5, 2, 3]), rng.integers(0, 256, 12, dtype=np.uint8).tobytes(), b"\x00\x00", rng.integers(0, 256, 18, dtype=np.uint8).tobytes()] + [b""] * 5]
+    bl += [[rng.integers(0, 256, int(n), dtype=np.uint8).tobytes() for n in rng.integers(0, 300, 9)] for _ in range(5)]
+    p = tmp_path / "a.llic"
+    fileio.write_llic(p, bl)
+    assert fileio.read_llic(p) == bl
+    raw = p.read_bytes()
+    assert raw[:4] == b"LLIC" and raw[5] == 49 and len(raw) == 6 + 4 * 49 + sum(len(s) for r in bl for s in r)
+    for bad in (raw[:-1], b"XLIC" + raw[4:], raw[:4] + b"\x09" + raw[5:], raw + b"\0"):
+        with pytest.raises(ValueError):
+            fileio.loads_llic(bad)
+    with pytest.raises(ValueError):
+        fileio.dumps_llic(bl[:5])
+    rgb = rng.integers(0, 256, (3, 37, 51), dtype=np.uint8)
+    for ext in (".ppm", ".png"):
+        q = tmp_path / ("img" + ext)
+        fileio.write_image(q, rgb)
+        assert np.array_equal(fileio.read_image(q), rgb)
+    (tmp_path / "c.ppm").write_bytes(b"P6\n# a comment\n51 37\n255\n" + rgb.transpose(1, 2, 0).tobytes())
+    assert np.array_equal(fileio.read_image(tmp_path / "c.ppm"), rgb)
