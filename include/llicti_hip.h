@@ -90,6 +90,18 @@ int llicti_unlift_u8(llicti_ctx *ctx, const int16_t *d_planes, int B, int H, int
 int llicti_band_params_f32(llicti_ctx *ctx, const float *d_fplanes, int B, int H, int W, int lvl, int band,
                            float *d_params, void *stream);
 
+/* Training / validation likelihood path (adjacent to the codec, same CNN kernel).
+ * llicti_lift_train_f32: uint8 RGB -> float planes [B][3][H][W] = (Y - 127/255, Co, Cg) of the FLOAT lift with
+ * torch.round (half to even), bit-exact to the reference's elementwise fp32 ops.
+ * Replaces get_YCoCg_R_from_RGB + "x[:,0] -= mean_y_ycocg" (LLICTI_nets.py:40-49, :108-110).
+ * llicti_selfinfo_f32: -log2 of the mixture likelihood of every target pixel of (lvl, band):
+ * d_bits [B][3 (Y, Co, Cg)][h][w]; d_params from llicti_band_params_f32 on the same planes.
+ * Replaces LLICTIEntropyModel4.get_self_infos (LLICTI_nets.py:862-880, :933-935) and
+ * GaussianConditionalLosslessGMM.forward / _likelihood_fk (entropy_layer_nets.py:117-139, :160-183). */
+int llicti_lift_train_f32(llicti_ctx *ctx, const uint8_t *d_rgb, int B, int H, int W, float *d_fplanes, void *stream);
+int llicti_selfinfo_f32(llicti_ctx *ctx, const float *d_fplanes, const float *d_params, int B, int H, int W,
+                        int lvl, int band, float *d_bits, void *stream);
+
 /* K6-K8 (full table): integer CDF rows of stream (lvl, band, clr) for every coded position:
  * d_tables [B][hc*wc][row_stride] uint16, row_stride >= Lp (entries beyond Lp are 0xFFFF).
  * Replaces the cross-channel mean update + LLICTIEntropyModel4.get_cdfs(int_cdf=True)

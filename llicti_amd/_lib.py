@@ -50,6 +50,8 @@ _SIGS = {
     "llicti_lift_u8": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "llicti_unlift_u8": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "llicti_band_params_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "llicti_lift_train_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "llicti_selfinfo_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "llicti_cdf_u16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "llicti_cdf_pairs_u32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "llicti_ac_encode_u16cdf": (_i, [_vp, _vp, _i, _i, _vp, _i, _l, _vp, _l, _vp, _vp]),

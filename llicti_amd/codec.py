@@ -108,6 +108,31 @@ class HipCodec:
         _lib.check(self.L.llicti_band_params_f32(self.ctx, _ptr(fplanes), B, H, W, lvl, band, _ptr(out), _stream_ptr(self.device)))
         return out.view(B, h, w, 64)           # 4 heads x 16 (15 used); params60() gives the reference's 60 channels
 
+    def lift_train(self, rgb):
+        """uint8 [B,3,H,W] -> float32 [B,3,H,W] planes of the training path's float lift (Y - 127/255, Co, Cg)."""
+        B, _, H, W = rgb.shape
+        fplanes = torch.empty((B, 3, H, W), dtype=torch.float32, device=self.device)
+        _lib.check(self.L.llicti_lift_train_f32(self.ctx, _ptr(rgb), B, H, W, _ptr(fplanes), _stream_ptr(self.device)))
+        return fplanes
+
+    def selfinfo(self, fplanes, params, lvl, band):
+        """-> float32 [B, 3, h, w]: -log2 pmf (bits) of the band's Y, Co, Cg targets."""
+        B, _, H, W = fplanes.shape
+        _, _, h, w, _, _, _, _ = _lib.level_geom(H, W, lvl, band)
+        out = torch.empty((B, 3, h, w), dtype=torch.float32, device=self.device)
+        _lib.check(self.L.llicti_selfinfo_f32(self.ctx, _ptr(fplanes), _ptr(params), B, H, W, lvl, band, _ptr(out),
+                                              _stream_ptr(self.device)))
+        return out
+
+    def forward_selfinfo(self, rgb):
+        """LLICTI.forward: list of 5 tensors [B, 9, h, w] (scale 0 first; channel 3*band + colour)."""
+        fplanes = self.lift_train(rgb)
+        res = []
+        for lvl in range(5):
+            bands = [self.selfinfo(fplanes, self.band_params(fplanes, lvl, b).reshape(rgb.shape[0], -1, 64), lvl, b) for b in range(3)]
+            res.append(torch.cat(bands, dim=1))
+        return res
+
     @staticmethod
     def params60(p64):
         """[.., 64] device layout -> [.., 60] in the reference's channel order (LLICTI_nets.py:381-387)."""

@@ -196,6 +196,72 @@ __global__ __launch_bounds__(256) void unlift_kernel(const int16_t *__restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------ likelihood path
+// LLICTI.forward (LLICTI_nets.py:101-123): the float lift of the training path -- elementwise IEEE fp32 with
+// torch.round (half to even) on Co * 255 / 2 (:40-49), then Y - 127/255 (:110) -- and, per band, the mixture
+// likelihood of every target pixel (get_self_infos :862-880, :933-935; GaussianConditionalLosslessGMM.forward,
+// entropy_layer_nets.py:160-183; _likelihood_fk :117-139) as -log2.
+__global__ __launch_bounds__(256) void lift_train_kernel(const uint8_t *__restrict__ rgb, long plane, float *__restrict__ fplanes)
+{
+    const int b = blockIdx.y;
+    const uint8_t *src = rgb + (long)b * 3 * plane;
+    float *dst = fplanes + (long)b * 3 * plane;
+    const float meanY = (float)(127.0 / 255.0);
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < plane; p += (long)gridDim.x * blockDim.x) {
+        const float R = (float)src[p] / 255.0f, G = (float)src[plane + p] / 255.0f, Bl = (float)src[2 * plane + p] / 255.0f;
+        const float Co = R - Bl;
+        const float t = Bl + __builtin_rintf(Co * 255.0f / 2.0f) / 255.0f;
+        const float Cg = G - t;
+        const float Y = t + __builtin_rintf(Cg * 255.0f / 2.0f) / 255.0f;
+        dst[p] = Y - meanY;
+        dst[plane + p] = Co;
+        dst[2 * plane + p] = Cg;
+    }
+}
+
+struct SelfGeom { int B, H, W, lvl, h, w, oi, oj, Hl, Wl; long plane; };
+
+// thread per band-grid position: out [B][3][h][w] (Y, Co, Cg) in bits
+__global__ __launch_bounds__(256) void selfinfo_kernel(const float *__restrict__ fplanes, const float *__restrict__ params, SelfGeom s,
+                                                       float *__restrict__ out)
+{
+    const int b = blockIdx.y;
+    const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= (long)s.h * s.w) return;
+    const int i = (int)(n / s.w), j = (int)(n - (long)i * s.w);
+    const float *par = params + ((long)b * s.h * s.w + n) * LLICTI_PARAM_STRIDE;
+    int rr = 2 * i + s.oi, cc = 2 * j + s.oj;
+    if (rr >= s.Hl) rr -= 2;                       // lazyDWT's replicate pad of the odd edge (pad=True geometry)
+    if (cc >= s.Wl) cc -= 2;
+    const long off = (long)b * 3 * s.plane + ((long)rr << s.lvl) * s.W + ((long)cc << s.lvl);
+    float v[3];
+    v[0] = fplanes[off]; v[1] = fplanes[off + s.plane]; v[2] = fplanes[off + 2 * s.plane];
+    const float half = (float)(0.5 / 255.0);
+#pragma unroll
+    for (int clr = 0; clr < 3; ++clr) {
+        float wv[5], lik[5], wsum = 0.0f;
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+            float sg = par[5 * clr + m], mu = par[16 + 5 * clr + m];
+            if (clr == 1) { const float t = par[48 + m] * v[0]; mu = mu + t; }
+            else if (clr == 2) { const float t1 = par[48 + 5 + m] * v[0]; const float t2 = par[48 + 10 + m] * v[1]; const float t = t1 + t2; mu = mu + t; }
+            sg = (sg > kScaleBound) ? sg : kScaleBound;
+            const float d = __builtin_fabsf(v[clr] - mu);
+            const float up = 0.5f * erfc_spec(kNegRsqrt2 * ((half - d) / sg));
+            const float lo = 0.5f * erfc_spec(kNegRsqrt2 * ((-half - d) / sg));
+            lik[m] = up - lo;
+            const float wk = par[32 + 5 * clr + m];
+            wv[m] = (wk > kWeightBound) ? wk : kWeightBound;
+            wsum = (m == 0) ? wv[m] : wsum + wv[m];
+        }
+        float L = 0.0f;
+#pragma unroll
+        for (int m = 0; m < 5; ++m) { const float t = (wv[m] / wsum) * lik[m]; L = (m == 0) ? t : L + t; }
+        if (!(L > 1e-9f)) L = 1e-9f;               // likelihood_lower_bound
+        out[(((long)b * 3 + clr) * s.h + i) * s.w + j] = -__builtin_log2f(L);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ band CNN
 // Layer-0 convolutions of band b (LLICTI_nets.py:651-675): source sub-band, kernel size, top / left pad.
 struct ConvDef { int src, kh, kw, pt, pl; };
@@ -1734,6 +1800,33 @@ extern "C" int llicti_band_params_f32(llicti_ctx *c, const float *d_fplanes, int
     if (lvl < 0 || lvl >= LLICTI_NLEVELS || band < 0 || band > 2) return fail(LLICTI_EINVAL, "band_params: bad level/band");
     Geom g = make_geom(B, H, W, lvl);
     return launch_band_params(c, d_fplanes, g, band, d_params, (hipStream_t)stream);
+}
+
+extern "C" int llicti_lift_train_f32(llicti_ctx *c, const uint8_t *d_rgb, int B, int H, int W, float *d_fplanes, void *stream)
+{
+    if (!c || !d_rgb || !d_fplanes) return fail(LLICTI_EINVAL, "lift_train: null pointer");
+    if (check_dims(B, H, W)) return LLICTI_EINVAL;
+    const long plane = (long)H * W;
+    const int gx = (int)std::min<long>((plane + 255) / 256, 2048);
+    lift_train_kernel<<<dim3(gx, B), 256, 0, (hipStream_t)stream>>>(d_rgb, plane, d_fplanes);
+    HIPCHK(hipGetLastError());
+    return LLICTI_OK;
+}
+
+extern "C" int llicti_selfinfo_f32(llicti_ctx *c, const float *d_fplanes, const float *d_params, int B, int H, int W,
+                                   int lvl, int band, float *d_bits, void *stream)
+{
+    if (!c || !d_fplanes || !d_params || !d_bits) return fail(LLICTI_EINVAL, "selfinfo: null pointer");
+    if (check_dims(B, H, W)) return LLICTI_EINVAL;
+    if (lvl < 0 || lvl >= LLICTI_NLEVELS || band < 0 || band > 2) return fail(LLICTI_EINVAL, "selfinfo: bad level/band");
+    Geom g = make_geom(B, H, W, lvl);
+    StageGeom sg = make_stage(g, band);
+    SelfGeom s;
+    s.B = B; s.H = H; s.W = W; s.lvl = lvl; s.h = g.h; s.w = g.w; s.oi = sg.oi; s.oj = sg.oj; s.Hl = g.Hl; s.Wl = g.Wl; s.plane = g.plane;
+    const long n = (long)g.h * g.w;
+    selfinfo_kernel<<<dim3((unsigned)((n + 255) / 256), B), 256, 0, (hipStream_t)stream>>>(d_fplanes, d_params, s, d_bits);
+    HIPCHK(hipGetLastError());
+    return LLICTI_OK;
 }
 
 static int launch_cdf_pairs(const int16_t *planes, const float *params, const int32_t *mm, const Geom &g, int band,

@@ -124,9 +124,18 @@ class LLICTI(nn.Module):
             self._weights_version = key
         return self._codec
 
+    @torch.no_grad()
     def forward(self, x):
-        raise NotImplementedError("LLICTI.forward (training likelihood, LLICTI_nets.py:101-123) is outside the encode/decode "
-                                  "hot path this package accelerates (SURVEY.md section 8f)")
+        """Validation likelihood (LLICTI_nets.py:101-123): x float32 [B,3,H,W] in {k/255} (or uint8), H and W
+        multiples of 32 (lazyDWT(pad=False) needs equal sub-band sizes; the reference's validate() pads first,
+        llicti_agent.py:105-113) -> list of 5 tensors [B, 9, h, w] of -log2 pmf in bits, scale 0 first,
+        channel = 3 * band + colour.  Inference only: the kernels do not produce gradients (training stays
+        outside this package)."""
+        assert x.dim() == 4 and x.shape[1] == 3
+        if x.shape[2] % 32 or x.shape[3] % 32:
+            raise ValueError("forward() needs H and W to be multiples of 32 (pad first, as llicti_agent.py:105-113 does)")
+        codec = self.codec(x.device if x.is_cuda else None)
+        return codec.forward_selfinfo(self._to_u8(x).to(codec.device).contiguous())
 
     @staticmethod
     def _to_u8(x):

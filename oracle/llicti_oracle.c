@@ -263,8 +263,22 @@ static int build_taps(int band, tap_t *taps)
 }
 
 /* ------------------------------------------------------------------ interpolator CNN */
-void orc_band_params(const int16_t *planes, int H, int W, int lvl, int band,
-                     const orc_band_weights *bw, float *out)
+static inline float band_pxf(const float *plane, int W, int lvl, int Hl, int Wl, int h, int w, int src, int i, int j)
+{
+    if (i < 0) i = 0;
+    if (i > h - 1) i = h - 1;
+    if (j < 0) j = 0;
+    if (j > w - 1) j = w - 1;
+    int r = 2 * i + BAND_OI[src];
+    int c = 2 * j + BAND_OJ[src];
+    if (r >= Hl) r -= 2;
+    if (c >= Wl) c -= 2;
+    return plane[((long)r << lvl) * W + ((long)c << lvl)];
+}
+
+/* fplanes: float [3][H][W] (codec path: int16 / 255; training path: the float lift) */
+void orc_band_params_f(const float *fplanes, int H, int W, int lvl, int band,
+                       const orc_band_weights *bw, float *out)
 {
     int Hl, Wl, h, w, padH, padW;
     orc_level_geom(H, W, lvl, &Hl, &Wl, &h, &w, &padH, &padW);
@@ -292,9 +306,8 @@ void orc_band_params(const int16_t *planes, int H, int W, int lvl, int band,
         float x[120];
         float h0[ORC_NCH], h1[ORC_NCH], o2[64];
         for (int k = 0; k < K0; ++k) {
-            int v = band_px(planes + taps[k].ci * plane_sz, H, W, lvl, Hl, Wl, h, w,
+            x[k] = band_pxf(fplanes + taps[k].ci * plane_sz, W, lvl, Hl, Wl, h, w,
                             taps[k].src, i + taps[k].dy, j + taps[k].dx);
-            x[k] = (float)v / 255.0f;
         }
         for (int c = 0; c < ORC_NCH; ++c) h0[c] = bw->b0[c];
         for (int k = 0; k < K0; ++k) {
@@ -326,6 +339,76 @@ void orc_band_params(const int16_t *planes, int H, int W, int lvl, int band,
             for (int o = 0; o < 15; ++o) dst[g * 15 + o] = o2[g * 16 + o];
     }
     free(w0t); free(w1t); free(w2t);
+}
+
+void orc_band_params(const int16_t *planes, int H, int W, int lvl, int band,
+                     const orc_band_weights *bw, float *out)
+{
+    const long n = 3L * H * W;
+    float *fp = (float *)malloc(sizeof(float) * n);
+    for (long k = 0; k < n; ++k) fp[k] = (float)planes[k] / 255.0f;     /* LLICTI_nets.py:143-144, :563-565 */
+    orc_band_params_f(fp, H, W, lvl, band, bw, out);
+    free(fp);
+}
+
+/* ------------------------------------------------------------------ training / validation likelihood path
+ * LLICTI.forward (LLICTI_nets.py:101-123): float lift with torch.round (half to even) on fp32 values
+ * (:40-49), Y - 127/255 (:110), lazyDWT(pad=False) (:182-245), per band get_params + get_self_infos
+ * (:802-811, :862-880, :933-935) -> GaussianConditionalLosslessGMM.forward (entropy_layer_nets.py:160-183)
+ * with _likelihood_fk (:117-139).  Every step is an elementwise IEEE fp32 operation in the reference, restated
+ * in the same order; the mixture sum runs m = 0..4. */
+void orc_lift_train(const uint8_t *rgb, int H, int W, float *fplanes)
+{
+    const long n = (long)H * W;
+    const float meanY = (float)(127.0 / 255.0);
+    for (long p = 0; p < n; ++p) {
+        const float R = (float)rgb[p] / 255.0f, G = (float)rgb[n + p] / 255.0f, B = (float)rgb[2 * n + p] / 255.0f;
+        const float Co = R - B;
+        const float t = B + rintf(Co * 255.0f / 2.0f) / 255.0f;
+        const float Cg = G - t;
+        const float Y = t + rintf(Cg * 255.0f / 2.0f) / 255.0f;
+        fplanes[p] = Y - meanY;
+        fplanes[n + p] = Co;
+        fplanes[2 * n + p] = Cg;
+    }
+}
+
+/* out: [3 (Y, Co, Cg)][h][w] self-information in bits of band `band` of level `lvl`; params: [h*w][60] */
+void orc_selfinfo(const float *fplanes, int H, int W, int lvl, int band, const float *params, float *out)
+{
+    int Hl, Wl, h, w, padH, padW;
+    orc_level_geom(H, W, lvl, &Hl, &Wl, &h, &w, &padH, &padW);
+    const long plane_sz = (long)H * W;
+    const int oi = BAND_OI[band + 1], oj = BAND_OJ[band + 1];
+    const float half = (float)(0.5 / 255.0);
+    const float kneg = (float)(-0.70710678118654752440);
+    const float sbound = (float)(0.11 / 255.0);
+    for (int i = 0; i < h; ++i)
+        for (int j = 0; j < w; ++j) {
+            const float *par = params + ((long)i * w + j) * ORC_NPAR;
+            float v[3];
+            for (int c = 0; c < 3; ++c) v[c] = band_pxf(fplanes + c * plane_sz, W, lvl, Hl, Wl, h, w, band + 1, i, j);
+            for (int clr = 0; clr < 3; ++clr) {
+                float wv[5], lik[5], wsum = 0.0f;
+                for (int m = 0; m < 5; ++m) {
+                    float sg = par[5 * clr + m], mu = par[15 + 5 * clr + m];
+                    if (clr == 1) { const float t = par[45 + m] * v[0]; mu = mu + t; }
+                    else if (clr == 2) { const float t1 = par[50 + m] * v[0]; const float t2 = par[55 + m] * v[1]; const float t = t1 + t2; mu = mu + t; }
+                    sg = (sg > sbound) ? sg : sbound;
+                    const float d = fabsf(v[clr] - mu);
+                    const float up = 0.5f * erfc_spec(kneg * ((half - d) / sg));
+                    const float lo = 0.5f * erfc_spec(kneg * ((-half - d) / sg));
+                    lik[m] = up - lo;
+                    const float wk = par[30 + 5 * clr + m];
+                    wv[m] = (wk > 1e-6f) ? wk : 1e-6f;
+                    wsum = (m == 0) ? wv[m] : wsum + wv[m];
+                }
+                float L = 0.0f;
+                for (int m = 0; m < 5; ++m) { const float t = (wv[m] / wsum) * lik[m]; L = (m == 0) ? t : L + t; }
+                if (!(L > 1e-9f)) L = 1e-9f;                   /* likelihood_lower_bound */
+                out[((long)clr * h + i) * w + j] = -log2f(L);
+            }
+        }
 }
 
 /* ------------------------------------------------------------------ arithmetic coder (torchac 0.9.3 algorithm) */

@@ -68,6 +68,13 @@ void orc_level_geom(int H, int W, int lvl, int *Hl, int *Wl, int *h, int *w, int
 /* ---- interpolator CNN for one (level, band): out[i*w + j][60] on the full (padded) h x w grid ---- */
 void orc_band_params(const int16_t *planes, int H, int W, int lvl, int band,
                      const orc_band_weights *bw, float *out);
+/* same network on float planes [3][H][W] */
+void orc_band_params_f(const float *fplanes, int H, int W, int lvl, int band,
+                       const orc_band_weights *bw, float *out);
+
+/* training / validation likelihood path (LLICTI.forward, LLICTI_nets.py:101-123; entropy_layer_nets.py:117-183) */
+void orc_lift_train(const uint8_t *rgb, int H, int W, float *fplanes);
+void orc_selfinfo(const float *fplanes, int H, int W, int lvl, int band, const float *params, float *out);
 
 /* ---- one row of the integer CDF table (LLICTI_nets.py:938-983 + entropy_layer_nets.py:185-204) ----
  * par: the 60 raw CNN outputs of the position; yv/cov: the band's own Y / Co pixel as int/255

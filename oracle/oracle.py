@@ -116,6 +116,44 @@ def band_params(planes, lvl, band, weights: Weights):
     return out
 
 
+def lift_train(rgb):
+    """uint8 [3,H,W] -> float32 [3,H,W]: (Y - 127/255, Co, Cg) of the training path's float lift."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    _, H, W = rgb.shape
+    out = np.empty((3, H, W), np.float32)
+    lib().orc_lift_train(_p(rgb), H, W, _p(out))
+    return out
+
+
+def band_params_f(fplanes, lvl, band, weights: "Weights"):
+    fplanes = np.ascontiguousarray(fplanes, dtype=np.float32)
+    _, H, W = fplanes.shape
+    _, _, h, w, _, _ = level_geom(H, W, lvl)
+    out = np.empty((h, w, 60), np.float32)
+    lib().orc_band_params_f(_p(fplanes), H, W, lvl, band, weights.band_ptr(band), _p(out))
+    return out
+
+
+def selfinfo(fplanes, lvl, band, params):
+    """-> float32 [3, h, w]: -log2 pmf of the band's Y, Co, Cg targets (reference get_self_infos)."""
+    fplanes = np.ascontiguousarray(fplanes, dtype=np.float32)
+    params = np.ascontiguousarray(params, dtype=np.float32)
+    _, H, W = fplanes.shape
+    _, _, h, w, _, _ = level_geom(H, W, lvl)
+    out = np.empty((3, h, w), np.float32)
+    lib().orc_selfinfo(_p(fplanes), H, W, lvl, band, _p(params), _p(out))
+    return out
+
+
+def forward(rgb, weights: "Weights"):
+    """LLICTI.forward on one uint8 image (H, W multiples of 32): list of 5 arrays [9, h, w], scale 0 first."""
+    fp = lift_train(rgb)
+    res = []
+    for lvl in range(5):
+        res.append(np.concatenate([selfinfo(fp, lvl, b, band_params_f(fp, lvl, b, weights)) for b in range(3)]))
+    return res
+
+
 def cdf_row(par, clr, yv, cov, minv, maxv):
     par = np.ascontiguousarray(par, dtype=np.float32)
     row = np.empty(maxv - minv + 2, np.uint16)

@@ -150,3 +150,27 @@ def test_rans_container_oracle_roundtrip(M, oracle_weights):
     n_ac = sum(len(x) for row in orc.encode_image(c["rgb"], W) for x in row)
     n_r = sum(len(x) for row in bl for x in row)
     assert -64 <= n_r - n_ac <= 260 * M + 64
+
+
+@pytest.mark.parametrize("case,wname", [("fwd_smooth_64x96_tl", "trainedlike"), ("fwd_noise_32x64_rand", "rand1337")])
+def test_forward_selfinfo_vs_reference(case, wname, oracle_weights):
+    """Training / validation likelihood path against the reference's LLICTI.forward output
+    (tests/golden/fwd_*.npz, generated by make_fixtures_f.py): the float lift is elementwise IEEE fp32 and must
+    be bit-exact; self-information within 1e-3 bits + 1e-4 relative (fp32 erfc / log2 of a different library)."""
+    from oracle import oracle as orc
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, f"{case}.npz"))
+    rgb = g["rgb"]
+    fp = orc.lift_train(rgb)
+    ref = g["ycocg_train_f32"].copy()
+    ref[0] = ref[0] - np.float32(127.0 / 255.0)
+    assert np.array_equal(fp, ref)
+    infos = orc.forward(rgb, oracle_weights(wname))
+    tot = 0.0
+    for s in range(5):
+        r = g[f"selfinfo_s{s}"]
+        assert infos[s].shape == r.shape
+        assert np.allclose(infos[s], r, rtol=1e-4, atol=1e-3), (s, float(np.abs(infos[s] - r).max()))
+        tot += float(infos[s].astype(np.float64).sum())
+    assert abs(tot - float(g["total_bits"][0])) < 1e-5 * float(g["total_bits"][0])
