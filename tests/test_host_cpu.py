@@ -183,3 +183,23 @@ def test_llic_file_and_ppm_roundtrip(tmp_path):
         assert np.array_equal(fileio.read_image(q), rgb)
     (tmp_path / "c.ppm").write_bytes(b"P6\n# a comment\n51 37\n255\n" + rgb.transpose(1, 2, 0).tobytes())
     assert np.array_equal(fileio.read_image(tmp_path / "c.ppm"), rgb)
+
+
+def test_div255_shortcut_is_exact():
+    """numerics.hpp::div255_exact -- q = x * RN(1/255); r = fma(-q, 255, x); q' = fma(r, RN(1/255), q) -- equals the
+    correctly rounded x / 255 for every half-integer |x| <= 350 (all regular sample points of any table), so the
+    kernels' three-operation form and the oracle's IEEE division define the same grid.  Exact rational arithmetic."""
+    from fractions import Fraction as Fr
+
+    def rn(fr):                                    # round a rational to the nearest float32, ties to even
+        c = np.float32(float(fr))
+        cand = [c, np.nextafter(c, np.float32(np.inf)), np.nextafter(c, np.float32(-np.inf))]
+        return min(cand, key=lambda v: (abs(Fr(float(v)) - fr), int(np.float32(v).view(np.uint32)) & 1))
+    r255 = rn(Fr(1, 255))
+    assert float(r255).hex() == "0x1.0101020000000p-8"          # the constant in numerics.hpp
+    for k in range(-700, 701):
+        x = Fr(k, 2)
+        q = rn(x * Fr(float(r255)))
+        rem = rn(x - Fr(float(q)) * 255)
+        q2 = rn(Fr(float(q)) + Fr(float(rem)) * Fr(float(r255)))
+        assert q2 == rn(x / 255), k
