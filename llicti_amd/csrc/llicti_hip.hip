@@ -1159,43 +1159,50 @@ __global__ __launch_bounds__(64) void rans_init_kernel(const uint8_t *__restrict
     if (lane == 0) rpos[sidx] = 0;
 }
 
-// One stage (level, band, colour channel) of all images.  One workgroup of 6 wavefronts per stream.  Every
-// wave keeps its own copy of the 64 rANS states (the update is cheap and identical in all of them), so a
-// step needs ONE barrier.  A wave resolves 12 of the step's 64 symbols, 5 lanes per symbol (three groups per
-// 16-lane DPP row, lane 15 idle): lane m of a group evaluates mixture component m of the probed table entry,
-// the five terms are summed in the spec's order over DPP row shifts, and a ballot hands the comparison to the
+// One stage (level, band, colour channel) of all images.  One workgroup of 4 wavefronts per stream (one per
+// SIMD: with the stage VALU-issue bound, the busiest SIMD sets the pace, so waves per workgroup is a multiple
+// of 4).  Every wave keeps its own copy of the 64 rANS states (the update is cheap and identical in all of
+// them), so a step needs ONE barrier.  A wave resolves 16 of the step's 64 symbols, 4 lanes per symbol: lanes
+// 0..2 of a group evaluate mixture components 0..2 of the probed table entry, lane 3 components 3 and 4; the
+// five terms are summed in the spec's order over DPP row shifts, and a ballot hands the comparison to the
 // group's lanes.  The symbol is first located with a CHEAP approximate CDF (Abramowitz-Stegun 7.1.26 erfc on
 // v_rcp / v_exp, ~0.01 table counts of error) by bisection, then PROVEN with the exact spec arithmetic:
 // entry[s] <= slot < entry[s+1] is checked with cdf_entry()'s operations, and if the guess is off the exact
 // search gallops away from it and bisects -- so the result is bit-identical to an exact search whatever the
 // approximation does.  The 64 (c_low, c_high) pairs meet in a ping-pong LDS buffer, after which every wave
 // updates and renormalises its state copy.  No table in HBM.
-constexpr int kRansWaves = 6;
+constexpr int kRansWaves = 4;
 
-__device__ __forceinline__ float dpp_sum5(float t)      // (((t0 + t1) + t2) + t3) + t4 of lanes l .. l+4, in lane l
+// (((tA0 + tA1) + tA2) + tA3) + tB3 of the 4-lane group starting at this lane (meaningful in the group's first lane)
+__device__ __forceinline__ float dpp_sum5(float tA, float tB)
 {
-    float acc = t + dpp_row_shl(t, 1);
-    acc = acc + dpp_row_shl(t, 2);
-    acc = acc + dpp_row_shl(t, 3);
-    acc = acc + dpp_row_shl(t, 4);
+    float acc = tA + dpp_row_shl(tA, 1);
+    acc = acc + dpp_row_shl(tA, 2);
+    acc = acc + dpp_row_shl(tA, 3);
+    acc = acc + dpp_row_shl(tB, 3);
     return acc;
 }
+__device__ __forceinline__ float quad_lane0(float v)    // broadcast lane (l & ~3) to its quad
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x00, 0xF, 0xF, true));   // quad_perm [0,0,0,0]
+}
 
-// exact table entry i (numerics spec); valid in the group's first lane
-__device__ __forceinline__ uint32_t group_cdf_entry(float mu, float rsig, float wn, const Grid &g, int i)
+struct Comp { float mu, rsig, wn; };
+
+// exact table entry i (numerics spec); valid in the group's first lane.  erfc_spec_nobranch returns the same
+// bits as erfc_spec (the saturation test selects the result instead of skipping the polynomial), which lets
+// the two components' dependent chains interleave.
+__device__ __forceinline__ uint32_t group_cdf_entry(const Comp &A, const Comp &B, const Grid &g, int i)
 {
     const float pt = sample_pt(g, i);
-    const float z = (pt - mu) * rsig;
-    const float t = wn * (0.5f * erfc_spec(kNegRsqrt2 * z));
-    const float q = __builtin_rintf(dpp_sum5(t) * g.scale);
+    const float tA = A.wn * (0.5f * erfc_spec_nobranch(kNegRsqrt2 * ((pt - A.mu) * A.rsig)));
+    const float tB = B.wn * (0.5f * erfc_spec_nobranch(kNegRsqrt2 * ((pt - B.mu) * B.rsig)));
+    const float q = __builtin_rintf(dpp_sum5(tA, tB) * g.scale);
     return (uint32_t)((int)q + i) & 0xFFFFu;
 }
 
-// approximate table entry i, 0 < i < Lp - 1 (search hint only -- never used as a result)
-__device__ __forceinline__ int group_cdf_entry_fast(float mu, float rsig, float wn, float fbase, float scale, int i)
+__device__ __forceinline__ float erfc_fast(float x)     // Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7
 {
-    const float pt = div255_exact(fbase + (float)i);     // the exact sample point: near a narrow component the CDF moves by counts per ulp of pt
-    const float x = kNegRsqrt2 * ((pt - mu) * rsig);
     const float a = __builtin_fabsf(x);
     const float u = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, a, 1.0f));
     float p = __builtin_fmaf(1.061405429f, u, -1.453152027f);
@@ -1203,12 +1210,20 @@ __device__ __forceinline__ int group_cdf_entry_fast(float mu, float rsig, float 
     p = __builtin_fmaf(p, u, -0.284496736f);
     p = __builtin_fmaf(p, u, 0.254829592f);
     const float E = (p * u) * __builtin_amdgcn_exp2f((a * a) * -1.4426950409f);
-    const float er = (x < 0.0f) ? 2.0f - E : E;
-    const float t = wn * (0.5f * er);
-    return (int)__builtin_rintf(dpp_sum5(t) * scale) + i;
+    return (x < 0.0f) ? 2.0f - E : E;
 }
 
-__global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(const float *__restrict__ params, StageGeom sg, int clr, int M,
+// approximate table entry i, 0 < i < Lp - 1 (search hint only -- never used as a result)
+__device__ __forceinline__ int group_cdf_entry_fast(const Comp &A, const Comp &B, float fbase, float scale, int i)
+{
+    const float pt = div255_exact(fbase + (float)i);     // the exact sample point: near a narrow component the CDF moves by counts per ulp of pt
+    const float tA = A.wn * (0.5f * erfc_fast(kNegRsqrt2 * ((pt - A.mu) * A.rsig)));
+    const float tB = B.wn * (0.5f * erfc_fast(kNegRsqrt2 * ((pt - B.mu) * B.rsig)));
+    return (int)__builtin_rintf(dpp_sum5(tA, tB) * scale) + i;
+}
+
+template <int CLR>
+__global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(const float *__restrict__ params, StageGeom sg, int M,
                                                                const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
                                                                int rslot_cap, uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos,
                                                                int16_t *__restrict__ planes, float *__restrict__ fplanes,
@@ -1224,34 +1239,47 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
     uint32_t x = rstate[(long)sidx * 64 + lane], pos = rpos[sidx];      // every wave: its own copy
     const uint16_t *words = reinterpret_cast<const uint16_t *>(slots + rslot_off[sidx] + 256);
     const uint32_t max_words = (uint32_t)((rslot_cap - 256) / 2);
+    constexpr int clr = CLR;                     // compile-time: no branch (hence no register merge, hence no s_waitcnt vmcnt(0)) next to the prefetch loads
     int minv, maxv, shift;
     clr_range(minmax + 4 * b, clr, minv, maxv, shift);
     const Grid gr = make_grid(minv, maxv);
     const int max_symbol = gr.Lp - 2;
     const float fbase = (float)minv - 0.5f;
     const long img = (long)b * 3 * sg.plane;
-    const int l16 = lane & 15, g3 = min(l16 / 5, 2);                    // lane 15 shadows the last lane of group 2 (its values are never read)
-    const int mi = min(l16 - 5 * g3, 4);                                // mixture component of this lane
-    const int gsym = 12 * wave + 3 * (lane >> 4) + g3;                  // symbol (lane of the stream) this group resolves
-    const int gbit = (lane & 48) + 5 * g3;                              // ballot bit of the group's first lane
-    const bool head = (l16 == 5 * g3);
+    const int mA = lane & 3;                                            // component A of this lane; component B is 4 (read from lane 3 only)
+    const int gsym = 16 * wave + (lane >> 2);                           // symbol (lane of the stream) this 4-lane group resolves
+    const int gbit = lane & ~3;                                         // ballot bit of the group's first lane
+    const bool head = (mA == 0);
     // Raw CNN outputs / prior-channel pixels of this group's symbol in step k: requested one step ahead, so the
     // memory round trip runs under the previous step's search instead of in front of this one's.
-    struct Raw { float sgm, mu, wk, a0, a1, y, co; long off; bool on; };
+    struct Raw { float sgA, muA, wkA, a0A, a1A, sgB, muB, wkB, a0B, a1B, y, co; long off; bool on; };
     auto fetch = [&](int k) -> Raw {
         Raw r;
         const int n = min(64 * (m + k * M) + gsym, nc - 1);          // clamped: the loads are unconditional
         const int i = n / sg.wc, j = n - i * sg.wc;
         const float *par = params + ((long)b * sg.h * sg.w + (long)i * sg.w + j) * LLICTI_PARAM_STRIDE;
         r.off = img + ((long)(2 * i + sg.oi) << sg.lvl) * sg.W + ((long)(2 * j + sg.oj) << sg.lvl);
-        r.sgm = par[5 * clr + mi];
-        r.mu = par[16 + 5 * clr + mi];
-        r.wk = par[32 + 5 * clr + mi];
-        r.a0 = r.a1 = r.y = r.co = 0.0f;
-        if (clr == 1) { r.a0 = par[48 + mi]; r.y = fplanes[r.off]; }
-        else if (clr == 2) { r.a0 = par[48 + 5 + mi]; r.a1 = par[48 + 10 + mi]; r.y = fplanes[r.off]; r.co = fplanes[r.off + sg.plane]; }
-        r.on = (k < K) && gsym < 64 && (64 * (m + k * M) + gsym) < nc;
+        r.sgA = par[5 * clr + mA]; r.muA = par[16 + 5 * clr + mA]; r.wkA = par[32 + 5 * clr + mA];
+        r.sgB = par[5 * clr + 4];  r.muB = par[16 + 5 * clr + 4];  r.wkB = par[32 + 5 * clr + 4];
+        r.a0A = r.a1A = r.a0B = r.a1B = r.y = r.co = 0.0f;
+        if constexpr (clr == 1) { r.a0A = par[48 + mA]; r.a0B = par[48 + 4]; r.y = fplanes[r.off]; }
+        else if constexpr (clr == 2) {
+            r.a0A = par[48 + 5 + mA]; r.a1A = par[48 + 10 + mA]; r.a0B = par[48 + 5 + 4]; r.a1B = par[48 + 10 + 4];
+            r.y = fplanes[r.off]; r.co = fplanes[r.off + sg.plane];
+        }
+        r.on = (k < K) && (64 * (m + k * M) + gsym) < nc;
         return r;
+    };
+    // component (sigma, mu, w) -> (mu with the cross-channel update, 1 / max(sigma, bound), max(w, bound)), as mix_prepare()
+    auto prep = [&](float sgm, float mu, float wk, float a0, float a1, float y, float co, float &w) -> Comp {
+        Comp cpt;
+        if constexpr (clr == 1) { const float t = a0 * y; mu = mu + t; }
+        else if constexpr (clr == 2) { const float t1 = a0 * y; const float t2 = a1 * co; const float t = t1 + t2; mu = mu + t; }
+        cpt.mu = mu;
+        cpt.rsig = 1.0f / ((sgm > kScaleBound) ? sgm : kScaleBound);
+        w = (wk > kWeightBound) ? wk : kWeightBound;
+        cpt.wn = 0.0f;
+        return cpt;
     };
     // Stream words: lane l holds word wbase + l, a second register the 64 after them; a step consumes at most
     // 64 words, pulled with ds_bpermute instead of a dependent global load.
@@ -1263,51 +1291,57 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
         const int chunk0 = 64 * (m + k * M);
         const Raw nxt = fetch(min(k + 1, K - 1));
         // slot of this group's symbol = low half of the state in lane gsym of this wave's copy
-        const uint32_t slot = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (gsym & 63), (int)x) & 0xFFFFu;
+        const uint32_t slot = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * gsym, (int)x) & 0xFFFFu;
         {
             if (cur.on) {                        // uniform within the group
                 const long off = cur.off;
-                // this lane's component, prepared exactly as mix_prepare() does
-                const float sgm = cur.sgm;
-                float mu = cur.mu;
-                const float wk = cur.wk;
-                if (clr == 1) {
-                    const float t = cur.a0 * cur.y;
-                    mu = mu + t;
-                } else if (clr == 2) {
-                    const float t1 = cur.a0 * cur.y;
-                    const float t2 = cur.a1 * cur.co;
-                    const float t = t1 + t2;
-                    mu = mu + t;
-                }
-                const float rsig = 1.0f / ((sgm > kScaleBound) ? sgm : kScaleBound);
-                const float w = (wk > kWeightBound) ? wk : kWeightBound;
-                float ssum = dpp_sum5(w);                            // (((w0 + w1) + w2) + w3) + w4 in the group's first lane
-                ssum = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * gbit, __float_as_int(ssum)));
-                const float wn = w / (1e-9f + ssum);
+                float wA, wB;
+                Comp A = prep(cur.sgA, cur.muA, cur.wkA, cur.a0A, cur.a1A, cur.y, cur.co, wA);
+                Comp B = prep(cur.sgB, cur.muB, cur.wkB, cur.a0B, cur.a1B, cur.y, cur.co, wB);
+                const float ssum = quad_lane0(dpp_sum5(wA, wB));     // (((w0 + w1) + w2) + w3) + w4
+                const float den = 1e-9f + ssum;
+                A.wn = wA / den;
+                B.wn = wB / den;
 
-                // 1. hint: bisection on the approximate table
+                // 1. hint: bisection on the approximate table (a 4-ary round with three probes costs three times
+                //    a probe: the phase is instruction-issue bound, not latency bound -- measured with in-kernel stamps)
                 int glo = 0, ghi = max_symbol + 1;
                 while (ghi - glo > 1) {
                     const int mid = (glo + ghi) >> 1;
-                    const int e = group_cdf_entry_fast(mu, rsig, wn, fbase, gr.scale, mid);
+                    const int e = group_cdf_entry_fast(A, B, fbase, gr.scale, mid);
                     const uint64_t bal = __ballot(e <= (int)slot);
                     if ((bal >> gbit) & 1ull) glo = mid; else ghi = mid;
                 }
-                // 2. proof: exact entries around the hint; gallop away from it, then bisect, if it is off
+                // 2. proof with the exact spec arithmetic: entries glo and glo + 1 in one round (independent chains);
+                //    if the hint is off, gallop away from it and bisect
                 int lo = 0, hi = max_symbol + 1;
                 uint32_t vlo = 0, vhi = 0x10000u;                    // meaningful in the group's first lane only
                 bool have_lo = false, have_hi = false;
-                int probe = max(1, min(glo, max_symbol)), step = 1;
+                {
+                    const int s1 = glo, s2 = min(glo + 1, max_symbol);
+                    const uint32_t eA = group_cdf_entry(A, B, gr, s1);
+                    const uint32_t eB = group_cdf_entry(A, B, gr, s2);
+                    const bool bA = (__ballot(eA <= slot) >> gbit) & 1ull;
+                    const bool bB = (__ballot(eB <= slot) >> gbit) & 1ull;
+                    const bool leA = (s1 == 0) || bA;                // entry 0 is the floor of the search (torchac: left = 0)
+                    const bool leB = (s1 + 1 <= max_symbol) && bB;   // past the top symbol: c_high = 0x10000 by definition
+                    if (leA) {
+                        lo = s1; vlo = eA; have_lo = true;
+                        if (leB) { lo = s2; vlo = eB; }
+                        else if (s1 + 1 <= max_symbol) { hi = s2; vhi = eB; have_hi = true; }
+                    } else { hi = s1; vhi = eA; have_hi = true; }
+                }
+                int step = 2;
                 while (hi - lo > 1) {
-                    const uint32_t e = group_cdf_entry(mu, rsig, wn, gr, probe);
-                    const uint64_t bal = __ballot(e <= slot);
-                    if ((bal >> gbit) & 1ull) { lo = probe; vlo = e; have_lo = true; } else { hi = probe; vhi = e; have_hi = true; }
+                    int probe;
                     if (have_lo && have_hi) probe = (lo + hi) >> 1;
                     else if (have_lo) { probe = min(lo + step, hi - 1); step <<= 1; }
                     else { probe = max(hi - step, lo + 1); step <<= 1; }
+                    const uint32_t e = group_cdf_entry(A, B, gr, probe);
+                    const uint64_t bal = __ballot(e <= slot);
+                    if ((bal >> gbit) & 1ull) { lo = probe; vlo = e; have_lo = true; } else { hi = probe; vhi = e; have_hi = true; }
                 }
-                if (!have_lo) vlo = group_cdf_entry(mu, rsig, wn, gr, 0);
+                if (!have_lo) vlo = group_cdf_entry(A, B, gr, 0);
                 if (head) {
                     sh_res[k & 1][gsym][0] = vlo;
                     sh_res[k & 1][gsym][1] = vhi;
@@ -2054,9 +2088,11 @@ static int decode_sub(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in
             if (int rc = launch_band_params(c, fplanes, g, band, params, s)) return rc;
             StageGeom sg = make_stage(g, band);
             const long nc = (long)sg.hc * sg.wc;
-            for (int clr = 0; clr < 3 && M > 0; ++clr)
-                rans_decode_stage_kernel<<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, clr, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos,
-                                                              planes, fplanes, mm);
+            if (M > 0) {
+                rans_decode_stage_kernel<0><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, planes, fplanes, mm);
+                rans_decode_stage_kernel<1><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, planes, fplanes, mm);
+                rans_decode_stage_kernel<2><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, planes, fplanes, mm);
+            }
             for (int clr = 0; clr < 3 && M == 0; ++clr) {
                 const int row_stride = (clr == 0) ? 264 : 512;      // Y: Lp = 257; Co/Cg: Lp <= 512
                 if (int rc = launch_cdf_table(planes, params, mm, g, band, clr, tables, row_stride, s)) return rc;

@@ -35,9 +35,8 @@ __device__ __forceinline__ float exp_spec(float y)          // y in [-49, 0]
     return __int_as_float(__float_as_int(q) + (ji << 23));
 }
 
-__device__ __forceinline__ float erfc_pos(float x)          // x >= 0;  := 0 for x >= 7 (and NaN)
+__device__ __forceinline__ float erfc_pos_body(float x)     // x >= 0 (the value is used only for x < 7)
 {
-    if (!(x < 7.0f)) return 0.0f;
     const float r = 1.0f / (x + 2.0f);
     const float t = (x - 2.0f) * r;
     float p = 0x1.73901ap-15f;
@@ -56,6 +55,21 @@ __device__ __forceinline__ float erfc_pos(float x)          // x >= 0;  := 0 for
     float ex = exp_spec(-s);
     ex = __builtin_fmaf(-e, ex, ex);
     return (p * ex) * r;
+}
+
+__device__ __forceinline__ float erfc_pos(float x)          // x >= 0;  := 0 for x >= 7 (and NaN)
+{
+    if (!(x < 7.0f)) return 0.0f;
+    return erfc_pos_body(x);
+}
+
+// same bits as erfc_spec, without control flow: the saturated result is selected, not branched to
+__device__ __forceinline__ float erfc_spec_nobranch(float x)
+{
+    const float a = __builtin_fabsf(x);
+    const float body = erfc_pos_body(a < 7.0f ? a : 0.0f);    // clamp: keeps exp_spec's exponent arithmetic in range
+    const float v = (a < 7.0f) ? body : 0.0f;
+    return (x < 0.0f) ? 2.0f - v : v;
 }
 
 __device__ __forceinline__ float erfc_spec(float x)
