@@ -1201,25 +1201,36 @@ __device__ __forceinline__ uint32_t group_cdf_entry(const Comp &A, const Comp &B
     return (uint32_t)((int)q + i) & 0xFFFFu;
 }
 
-__device__ __forceinline__ float erfc_fast(float x)     // Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7
+// Approximate table entry i, 0 < i < Lp - 1 (search hint only -- never used as a result): Abramowitz-Stegun
+// 7.1.26 erfc (|error| <= 1.5e-7) on v_rcp_f32 / v_exp_f32, with everything that does not depend on the sample
+// point folded into per-component constants: x' = sqrt(log2 e) * x = c1 * pt + c0, exp(-x^2) = exp2(-x'^2),
+// term = wh * erfc (wh = wn / 2).  15 vector operations per component and probe.
+struct CompFast { float c1, c0, wh, wn; };
+__device__ __forceinline__ CompFast comp_fast(const Comp &c)
 {
+    CompFast f;
+    f.c1 = (kNegRsqrt2 * 1.2011224087864498f) * c.rsig;
+    f.c0 = -c.mu * f.c1;
+    f.wh = 0.5f * c.wn;
+    f.wn = c.wn;
+    return f;
+}
+__device__ __forceinline__ float term_fast(const CompFast &c, float pt)
+{
+    const float x = __builtin_fmaf(pt, c.c1, c.c0);
     const float a = __builtin_fabsf(x);
-    const float u = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, a, 1.0f));
+    const float u = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f / 1.2011224087864498f, a, 1.0f));
     float p = __builtin_fmaf(1.061405429f, u, -1.453152027f);
     p = __builtin_fmaf(p, u, 1.421413741f);
     p = __builtin_fmaf(p, u, -0.284496736f);
     p = __builtin_fmaf(p, u, 0.254829592f);
-    const float E = (p * u) * __builtin_amdgcn_exp2f((a * a) * -1.4426950409f);
-    return (x < 0.0f) ? 2.0f - E : E;
+    const float E = ((p * u) * __builtin_amdgcn_exp2f(-(a * a))) * c.wh;
+    return (x < 0.0f) ? c.wn - E : E;
 }
-
-// approximate table entry i, 0 < i < Lp - 1 (search hint only -- never used as a result)
-__device__ __forceinline__ int group_cdf_entry_fast(const Comp &A, const Comp &B, float fbase, float scale, int i)
+__device__ __forceinline__ int group_cdf_entry_fast(const CompFast &A, const CompFast &B, float fbase, float scale, int i)
 {
     const float pt = div255_exact(fbase + (float)i);     // the exact sample point: near a narrow component the CDF moves by counts per ulp of pt
-    const float tA = A.wn * (0.5f * erfc_fast(kNegRsqrt2 * ((pt - A.mu) * A.rsig)));
-    const float tB = B.wn * (0.5f * erfc_fast(kNegRsqrt2 * ((pt - B.mu) * B.rsig)));
-    return (int)__builtin_rintf(dpp_sum5(tA, tB) * scale) + i;
+    return (int)__builtin_rintf(dpp_sum5(term_fast(A, pt), term_fast(B, pt)) * scale) + i;
 }
 
 template <int CLR>
@@ -1305,10 +1316,11 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
 
                 // 1. hint: bisection on the approximate table (a 4-ary round with three probes costs three times
                 //    a probe: the phase is instruction-issue bound, not latency bound -- measured with in-kernel stamps)
+                const CompFast Af = comp_fast(A), Bf = comp_fast(B);
                 int glo = 0, ghi = max_symbol + 1;
                 while (ghi - glo > 1) {
                     const int mid = (glo + ghi) >> 1;
-                    const int e = group_cdf_entry_fast(A, B, fbase, gr.scale, mid);
+                    const int e = group_cdf_entry_fast(Af, Bf, fbase, gr.scale, mid);
                     const uint64_t bal = __ballot(e <= (int)slot);
                     if ((bal >> gbit) & 1ull) glo = mid; else ghi = mid;
                 }
@@ -1319,8 +1331,24 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
                 bool have_lo = false, have_hi = false;
                 {
                     const int s1 = glo, s2 = min(glo + 1, max_symbol);
-                    const uint32_t eA = group_cdf_entry(A, B, gr, s1);
-                    const uint32_t eB = group_cdf_entry(A, B, gr, s2);
+                    // components 0..3 of both entries in their own lanes; component 4 of entry s1 in the group's
+                    // lane 0 and of entry s2 in lane 1 (every lane holds component 4's parameters): three
+                    // evaluations per lane instead of four
+                    const float p1 = sample_pt(gr, s1), p2 = sample_pt(gr, s2);
+                    const float pX = (mA == 1) ? p2 : p1;
+                    const float t1 = A.wn * (0.5f * erfc_spec_nobranch(kNegRsqrt2 * ((p1 - A.mu) * A.rsig)));
+                    const float t2 = A.wn * (0.5f * erfc_spec_nobranch(kNegRsqrt2 * ((p2 - A.mu) * A.rsig)));
+                    const float tX = B.wn * (0.5f * erfc_spec_nobranch(kNegRsqrt2 * ((pX - B.mu) * B.rsig)));
+                    float a1 = t1 + dpp_row_shl(t1, 1);              // (((t0 + t1) + t2) + t3) + t4, in the group's lane 0
+                    a1 = a1 + dpp_row_shl(t1, 2);
+                    a1 = a1 + dpp_row_shl(t1, 3);
+                    a1 = a1 + tX;
+                    float a2 = t2 + dpp_row_shl(t2, 1);
+                    a2 = a2 + dpp_row_shl(t2, 2);
+                    a2 = a2 + dpp_row_shl(t2, 3);
+                    a2 = a2 + dpp_row_shl(tX, 1);
+                    const uint32_t eA = (uint32_t)((int)__builtin_rintf(a1 * gr.scale) + s1) & 0xFFFFu;
+                    const uint32_t eB = (uint32_t)((int)__builtin_rintf(a2 * gr.scale) + s2) & 0xFFFFu;
                     const bool bA = (__ballot(eA <= slot) >> gbit) & 1ull;
                     const bool bB = (__ballot(eB <= slot) >> gbit) & 1ull;
                     const bool leA = (s1 == 0) || bA;                // entry 0 is the floor of the search (torchac: left = 0)
