@@ -243,7 +243,8 @@ def main():
     # the other container on the same batch (untimed region; informational): the torchac-compatible AC
     # container is what bit-exactness with the reference's format is claimed on
     other = {}
-    if mode != MODE_AC and not args.no_extras:
+    extras = (world == 1) and not args.no_extras         # informational legs: N = 1 only (as cpu_baseline)
+    if mode != MODE_AC and extras:
         cont2 = torch.empty_like(cont)
         seg2 = torch.zeros_like(seg)
         enc(MODE_AC, cont2, seg2)
@@ -264,7 +265,7 @@ def main():
     else:
         seg_ac_h = cont_ac0 = None
     tab_roof = None
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and extras:
         cont2 = seg2 = None
         torch.cuda.empty_cache()
         tab_roof = table_kernel_roofline(codec, torch)
@@ -299,7 +300,7 @@ def main():
         out.update(other)
         if tab_roof is not None:
             out["roofline_cdf_table"] = tab_roof
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             cb, bl = cpu_baseline(H, W)
             if cont_ac0 is not None:
                 # the same image through the HIP path (AC container) must give the oracle's bytes

@@ -860,8 +860,10 @@ __global__ __launch_bounds__(64) void ac_encode_pairs_kernel(const uint32_t *__r
                                                              int n_streams, uint8_t *__restrict__ slots,
                                                              int32_t *__restrict__ slot_len, int32_t *status)
 {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_streams) return;
+    // one wavefront per stream, one working lane: the coder is a serial chain, and a lone lane per wave runs
+    // it without divergence on its own SIMD (64 streams sharing a wave executed both sides of every branch)
+    const int s = blockIdx.x;
+    if (s >= n_streams || threadIdx.x != 0) return;
     const StreamDesc d = desc[s];
     const uint32_t *p = pairs + d.pair_off;
     BitWriter bw = { reinterpret_cast<uint32_t *>(slots + d.out_off), d.cap / 4, 0, 0, 0, 0 };
@@ -2072,7 +2074,7 @@ extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, 
     const int hdr_bytes = 17 + 3 * g4.h * g4.w;
     if (M == 0) {
         const int n_streams = LLICTI_NSTREAMS * B;
-        ac_encode_pairs_kernel<<<(n_streams + 63) / 64, 64, 0, s>>>(pairs, pd->d_desc, n_streams, slots, slot_len, status);
+        ac_encode_pairs_kernel<<<n_streams, 64, 0, s>>>(pairs, pd->d_desc, n_streams, slots, slot_len, status);
         pack_kernel<<<dim3(LLICTI_NSTREAMS, B), 256, 0, s>>>(slots, pd->d_slot_off, slot_len, B, hdr_bytes, d_out, (long)out_stride, d_seg_len, status);
     } else {
         int32_t *rinfo = (int32_t *)(ws + p.off_rinfo);
