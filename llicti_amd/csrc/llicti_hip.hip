@@ -1579,6 +1579,7 @@ struct llicti_ctx {
     std::map<std::tuple<int, int, int, int>, struct PlanDev *> plans;   // (B, H, W, M) -> plan + its device arrays
     hipStream_t sub[kMaxSub] = { nullptr, nullptr, nullptr, nullptr };    // sub-batch pipelining (decode)
     hipEvent_t ev_fork = nullptr, ev_join[kMaxSub] = { nullptr, nullptr, nullptr, nullptr };
+    int pipeline_s = 4;
     bool pipeline = false;     // sub-batch pipelining of decode: measured neutral (co-resident CNN and rANS waves share VALU issue)
     int32_t *d_status = nullptr;      // small persistent status word (for the kernel-level entry points)
     bool profiling = false;
@@ -1722,6 +1723,7 @@ extern "C" int llicti_create(llicti_ctx **out, int device)
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(LLICTI_ENODEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
     llicti_ctx *c = new llicti_ctx();
     c->device = device;
+    if (const char *e = getenv("LLICTI_PIPELINE")) { c->pipeline = atoi(e) != 0; c->pipeline_s = atoi(e); }     // experiment switch: sub-batch pipelining of decode
     HIPCHK(hipMalloc(&c->d_status, 64));
     HIPCHK(hipMemset(c->d_status, 0, 64));
     HIPCHK(hipEventCreate(&c->ev_call[0]));
@@ -2001,7 +2003,7 @@ static int get_plan(llicti_ctx *c, int B, int H, int W, int M, PlanDev **out)
 static int sub_batches(const llicti_ctx *c, int B, int M)
 {
     if (!c->pipeline || c->profiling || M == 0) return 1;
-    if (B % 4 == 0 && B >= 8) return 4;
+    if (c->pipeline_s >= 4 && B % 4 == 0 && B >= 8) return 4;
     if (B % 2 == 0 && B >= 4) return 2;
     return 1;
 }
