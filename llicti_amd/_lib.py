@@ -13,8 +13,9 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 SO_PATH = os.environ.get("LLICTI_HIP_SO") or os.path.join(_HERE, "libllicti_hip.so")   # env override: A/B builds
-SOURCES = [os.path.join(_HERE, "csrc", "llicti_hip.hip"), os.path.join(_HERE, "csrc", "numerics.hpp"),
-           os.path.join(ROOT, "include", "llicti_hip.h")]
+_CSRC = os.path.join(_HERE, "csrc")
+SOURCES = [os.path.join(_CSRC, "llicti_hip.hip")] + sorted(os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(".hpp")) + \
+          [os.path.join(ROOT, "include", "llicti_hip.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                "-Wno-unused-value"]
 

@@ -1,0 +1,345 @@
+// band_cnn.hpp -- interpolator CNN: three chained fp32-MFMA GEMMs per pixel tile (K4-K5).
+// Part of the single translation unit llicti_hip.hip (included in order; not a stand-alone header).
+#pragma once
+
+// ------------------------------------------------------------------------------------------------ band CNN
+// Layer-0 convolutions of band b (LLICTI_nets.py:651-675): source sub-band, kernel size, top / left pad.
+struct ConvDef { int src, kh, kw, pt, pl; };
+constexpr ConvDef kConvs[3][3] = {
+    { { 0, 4, 4, 1, 1 }, { -1, 0, 0, 0, 0 }, { -1, 0, 0, 0, 0 } },
+    { { 0, 3, 4, 1, 1 }, { 1, 4, 3, 2, 1 }, { -1, 0, 0, 0, 0 } },
+    { { 0, 4, 3, 1, 1 }, { 1, 3, 4, 1, 2 }, { 2, 4, 4, 1, 2 } },
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kHead = 88;          // channels per head (configs/llicti_A.json chs[0])
+constexpr int kMT = 6;             // 16-row MFMA tiles per head (88 -> 96, rows >= 88 are zero)
+constexpr int kKS1 = 22;           // k-steps of the 88-deep layers (88 / 4)
+#ifndef CNN_NT
+#define CNN_NT 2
+#endif
+constexpr int kNT = CNN_NT;                    // pixel tiles (16 positions each) per wavefront
+constexpr int kCnnThreads = 64 * (32 / CNN_NT);    // NT=4: 8 wavefronts (2 per SIMD); NT=2: 16 wavefronts (4 per SIMD)
+constexpr int kTileH = 16;         // band-grid positions per workgroup tile: 16 rows x 32 columns,
+constexpr int kTileW = 32;         //   wave w owns rows 2w, 2w+1 (two 16-column pixel tiles each)
+constexpr int kInRows = kTileH + 4;    // taps reach rows i-2 .. i+2 and columns j-2 .. j+2
+constexpr int kInCols = kTileW + 4;
+constexpr int kInPitch = 48;       // = 16 (mod 32): B-fragment reads that stride by one row stay bank-conflict free
+constexpr int kInPlane = kInRows * kInPitch;
+constexpr int kParamStride = LLICTI_PARAM_STRIDE;
+#ifndef CNN_PREFETCH_L0
+#define CNN_PREFETCH_L0 1      // software-pipeline the layer-0 fragments one k-step ahead
+#endif
+#ifndef CNN_FENCE_L1
+#define CNN_FENCE_L1 4         // scheduler fence every N k-steps of layer 1 (0 = none)
+#endif
+#ifndef CNN_STAGE_SITES
+#define CNN_STAGE_SITES 4     // points of the tile at which the wave groups request the next tile's DMA (1, 2 or 4)
+#endif
+#ifndef CNN_STAGGER
+#define CNN_STAGGER 0          // delay waves 4-7 before the first tile (decorrelates the two waves of a SIMD)
+#endif
+
+// One MFMA k-step consumes 4 consecutive k of the canonical K order (llicti_amd/weights.py): the kernel's
+// length-4 axis.  Lane (q = lane>>4, px = lane&15) therefore reads the staged input tile at
+// U + q*S + pixel offset with U, S compile-time constants of the k-step.
+struct KStep { int U, S; };
+struct KTab { KStep s[30]; int n; };
+constexpr KTab make_ktab(int band)
+{
+    KTab t{};
+    int k = 0;
+    for (int c = 0; c < 3; ++c) {
+        const ConvDef cv = kConvs[band][c];
+        if (cv.src < 0) break;
+        for (int ci = 0; ci < 3; ++ci) {
+            const int plane = (cv.src * 3 + ci) * kInPlane;
+            if (cv.kw == 4) {
+                for (int ky = 0; ky < cv.kh; ++ky) { t.s[k].U = plane + (ky - cv.pt + 2) * kInPitch + (2 - cv.pl); t.s[k].S = 1; ++k; }
+            } else {
+                for (int kx = 0; kx < cv.kw; ++kx) { t.s[k].U = plane + (2 - cv.pt) * kInPitch + (kx - cv.pl + 2); t.s[k].S = kInPitch; ++k; }
+            }
+        }
+    }
+    t.n = k;
+    return t;
+}
+template <int BAND> inline constexpr KTab kKTab = make_ktab(BAND);
+
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// Per (band, head) weight pack, in MFMA-fragment order so that the LDS image is lane-linear:
+//   bias0 [6][4][4]            acc init of tile T, lane group q, reg r  = b0[16T + 4r + q]
+//   W0    [6][K0/4][64]        lane l of tile T, k-step t: W0[chan(T, l&15)][4t + (l>>4)]
+//   bias1 [6][4][4]
+//   W1    [6][22][64]
+//   bias2 [4][4]               acc init of lane group q, reg r = b2[4q + r]
+//   W2    [22][64]             lane l, k-step t: W2[l&15][4t + (l>>4)]
+// chan(T, rho) = 16T + 4(rho&3) + (rho>>2): this row permutation makes the accumulator registers of one
+// layer line up, untouched, as the B operand of the next layer's MFMAs in natural channel order
+// (C/D layout of v_mfma_f32_16x16x4_f32: col = lane&15, row = 4(lane>>4) + reg).
+static constexpr int pack_floats(int K0) { return 96 + kMT * (K0 / 4) * 64 + 96 + kMT * kKS1 * 64 + 16 + kKS1 * 64; }
+
+template <int K0>
+struct PackOff {
+    static constexpr int bias0 = 0;
+    static constexpr int w0 = 96;
+    static constexpr int bias1 = w0 + kMT * (K0 / 4) * 64;
+    static constexpr int w1 = bias1 + 96;
+    static constexpr int bias2 = w1 + kMT * kKS1 * 64;
+    static constexpr int w2 = bias2 + 16;
+    static constexpr int total = w2 + kKS1 * 64;
+};
+static constexpr int cnn_lds_bytes(int band)
+{
+    const int K0 = band == 0 ? 48 : band == 1 ? 72 : 120;
+    return (pack_floats(K0) + 2 * 3 * (band + 1) * kInPlane) * 4;     // weights + double-buffered input tile
+}
+
+__device__ __forceinline__ float relu(float x) { return (x > 0.0f) ? x : 0.0f; }
+__device__ __forceinline__ f32x4 relu4(f32x4 v) { v[0] = relu(v[0]); v[1] = relu(v[1]); v[2] = relu(v[2]); v[3] = relu(v[3]); return v; }
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+template <int BAND>
+__global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *__restrict__ fplanes, Geom g,
+                                                                  const float *__restrict__ wpack,
+                                                                  float *__restrict__ params, int tiles_x, int tiles_y, int n_tiles)
+{
+    constexpr int K0 = (BAND == 0) ? 48 : (BAND == 1) ? 72 : 120;
+    constexpr int NK0 = K0 / 4;
+    constexpr int NPL = 3 * (BAND + 1);          // staged input planes: (x00 | x11 | x01) x (Y, Co, Cg)
+    using PO = PackOff<K0>;
+    static_assert(kKTab<BAND>.n == NK0, "k-step table");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *lds_in = lds + PO::total;
+
+    const int head = blockIdx.y;
+    {   // stage this head's pack (lane-linear image: a straight copy)
+        const float4 *src = reinterpret_cast<const float4 *>(wpack + (long)head * PO::total);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+        for (int i = threadIdx.x; i < PO::total / 4; i += kCnnThreads) dst[i] = src[i];
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int q = lane >> 4;
+    const int px = lane & 15;
+    const int q_row = q * kInPitch;
+    const int pix0 = ((wave * kNT) >> 1) * kInPitch + px;      // + (n>>1)*pitch + 16*(n&1) for pixel tile n
+
+    // Input tile: LDS-DMA (global_load_lds), double buffered.  One wave-instruction fills 64 consecutive LDS
+    // floats, so the tile image [plane][20 rows][pitch 48] is cut into NPL*15 such pieces (the 12 pad columns
+    // of a row are filled with a duplicate of column 35); each lane computes its own clamped source address.
+    // Pitch 48 makes four tile rows exactly three 64-float pieces, so a piece's plane, row group and phase are
+    // functions of the wave-uniform piece index (scalar arithmetic) and only ~20 vector operations per piece
+    // depend on the lane: piece phase t covers row 4q+t from column 16t (lanes below 48-16t) and the head
+    // of row 4q+t+1 (the others).
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto stage = [&](int tile, float *dst) {
+        const int img = tile / (tiles_x * tiles_y);
+        const int trem = tile - img * (tiles_x * tiles_y);
+        const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+        const int i0 = ty * kTileH - 2, j0 = tx * kTileW - 2;
+        const float *base = fplanes + (long)img * 3 * g.plane;
+        for (int u = wave_u; u < NPL * (kInPlane / 64); u += kCnnThreads / 64) {
+            const int pl = u / 15, v = u - 15 * pl, q4 = v / 3, t = v - 3 * q4;       // wave-uniform
+            const int src = pl / 3, ci = pl - 3 * src;
+            const int thr = 48 - 16 * t;
+            const bool up = lane >= thr;
+            const int cidx = min(up ? lane - thr : lane + 16 * t, kInCols - 1);
+            const int r = 4 * q4 + t + (up ? 1 : 0);
+            const int bi = max(0, min(i0 + r, g.h - 1));            // the conv's replicate padding, in band coordinates
+            const int bj = max(0, min(j0 + cidx, g.w - 1));
+            int rr = 2 * bi + src_oi(src), cc = 2 * bj + src_oj(src);
+            if (rr >= g.Hl) rr -= 2;                   // lazyDWT's replicate pad of the odd edge (LLICTI_nets.py:226-240)
+            if (cc >= g.Wl) cc -= 2;
+            const unsigned off = (unsigned)(rr * g.W + cc) << g.lvl;   // < H * W
+            const float *gp = base + (long)ci * g.plane + off;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gp,
+                                             (__attribute__((address_space(3))) void *)(dst + u * 64), 4, 0, 0);
+        }
+    };
+    static_assert(kInPitch == 48 && kInRows % 4 == 0 && kInPlane / 64 == 15, "piece decomposition assumes pitch 48, 20 rows");
+    static_assert(kInPlane % 64 == 0, "tile plane must be a whole number of 64-float pieces");
+
+    const int stage_site = (__builtin_amdgcn_readfirstlane(wave) / (kCnnThreads / 256)) % CNN_STAGE_SITES;
+    int cur = 0;
+    if ((int)blockIdx.x < n_tiles) stage(blockIdx.x, lds_in);
+#if CNN_STAGGER
+    if (__builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_sleep(CNN_STAGGER);
+#endif
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int img = tile / (tiles_x * tiles_y);
+        const int trem = tile - img * (tiles_x * tiles_y);
+        const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+        const int i0 = ty * kTileH, j0 = tx * kTileW;
+        float *lds_cur = lds_in + cur * (NPL * kInPlane);
+
+        // this tile's pieces have landed (each wave drains its own DMA, then the barrier), and every wave has
+        // finished reading the other buffer (previous tile) -- which the next tile's DMA may now overwrite
+        __syncthreads();
+        // The next tile's DMA (address arithmetic + issue: pure VALU / VMEM work) is requested at four
+        // different points of the tile, one per wave group: a SIMD hosts one wave of each group, so while
+        // one of its waves stages, the other three keep the matrix pipe busy.  (All 16 waves staging right
+        // after the barrier left the pipe idle for ~9 % of the tile.)
+        const bool more = tile + (int)gridDim.x < n_tiles;
+        auto stage_next = [&](int site) {
+            if (more && stage_site == site % CNN_STAGE_SITES) stage(tile + gridDim.x, lds_in + (cur ^ 1) * (NPL * kInPlane));
+        };
+        stage_next(0);
+
+        // ---- layer 0: [96 x K0] x [K0 x 64 pixels]; bias preloaded into the accumulators
+        f32x4 a0[kMT][kNT];
+#pragma unroll
+        for (int T = 0; T < kMT; ++T) {
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(lds + PO::bias0 + (T * 4 + q) * 4);
+#pragma unroll
+            for (int n = 0; n < kNT; ++n) a0[T][n] = bv;
+        }
+#if CNN_PREFETCH_L0
+        {
+            float a_c[kMT], b_c[kNT];
+            {
+                constexpr int U = kKTab<BAND>.s[0].U, S = kKTab<BAND>.s[0].S;
+                const float *bp = lds_cur + U + pix0 + (S == 1 ? q : q_row);
+#pragma unroll
+                for (int n = 0; n < kNT; ++n) b_c[n] = bp[(n >> 1) * kInPitch + 16 * (n & 1)];
+#pragma unroll
+                for (int T = 0; T < kMT; ++T) a_c[T] = lds[PO::w0 + (T * NK0 + 0) * 64 + lane];
+            }
+            static_for<NK0>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                float a_n[kMT], b_n[kNT];
+                if constexpr (t + 1 < NK0) {       // next k-step's fragments are in flight while this one's MFMAs run
+                    constexpr int U = kKTab<BAND>.s[t + 1].U, S = kKTab<BAND>.s[t + 1].S;
+                    const float *bp = lds_cur + U + pix0 + (S == 1 ? q : q_row);
+#pragma unroll
+                    for (int n = 0; n < kNT; ++n) b_n[n] = bp[(n >> 1) * kInPitch + 16 * (n & 1)];
+#pragma unroll
+                    for (int T = 0; T < kMT; ++T) a_n[T] = lds[PO::w0 + (T * NK0 + t + 1) * 64 + lane];
+                }
+#pragma unroll
+                for (int T = 0; T < kMT; ++T)
+#pragma unroll
+                    for (int n = 0; n < kNT; ++n) a0[T][n] = MFMA4(a_c[T], b_c[n], a0[T][n]);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (t + 1 < NK0) {
+#pragma unroll
+                    for (int T = 0; T < kMT; ++T) a_c[T] = a_n[T];
+#pragma unroll
+                    for (int n = 0; n < kNT; ++n) b_c[n] = b_n[n];
+                }
+            });
+        }
+#else
+        static_for<NK0>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int U = kKTab<BAND>.s[t].U, S = kKTab<BAND>.s[t].S;
+            const float *bp = lds_cur + U + pix0 + (S == 1 ? q : q_row);
+            float bf[kNT];
+#pragma unroll
+            for (int n = 0; n < kNT; ++n) bf[n] = bp[(n >> 1) * kInPitch + 16 * (n & 1)];
+#pragma unroll
+            for (int T = 0; T < kMT; ++T) {
+                const float a = lds[PO::w0 + (T * NK0 + t) * 64 + lane];
+#pragma unroll
+                for (int n = 0; n < kNT; ++n) a0[T][n] = MFMA4(a, bf[n], a0[T][n]);
+            }
+            __builtin_amdgcn_sched_barrier(0);     // one k-step per scheduling region (bounds VGPR pressure)
+        });
+#endif
+        if constexpr (CNN_STAGE_SITES > 1) stage_next(1);
+#pragma unroll
+        for (int T = 0; T < kMT; ++T)
+#pragma unroll
+            for (int n = 0; n < kNT; ++n) a0[T][n] = relu4(a0[T][n]);
+
+        // ---- layers 1 and 2, interleaved per 16-channel tile: the accumulator registers of one layer ARE
+        //      the B fragments of the next (k-step tt of the consumer = tile tt>>2, register tt&3)
+        f32x4 a2[kNT];
+        {
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(lds + PO::bias2 + q * 4);
+#pragma unroll
+            for (int n = 0; n < kNT; ++n) a2[n] = bv;
+        }
+        static_for<kMT>([&](auto Tc) {
+            constexpr int T = decltype(Tc)::value;
+            if constexpr (T == 2 && CNN_STAGE_SITES > 2) stage_next(2);
+            if constexpr (T == 4 && CNN_STAGE_SITES > 2) stage_next(3);
+            f32x4 a1[kNT];
+            {
+                const f32x4 bv = *reinterpret_cast<const f32x4 *>(lds + PO::bias1 + (T * 4 + q) * 4);
+#pragma unroll
+                for (int n = 0; n < kNT; ++n) a1[n] = bv;
+            }
+            static_for<kKS1>([&](auto ttc) {
+                constexpr int tt = decltype(ttc)::value;
+                const float a = lds[PO::w1 + (T * kKS1 + tt) * 64 + lane];
+#pragma unroll
+                for (int n = 0; n < kNT; ++n) a1[n] = MFMA4(a, a0[tt >> 2][n][tt & 3], a1[n]);
+#if CNN_FENCE_L1 > 0
+                if constexpr ((tt % CNN_FENCE_L1) == CNN_FENCE_L1 - 1) __builtin_amdgcn_sched_barrier(0);
+#endif
+            });
+#pragma unroll
+            for (int n = 0; n < kNT; ++n) a1[n] = relu4(a1[n]);
+            static_for<4>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                if constexpr (4 * T + r < kKS1) {
+                    const float a = lds[PO::w2 + (4 * T + r) * 64 + lane];
+#pragma unroll
+                    for (int n = 0; n < kNT; ++n) a2[n] = MFMA4(a, a1[n][r], a2[n]);
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+
+        // D row 4q + r = output 4q + r of this head; params[pos][head][16]
+#pragma unroll
+        for (int n = 0; n < kNT; ++n) {
+            const int i = i0 + ((wave * kNT) >> 1) + (n >> 1), j = j0 + 16 * (n & 1) + px;
+            if (i < g.h && j < g.w)
+                *reinterpret_cast<f32x4 *>(params + (((long)img * g.h + i) * g.w + j) * kParamStride + head * 16 + 4 * q) = a2[n];
+        }
+        cur ^= 1;
+    }
+}
+
+// host: canonical arrays -> fragment-ordered pack of one band (4 heads)
+static void pack_band(int K0, const float *w0, const float *b0, const float *w1, const float *b1,
+                      const float *w2, const float *b2, std::vector<float> &out)
+{
+    const int NK0 = K0 / 4;
+    const int total = pack_floats(K0);
+    out.assign((size_t)4 * total, 0.0f);
+    for (int hd = 0; hd < 4; ++hd) {
+        float *p = out.data() + (size_t)hd * total;
+        float *bias0 = p, *W0 = p + 96, *bias1 = W0 + kMT * NK0 * 64, *W1 = bias1 + 96;
+        float *bias2 = W1 + kMT * kKS1 * 64, *W2 = bias2 + 16;
+        for (int T = 0; T < kMT; ++T)
+            for (int q = 0; q < 4; ++q)
+                for (int r = 0; r < 4; ++r) {
+                    const int cl = 16 * T + 4 * r + q;
+                    bias0[(T * 4 + q) * 4 + r] = (cl < kHead) ? b0[hd * kHead + cl] : 0.0f;
+                    bias1[(T * 4 + q) * 4 + r] = (cl < kHead) ? b1[hd * kHead + cl] : 0.0f;
+                }
+        for (int T = 0; T < kMT; ++T)
+            for (int l = 0; l < 64; ++l) {
+                const int rho = l & 15, q = l >> 4;
+                const int cl = 16 * T + 4 * (rho & 3) + (rho >> 2);
+                for (int t = 0; t < NK0; ++t)
+                    W0[(T * NK0 + t) * 64 + l] = (cl < kHead) ? w0[(size_t)(hd * kHead + cl) * K0 + 4 * t + q] : 0.0f;
+                for (int t = 0; t < kKS1; ++t)
+                    W1[(T * kKS1 + t) * 64 + l] = (cl < kHead) ? w1[(size_t)(hd * kHead + cl) * kHead + 4 * t + q] : 0.0f;
+            }
+        for (int q = 0; q < 4; ++q)
+            for (int r = 0; r < 4; ++r) bias2[q * 4 + r] = (4 * q + r < 15) ? b2[hd * 15 + 4 * q + r] : 0.0f;
+        for (int l = 0; l < 64; ++l) {
+            const int o = l & 15, q = l >> 4;
+            for (int t = 0; t < kKS1; ++t) W2[t * 64 + l] = (o < 15) ? w2[(size_t)(hd * 15 + o) * kHead + 4 * t + q] : 0.0f;
+        }
+    }
+}

@@ -1,0 +1,155 @@
+// cdf.hpp -- mixture CDF kernels: encoder pairs and full uint16 tables (K6-K9).
+// Part of the single translation unit llicti_hip.hip (included in order; not a stand-alone header).
+#pragma once
+
+// ------------------------------------------------------------------------------------------------ CDF kernels
+struct StageGeom {      // one (level, band): band grid, coded crop, full-res addressing
+    int B, H, W, lvl, h, w, hc, wc, oi, oj;
+    long plane;
+};
+static StageGeom make_stage(const Geom &g, int band)
+{
+    static const int OI[4] = { 0, 1, 0, 1 }, OJ[4] = { 0, 1, 1, 0 };
+    StageGeom s;
+    s.B = g.B; s.H = g.H; s.W = g.W; s.lvl = g.lvl; s.h = g.h; s.w = g.w; s.plane = g.plane;
+    coded_dims(g, band, &s.hc, &s.wc);
+    s.oi = OI[band + 1]; s.oj = OJ[band + 1];
+    return s;
+}
+
+__device__ __forceinline__ void clr_range(const int32_t *mm, int clr, int &minv, int &maxv, int &shift)
+{
+    // LLICTI_nets.py:394-395, :544-547: Y uses the fixed range [-127,128], Co/Cg the image's own [min,max]
+    if (clr == 0) { minv = -127; maxv = 128; shift = 127; }
+    else { minv = mm[clr - 1]; maxv = mm[2 + clr - 1]; shift = -minv; }
+}
+
+// encoder: thread per coded position; the two entries the coder reads, for Y, Co, Cg
+__global__ __launch_bounds__(256) void cdf_pairs_kernel(const int16_t *__restrict__ planes, const float *__restrict__ params,
+                                                        const int32_t *__restrict__ minmax, StageGeom s,
+                                                        uint32_t *__restrict__ pairs)
+{
+    const int b = blockIdx.y;
+    const long nc = (long)s.hc * s.wc;
+    const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nc) return;
+    const int i = (int)(n / s.wc), j = (int)(n - (long)i * s.wc);
+    const float *par = params + ((long)b * s.h * s.w + (long)i * s.w + j) * LLICTI_PARAM_STRIDE;
+    const long off = (long)b * 3 * s.plane + ((long)(2 * i + s.oi) << s.lvl) * s.W + ((long)(2 * j + s.oj) << s.lvl);
+    const int vy = planes[off], vco = planes[off + s.plane], vcg = planes[off + 2 * s.plane];
+    const float yv = (float)vy / 255.0f, cov = (float)vco / 255.0f;
+    const int32_t *mm = minmax + 4 * b;
+#pragma unroll
+    for (int clr = 0; clr < 3; ++clr) {
+        int minv, maxv, shift;
+        clr_range(mm, clr, minv, maxv, shift);
+        const Grid gr = make_grid(minv, maxv);
+        const int v = (clr == 0) ? vy : (clr == 1) ? vco : vcg;
+        const int sym = v + shift;
+        Mix m;
+        mix_prepare(par, clr, yv, cov, m);
+        const uint32_t lo = cdf_entry(m, gr, sym);
+        const uint32_t hi = (sym == gr.Lp - 2) ? 0u : cdf_entry(m, gr, sym + 1);
+        pairs[((long)clr * s.B + b) * nc + n] = (hi << 16) | lo;
+    }
+}
+
+// decoder / seam export: full Lp-entry rows (entries >= Lp padded with 0xFFFF).  Persistent wavefronts, one
+// row per wave iteration, lane l owns entry 64k + l of block k.  Per row the wave derives, for every mixture
+// component, a conservative index interval outside which erfc_spec is exactly 0 (below) or 2 (above):
+// x = -(p - mu) * rsig / sqrt2 is monotone in the sample index, |x| >= 7 saturates, and the interval is widened
+// by 2 entries against rounding.  A (block, component) pair outside the interval contributes the constant 0
+// or wn (bit-identical to evaluating erfc_spec there); only pairs that overlap it run the polynomial.
+constexpr int kTabWaves = 4;
+
+__global__ __launch_bounds__(64 * kTabWaves) void cdf_table_kernel(const int16_t *__restrict__ planes, const float *__restrict__ params,
+                                                                   const int32_t *__restrict__ minmax, StageGeom s, int clr,
+                                                                   uint16_t *__restrict__ tables, int row_stride)
+{
+    const int b = blockIdx.y;
+    const int nc = s.hc * s.wc;
+    const int lane = threadIdx.x & 63;
+    const int wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * kTabWaves + (threadIdx.x >> 6)));
+    const int nwaves = gridDim.x * kTabWaves;
+    int minv, maxv, shift;
+    clr_range(minmax + 4 * b, clr, minv, maxv, shift);
+    const Grid gr = make_grid(minv, maxv);
+    const int nblk = (row_stride + 63) >> 6;             // <= 8
+    float pt[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pt[k] = sample_pt(gr, min(64 * k + lane, gr.Lp - 1));
+    const float fmin = (float)minv;
+    const long img = (long)b * 3 * s.plane;
+    const int mi = min(lane, 4);                         // lanes 0..4 prepare one mixture component each
+
+    for (int n = wave0; n < nc; n += nwaves) {
+        const int i = n / s.wc, j = n - i * s.wc;
+        const float *par = params + ((long)b * s.h * s.w + (long)i * s.w + j) * LLICTI_PARAM_STRIDE;
+        const long off = img + ((long)(2 * i + s.oi) << s.lvl) * s.W + ((long)(2 * j + s.oj) << s.lvl);
+        // component mi, prepared exactly as mix_prepare() does
+        const float sgm = par[5 * clr + mi];
+        float mu = par[16 + 5 * clr + mi];
+        const float wk = par[32 + 5 * clr + mi];
+        if (clr == 1) {
+            const float t = par[48 + mi] * ((float)planes[off] / 255.0f);
+            mu = mu + t;
+        } else if (clr == 2) {
+            const float t1 = par[48 + 5 + mi] * ((float)planes[off] / 255.0f);
+            const float t2 = par[48 + 10 + mi] * ((float)planes[off + s.plane] / 255.0f);
+            const float t = t1 + t2;
+            mu = mu + t;
+        }
+        const float sg = (sgm > kScaleBound) ? sgm : kScaleBound;
+        const float rsig = 1.0f / sg;
+        const float w = (wk > kWeightBound) ? wk : kWeightBound;
+        float ssum = w + dpp_row_shl(w, 1);              // (((w0 + w1) + w2) + w3) + w4 in lane 0
+        ssum = ssum + dpp_row_shl(w, 2);
+        ssum = ssum + dpp_row_shl(w, 3);
+        ssum = ssum + dpp_row_shl(w, 4);
+        ssum = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ssum)));
+        const float wn = w / (1e-9f + ssum);
+        // saturation interval in entry coordinates: entry i samples (minv - 0.5 + i) / 255 (the two pushed-out
+        // end points are further out on their own side, hence at least as saturated as this says)
+        const float c = mu * 255.0f - fmin + 0.5f, hw = 9.8994949f * 255.0f * sg + 2.0f;    // 7 * sqrt2
+        int lo = -1, hi = 1 << 20;                       // entries <= lo: erfc = 0;  entries >= hi: erfc = 2
+        if (c - hw > -1.0f && c - hw < 1e6f) lo = (int)(c - hw);
+        if (c + hw > -1e6f && c + hw < 1e6f) hi = (int)(c + hw) + 1;
+        if (!(c == c) || !(hw == hw)) { lo = -1; hi = 1 << 20; }
+        float mu_[5], rs_[5], wn_[5];
+        int lo_[5], hi_[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            mu_[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mu), k));
+            rs_[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rsig), k));
+            wn_[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wn), k));
+            lo_[k] = __builtin_amdgcn_readlane(lo, k);
+            hi_[k] = __builtin_amdgcn_readlane(hi, k);
+        }
+        uint16_t *row = tables + ((long)b * nc + n) * row_stride;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k < nblk) {
+                const int e = 64 * k + lane;
+                const int ec = min(e, gr.Lp - 1);
+                // index span of the block's sample points; entries 0 and Lp-1 sit 20 grey levels further out
+                const int bmin = (k == 0) ? -20 : 64 * k;
+                const int bmax = (64 * k + 63 >= gr.Lp - 1) ? gr.Lp + 19 : 64 * k + 63;
+                float acc = 0.0f;
+#pragma unroll
+                for (int m = 0; m < 5; ++m) {
+                    float t;
+                    if (bmax <= lo_[m]) t = 0.0f;                        // wn * (0.5 * 0)
+                    else if (bmin >= hi_[m]) t = wn_[m];                 // wn * (0.5 * 2)
+                    else {
+                        const float z = (pt[k] - mu_[m]) * rs_[m];
+                        t = wn_[m] * (0.5f * erfc_spec(kNegRsqrt2 * z));
+                    }
+                    acc = (m == 0) ? t : acc + t;
+                }
+                const float q = __builtin_rintf(acc * gr.scale);
+                const uint32_t v = (uint32_t)((int)q + ec) & 0xFFFFu;
+                if (e < row_stride) row[e] = (uint16_t)((e < gr.Lp) ? v : 0xFFFFu);
+            }
+        }
+    }
+}

@@ -1,0 +1,92 @@
+// common.hpp -- errors, geometry and small device helpers shared by every kernel file.
+// Part of the single translation unit llicti_hip.hip (included in order; not a stand-alone header).
+#pragma once
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(x)                                                                                    \
+    do {                                                                                             \
+        hipError_t e_ = (x);                                                                         \
+        if (e_ != hipSuccess) return fail(LLICTI_EHIP, "%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" const char *llicti_last_error(void) { return g_err.c_str(); }
+extern "C" const char *llicti_version(void) { return "llicti_hip 0.1 (gfx950, numerics spec v1)"; }
+
+// ------------------------------------------------------------------------------------------------ geometry
+struct Geom {
+    int B, H, W, lvl;
+    int Hl, Wl, h, w, padH, padW;
+    long plane;   // H*W
+};
+static Geom make_geom(int B, int H, int W, int lvl)
+{
+    Geom g;
+    g.B = B; g.H = H; g.W = W; g.lvl = lvl;
+    const int st = 1 << lvl;
+    g.Hl = (H + st - 1) / st;
+    g.Wl = (W + st - 1) / st;
+    g.h = (g.Hl + 1) / 2;
+    g.w = (g.Wl + 1) / 2;
+    g.padH = g.Hl & 1;
+    g.padW = g.Wl & 1;
+    g.plane = (long)H * W;
+    return g;
+}
+static void coded_dims(const Geom &g, int band, int *hc, int *wc)
+{
+    *hc = (band == 0 || band == 2) ? g.h - g.padH : g.h;   // LLICTI_nets.py:396-397
+    *wc = (band == 0 || band == 1) ? g.w - g.padW : g.w;
+}
+extern "C" int llicti_level_geom(int H, int W, int lvl, int band, int *Hl, int *Wl, int *h, int *w,
+                                 int *padH, int *padW, int *hc, int *wc)
+{
+    if (H < 1 || W < 1 || lvl < 0 || lvl >= LLICTI_NLEVELS || band < 0 || band > 2) return fail(LLICTI_EINVAL, "level_geom: bad argument");
+    Geom g = make_geom(1, H, W, lvl);
+    if (Hl) *Hl = g.Hl;
+    if (Wl) *Wl = g.Wl;
+    if (h) *h = g.h;
+    if (w) *w = g.w;
+    if (padH) *padH = g.padH;
+    if (padW) *padW = g.padW;
+    int a, b;
+    coded_dims(g, band, &a, &b);
+    if (hc) *hc = a;
+    if (wc) *wc = b;
+    return LLICTI_OK;
+}
+static int check_dims(int B, int H, int W)
+{
+    if (B < 1 || H < 32 || W < 32 || H > 8160 || W > 8160) return fail(LLICTI_EINVAL, "bad shape B=%d H=%d W=%d (need B>=1, 32<=H,W<=8160)", B, H, W);
+    return 0;
+}
+
+// source sub-bands in lazyDWT cat order x00, x11, x01, x10 (LLICTI_nets.py:241); band b predicts source b+1
+// (row, column) phase of source s: (0,0), (1,1), (0,1), (1,0) -- computed, not looked up: a table load inside
+// the CNN's staging loop would put an s_waitcnt vmcnt(0) between consecutive LDS-DMA pieces
+__device__ __forceinline__ int src_oi(int s) { return s & 1; }
+__device__ __forceinline__ int src_oj(int s) { return ((s + 1) >> 1) & 1; }
+
+
+__device__ __forceinline__ float dpp_row_shl(float v, int n)   // lane i <- lane i+n within a 16-lane row (n = 1..4)
+{
+    int r;
+    const int iv = __float_as_int(v);
+    switch (n) {
+    case 1: r = __builtin_amdgcn_update_dpp(0, iv, 0x101, 0xF, 0xF, true); break;
+    case 2: r = __builtin_amdgcn_update_dpp(0, iv, 0x102, 0xF, 0xF, true); break;
+    case 3: r = __builtin_amdgcn_update_dpp(0, iv, 0x103, 0xF, 0xF, true); break;
+    default: r = __builtin_amdgcn_update_dpp(0, iv, 0x104, 0xF, 0xF, true); break;
+    }
+    return __int_as_float(r);
+}

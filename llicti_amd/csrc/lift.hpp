@@ -1,0 +1,95 @@
+// lift.hpp -- integer YCoCg-R lift / unlift, per-image min/max, float planes (K1-K3, K13).
+// Part of the single translation unit llicti_hip.hip (included in order; not a stand-alone header).
+#pragma once
+
+// ------------------------------------------------------------------------------------------------ lift
+__global__ void minmax_init_kernel(int32_t *mm, int B)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) { mm[4 * i + 0] = 32767; mm[4 * i + 1] = 32767; mm[4 * i + 2] = -32768; mm[4 * i + 3] = -32768; }
+}
+
+// 4 pixels per thread when the plane size allows 4-byte aligned uchar4 / short4 / float4 accesses
+template <int VEC>
+__global__ __launch_bounds__(256) void lift_kernel(const uint8_t *__restrict__ rgb, long plane, int16_t *__restrict__ planes,
+                                                   float *__restrict__ fplanes, int32_t *__restrict__ mm)
+{
+    const int b = blockIdx.y;
+    const uint8_t *src = rgb + (long)b * 3 * plane;
+    int16_t *dst = planes + (long)b * 3 * plane;
+    float *fdst = fplanes + (long)b * 3 * plane;
+    int mnCo = 32767, mnCg = 32767, mxCo = -32768, mxCg = -32768;
+    for (long p = ((long)blockIdx.x * blockDim.x + threadIdx.x) * VEC; p < plane; p += (long)gridDim.x * blockDim.x * VEC) {
+        uint8_t r[VEC], gch[VEC], bl[VEC];
+        if constexpr (VEC == 4) {
+            const uchar4 a = *reinterpret_cast<const uchar4 *>(src + p);
+            const uchar4 c = *reinterpret_cast<const uchar4 *>(src + plane + p);
+            const uchar4 d = *reinterpret_cast<const uchar4 *>(src + 2 * plane + p);
+            r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w;
+            gch[0] = c.x; gch[1] = c.y; gch[2] = c.z; gch[3] = c.w;
+            bl[0] = d.x; bl[1] = d.y; bl[2] = d.z; bl[3] = d.w;
+        } else {
+            r[0] = src[p]; gch[0] = src[plane + p]; bl[0] = src[2 * plane + p];
+        }
+        short y[VEC], co[VEC], cg[VEC];
+        float fy[VEC], fco[VEC], fcg[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const int R = r[k], G = gch[k], Bl = bl[k];
+            const int Co = R - Bl;
+            const int t = Bl + (Co >> 1);        // floor division (torch >= 1.13 '//'; JVT YCoCg-R '>> 1')
+            const int Cg = G - t;
+            const int Y = t + (Cg >> 1) - 127;
+            y[k] = (short)Y; co[k] = (short)Co; cg[k] = (short)Cg;
+            fy[k] = (float)Y / 255.0f; fco[k] = (float)Co / 255.0f; fcg[k] = (float)Cg / 255.0f;
+            mnCo = min(mnCo, Co); mxCo = max(mxCo, Co); mnCg = min(mnCg, Cg); mxCg = max(mxCg, Cg);
+        }
+        if constexpr (VEC == 4) {
+            *reinterpret_cast<short4 *>(dst + p) = make_short4(y[0], y[1], y[2], y[3]);
+            *reinterpret_cast<short4 *>(dst + plane + p) = make_short4(co[0], co[1], co[2], co[3]);
+            *reinterpret_cast<short4 *>(dst + 2 * plane + p) = make_short4(cg[0], cg[1], cg[2], cg[3]);
+            *reinterpret_cast<float4 *>(fdst + p) = make_float4(fy[0], fy[1], fy[2], fy[3]);
+            *reinterpret_cast<float4 *>(fdst + plane + p) = make_float4(fco[0], fco[1], fco[2], fco[3]);
+            *reinterpret_cast<float4 *>(fdst + 2 * plane + p) = make_float4(fcg[0], fcg[1], fcg[2], fcg[3]);
+        } else {
+            dst[p] = y[0]; dst[plane + p] = co[0]; dst[2 * plane + p] = cg[0];
+            fdst[p] = fy[0]; fdst[plane + p] = fco[0]; fdst[2 * plane + p] = fcg[0];
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mnCo = min(mnCo, __shfl_xor(mnCo, o)); mxCo = max(mxCo, __shfl_xor(mxCo, o));
+        mnCg = min(mnCg, __shfl_xor(mnCg, o)); mxCg = max(mxCg, __shfl_xor(mxCg, o));
+    }
+    // one set of atomics per workgroup, and only where it would change the running value (a stale read can
+    // only be larger than the true minimum / smaller than the true maximum, i.e. conservative): thousands
+    // of waves hitting the same 16 bytes otherwise serialise at the memory side
+    __shared__ int red[4][4];
+    if ((threadIdx.x & 63) == 0) {
+        const int wv = threadIdx.x >> 6;
+        red[wv][0] = mnCo; red[wv][1] = mnCg; red[wv][2] = mxCo; red[wv][3] = mxCg;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int k = threadIdx.x;
+        int v = red[0][k];
+        for (int wv = 1; wv < 4; ++wv) v = (k < 2) ? min(v, red[wv][k]) : max(v, red[wv][k]);
+        const int cur = __hip_atomic_load(&mm[4 * b + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (k < 2) { if (v < cur) atomicMin(&mm[4 * b + k], v); }
+        else { if (v > cur) atomicMax(&mm[4 * b + k], v); }
+    }
+}
+
+__global__ __launch_bounds__(256) void unlift_kernel(const int16_t *__restrict__ planes, long plane, uint8_t *__restrict__ rgb)
+{
+    const int b = blockIdx.y;
+    const int16_t *src = planes + (long)b * 3 * plane;
+    uint8_t *dst = rgb + (long)b * 3 * plane;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < plane; p += (long)gridDim.x * blockDim.x) {
+        const int Y = src[p] + 127, Co = src[plane + p], Cg = src[2 * plane + p];
+        const int t = Y - (Cg >> 1);
+        const int G = Cg + t;
+        const int Bl = t - (Co >> 1);
+        const int R = Bl + Co;
+        dst[p] = (uint8_t)R; dst[plane + p] = (uint8_t)G; dst[2 * plane + p] = (uint8_t)Bl;
+    }
+}
