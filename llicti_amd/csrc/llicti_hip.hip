@@ -393,7 +393,9 @@ static int launch_cdf_pairs(const int16_t *planes, const float *params, const in
 {
     StageGeom sg = make_stage(g, band);
     const long nc = (long)sg.hc * sg.wc;
-    cdf_pairs_kernel<<<dim3((unsigned)((nc + 255) / 256), g.B), 256, 0, s>>>(planes, params, mm, sg, pairs);
+    const long np = (long)sg.h * sg.w;                    // the kernel walks the band grid (rows of CNN outputs are contiguous there)
+    (void)nc;
+    cdf_pairs_kernel<<<dim3((unsigned)((np + 255) / 256), g.B), 256, 0, s>>>(planes, params, mm, sg, pairs);
     HIPCHK(hipGetLastError());
     return 0;
 }
