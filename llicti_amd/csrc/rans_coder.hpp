@@ -29,16 +29,15 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restr
         if (nchunks <= m) continue;
         const int K = (nchunks - m + M - 1) / M;
         const uint32_t *pp = pairs + d.pair_off;
-        // the pair loads do not depend on the coder state: keep three steps in flight.  The loads are
-        // unconditional (clamped address) and the raw value is masked only where it is consumed: a select
-        // next to the load would make the compiler wait for it on the spot
+        // The pair loads do not depend on the coder state: four steps are kept in flight in four registers with
+        // FIXED roles (the loop is unrolled by four; a rotating ring r0 = r1 ... makes the compiler copy the
+        // newest load, i.e. wait for it with s_waitcnt vmcnt(0) in every step).  Loads are unconditional
+        // (clamped address); the raw value is masked only where it is consumed.
         auto fetch = [&](int k) -> uint32_t { return pp[min(64 * (m + max(k, 0) * M) + lane, d.n - 1)]; };
-        uint32_t r0 = fetch(K - 1), r1 = fetch(K - 2), r2 = fetch(K - 3);
-        for (int k = K - 1; k >= 0; --k) {
+        auto code = [&](int k, uint32_t raw) {
             const int n = 64 * (m + k * M) + lane;
-            const bool active = n < d.n;
-            const uint32_t v = active ? r0 : 0x00010000u;
-            r0 = r1; r1 = r2; r2 = fetch(k - 3);
+            const bool active = k >= 0 && n < d.n;
+            const uint32_t v = active ? raw : 0x00010000u;
             const uint32_t lo = v & 0xFFFFu;
             uint32_t hi = v >> 16;
             if (hi == 0) hi = 0x10000u;
@@ -50,9 +49,21 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restr
             if (p < 128) { bad = 2; p = 128; }
             if (emit) { w16[p + lanes_below(E)] = (uint16_t)(x & 0xFFFFu); x >>= 16; }
             if (active) {
-                const uint32_t q = x / freq;
-                x = (q << 16) + (x - q * freq) + lo;
+                // x < freq << 16 here, so the quotient fits 16 bits: a float reciprocal estimate is off by at most
+                // one, and one signed remainder test repairs it (8 operations instead of a 32-bit division)
+                uint32_t q = (uint32_t)((float)x * __builtin_amdgcn_rcpf((float)freq));
+                int32_t r = (int32_t)(x - q * freq);
+                if (r < 0) { q -= 1; r += (int32_t)freq; }
+                else if (r >= (int32_t)freq) { q += 1; r -= (int32_t)freq; }
+                x = (q << 16) + (uint32_t)r + lo;
             }
+        };
+        uint32_t r0 = fetch(K - 1), r1 = fetch(K - 2), r2 = fetch(K - 3), r3 = fetch(K - 4);
+        for (int k = K - 1; k >= 0; k -= 4) {                 // steps k, k-1, k-2, k-3 (those below 0 are no-ops)
+            code(k, r0);     r0 = fetch(k - 4);
+            code(k - 1, r1); r1 = fetch(k - 5);
+            code(k - 2, r2); r2 = fetch(k - 6);
+            code(k - 3, r3); r3 = fetch(k - 7);
         }
     }
     p -= 128;                                       // 64 final states, little-endian uint32, lane order
