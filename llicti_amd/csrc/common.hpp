@@ -90,3 +90,21 @@ __device__ __forceinline__ float dpp_row_shl(float v, int n)   // lane i <- lane
     }
     return __int_as_float(r);
 }
+
+// Block-cooperative byte copy of n bytes with arbitrary (mutually different) alignment of source and destination:
+// bytes up to the destination's first 16-byte boundary, then 16-byte stores fed by unaligned 16-byte loads
+// (gfx950 global memory handles unaligned dwordx4 accesses in hardware), then the tail bytes.
+struct __attribute__((packed, aligned(1))) u128_unaligned { uint32_t v[4]; };
+__device__ __forceinline__ void block_copy_bytes(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, int n)
+{
+    const int head = min(n, (int)((16u - ((uint32_t)(uintptr_t)dst & 15u)) & 15u));
+    for (int t = threadIdx.x; t < head; t += blockDim.x) dst[t] = src[t];
+    const int nvec = (n - head) >> 4;
+    uint4 *d4 = reinterpret_cast<uint4 *>(dst + head);
+    const u128_unaligned *s4 = reinterpret_cast<const u128_unaligned *>(src + head);
+    for (int t = threadIdx.x; t < nvec; t += blockDim.x) {
+        const u128_unaligned v = s4[t];
+        d4[t] = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
+    }
+    for (int t = head + (nvec << 4) + threadIdx.x; t < n; t += blockDim.x) dst[t] = src[t];
+}

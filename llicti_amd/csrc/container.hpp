@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ s
     if (dst + n > out_stride) { if (threadIdx.x == 0) atomicExch(&status[0], LLICTI_ENOSPACE); return; }
     const uint8_t *src = slots + slot_off[(long)st * B + b];
     uint8_t *o = out + (long)b * out_stride + dst;
-    for (int t = threadIdx.x; t < n; t += blockDim.x) o[t] = src[t];
+    block_copy_bytes(o, src, n);
     if (threadIdx.x == 0) seg_len[(long)b * LLICTI_NSEG + 4 + st] = n;
 }
 
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void unpack_kernel(const uint8_t *__restrict__
     if (n < 0 || n + 16 > cap || src + n > in_stride) { if (threadIdx.x == 0) atomicExch(&status[0], LLICTI_EFORMAT); n = 0; }
     const uint8_t *p = in + (long)b * in_stride + src;
     uint8_t *o = slots + slot_off[(long)st * B + b];
-    for (int t = threadIdx.x; t < n; t += blockDim.x) o[t] = p[t];
+    block_copy_bytes(o, p, n);
     const int padded = min(cap, ((n + 3) & ~3) + 16);
     for (int t = n + threadIdx.x; t < padded; t += blockDim.x) o[t] = 0;
 }

@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void rans_pack_kernel(const uint8_t *__restric
     if (dst + n > out_stride) { if (threadIdx.x == 0) atomicExch(&status[0], LLICTI_ENOSPACE); return; }
     const uint8_t *src = slots + rslot_off[b * M + m] + rinfo[2 * (b * M + m)];
     uint8_t *o = out + (long)b * out_stride + dst;
-    for (int t = threadIdx.x; t < n; t += blockDim.x) o[t] = src[t];
+    block_copy_bytes(o, src, n);
     if (threadIdx.x == 0) {
         seg_len[(long)b * LLICTI_NSEG + 4 + m] = n;
         if (m == 0) for (int k = 4 + M; k < LLICTI_NSEG; ++k) seg_len[(long)b * LLICTI_NSEG + k] = 0;
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void rans_unpack_kernel(const uint8_t *__restr
         n = 256;
     } else {
         const uint8_t *p = in + (long)b * in_stride + src;
-        for (int t = threadIdx.x; t < n; t += blockDim.x) o[t] = p[t];
+        block_copy_bytes(o, p, n);
     }
     const int padded = min(rslot_cap, n + 64);
     for (int t = n + threadIdx.x; t < padded; t += blockDim.x) o[t] = 0;
