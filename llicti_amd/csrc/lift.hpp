@@ -3,16 +3,30 @@
 #pragma once
 
 // ------------------------------------------------------------------------------------------------ lift
-__global__ void minmax_init_kernel(int32_t *mm, int B)
+// Per-image min / max of Co and Cg in two steps without atomics: every workgroup of lift_kernel leaves its four
+// partial values in part[b][blockIdx.x][4], one small workgroup per image folds them.  (Thousands of atomicMin /
+// atomicMax on the same 16 bytes of an image serialise at the memory side: 150 of the kernel's 180 us.)
+constexpr int kLiftMaxParts = 65536;        // entries of the partials scratch: B * gridDim.x <= this
+
+__global__ __launch_bounds__(64) void minmax_reduce_kernel(const int32_t *__restrict__ part, int gx, int32_t *__restrict__ mm)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < B) { mm[4 * i + 0] = 32767; mm[4 * i + 1] = 32767; mm[4 * i + 2] = -32768; mm[4 * i + 3] = -32768; }
+    const int b = blockIdx.x;
+    int mnCo = 32767, mnCg = 32767, mxCo = -32768, mxCg = -32768;
+    for (int t = threadIdx.x; t < gx; t += 64) {
+        const int32_t *q = part + ((long)b * gx + t) * 4;
+        mnCo = min(mnCo, q[0]); mnCg = min(mnCg, q[1]); mxCo = max(mxCo, q[2]); mxCg = max(mxCg, q[3]);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mnCo = min(mnCo, __shfl_xor(mnCo, o)); mxCo = max(mxCo, __shfl_xor(mxCo, o));
+        mnCg = min(mnCg, __shfl_xor(mnCg, o)); mxCg = max(mxCg, __shfl_xor(mxCg, o));
+    }
+    if (threadIdx.x == 0) { mm[4 * b + 0] = mnCo; mm[4 * b + 1] = mnCg; mm[4 * b + 2] = mxCo; mm[4 * b + 3] = mxCg; }
 }
 
 // 4 pixels per thread when the plane size allows 4-byte aligned uchar4 / short4 / float4 accesses
 template <int VEC>
 __global__ __launch_bounds__(256) void lift_kernel(const uint8_t *__restrict__ rgb, long plane, int16_t *__restrict__ planes,
-                                                   float *__restrict__ fplanes, int32_t *__restrict__ mm)
+                                                   float *__restrict__ fplanes, int32_t *__restrict__ part)
 {
     const int b = blockIdx.y;
     const uint8_t *src = rgb + (long)b * 3 * plane;
@@ -60,9 +74,6 @@ __global__ __launch_bounds__(256) void lift_kernel(const uint8_t *__restrict__ r
         mnCo = min(mnCo, __shfl_xor(mnCo, o)); mxCo = max(mxCo, __shfl_xor(mxCo, o));
         mnCg = min(mnCg, __shfl_xor(mnCg, o)); mxCg = max(mxCg, __shfl_xor(mxCg, o));
     }
-    // one set of atomics per workgroup, and only where it would change the running value (a stale read can
-    // only be larger than the true minimum / smaller than the true maximum, i.e. conservative): thousands
-    // of waves hitting the same 16 bytes otherwise serialise at the memory side
     __shared__ int red[4][4];
     if ((threadIdx.x & 63) == 0) {
         const int wv = threadIdx.x >> 6;
@@ -73,9 +84,7 @@ __global__ __launch_bounds__(256) void lift_kernel(const uint8_t *__restrict__ r
         const int k = threadIdx.x;
         int v = red[0][k];
         for (int wv = 1; wv < 4; ++wv) v = (k < 2) ? min(v, red[wv][k]) : max(v, red[wv][k]);
-        const int cur = __hip_atomic_load(&mm[4 * b + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (k < 2) { if (v < cur) atomicMin(&mm[4 * b + k], v); }
-        else { if (v > cur) atomicMax(&mm[4 * b + k], v); }
+        part[((long)b * gridDim.x + blockIdx.x) * 4 + k] = v;
     }
 }
 

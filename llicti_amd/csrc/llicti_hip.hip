@@ -43,6 +43,7 @@ using namespace llicti;
 // ------------------------------------------------------------------------------------------------ context
 struct Plan {                 // workspace carving for (B, H, W)
     int B = 0, H = 0, W = 0;
+    size_t off_lift_part;
     size_t off_planes, off_fplanes, off_minmax, off_status, off_params, off_pairs, off_slots, off_slot_len, off_tables;
     size_t total;
     std::vector<StreamDesc> desc;       // stage-major, image-minor: index (stage * B + b)
@@ -75,6 +76,7 @@ struct llicti_ctx {
     int pipeline_s = 4;
     bool pipeline = false;     // sub-batch pipelining of decode: measured neutral (co-resident CNN and rANS waves share VALU issue)
     int32_t *d_status = nullptr;      // small persistent status word (for the kernel-level entry points)
+    int32_t *d_lift_part = nullptr;   // min/max partials of llicti_lift_u8 (1 MB; calls on one context are not concurrent)
     bool profiling = false;
     std::vector<hipEvent_t> ev;       // pairs around band-CNN launches
     int ev_used = 0;
@@ -96,6 +98,7 @@ static void build_plan(Plan &p, int B, int H, int W, int M)
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
     p.off_status = take(64);
     p.off_minmax = take((size_t)B * 4 * sizeof(int32_t));
+    p.off_lift_part = take((size_t)kLiftMaxParts * 4 * sizeof(int32_t));
     p.off_planes = take((size_t)B * 3 * plane * sizeof(int16_t));
     p.off_fplanes = take((size_t)B * 3 * plane * sizeof(float));
     Geom g0 = make_geom(B, H, W, 0);
@@ -218,6 +221,7 @@ extern "C" int llicti_create(llicti_ctx **out, int device)
     c->device = device;
     if (const char *e = getenv("LLICTI_PIPELINE")) { c->pipeline = atoi(e) != 0; c->pipeline_s = atoi(e); }     // experiment switch: sub-batch pipelining of decode
     HIPCHK(hipMalloc(&c->d_status, 64));
+    HIPCHK(hipMalloc(&c->d_lift_part, (size_t)kLiftMaxParts * 4 * sizeof(int32_t)));
     HIPCHK(hipMemset(c->d_status, 0, 64));
     HIPCHK(hipEventCreate(&c->ev_call[0]));
     HIPCHK(hipEventCreate(&c->ev_call[1]));
@@ -252,6 +256,7 @@ extern "C" int llicti_destroy(llicti_ctx *c)
     }
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->d_status) hipFree(c->d_status);
+    if (c->d_lift_part) hipFree(c->d_lift_part);
     for (auto e : c->ev) hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) if (c->ev_call[i]) hipEventDestroy(c->ev_call[i]);
     delete c;
@@ -281,18 +286,17 @@ extern "C" int llicti_set_profiling(llicti_ctx *c, int enable)
 }
 
 // ------------------------------------------------------------------------------------------------ launches
-static int launch_lift(const uint8_t *d_rgb, int B, int H, int W, int16_t *planes, float *fplanes, int32_t *mm, hipStream_t s)
+// part: scratch of kLiftMaxParts x 4 int32 (the workspace's for the whole-batch calls, the context's for llicti_lift_u8)
+static int launch_lift(const uint8_t *d_rgb, int B, int H, int W, int16_t *planes, float *fplanes, int32_t *mm, int32_t *part, hipStream_t s)
 {
     const long plane = (long)H * W;
-    minmax_init_kernel<<<(B + 63) / 64, 64, 0, s>>>(mm, B);
     const bool vec = (plane % 4 == 0) && (((uintptr_t)d_rgb | (uintptr_t)planes | (uintptr_t)fplanes) % 16 == 0);
-    if (vec) {
-        const int gx = (int)std::min<long>((plane / 4 + 255) / 256, std::max(8, 4096 / B));
-        lift_kernel<4><<<dim3(gx, B), 256, 0, s>>>(d_rgb, plane, planes, fplanes, mm);
-    } else {
-        const int gx = (int)std::min<long>((plane + 255) / 256, std::max(8, 4096 / B));
-        lift_kernel<1><<<dim3(gx, B), 256, 0, s>>>(d_rgb, plane, planes, fplanes, mm);
-    }
+    const long want = vec ? (plane / 4 + 255) / 256 : (plane + 255) / 256;
+    const int gx = (int)std::max<long>(1, std::min<long>(std::min<long>(want, std::max(8, 4096 / B)), kLiftMaxParts / B));
+    if ((long)B * gx > kLiftMaxParts) return fail(LLICTI_EINVAL, "lift: batch of %d images exceeds the partials scratch", B);
+    if (vec) lift_kernel<4><<<dim3(gx, B), 256, 0, s>>>(d_rgb, plane, planes, fplanes, part);
+    else lift_kernel<1><<<dim3(gx, B), 256, 0, s>>>(d_rgb, plane, planes, fplanes, part);
+    minmax_reduce_kernel<<<B, 64, 0, s>>>(part, gx, mm);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -337,7 +341,7 @@ extern "C" int llicti_lift_u8(llicti_ctx *c, const uint8_t *d_rgb, int B, int H,
 {
     if (!c || !d_rgb || !d_planes || !d_fplanes || !d_minmax) return fail(LLICTI_EINVAL, "lift: null pointer");
     if (check_dims(B, H, W)) return LLICTI_EINVAL;
-    return launch_lift(d_rgb, B, H, W, d_planes, d_fplanes, d_minmax, (hipStream_t)stream);
+    return launch_lift(d_rgb, B, H, W, d_planes, d_fplanes, d_minmax, c->d_lift_part, (hipStream_t)stream);
 }
 
 extern "C" int llicti_unlift_u8(llicti_ctx *c, const int16_t *d_planes, int B, int H, int W, uint8_t *d_rgb, void *stream)
@@ -556,7 +560,7 @@ extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, 
 
     begin_call(c, s);
     HIPCHK(hipMemsetAsync(status, 0, 64, s));
-    if (int rc = launch_lift(d_rgb, B, H, W, planes, fplanes, mm, s)) return rc;
+    if (int rc = launch_lift(d_rgb, B, H, W, planes, fplanes, mm, (int32_t *)(ws + p.off_lift_part), s)) return rc;
     Geom g4 = make_geom(B, H, W, 4);
     const int byte0 = M ? (0x80 | (ilog2(M) << 4) | LLICTI_NLEVELS) : LLICTI_NLEVELS;
     header_write_kernel<<<B, 256, 0, s>>>(d_rgb, mm, H, W, g4.h, g4.w, pad_int(H, W), byte0, d_out, (long)out_stride, d_seg_len);
