@@ -188,9 +188,14 @@ __device__ __forceinline__ u32x4 lds_read_b128_hidden(const void *p)
     return v;
 }
 
+// A launch decodes symbols [n0, n0 + cnt) of every stream (n0 a multiple of 64); a stream's coder state
+// travels between the launches of a stage in `state` (8 words per stream), so that a stage can be cut into
+// chunks and the three colour channels of a band decoded as a pipeline (Co's tables need Y's pixels, Cg's need
+// Y's and Co's -- of the SAME positions only).  Table rows of the chunk: cdf[stream][cap_rows][row_stride].
+struct AcChunk { int n0, cnt, n_total, cap_rows; uint32_t *state; };
+
 __global__ __launch_bounds__(64) void ac_decode_kernel(const uint16_t *__restrict__ cdf, int Lp_fixed, int row_stride,
-                                                       const uint8_t *__restrict__ in, long in_stride,
-                                                       const int32_t *__restrict__ len, int len_stride, long N_, DecOut o)
+                                                       const uint8_t *__restrict__ in, long in_stride, AcChunk ck, DecOut o)
 {
     // Table rows reach the wave through an LDS ring filled by LDS-DMA (global_load_lds_dwordx4: one
     // instruction moves a whole 1 KB row), waited for with explicit vmcnt counts: rows held in registers
@@ -198,9 +203,10 @@ __global__ __launch_bounds__(64) void ac_decode_kernel(const uint16_t *__restric
     __shared__ uint4 ring[kDecRing][64];
     const int s = blockIdx.x;
     const int lane = threadIdx.x;
-    const int N = (int)N_;
+    const int N = ck.cnt;                                // symbols of this launch (local index nl; absolute n0 + nl)
+    const bool first = ck.n0 == 0, last = ck.n0 + ck.cnt >= ck.n_total;
     const uint32_t *words = reinterpret_cast<const uint32_t *>(in + (long)s * in_stride);
-    (void)len; (void)len_stride;   // streams are zero padded: reads past the end return 0 bits like torchac's get()
+    // streams are zero padded: reads past the end return 0 bits like torchac's get()
     int Lp = Lp_fixed, shift = 0;
     if (o.planes) {
         int minv, maxv;
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(64) void ac_decode_kernel(const uint16_t *__restric
         Lp = maxv - minv + 2;
     }
     const uint32_t max_symbol = (uint32_t)(Lp - 2);
-    const uint16_t *tab = cdf + (long)s * N * row_stride;
+    const uint16_t *tab = cdf + (long)s * ck.cap_rows * row_stride;
     const int vec_per_row = row_stride >> 3;             // uint4 (8 entries) per row
     // every lane transfers (lanes past the row re-read its last vector; their entries fail idx <= max_symbol)
     const int lane_vec = min(lane, vec_per_row - 1);
@@ -224,9 +230,10 @@ __global__ __launch_bounds__(64) void ac_decode_kernel(const uint16_t *__restric
     // emit s_waitcnt vmcnt(0) at every merge point, which would drain the row ring as well).
     const int in_words = (int)(in_stride >> 2);
     auto load_win = [&](int w0) -> uint32_t { return words[min(w0 + lane, in_words - 1)]; };
-    uint32_t win_cur = load_win(0);
+    uint32_t *st = ck.state ? ck.state + 8 * s : nullptr;
+    int wpos = first ? 3 : (int)st[6];                  // next word to pull (wave-uniform)
+    uint32_t win_cur = load_win(first ? 0 : (wpos & ~63));
     asm volatile("" : "+v"(win_cur));
-    int wpos = 3;                                       // next word to pull (wave-uniform)
     auto next_word = [&]() -> uint32_t {
         uint32_t w = bswap32((uint32_t)__builtin_amdgcn_readlane((int)win_cur, wpos & 63));
         if (wpos >= in_words) w = 0;                    // reads past the slot return 0 bits
@@ -241,6 +248,9 @@ __global__ __launch_bounds__(64) void ac_decode_kernel(const uint16_t *__restric
     uint64_t buf = ((uint64_t)w1_ << 32) | w2_;        // next 64 bits, MSB first (readlane returns a signed int: no sign extension here)
     int have = 64;
     uint32_t low = 0, high = 0xFFFFFFFFu;
+    if (!first) {                                       // resume where the previous chunk of this stage stopped
+        low = st[0]; high = st[1]; value = st[2]; buf = ((uint64_t)st[3] << 32) | st[4]; have = (int)st[5];
+    }
     const bool lane_ok = 8u * (uint32_t)lane <= max_symbol;      // this lane's first entry is a real table entry
     const int e = lane & 7;
 
@@ -249,7 +259,7 @@ __global__ __launch_bounds__(64) void ac_decode_kernel(const uint16_t *__restric
     auto flush = [&](int n_first, int count) {
         if (lane < count) {
             const int n = n_first + lane;
-            if (o.sym) o.sym[(long)s * N + n] = (int16_t)mysym;
+            if (o.sym) o.sym[(long)s * ck.n_total + n] = (int16_t)mysym;
             if (o.planes) {
                 const int i = n / o.sg.wc, j = n - i * o.sg.wc;
                 const long off = (long)s * 3 * o.sg.plane + (long)o.clr * o.sg.plane +
@@ -290,11 +300,11 @@ __global__ __launch_bounds__(64) void ac_decode_kernel(const uint16_t *__restric
         const uint32_t hi_nx = __builtin_amdgcn_readlane(sc1, (L + 1) & 63);     // ... when it is the next lane's first entry
         const uint32_t high_add = (sidx == max_symbol) ? r + 1u : (es == 7 ? hi_nx : hi_in);   // top symbol: c_high = 0x10000
         if (lane == (n & 63)) mysym = (int)sidx;
-        if ((n & 63) == 63) flush(n - 63, 64);
+        if ((n & 63) == 63) flush(ck.n0 + n - 63, 64);
         // slot's row sits in `cur` (read one iteration ago): refill it with row n + kDecRing
         dma_row(n + kDecRing, slot);
         cur = nxt;
-        if (n == N - 1) break;
+        if (n == N - 1 && last) break;                  // torchac does not update after the stream's last symbol
         high = (low - 1) + high_add;
         low = low + low_add;
         int n1 = __clz((int)(low ^ high));
@@ -322,6 +332,9 @@ __global__ __launch_bounds__(64) void ac_decode_kernel(const uint16_t *__restric
             }
         }
     }
-    if (N & 63) flush(N & ~63, N & 63);
+    if (N & 63) flush(ck.n0 + (N & ~63), N & 63);
+    if (!last && lane == 0) {
+        st[0] = low; st[1] = high; st[2] = value; st[3] = (uint32_t)(buf >> 32); st[4] = (uint32_t)buf; st[5] = (uint32_t)have; st[6] = (uint32_t)wpos;
+    }
     VMCNT_WAIT(0);                                      // no transfer may still target this workgroup's LDS at exit
 }

@@ -88,7 +88,8 @@ constexpr int kTabWaves = 4;
 
 __global__ __launch_bounds__(64 * kTabWaves) void cdf_table_kernel(const int16_t *__restrict__ planes, const float *__restrict__ params,
                                                                    const int32_t *__restrict__ minmax, StageGeom s, int clr,
-                                                                   uint16_t *__restrict__ tables, int row_stride)
+                                                                   uint16_t *__restrict__ tables, int row_stride,
+                                                                   int n0, int cnt, int cap_rows)
 {
     const int b = blockIdx.y;
     const int nc = s.hc * s.wc;
@@ -106,7 +107,8 @@ __global__ __launch_bounds__(64 * kTabWaves) void cdf_table_kernel(const int16_t
     const long img = (long)b * 3 * s.plane;
     const int mi = min(lane, 4);                         // lanes 0..4 prepare one mixture component each
 
-    for (int n = wave0; n < nc; n += nwaves) {
+    // rows [n0, n0 + cnt) of every image -> tables[b][cap_rows][row_stride] (row n at index n - n0)
+    for (int n = n0 + wave0; n < min(nc, n0 + cnt); n += nwaves) {
         const int i = n / s.wc, j = n - i * s.wc;
         const float *par = params + ((long)b * s.h * s.w + (long)i * s.w + j) * LLICTI_PARAM_STRIDE;
         const long off = img + ((long)(2 * i + s.oi) << s.lvl) * s.W + ((long)(2 * j + s.oj) << s.lvl);
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(64 * kTabWaves) void cdf_table_kernel(const int16_t
             lo_[k] = __builtin_amdgcn_readlane(lo, k);
             hi_[k] = __builtin_amdgcn_readlane(hi, k);
         }
-        uint16_t *row = tables + ((long)b * nc + n) * row_stride;
+        uint16_t *row = tables + ((long)b * cap_rows + (n - n0)) * row_stride;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             if (k < nblk) {

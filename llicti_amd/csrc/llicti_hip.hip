@@ -43,7 +43,8 @@ using namespace llicti;
 // ------------------------------------------------------------------------------------------------ context
 struct Plan {                 // workspace carving for (B, H, W)
     int B = 0, H = 0, W = 0;
-    size_t off_lift_part;
+    size_t off_lift_part, off_acstate;
+    long ac_cap_rows = 0;             // rows per image of one colour's chunk table buffer
     size_t off_planes, off_fplanes, off_minmax, off_status, off_params, off_pairs, off_slots, off_slot_len, off_tables;
     size_t total;
     std::vector<StreamDesc> desc;       // stage-major, image-minor: index (stage * B + b)
@@ -73,6 +74,8 @@ struct llicti_ctx {
     std::map<std::tuple<int, int, int, int>, struct PlanDev *> plans;   // (B, H, W, M) -> plan + its device arrays
     hipStream_t sub[kMaxSub] = { nullptr, nullptr, nullptr, nullptr };    // sub-batch pipelining (decode)
     hipEvent_t ev_fork = nullptr, ev_join[kMaxSub] = { nullptr, nullptr, nullptr, nullptr };
+    hipEvent_t ev_ac[2][8] = {};      // AC decode pipeline: chunk c of Y / Co done
+    hipEvent_t ev_ac_band = nullptr, ev_ac_end[2] = { nullptr, nullptr };
     int pipeline_s = 4;
     bool pipeline = false;     // sub-batch pipelining of decode: measured neutral (co-resident CNN and rANS waves share VALU issue)
     int32_t *d_status = nullptr;      // small persistent status word (for the kernel-level entry points)
@@ -85,6 +88,11 @@ struct llicti_ctx {
     int last_launches = 0;
     bool timing_pending = false;
 };
+
+// AC decode: a stage of nc symbols per stream is cut into C chunks (multiples of 64 symbols) so that the Y, Co and Cg
+// streams of a band run as a three-deep pipeline on three HIP streams (see decode_sub)
+static int ac_chunks(long nc) { return nc >= 8192 ? 8 : nc >= 2048 ? 4 : 1; }
+static long ac_chunk_rows(long nc) { const int C = ac_chunks(nc); return ((nc + C - 1) / C + 63) / 64 * 64; }
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -160,7 +168,16 @@ static void build_plan(Plan &p, int B, int H, int W, int M)
     p.off_slot_len = take((size_t)LLICTI_NSTREAMS * B * sizeof(int32_t));
     int hc0, wc0;
     coded_dims(g0, 1, &hc0, &wc0);
-    p.off_tables = take((size_t)B * g0.h * g0.w * 512 * sizeof(uint16_t));
+    for (int lvl = 0; lvl < LLICTI_NLEVELS; ++lvl) {
+        Geom gl = make_geom(B, H, W, lvl);
+        for (int band = 0; band < 3; ++band) {
+            int hcl, wcl;
+            coded_dims(gl, band, &hcl, &wcl);
+            p.ac_cap_rows = std::max(p.ac_cap_rows, ac_chunk_rows((long)hcl * wcl));
+        }
+    }
+    p.off_tables = take((size_t)3 * B * p.ac_cap_rows * 512 * sizeof(uint16_t));     // one chunk buffer per colour channel
+    p.off_acstate = take((size_t)3 * B * 8 * sizeof(uint32_t));
     p.total = o;
 }
 
@@ -226,6 +243,11 @@ extern "C" int llicti_create(llicti_ctx **out, int device)
     HIPCHK(hipEventCreate(&c->ev_call[0]));
     HIPCHK(hipEventCreate(&c->ev_call[1]));
     HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    for (int k = 0; k < 2; ++k) {
+        for (int i = 0; i < 8; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev_ac[k][i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_ac_end[k], hipEventDisableTiming));
+    }
+    HIPCHK(hipEventCreateWithFlags(&c->ev_ac_band, hipEventDisableTiming));
     for (int i = 1; i < kMaxSub; ++i) {
         HIPCHK(hipStreamCreateWithFlags(&c->sub[i], hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
@@ -255,6 +277,11 @@ extern "C" int llicti_destroy(llicti_ctx *c)
         if (c->ev_join[i]) hipEventDestroy(c->ev_join[i]);
     }
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    for (int k = 0; k < 2; ++k) {
+        for (int i = 0; i < 8; ++i) if (c->ev_ac[k][i]) hipEventDestroy(c->ev_ac[k][i]);
+        if (c->ev_ac_end[k]) hipEventDestroy(c->ev_ac_end[k]);
+    }
+    if (c->ev_ac_band) hipEventDestroy(c->ev_ac_band);
     if (c->d_status) hipFree(c->d_status);
     if (c->d_lift_part) hipFree(c->d_lift_part);
     for (auto e : c->ev) hipEventDestroy(e);
@@ -404,13 +431,13 @@ static int launch_cdf_pairs(const int16_t *planes, const float *params, const in
     return 0;
 }
 static int launch_cdf_table(const int16_t *planes, const float *params, const int32_t *mm, const Geom &g, int band, int clr,
-                            uint16_t *tables, int row_stride, hipStream_t s)
+                            uint16_t *tables, int row_stride, long n0, long cnt, long cap_rows, hipStream_t s)
 {
     StageGeom sg = make_stage(g, band);
-    const long nc = (long)sg.hc * sg.wc;
-    const long want = (nc + kTabWaves - 1) / kTabWaves;                     // one row per wave ...
+    const long want = (cnt + kTabWaves - 1) / kTabWaves;                    // one row per wave ...
     const long cap = std::max<long>(1, (256L * 8 * 2) / std::max(1, g.B));   // ... up to ~16 waves per SIMD-quad in flight per image set
-    cdf_table_kernel<<<dim3((unsigned)std::min(want, cap), g.B), 64 * kTabWaves, 0, s>>>(planes, params, mm, sg, clr, tables, row_stride);
+    cdf_table_kernel<<<dim3((unsigned)std::max<long>(1, std::min(want, cap)), g.B), 64 * kTabWaves, 0, s>>>(planes, params, mm, sg, clr, tables, row_stride,
+                                                                                                  (int)n0, (int)cnt, (int)cap_rows);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -423,7 +450,10 @@ extern "C" int llicti_cdf_u16(llicti_ctx *c, const int16_t *d_planes, const floa
     if (lvl < 0 || lvl >= LLICTI_NLEVELS || band < 0 || band > 2 || clr < 0 || clr > 2) return fail(LLICTI_EINVAL, "cdf_u16: bad level/band/clr");
     if (row_stride < 8 || row_stride > 512 || (row_stride & 7)) return fail(LLICTI_EINVAL, "cdf_u16: row_stride must be a multiple of 8 in [8,512]");
     Geom g = make_geom(B, H, W, lvl);
-    return launch_cdf_table(d_planes, d_params, d_minmax, g, band, clr, d_tables, row_stride, (hipStream_t)stream);
+    int hc, wc;
+    coded_dims(g, band, &hc, &wc);
+    const long nc = (long)hc * wc;
+    return launch_cdf_table(d_planes, d_params, d_minmax, g, band, clr, d_tables, row_stride, 0, nc, nc, (hipStream_t)stream);
 }
 
 extern "C" int llicti_cdf_pairs_u32(llicti_ctx *c, const int16_t *d_planes, const float *d_params, const int32_t *d_minmax,
@@ -458,7 +488,9 @@ extern "C" int llicti_ac_decode_u16cdf(llicti_ctx *c, const uint16_t *d_cdf, int
     DecOut o;
     memset(&o, 0, sizeof o);
     o.sym = d_sym;
-    ac_decode_kernel<<<n_streams, 64, 0, (hipStream_t)stream>>>(d_cdf, Lp, row_stride, d_in, in_stride, d_len, 1, N, o);
+    (void)d_len;
+    AcChunk ck = { 0, (int)N, (int)N, (int)N, nullptr };
+    ac_decode_kernel<<<n_streams, 64, 0, (hipStream_t)stream>>>(d_cdf, Lp, row_stride, d_in, in_stride, ck, o);
     HIPCHK(hipGetLastError());
     return LLICTI_OK;
 }
@@ -599,6 +631,7 @@ static int decode_sub(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in
     float *params = (float *)(ws + p.off_params);
     uint8_t *slots = ws + p.off_slots;
     uint16_t *tables = (uint16_t *)(ws + p.off_tables);
+    uint32_t *acstate = (uint32_t *)(ws + p.off_acstate);
 
     HIPCHK(hipMemsetAsync(status, 0, 64, s));
     Geom g4 = make_geom(B, H, W, 4);
@@ -624,17 +657,44 @@ static int decode_sub(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in
                 rans_decode_stage_kernel<1><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, planes, fplanes, mm);
                 rans_decode_stage_kernel<2><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, planes, fplanes, mm);
             }
-            for (int clr = 0; clr < 3 && M == 0; ++clr) {
-                const int row_stride = (clr == 0) ? 264 : 512;      // Y: Lp = 257; Co/Cg: Lp <= 512
-                if (int rc = launch_cdf_table(planes, params, mm, g, band, clr, tables, row_stride, s)) return rc;
-                const int st = stage_index(lvl, band, clr);
-                DecOut o;
-                memset(&o, 0, sizeof o);
-                o.planes = planes; o.fplanes = fplanes; o.minmax = mm; o.sg = sg; o.clr = clr;
-                // the B streams of one stage sit in consecutive slots of equal capacity
-                const long in_stride_slots = p.slot_cap[(size_t)st * B];
-                ac_decode_kernel<<<B, 64, 0, s>>>(tables, 0, row_stride, slots + p.slot_off[(size_t)st * B], in_stride_slots,
-                                                  nullptr, 0, nc, o);
+            if (M == 0) {
+                // Y, Co, Cg of this band as a pipeline over chunks of the stage: chunk c of Co needs only chunk c
+                // of Y (mean update from the SAME pixel, LLICTI_nets.py:474-477), chunk c of Cg only chunk c of
+                // Y and Co.  Three HIP streams; tables are built per chunk into one buffer per colour; the coder
+                // state of a stream travels between its chunk launches in `acstate`.
+                const int C = ac_chunks(nc);
+                const long rows = ac_chunk_rows(nc);
+                hipStream_t q[3] = { s, c->sub[1], c->sub[2] };
+                if (C > 1) {
+                    HIPCHK(hipEventRecord(c->ev_ac_band, s));
+                    HIPCHK(hipStreamWaitEvent(q[1], c->ev_ac_band, 0));
+                    HIPCHK(hipStreamWaitEvent(q[2], c->ev_ac_band, 0));
+                }
+                for (int ch = 0; ch < C; ++ch) {
+                    const long n0 = (long)ch * rows, cnt = std::min(rows, nc - n0);
+                    for (int clr = 0; clr < 3; ++clr) {
+                        hipStream_t qs = (C > 1) ? q[clr] : s;
+                        if (C > 1 && clr > 0) HIPCHK(hipStreamWaitEvent(qs, c->ev_ac[clr - 1][ch], 0));
+                        const int row_stride = (clr == 0) ? 264 : 512;      // Y: Lp = 257; Co/Cg: Lp <= 512
+                        uint16_t *tab = tables + (size_t)clr * B * p.ac_cap_rows * 512;
+                        if (int rc = launch_cdf_table(planes, params, mm, g, band, clr, tab, row_stride, n0, cnt, p.ac_cap_rows, qs)) return rc;
+                        const int st = stage_index(lvl, band, clr);
+                        DecOut o;
+                        memset(&o, 0, sizeof o);
+                        o.planes = planes; o.fplanes = fplanes; o.minmax = mm; o.sg = sg; o.clr = clr;
+                        // the B streams of one stage sit in consecutive slots of equal capacity
+                        const long in_stride_slots = p.slot_cap[(size_t)st * B];
+                        AcChunk ck = { (int)n0, (int)cnt, (int)nc, (int)p.ac_cap_rows, acstate + (size_t)clr * B * 8 };
+                        ac_decode_kernel<<<B, 64, 0, qs>>>(tab, 0, row_stride, slots + p.slot_off[(size_t)st * B], in_stride_slots, ck, o);
+                        if (C > 1 && clr < 2) HIPCHK(hipEventRecord(c->ev_ac[clr][ch], qs));
+                    }
+                }
+                if (C > 1) {
+                    for (int k = 1; k < 3; ++k) {
+                        HIPCHK(hipEventRecord(c->ev_ac_end[k - 1], q[k]));
+                        HIPCHK(hipStreamWaitEvent(s, c->ev_ac_end[k - 1], 0));
+                    }
+                }
             }
         }
     }
