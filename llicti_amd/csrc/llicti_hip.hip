@@ -74,7 +74,7 @@ struct llicti_ctx {
     std::map<std::tuple<int, int, int, int>, struct PlanDev *> plans;   // (B, H, W, M) -> plan + its device arrays
     hipStream_t sub[kMaxSub] = { nullptr, nullptr, nullptr, nullptr };    // sub-batch pipelining (decode)
     hipEvent_t ev_fork = nullptr, ev_join[kMaxSub] = { nullptr, nullptr, nullptr, nullptr };
-    hipEvent_t ev_ac[2][8] = {};      // AC decode pipeline: chunk c of Y / Co done
+    hipEvent_t ev_ac[2][16] = {};      // AC decode pipeline: chunk c of Y / Co done
     hipEvent_t ev_ac_band = nullptr, ev_ac_end[2] = { nullptr, nullptr };
     int pipeline_s = 4;
     bool pipeline = false;     // sub-batch pipelining of decode: measured neutral (co-resident CNN and rANS waves share VALU issue)
@@ -91,7 +91,7 @@ struct llicti_ctx {
 
 // AC decode: a stage of nc symbols per stream is cut into C chunks (multiples of 64 symbols) so that the Y, Co and Cg
 // streams of a band run as a three-deep pipeline on three HIP streams (see decode_sub)
-static int ac_chunks(long nc) { return nc >= 8192 ? 8 : nc >= 2048 ? 4 : 1; }
+static int ac_chunks(long nc) { return nc >= 32768 ? 16 : nc >= 4096 ? 8 : nc >= 1024 ? 4 : nc >= 256 ? 2 : 1; }
 static long ac_chunk_rows(long nc) { const int C = ac_chunks(nc); return ((nc + C - 1) / C + 63) / 64 * 64; }
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -244,7 +244,7 @@ extern "C" int llicti_create(llicti_ctx **out, int device)
     HIPCHK(hipEventCreate(&c->ev_call[1]));
     HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     for (int k = 0; k < 2; ++k) {
-        for (int i = 0; i < 8; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev_ac[k][i], hipEventDisableTiming));
+        for (int i = 0; i < 16; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev_ac[k][i], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->ev_ac_end[k], hipEventDisableTiming));
     }
     HIPCHK(hipEventCreateWithFlags(&c->ev_ac_band, hipEventDisableTiming));
@@ -278,7 +278,7 @@ extern "C" int llicti_destroy(llicti_ctx *c)
     }
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     for (int k = 0; k < 2; ++k) {
-        for (int i = 0; i < 8; ++i) if (c->ev_ac[k][i]) hipEventDestroy(c->ev_ac[k][i]);
+        for (int i = 0; i < 16; ++i) if (c->ev_ac[k][i]) hipEventDestroy(c->ev_ac[k][i]);
         if (c->ev_ac_end[k]) hipEventDestroy(c->ev_ac_end[k]);
     }
     if (c->ev_ac_band) hipEventDestroy(c->ev_ac_band);
