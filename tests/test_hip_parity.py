@@ -530,3 +530,44 @@ def test_forward_selfinfo(torch_mod, codecs, oracle_weights, case, wname):
         assert coded_bits < tot
     with pytest.raises(ValueError):
         model.forward(x[:, :, :31, :])
+
+
+def _edge_images():
+    rng = np.random.default_rng(123)
+    H, W = 40, 72
+    imgs = {
+        "black": np.zeros((3, H, W), np.uint8),
+        "white": np.full((3, H, W), 255, np.uint8),
+        "constant": np.broadcast_to(np.array([17, 200, 93], np.uint8)[:, None, None], (3, H, W)).copy(),   # Co, Cg ranges of one value: Lp = 2
+        "grey_ramp": np.broadcast_to((np.arange(W) * 3 % 256).astype(np.uint8)[None, None, :], (3, H, W)).copy(),   # Co = Cg = 0 everywhere
+        "extremes": rng.choice(np.array([0, 255], np.uint8), size=(3, H, W)),                              # Co, Cg span [-255, 255]: Lp = 512
+        "one_pixel": np.zeros((3, H, W), np.uint8),
+    }
+    imgs["one_pixel"][:, 13, 29] = (255, 0, 128)
+    return imgs
+
+
+@pytest.mark.parametrize("wname", ["rand1337", "trainedlike"])
+def test_degenerate_images_bitexact_and_roundtrip(torch_mod, codecs, oracle_weights, wname):
+    """Alphabets of one symbol (Lp = 2), full-width alphabets (Lp = 512), saturated pixels: both containers
+    against the oracle, byte for byte, and back to the pixels."""
+    from llicti_amd.codec import MODE_RANS, container_to_bytestream_list
+    from oracle import oracle as orc
+    torch = torch_mod
+    c = codecs(wname)
+    W_o = oracle_weights(wname)
+    imgs = _edge_images()
+    rgb = np.stack(list(imgs.values()))
+    lists, cont, seg = _encode_to_lists(c, torch, rgb)
+    rec = c.decode(cont, seg, rgb.shape[2], rgb.shape[3])
+    c.check()
+    assert np.array_equal(rec.cpu().numpy(), rgb)
+    cont_r, seg_r = c.encode(_dev(torch, rgb), mode=MODE_RANS(2))
+    c.check()
+    rec = c.decode(cont_r, seg_r, rgb.shape[2], rgb.shape[3], mode=MODE_RANS(2))
+    c.check()
+    assert np.array_equal(rec.cpu().numpy(), rgb)
+    cont_h, seg_h = cont_r.cpu().numpy(), seg_r.cpu().numpy()
+    for b, name in enumerate(imgs):
+        assert lists[b] == orc.encode_image(rgb[b], W_o), name
+        assert container_to_bytestream_list(cont_h[b], seg_h[b]) == orc.encode_image_rans(rgb[b], W_o, 2), name
