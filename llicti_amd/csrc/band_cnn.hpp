@@ -34,6 +34,9 @@ constexpr int kParamStride = LLICTI_PARAM_STRIDE;
 #ifndef CNN_FENCE_L1
 #define CNN_FENCE_L1 4         // scheduler fence every N k-steps of layer 1 (0 = none)
 #endif
+#ifndef CNN_PRIO
+#define CNN_PRIO 1            // progress-based wave priority (see the tile loop)
+#endif
 #ifndef CNN_STAGE_SITES
 #define CNN_STAGE_SITES 4     // points of the tile at which the wave groups request the next tile's DMA (1, 2 or 4)
 #endif
@@ -104,6 +107,13 @@ __device__ __forceinline__ float relu(float x) { return (x > 0.0f) ? x : 0.0f; }
 __device__ __forceinline__ f32x4 relu4(f32x4 v) { v[0] = relu(v[0]); v[1] = relu(v[1]); v[2] = relu(v[2]); v[3] = relu(v[3]); return v; }
 #define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// priority to switch to when the wave's issued-MFMA count passes a quarter mark of the tile inside (before, after]; -1: none
+constexpr int prio_step(int before, int after, int total)
+{
+    for (int i = 1; i <= 3; ++i) if (before < total * i / 4 && after >= total * i / 4) return 3 - i;
+    return -1;
+}
+
 template <int BAND>
 __global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *__restrict__ fplanes, Geom g,
                                                                   const float *__restrict__ wpack,
@@ -112,6 +122,7 @@ __global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *_
     constexpr int K0 = (BAND == 0) ? 48 : (BAND == 1) ? 72 : 120;
     constexpr int NK0 = K0 / 4;
     constexpr int NPL = 3 * (BAND + 1);          // staged input planes: (x00 | x11 | x01) x (Y, Co, Cg)
+    constexpr int kMfmaL0 = kMT * NK0 * kNT, kMfmaT12 = (kKS1 + 4) * kNT, kMfmaTile = kMfmaL0 + kMT * kMfmaT12;   // MFMAs of a wave per tile (approx.)
     using PO = PackOff<K0>;
     static_assert(kKTab<BAND>.n == NK0, "k-step table");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -189,6 +200,12 @@ __global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *_
         auto stage_next = [&](int site) {
             if (more && stage_site == site % CNN_STAGE_SITES) stage(tile + gridDim.x, lds_in + (cur ^ 1) * (NPL * kInPlane));
         };
+        // Wave priority falls as the wave advances through its tile (3, 2, 1, 0 by quarter of the MFMA work): the
+        // SIMD's arbiter otherwise serves the OLDEST wave first, which then finishes its tile ~24 % of a tile time
+        // before the barrier opens while the youngest runs the last stretch alone, with nobody to fill its LDS /
+        // VALU bubbles (in-kernel stamps: barrier wait 23.5k cycles for wave 0, 6.5k for wave 8, tile 99k).
+        // A wave that is behind now outranks one that is ahead, so the four waves of a SIMD reach the barrier together.
+        if constexpr (CNN_PRIO) __builtin_amdgcn_s_setprio(3);
         stage_next(0);
 
         // ---- layer 0: [96 x K0] x [K0 x 64 pixels]; bias preloaded into the accumulators
@@ -212,6 +229,8 @@ __global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *_
             }
             static_for<NK0>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
+                if constexpr (CNN_PRIO && prio_step(kMfmaL0 * t / NK0, kMfmaL0 * (t + 1) / NK0, kMfmaTile) >= 0)
+                    __builtin_amdgcn_s_setprio(prio_step(kMfmaL0 * t / NK0, kMfmaL0 * (t + 1) / NK0, kMfmaTile));
                 float a_n[kMT], b_n[kNT];
                 if constexpr (t + 1 < NK0) {       // next k-step's fragments are in flight while this one's MFMAs run
                     constexpr int U = kKTab<BAND>.s[t + 1].U, S = kKTab<BAND>.s[t + 1].S;
@@ -267,6 +286,8 @@ __global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *_
         }
         static_for<kMT>([&](auto Tc) {
             constexpr int T = decltype(Tc)::value;
+            if constexpr (CNN_PRIO && prio_step(kMfmaL0 + T * kMfmaT12, kMfmaL0 + (T + 1) * kMfmaT12, kMfmaTile) >= 0)
+                __builtin_amdgcn_s_setprio(prio_step(kMfmaL0 + T * kMfmaT12, kMfmaL0 + (T + 1) * kMfmaT12, kMfmaTile));
             if constexpr (T == 2 && CNN_STAGE_SITES > 2) stage_next(2);
             if constexpr (T == 4 && CNN_STAGE_SITES > 2) stage_next(3);
             f32x4 a1[kNT];
