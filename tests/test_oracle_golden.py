@@ -174,3 +174,34 @@ def test_forward_selfinfo_vs_reference(case, wname, oracle_weights):
         assert np.allclose(infos[s], r, rtol=1e-4, atol=1e-3), (s, float(np.abs(infos[s] - r).max()))
         tot += float(infos[s].astype(np.float64).sum())
     assert abs(tot - float(g["total_bits"][0])) < 1e-5 * float(g["total_bits"][0])
+
+
+def test_oracle_roundtrip_random_shapes(oracle_weights):
+    """Property test of the checker itself: any shape in the format's range (incl. odd sizes with either pad flag),
+    any pixel content, both containers -- decode(encode(x)) == x and the header reproduces the shape."""
+    from hypothesis import given, settings, strategies as st
+    from oracle import oracle as orc
+    W_o = oracle_weights("trainedlike")
+
+    @settings(max_examples=12, deadline=None)
+    @given(st.integers(32, 75), st.integers(32, 75), st.integers(0, 2 ** 31 - 1), st.sampled_from(["noise", "flat", "smooth"]),
+           st.sampled_from([0, 1, 4]))
+    def run(H, W, seed, kind, M):
+        rng = np.random.default_rng(seed)
+        if kind == "noise":
+            rgb = rng.integers(0, 256, size=(3, H, W), dtype=np.uint8)
+        elif kind == "flat":
+            rgb = np.broadcast_to(rng.integers(0, 256, size=(3, 1, 1), dtype=np.uint8), (3, H, W)).copy()
+        else:
+            base = rng.integers(0, 256, size=(3, 1, 1)) + np.cumsum(rng.integers(-2, 3, size=(3, H, W)), axis=2)
+            rgb = np.clip(base, 0, 255).astype(np.uint8)
+        if M == 0:
+            bl = orc.encode_image(rgb, W_o)
+            rec = orc.decode_image(bl, W_o)
+        else:
+            bl = orc.encode_image_rans(rgb, W_o, M)
+            rec = orc.decode_image_rans(bl, W_o)
+        assert np.array_equal(rec, rgb)
+        assert len(bl) == 6 and all(len(r) == 9 for r in bl)
+        assert bl[0][0][1] == (((H + 15) // 16 + 1) // 2) and bl[0][0][2] == (((W + 15) // 16 + 1) // 2)     # h4, w4 of level 4
+    run()
