@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Large-configuration round trips on one MI355X (not part of the test suite: minutes of GPU time, tens of GB):
+BASELINE.json configs[4]'s whole 256-image batch on ONE GPU, a 64-image batch through the AC container, and the
+format's largest image (8160 x 8160)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from llicti_amd.codec import HipCodec, MODE_AC, MODE_RANS
+from llicti_amd.config import default_config
+from llicti_amd.graphs.models.LLICTI_nets import LLICTI
+
+torch.manual_seed(1337)
+codec = HipCodec(torch.device("cuda", 0))
+codec.load_state_dict(LLICTI(default_config()).state_dict())
+def run(B, H, W, mode, name):
+    g = torch.Generator(device="cuda").manual_seed(B + H)
+    rgb = torch.randint(0, 256, (B, 3, H, W), dtype=torch.uint8, device="cuda", generator=g)
+    torch.cuda.synchronize(); t0 = time.time()
+    cont, seg = codec.encode(rgb, mode=mode)
+    codec.check(); torch.cuda.synchronize(); t1 = time.time()
+    rec = codec.decode(cont, seg, H, W, mode=mode)
+    codec.check(); torch.cuda.synchronize(); t2 = time.time()
+    ok = bool(torch.equal(rec, rgb))
+    mp = B * H * W / 1e6
+    print(f"{name}: B={B} {W}x{H} ok={ok} enc {mp/(t1-t0):.1f} MPix/s dec {mp/(t2-t1):.1f} MPix/s bpp {8.0*float(seg.sum())/(B*H*W):.3f} "
+          f"workspace {codec._ws.numel()/2**30:.2f} GiB peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
+    assert ok
+    del rgb, cont, seg, rec
+    codec._ws = None; codec._ws_key = None
+    torch.cuda.empty_cache()
+run(256, 512, 768, MODE_RANS(16), "configs[4] batch on one GPU (rans16)")
+run(256, 512, 768, MODE_RANS(16), "same, warm")
+run(64, 512, 768, MODE_AC, "AC container")
+run(1, 8160, 8160, MODE_RANS(32), "largest image (rans32)")
+run(2, 2160, 3840, MODE_AC, "two 4K images, AC container")
