@@ -229,13 +229,13 @@ __global__ __launch_bounds__(64) void ac_decode_kernel(const uint16_t *__restric
     // 150 symbols, and no register with a load in flight across loop iterations (those make the compiler
     // emit s_waitcnt vmcnt(0) at every merge point, which would drain the row ring as well).
     const int in_words = (int)(in_stride >> 2);
-    auto load_win = [&](int w0) -> uint32_t { return words[min(w0 + lane, in_words - 1)]; };
+    auto load_win = [&](int w0) -> uint32_t { return bswap32(words[min(w0 + lane, in_words - 1)]); };   // big-endian words, swapped once per reload
     uint32_t *st = ck.state ? ck.state + 8 * s : nullptr;
     int wpos = first ? 3 : (int)st[6];                  // next word to pull (wave-uniform)
     uint32_t win_cur = load_win(first ? 0 : (wpos & ~63));
     asm volatile("" : "+v"(win_cur));
     auto next_word = [&]() -> uint32_t {
-        uint32_t w = bswap32((uint32_t)__builtin_amdgcn_readlane((int)win_cur, wpos & 63));
+        uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)win_cur, wpos & 63);
         if (wpos >= in_words) w = 0;                    // reads past the slot return 0 bits
         ++wpos;
         if ((wpos & 63) == 0) { win_cur = load_win(wpos); asm volatile("" : "+v"(win_cur)); }   // wait for it here, not at every later pull
@@ -243,8 +243,8 @@ __global__ __launch_bounds__(64) void ac_decode_kernel(const uint16_t *__restric
     };
 #pragma unroll
     for (int k = 0; k < kDecRing; ++k) dma_row(k, k);
-    uint32_t value = bswap32((uint32_t)__builtin_amdgcn_readlane((int)win_cur, 0));
-    const uint32_t w1_ = bswap32((uint32_t)__builtin_amdgcn_readlane((int)win_cur, 1)), w2_ = bswap32((uint32_t)__builtin_amdgcn_readlane((int)win_cur, 2));
+    uint32_t value = (uint32_t)__builtin_amdgcn_readlane((int)win_cur, 0);
+    const uint32_t w1_ = (uint32_t)__builtin_amdgcn_readlane((int)win_cur, 1), w2_ = (uint32_t)__builtin_amdgcn_readlane((int)win_cur, 2);
     uint64_t buf = ((uint64_t)w1_ << 32) | w2_;        // next 64 bits, MSB first (readlane returns a signed int: no sign extension here)
     int have = 64;
     uint32_t low = 0, high = 0xFFFFFFFFu;
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(64) void ac_decode_kernel(const uint16_t *__restric
         const uint32_t c1 = cur.x & 0xFFFFu;
         const uint32_t sc1 = __umul24(rh, c1) + ((__umul24(rl, c1) + c1) >> 16);
         const bool p1 = (lane == 0) || (lane_ok && sc1 <= T);
-        const int L = __builtin_popcountll(__ballot(p1)) - 1;
+        const int L = __builtin_popcountll(ballot64(p1)) - 1;
         const uint32_t w0 = __builtin_amdgcn_readlane(cur.x, L), w1 = __builtin_amdgcn_readlane(cur.y, L);
         const uint32_t w2 = __builtin_amdgcn_readlane(cur.z, L), w3 = __builtin_amdgcn_readlane(cur.w, L);
         // round 2: the 8 entries of lane L, one per lane e = lane & 7
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(64) void ac_decode_kernel(const uint16_t *__restric
         const uint32_t sc2 = __umul24(rh, c2) + ((__umul24(rl, c2) + c2) >> 16);
         const uint32_t idx = 8u * (uint32_t)L + (uint32_t)e;
         const bool p2 = (e == 0) || (idx <= max_symbol && sc2 <= T);
-        const int es = __builtin_popcount((uint32_t)__ballot(p2) & 0xFFu) - 1;
+        const int es = __builtin_popcount((uint32_t)ballot64(p2) & 0xFFu) - 1;
         const uint32_t sidx = 8u * (uint32_t)L + (uint32_t)es;
         const uint32_t low_add = __builtin_amdgcn_readlane(sc2, es);
         const uint32_t hi_in = __builtin_amdgcn_readlane(sc2, (es + 1) & 7);      // entry sidx + 1 when es < 7
@@ -307,28 +307,37 @@ __global__ __launch_bounds__(64) void ac_decode_kernel(const uint16_t *__restric
         if (n == N - 1 && last) break;                  // torchac does not update after the stream's last symbol
         high = (low - 1) + high_add;
         low = low + low_add;
+        // renormalisation in closed form: n1 leading bits on which low and high agree (E1 / E2 steps), then n2
+        // underflow steps (E3: low = 01.., high = 10..); both shifts of `value` happen at once, with one refill
         int n1 = __clz((int)(low ^ high));
         if (n1 > 31) n1 = 31;
-        if (n1 > 0) {
-            low <<= n1;
-            high = (high << n1) | ((1u << n1) - 1u);
-            value = (value << n1) | (uint32_t)(buf >> (64 - n1));
-            buf <<= n1; have -= n1;
-            if (have <= 32) {
-                buf |= (uint64_t)next_word() << (32 - have);
-                have += 32;
-            }
-        }
-        int n2 = min(__clz((int)~(low << 1)), __clz((int)(high << 1)));
+        const uint32_t low1 = low << n1, high1 = (high << n1) | ((1u << n1) - 1u);
+        int n2 = min(__clz((int)~(low1 << 1)), __clz((int)(high1 << 1)));
         if (n2 > 31) n2 = 31;
-        if (n2 > 0) {
-            low = (low << n2) & 0x7FFFFFFFu;
-            high = ((high << n2) | ((1u << n2) - 1u)) | 0x80000000u;
-            value = ((value << n2) ^ 0x80000000u) | (uint32_t)(buf >> (64 - n2));
-            buf <<= n2; have -= n2;
-            if (have <= 32) {
-                buf |= (uint64_t)next_word() << (32 - have);
-                have += 32;
+        const int nsh = n1 + n2;
+        if (nsh > 0) {
+            if (nsh < 32) {
+                const uint32_t e3 = n2 > 0 ? 0x80000000u : 0u;
+                low = (low1 << n2) & ~e3;
+                high = ((high1 << n2) | ((1u << n2) - 1u)) | e3;
+                value = ((value << nsh) | (uint32_t)(buf >> (64 - nsh))) ^ e3;
+                buf <<= nsh; have -= nsh;
+                if (have <= 32) {
+                    buf |= (uint64_t)next_word() << (32 - have);
+                    have += 32;
+                }
+            } else {                                    // >= 32 bits consumed by one symbol: never with 16-bit tables, kept for completeness
+                low = low1; high = high1;
+                if (n1 > 0) {
+                    value = (value << n1) | (uint32_t)(buf >> (64 - n1));
+                    buf <<= n1; have -= n1;
+                    if (have <= 32) { buf |= (uint64_t)next_word() << (32 - have); have += 32; }
+                }
+                low = (low << n2) & 0x7FFFFFFFu;
+                high = ((high << n2) | ((1u << n2) - 1u)) | 0x80000000u;
+                value = ((value << n2) ^ 0x80000000u) | (uint32_t)(buf >> (64 - n2));
+                buf <<= n2; have -= n2;
+                if (have <= 32) { buf |= (uint64_t)next_word() << (32 - have); have += 32; }
             }
         }
     }

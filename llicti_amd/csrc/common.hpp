@@ -78,6 +78,10 @@ __device__ __forceinline__ int src_oi(int s) { return s & 1; }
 __device__ __forceinline__ int src_oj(int s) { return ((s + 1) >> 1) & 1; }
 
 
+// wave-wide vote as a 64-bit lane mask, straight from the comparison (HIP's __ballot(int) first materialises the
+// predicate as 0/1 in a VGPR and compares it again: two extra vector operations per vote)
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 __device__ __forceinline__ float dpp_row_shl(float v, int n)   // lane i <- lane i+n within a 16-lane row (n = 1..4)
 {
     int r;

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restr
             uint32_t freq = hi - lo;
             if (active && (freq == 0 || hi < lo)) { bad = 1; freq = 1; }
             const bool emit = active && ((uint64_t)x >= ((uint64_t)freq << 16));
-            const uint64_t E = __ballot(emit);
+            const uint64_t E = ballot64(emit);
             p -= __builtin_popcountll(E);
             if (p < 128) { bad = 2; p = 128; }
             if (emit) { w16[p + lanes_below(E)] = (uint16_t)(x & 0xFFFFu); x >>= 16; }
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
                 while (ghi - glo > 1) {
                     const int mid = (glo + ghi) >> 1;
                     const int e = group_cdf_entry_fast(Af, Bf, fbase, gr.scale, mid);
-                    const uint64_t bal = __ballot(e <= (int)slot);
+                    const uint64_t bal = ballot64(e <= (int)slot);
                     if ((bal >> gbit) & 1ull) glo = mid; else ghi = mid;
                 }
                 // 2. proof with the exact spec arithmetic: entries glo and glo + 1 in one round (independent chains);
@@ -271,8 +271,8 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
                     a2 = a2 + dpp_row_shl(tX, 1);
                     const uint32_t eA = (uint32_t)((int)__builtin_rintf(a1 * gr.scale) + s1) & 0xFFFFu;
                     const uint32_t eB = (uint32_t)((int)__builtin_rintf(a2 * gr.scale) + s2) & 0xFFFFu;
-                    const bool bA = (__ballot(eA <= slot) >> gbit) & 1ull;
-                    const bool bB = (__ballot(eB <= slot) >> gbit) & 1ull;
+                    const bool bA = (ballot64(eA <= slot) >> gbit) & 1ull;
+                    const bool bB = (ballot64(eB <= slot) >> gbit) & 1ull;
                     const bool leA = (s1 == 0) || bA;                // entry 0 is the floor of the search (torchac: left = 0)
                     const bool leB = (s1 + 1 <= max_symbol) && bB;   // past the top symbol: c_high = 0x10000 by definition
                     if (leA) {
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
                     else if (have_lo) { probe = min(lo + step, hi - 1); step <<= 1; }
                     else { probe = max(hi - step, lo + 1); step <<= 1; }
                     const uint32_t e = group_cdf_entry(A, B, gr, probe);
-                    const uint64_t bal = __ballot(e <= slot);
+                    const uint64_t bal = ballot64(e <= slot);
                     if ((bal >> gbit) & 1ull) { lo = probe; vlo = e; have_lo = true; } else { hi = probe; vhi = e; have_hi = true; }
                 }
                 if (!have_lo) vlo = group_cdf_entry(A, B, gr, 0);
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
                 x = (vhi - vlo) * (x >> 16) + (x & 0xFFFFu) - vlo;
             }
             const bool need = active && x < 0x10000u;
-            const uint64_t E = __ballot(need);
+            const uint64_t E = ballot64(need);
             const uint32_t idx = pos + (uint32_t)lanes_below(E);
             const uint32_t rel = idx - wbase;                                   // < 128
             const uint32_t wa = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (int)(rel & 63u), (int)win0);
