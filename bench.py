@@ -99,6 +99,61 @@ def cpu_baseline(H, W):
             "enc_s": round(t_enc, 3), "dec_s": round(t_dec, 3)}, bl0
 
 
+def natural_like_leg(torch, dev, B, H, W, mode):
+    """uniform noise + sigma-floor random weights is the worst case for alphabet width and far
+    from natural statistics, so the same shapes are also run on a SMOOTH set (low-pass noise + gradient, seed-fixed,
+    generated on the GPU) with the "trained-like" weights of tests/golden (sigma of a few grey levels): Lp and bpp
+    in a natural range.  Informational; the headline stays on BASELINE.json's uniform-noise workload."""
+    from llicti_amd.codec import HipCodec
+    wfile = os.path.join(ROOT, "tests", "golden", "weights_trainedlike.npz")
+    if not os.path.exists(wfile):
+        return None
+    codec = HipCodec(dev)
+    codec.load_state_dict({k: v for k, v in np.load(wfile).items()})
+    g = torch.Generator(device=dev).manual_seed(2024)
+    x = torch.randn((B, 3, H + 32, W + 32), device=dev, generator=g)
+    k = torch.ones((3, 1, 9, 9), device=dev) / 81.0
+    for _ in range(2):
+        x = torch.nn.functional.conv2d(x, k, padding=4, groups=3)
+    x = x[:, :, 16:16 + H, 16:16 + W]
+    lum = x[:, 0:1] * 900.0
+    ramp = torch.linspace(-40, 40, W, device=dev)[None, None, None, :]
+    img = 128 + lum + x * 250.0 + ramp + torch.randn((B, 3, H, W), device=dev, generator=g) * 2.0
+    rgb = img.round().clamp(0, 255).to(torch.uint8).contiguous()
+    stride = codec.max_container_bytes(H, W)
+    cont = torch.empty((B, stride), dtype=torch.uint8, device=dev)
+    seg = torch.zeros((B, 49), dtype=torch.int32, device=dev)
+    rec = torch.empty_like(rgb)
+
+    def e():
+        codec.encode(rgb, mode=mode, out=cont, seg_len=seg)
+
+    def d():
+        codec.decode(cont, seg, H, W, mode=mode, out=rec)
+    e(); d(); codec.check()
+    assert torch.equal(rec, rgb)
+
+    def timed(fn, n=3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+    te, td = timed(e), timed(d)
+    mp = B * H * W / 1e6
+    mm = None
+    try:
+        _, _, mmt = codec.lift(rgb[:1])
+        mm = [int(v) for v in mmt[0].cpu().numpy()]
+    except Exception:
+        pass
+    codec.close()
+    return {"workload": f"{B}x{W}x{H} smooth synthetic RGB, trained-like weights (tests/golden)", "encdec_mpix_s": round(mp / (te + td), 3),
+            "enc_mpix_s": round(mp / te, 3), "dec_mpix_s": round(mp / td, 3), "bpp": round(8.0 * float(seg.sum().item()) / (B * H * W), 4),
+            "chroma_range_image0": mm}
+
+
 def table_kernel_roofline(codec, torch, H=2160, W=3840):
     """BASELINE.json configs[3]: one 3840x2160 image, the full-table CDF kernel (the reference's get_cdfs +
     _convert_to_int_and_normalize, LLICTI_nets.py:938-983) at level 0 -- HBM-write bound by construction.
@@ -264,7 +319,9 @@ def main():
         seg_ac_h, cont_ac0 = seg_h, cont[0].cpu().numpy()
     else:
         seg_ac_h = cont_ac0 = None
-    tab_roof = None
+    tab_roof = nat = None
+    if rank == 0 and extras:
+        nat = natural_like_leg(torch, dev, B, H, W, mode)
     if rank == 0 and extras:
         cont2 = seg2 = None
         torch.cuda.empty_cache()
@@ -298,6 +355,8 @@ def main():
         }
         out["roofline"]["traffic"] = pmc_traffic()
         out.update(other)
+        if nat is not None:
+            out["natural_like"] = nat
         if tab_roof is not None:
             out["roofline_cdf_table"] = tab_roof
         if not args.no_cpu_baseline and world == 1:
