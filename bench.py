@@ -217,7 +217,17 @@ def main():
     if world > 1:
         # RCCL over xGMI; used for the barrier + two scalar all-reduces only (no data-path collective)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            try:
+                dist.init_process_group("nccl", device_id=dev)
+                probe = torch.zeros(1, device=dev)
+                dist.all_reduce(probe)                      # forces communicator set-up now, outside any timed region
+                torch.cuda.synchronize()
+            except Exception as e:                          # the collectives carry three scalars: gloo is a safe stand-in
+                print(f"[bench] RCCL init failed on rank {rank} ({e!r}); falling back to gloo", file=sys.stderr, flush=True)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                args.backend = "gloo"
+                dist.init_process_group("gloo")
         else:
             dist.init_process_group(args.backend)
 
