@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Randomised HIP-vs-oracle parity hunt (GPU box): random shapes, image kinds, weight perturbations, containers.
+usage: tools/fuzz_parity.py [N_CASES] [SEED]   -- stops at the first mismatch with a reproducer line."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np, torch
+from llicti_amd.codec import HipCodec, MODE_AC, MODE_RANS, container_to_bytestream_list
+from llicti_amd.weights import pack_state_dict
+from oracle import oracle as orc
+from helpers import make_image
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+gold = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+base = {w: dict(np.load(os.path.join(gold, f"weights_{w}.npz"))) for w in ("rand1337", "trainedlike")}
+t0 = time.time()
+for case in range(N):
+    wname = ("rand1337", "trainedlike")[int(rng.integers(0, 2))]
+    sd = {k: np.array(v) for k, v in base[wname].items()}
+    scale = float(rng.choice([1.0, 1.0, 0.3, 3.0, 12.0, 60.0]))
+    if scale != 1.0:
+        for k in sd:
+            if "layers1toL.2" in k:
+                sd[k] = (sd[k] * scale).astype(np.float32)
+    H, W = int(rng.integers(32, 161)), int(rng.integers(32, 201))
+    B = int(rng.integers(1, 4))
+    kind = ("noise", "smooth", "flat", "binary")[int(rng.integers(0, 4))]
+    imgs = []
+    for b in range(B):
+        seed = int(rng.integers(0, 2 ** 31))
+        if kind in ("noise", "smooth"):
+            imgs.append(make_image(kind, H, W, seed))
+        elif kind == "flat":
+            imgs.append(np.broadcast_to(np.random.default_rng(seed).integers(0, 256, (3, 1, 1), dtype=np.uint8), (3, H, W)).copy())
+        else:
+            imgs.append(np.random.default_rng(seed).choice(np.array([0, 255], np.uint8), size=(3, H, W)))
+    rgb = np.stack(imgs)
+    M = int(rng.choice([0, 1, 2, 8, 16, 32]))
+    mode = MODE_AC if M == 0 else MODE_RANS(M)
+    tag = f"case {case}: {wname} x{scale} {kind} B={B} {W}x{H} M={M}"
+    codec = HipCodec("cuda:0")
+    codec.load_state_dict(sd)
+    W_o = orc.Weights(pack_state_dict(sd))
+    x = torch.from_numpy(rgb).cuda()
+    cont, seg = codec.encode(x, mode=mode)
+    codec.check()
+    rec = codec.decode(cont, seg, H, W, mode=mode)
+    codec.check()
+    assert torch.equal(rec, x), "ROUND TRIP " + tag
+    ch, sh = cont.cpu().numpy(), seg.cpu().numpy()
+    for b in range(B):
+        ref = orc.encode_image(rgb[b], W_o) if M == 0 else orc.encode_image_rans(rgb[b], W_o, M)
+        assert container_to_bytestream_list(ch[b], sh[b]) == ref, "BYTES " + tag + f" image {b}"
+    codec.close()
+    if case % 10 == 9:
+        print(f"{case + 1} cases ok ({time.time() - t0:.0f} s); last: {tag}", flush=True)
+print("fuzz ok:", N, "cases")
