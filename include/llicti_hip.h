@@ -10,11 +10,14 @@
  *     (e.g. torch.Tensor.data_ptr()); `stream` is a hipStream_t passed as void* (NULL = default stream)
  *   - every function returns 0 on success or a negative LLICTI_E* code; llicti_last_error() gives the
  *     message of the calling thread's last failure
- *   - nothing allocates device memory except llicti_create / llicti_set_band_weights (weights) --
- *     all working memory comes from the caller-sized workspace (llicti_workspace_bytes)
+ *   - nothing allocates device memory except llicti_create (status word, 1 MB of lift partials, streams and events
+ *     of the AC decode pipeline), llicti_set_band_weights (weights) and the first whole-batch call of a new
+ *     (B, H, W, mode) (stream descriptors of the plan, cached) -- all working memory comes from the caller-sized
+ *     workspace (llicti_workspace_bytes)
  *   - launches are asynchronous on `stream`; functions that return host-visible results say so and
  *     synchronise the stream themselves
- *   - one context per GPU / host thread; a context is not thread-safe
+ *   - one context per GPU / host thread; a context is not thread-safe and its calls must not overlap on different
+ *     streams (llicti_decode_images with the AC container fans out over two internal streams and joins back on `stream`)
  *   - all images of one call share H x W (32 <= H, W <= 8160: the header stores h4, w4 as uint8,
  *     LLICTI_nets.py:347)
  *
