@@ -18,6 +18,18 @@ from ..graphs.models.LLICTI_nets import LLICTI
 from ..loggers.rate import RateLogger
 
 
+class TrainRLossList:
+    """graphs/losses/rate_dist.py:79-103: per scale the 9 (band, colour) sums of self-information / numel * 3."""
+
+    def forward(self, numel_x, sinfoslist):
+        self.rate1, self.rate1list = 0.0, []
+        for t in sinfoslist:
+            r = torch.sum(t, dim=(0, 2, 3)) / numel_x * 3
+            self.rate1list.append([float(v) for v in r])
+            self.rate1 = self.rate1 + float(torch.sum(r))
+        return self.rate1, self.rate1list
+
+
 class CompressionRLossList:
     """graphs/losses/rate_dist.py:125-135: bpp of every stream, len*8/numel*3."""
 
@@ -56,6 +68,8 @@ class LLICTIAgent:
         assert config.wtr_type in ("lazydwt", "x")
         self.model = LLICTI(config).to(self.device)
         self.compr_loss = CompressionRLossList()
+        self.train_loss = TrainRLossList()             # llicti_agent.py:22 (used by validate, :96)
+        self.valid_logger = RateLogger()               # llicti_agent.py:39
         self.test_logger = RateLogger()                # llicti_agent.py:40
         self.results = []
         if config.mode in ("test", "validate", "debug", "eval_model"):
@@ -77,7 +91,33 @@ class LLICTIAgent:
     def run(self):
         if self.config.mode == "eval_model":
             return self.eval_model()
-        raise NameError("'" + str(self.config.mode) + "' is not available on the MI355X hot path (only eval_model)")
+        if self.config.mode == "validate":
+            return self.validate()
+        raise NameError("'" + str(self.config.mode) + "' is not available on the MI355X hot path (eval_model, validate)")
+
+    def _pad_img(self, x):
+        """llicti_agent.py:105-113: replicate-pad right / bottom to multiples of 2**(max(dwtlevels)+1) = 32."""
+        blk = 2 ** (max(self.config.dwtlevels) + 1)
+        h, w = x.size(2), x.size(3)
+        nh, nw = (h + blk - 1) // blk * blk, (w + blk - 1) // blk * blk
+        return torch.nn.functional.pad(x, (0, nw - w, 0, nh - h), mode="replicate")
+
+    @torch.no_grad()
+    def validate(self):
+        """llicti_agent.py:85-103 without the LR scheduler: estimated rate (self-information of LLICTI.forward) of the
+        validation images -- here the same image source as eval_model -- logged as the scale x band x colour table."""
+        self.model.eval()
+        n = 0
+        for x in _iter_test_images(self.config, self.device):
+            x = self._pad_img(x)
+            infos = self.model(x)
+            _, rate1_list = self.train_loss.forward(torch.numel(x), infos)
+            self.valid_logger(rate1_list)
+            n += 1
+        if n == 0:
+            return 0.0
+        rate, rate2 = self.valid_logger.display(lr=0.0, typ="va")
+        return float(rate + rate2)
 
     @torch.no_grad()
     def eval_model(self):

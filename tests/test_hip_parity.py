@@ -571,3 +571,23 @@ def test_degenerate_images_bitexact_and_roundtrip(torch_mod, codecs, oracle_weig
     for b, name in enumerate(imgs):
         assert lists[b] == orc.encode_image(rgb[b], W_o), name
         assert container_to_bytestream_list(cont_h[b], seg_h[b]) == orc.encode_image_rans(rgb[b], W_o, 2), name
+
+
+def test_agent_validate_mode(torch_mod, oracle_weights, caplog):
+    """agents/llicti_agent.py:85-103: estimated rate over the image set = mean of sum(self-information) / numel * 3,
+    images replicate-padded to multiples of 32 first (:105-113); checked against the oracle's forward()."""
+    import logging
+    from llicti_amd.agents.llicti_agent import LLICTIAgent
+    from llicti_amd.config import default_config
+    from oracle import oracle as orc
+    caplog.set_level(logging.INFO)
+    agent = LLICTIAgent(default_config(test_data="synthetic:40x70x2", mode="validate"))
+    got = agent.run()
+    W_o = oracle_weights("rand1337")          # the agent seeds the default init with 1337 as well
+    tot = 0.0
+    for i in range(2):
+        rgb = np.random.default_rng(i).integers(0, 256, size=(3, 40, 70), dtype=np.uint8)
+        pad = np.pad(rgb, ((0, 0), (0, 24), (0, 26)), mode="edge")
+        tot += sum(float(t.astype(np.float64).sum()) for t in orc.forward(pad, W_o)) / pad.size * 3
+    assert abs(got - tot / 2) < 1e-4 * (tot / 2)
+    assert any("Valid Epoch" in r.message for r in caplog.records)
