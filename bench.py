@@ -2,32 +2,40 @@
 """bench.py -- LLICTI encode+decode throughput on MI355X (BASELINE.json metric: MPix/s encode+decode).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one pass of the hot path over one batch of synthetic input on every rank: encode the batch
-(uint8 RGB already resident in HBM -> containers in HBM) and decode it again (containers in HBM -> uint8
-RGB in HBM).  Workload: 24 x 768x512 RGB per GPU in the rANS container (BASELINE.json configs[2]: "Batch
-of 24x 768x512 RGB, HIP rANS replacing torchac end-to-end", the shape the north-star target is quoted on;
---batch 1 gives configs[1]'s single image, --container ac the torchac-compatible container), i.i.d.
-uniform noise, seeds 0..B-1 per rank, weights = seed-1337 default init (the
-reference does the same when its checkpoint is missing).  Images shard across ranks with no data-path collective ("weak" scaling): the
-only collectives are the timing barrier and a MAX / SUM of scalars at the end.
+N > 1 needs no external launcher: when WORLD_SIZE is unset the parent process -- before it imports torch or touches
+the GPU -- starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` as a
+CHILD, relays rank 0's JSON line and exits with the child's code.  Under an external torch.distributed.run the ranks
+are used as they are.
 
-One JSON line is printed by rank 0.  `value` = pixels of all ranks x K / max-over-ranks time of the K
-steps.  `roofline` is for the dominant kernel (the fp32-MFMA interpolator CNN): algorithmic FLOPs of the
-launches in one encode+decode / their summed HIP-event durations, measured live in extra profiled steps
-after the timed region.  `cpu_baseline` times the CPU oracle in the reference's structure (materialised
-Lp-entry tables, single-thread coder) on the host cores, on a bounded sample.
+A "step" is one pass of the hot path over one batch of synthetic input on every rank: encode the batch (uint8 RGB
+resident in HBM -> containers in HBM) and decode it again (containers -> uint8 RGB in HBM).  Workload at N = 1..4:
+24 x 768x512 RGB per GPU (BASELINE.json configs[2], the shape the north-star target is quoted on); at N = 8:
+32 per GPU = configs[4]'s 256 images over 8 GPUs.  i.i.d. uniform noise, seeds rank*B .. rank*B+B-1, weights =
+seed-1337 default init (the reference does the same when its checkpoint is missing).  Images
+shard across ranks with no data-path collective ("weak" scaling): the only collectives are the RCCL probe, the timing
+barrier and a MAX / SUM of scalars at the end.
+
+One JSON line is printed by rank 0.
+  value                 pixels of all ranks x K / max-over-ranks time of the K steps, inputs and outputs RESIDENT in HBM
+  value_pcie_inclusive  the same steps with H2D of the uint8 RGB, D2H of the containers (encode) and H2D of the containers,
+                        D2H of the RGB (decode) inside the timed region, pinned host buffers (SURVEY.md 8(d)'s wording)
+  roofline              the dominant kernel (fp32-MFMA interpolator CNN): algorithmic FLOP of the launches of one
+                        encode+decode / their summed HIP-event durations (events on the launch stream, extra profiled steps)
+  roofline_cdf_table    configs[3]: the full-table CDF kernel on one 3840x2160 image, SURVEY 8(d)'s bytes (2 Lp + 60 per symbol)
+  bpp_delta_vs_reference, m_sweep, ac_container, ac_container_large, single_image, image_4k, natural_like
+                        informational legs, N = 1 only, outside the timed region
+  cpu_baseline          the CPU oracle in the reference's structure on the host cores, bounded sample
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -35,6 +43,42 @@ sys.path.insert(0, ROOT)
 MAC_PER_POSITION = 193248            # 84,480 layer-0 + 92,928 mid + 15,840 out
 PEAK_FP32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_HBM_GBS = 8000.0
+DEFAULT_CONTAINER = "rans16"
+LARGE_AC_BATCH = 256                 # the batch at which the reference-format container is also measured (untimed leg)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default: 24; 32 at --gpus 8 = BASELINE.json configs[4])")
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=768)
+    ap.add_argument("--container", default=DEFAULT_CONTAINER, help="rans<M> (M streams per image) or ac (torchac-compatible)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed informational legs (profiling runs)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch / rendezvous / aggregation only, no GPU work (CPU test of the N > 1 path); prints a line with metric 'dry_run'")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_children(args, argv):
+    """N > 1 from a bare shell: this process has not imported torch and never touches the GPU; the ranks are children."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
 
 
 def positions_per_image(H, W):
@@ -47,26 +91,36 @@ def positions_per_image(H, W):
 
 
 def make_batch(B, H, W, seed0):
+    import numpy as np
     return np.stack([np.random.default_rng(seed0 + i).integers(0, 256, size=(3, H, W), dtype=np.uint8) for i in range(B)])
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes of this same command (FETCH_SIZE and
-    WRITE_SIZE in separate passes; collected by tools/collect_pmc.sh and committed as profiles/<round>/pmc_traffic.json --
-    counters cannot be read from inside this process).  None when no such file is committed."""
+def _latest_profile_json(name):
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name)))
     if not files:
-        return None
+        return None, None
     try:
         with open(files[-1]) as fh:
-            return json.load(fh)["band_params_kernel"]["hbm_bytes_per_launch"]
+            return json.load(fh), os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
+
+
+def pmc_traffic(kernel="band_params_kernel"):
+    """HBM bytes per launch of a kernel from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE
+    doubled per MI355X_MICROARCH.md "HBM"; tools/collect_pmc.sh + tools/pmc_traffic.py, committed as
+    profiles/<round>/pmc_traffic.json -- counters cannot be read from inside this process).  None when not committed."""
+    d, _ = _latest_profile_json("pmc_traffic.json")
+    try:
+        return d[kernel]["hbm_bytes_per_launch"]
     except Exception:
         return None
 
 
 def cpu_baseline(H, W):
-    """Oracle ("port"), reference structure, on a bounded sample: ONE H x W image of the same workload."""
+    """Oracle ("port": C + OpenMP restatement in the reference's structure), on a bounded sample of the same workload."""
+    import numpy as np
     from llicti_amd.config import default_config
     from llicti_amd.graphs.models.LLICTI_nets import LLICTI
     from llicti_amd.weights import pack_state_dict
@@ -95,8 +149,47 @@ def cpu_baseline(H, W):
         n_img += 1
     return {"value": round(n_img * H * W / 1e6 / (t_enc + t_dec), 5), "unit": "MPix/s", "cores": cores, "kind": "port",
             "sample": f"{n_img} images {W}x{H} uniform-noise RGB (seeds 0..{n_img - 1}), encode {t_enc:.2f}s + decode {t_dec:.2f}s, "
-                      "materialised Lp-entry tables (OpenMP) + single-thread range coder",
+                      "C/OpenMP oracle: materialised Lp-entry tables (OpenMP over positions) + single-thread range coder",
             "enc_s": round(t_enc, 3), "dec_s": round(t_dec, 3)}, bl0
+
+
+class Legs:
+    """Untimed informational legs on rank 0 at N = 1.  Every leg checks decode(encode(x)) == x on a POISONED workspace."""
+
+    def __init__(self, torch, codec, dev):
+        self.torch, self.codec, self.dev = torch, codec, dev
+
+    def run(self, rgb, mode, reps=2, keep=False):
+        torch, codec = self.torch, self.codec
+        B, _, H, W = rgb.shape
+        cont, seg = codec.encode(rgb, mode=mode)
+        codec.check()
+        codec.poison_workspace()
+        rec = codec.decode(cont, seg, H, W, mode=mode)
+        codec.check()
+        assert torch.equal(rec, rgb), "decode(encode(x)) != x"
+
+        def timed(fn):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / reps
+        te = timed(lambda: codec.encode(rgb, mode=mode, out=cont, seg_len=seg))
+        td = timed(lambda: codec.decode(cont, seg, H, W, mode=mode, out=rec))
+        mp = B * H * W / 1e6
+        nbytes = int(seg.sum().item())
+        r = {"batch": B, "enc_mpix_s": round(mp / te, 2), "dec_mpix_s": round(mp / td, 2), "encdec_mpix_s": round(mp / (te + td), 2),
+             "enc_ms": round(te * 1e3, 3), "dec_ms": round(td * 1e3, 3), "bpp": round(8.0 * nbytes / (B * H * W), 5), "bytes": nbytes}
+        if keep:
+            return r, cont, seg
+        return r
+
+    def free(self):
+        self.codec._ws = None
+        self.codec._ws_key = None
+        self.torch.cuda.empty_cache()
 
 
 def natural_like_leg(torch, dev, B, H, W, mode):
@@ -104,6 +197,7 @@ def natural_like_leg(torch, dev, B, H, W, mode):
     from natural statistics, so the same shapes are also run on a SMOOTH set (low-pass noise + gradient, seed-fixed,
     generated on the GPU) with the "trained-like" weights of tests/golden (sigma of a few grey levels): Lp and bpp
     in a natural range.  Informational; the headline stays on BASELINE.json's uniform-noise workload."""
+    import numpy as np
     from llicti_amd.codec import HipCodec
     wfile = os.path.join(ROOT, "tests", "golden", "weights_trainedlike.npz")
     if not os.path.exists(wfile):
@@ -120,28 +214,7 @@ def natural_like_leg(torch, dev, B, H, W, mode):
     ramp = torch.linspace(-40, 40, W, device=dev)[None, None, None, :]
     img = 128 + lum + x * 250.0 + ramp + torch.randn((B, 3, H, W), device=dev, generator=g) * 2.0
     rgb = img.round().clamp(0, 255).to(torch.uint8).contiguous()
-    stride = codec.max_container_bytes(H, W)
-    cont = torch.empty((B, stride), dtype=torch.uint8, device=dev)
-    seg = torch.zeros((B, 49), dtype=torch.int32, device=dev)
-    rec = torch.empty_like(rgb)
-
-    def e():
-        codec.encode(rgb, mode=mode, out=cont, seg_len=seg)
-
-    def d():
-        codec.decode(cont, seg, H, W, mode=mode, out=rec)
-    e(); d(); codec.check()
-    assert torch.equal(rec, rgb)
-
-    def timed(fn, n=3):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / n
-    te, td = timed(e), timed(d)
-    mp = B * H * W / 1e6
+    r = Legs(torch, codec, dev).run(rgb, mode, reps=3)
     mm = None
     try:
         _, _, mmt = codec.lift(rgb[:1])
@@ -149,22 +222,25 @@ def natural_like_leg(torch, dev, B, H, W, mode):
     except Exception:
         pass
     codec.close()
-    return {"workload": f"{B}x{W}x{H} smooth synthetic RGB, trained-like weights (tests/golden)", "encdec_mpix_s": round(mp / (te + td), 3),
-            "enc_mpix_s": round(mp / te, 3), "dec_mpix_s": round(mp / td, 3), "bpp": round(8.0 * float(seg.sum().item()) / (B * H * W), 4),
-            "chroma_range_image0": mm}
+    r["workload"] = f"{B}x{W}x{H} smooth synthetic RGB, trained-like weights (tests/golden)"
+    r["chroma_range_image0"] = mm
+    return r
 
 
 def table_kernel_roofline(codec, torch, H=2160, W=3840):
     """BASELINE.json configs[3]: one 3840x2160 image, the full-table CDF kernel (the reference's get_cdfs +
     _convert_to_int_and_normalize, LLICTI_nets.py:938-983) at level 0 -- HBM-write bound by construction.
-    Algorithmic bytes per coded symbol: 2 * row_stride written (264 entries for Y, 512 for Co/Cg) + 256 B of
-    CNN outputs read; duration from events on the launch stream."""
+    Algorithmic bytes per coded symbol: 2 * Lp written + 60 B of mixture parameters read (the row
+    pitch in HBM is 264 / 512 entries and the kernel reads 256-byte CNN rows; the padding is not counted);
+    duration from events on the launch stream."""
     rgb = torch.from_numpy(make_batch(1, H, W, 0)).cuda()
     planes, fplanes, mm = codec.lift(rgb)
+    mm_h = [int(v) for v in mm[0].cpu().numpy()]
     params = codec.band_params(fplanes, 0, 0)
     out = {}
     tot_b, tot_ms = 0.0, 0.0
     for clr, stride in ((0, 264), (1, 512), (2, 512)):
+        Lp = 257 if clr == 0 else (mm_h[2 + clr - 1] - mm_h[clr - 1] + 2)
         codec.cdf_tables(planes, params, mm, 0, 0, clr, row_stride=stride)       # warm-up
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -178,65 +254,74 @@ def table_kernel_roofline(codec, torch, H=2160, W=3840):
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / n
         rows = tabs.shape[1]
-        nbytes = rows * (2.0 * stride + 256.0)
-        out[("Y", "Co", "Cg")[clr]] = {"ms": round(ms, 3), "GB_s": round(nbytes / ms / 1e6, 1)}
+        nbytes = rows * (2.0 * Lp + 60.0)
+        out[("Y", "Co", "Cg")[clr]] = {"ms": round(ms, 3), "Lp": Lp, "GB_s": round(nbytes / ms / 1e6, 1)}
         tot_b += nbytes
         tot_ms += ms
         del tabs
     ach = tot_b / tot_ms / 1e6
     return {"bound": "hbm", "kernel": "cdf_table_kernel", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
-            "workload": f"{W}x{H} image, level 0 band x11: {rows} rows x (Y 264 | Co 512 | Cg 512) uint16 entries; BASELINE.json configs[3]",
-            "per_channel": out, "bytes_per_launch_avg": tot_b / 3.0}
+            "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": pmc_traffic("cdf_table_kernel"),
+            "workload": f"{W}x{H} image, level 0 band x11: {rows} rows, Lp = 257 (Y) / per-image (Co, Cg) uint16 entries; BASELINE.json configs[3]",
+            "per_channel": out, "bytes_per_launch_avg": tot_b / 3.0,
+            "bytes_model": "SURVEY 8(d)(ii): 2*Lp + 60 B per coded symbol"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=24, help="images per GPU per step")
-    ap.add_argument("--height", type=int, default=512)
-    ap.add_argument("--width", type=int, default=768)
-    ap.add_argument("--container", default="rans16", help="rans<M> (M streams per image) or ac (torchac-compatible)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the untimed AC-container and 4K table-kernel legs (profiling runs)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
-    args = ap.parse_args()
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_children(args, argv)
 
+    import numpy as np
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks (WORLD_SIZE)")
+    B = args.batch or (32 if world == 8 else 24)
+    H, W = args.height, args.width
+
+    if args.dry_run:
+        # the N > 1 plumbing without a GPU: rendezvous, barrier, MAX / SUM aggregation, one line from rank 0
+        from llicti_amd import shard
+        if world > 1:
+            dist.init_process_group("gloo" if args.backend != "nccl" or not torch.cuda.is_available() else "nccl")
+        shard.barrier()
+        agg = shard.aggregate(1.0 + rank, 1000 * (rank + 1), B * H * W)
+        if rank == 0:
+            print(json.dumps({"metric": "dry_run", "value": None, "n_gpus": world, "ranks_seen": dist.get_world_size() if world > 1 else 1,
+                              "batch_per_gpu": B, "pixels": agg["pixels"], "bytes": agg["bytes"], "elapsed_max_s": agg["elapsed_s"]}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return 0
+
     local_dev = local_rank % max(1, torch.cuda.device_count())   # identity on a full node
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
+    rccl_ranks = 1
     if world > 1:
-        # RCCL over xGMI; used for the barrier + two scalar all-reduces only (no data-path collective)
+        # RCCL over xGMI; used for the probe, the barrier and two scalar all-reduces only (no data-path collective).
+        # The backend is ONE decision for the whole job: a rank whose RCCL set-up fails exits non-zero (no per-rank fallback
+        # to another backend, which would leave the ranks in different groups).
+        dist.init_process_group(args.backend, **({"device_id": dev} if args.backend == "nccl" else {}))
+        probe = torch.ones(1, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(probe)                      # forces communicator set-up now, outside any timed region
         if args.backend == "nccl":
-            try:
-                dist.init_process_group("nccl", device_id=dev)
-                probe = torch.zeros(1, device=dev)
-                dist.all_reduce(probe)                      # forces communicator set-up now, outside any timed region
-                torch.cuda.synchronize()
-            except Exception as e:                          # the collectives carry three scalars: gloo is a safe stand-in
-                print(f"[bench] RCCL init failed on rank {rank} ({e!r}); falling back to gloo", file=sys.stderr, flush=True)
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                args.backend = "gloo"
-                dist.init_process_group("gloo")
-        else:
-            dist.init_process_group(args.backend)
+            torch.cuda.synchronize()
+        rccl_ranks = int(round(float(probe.item())))
+        assert rccl_ranks == world == dist.get_world_size(), (rccl_ranks, world)
 
     from llicti_amd.codec import MODE_AC, MODE_RANS, HipCodec, container_to_bytestream_list
     from llicti_amd.config import default_config
     from llicti_amd.graphs.models.LLICTI_nets import LLICTI
+    from llicti_amd import shard
 
-    B, H, W = args.batch, args.height, args.width
-    mode = MODE_AC if args.container == "ac" else MODE_RANS(int(args.container[4:]))
+    def mode_of(name):
+        return MODE_AC if name == "ac" else MODE_RANS(int(name[4:]))
+    mode = mode_of(args.container)
     torch.manual_seed(1337)
     sd = LLICTI(default_config()).state_dict()                # seed-1337 default init, identical on every rank
     codec = HipCodec(dev)
@@ -248,22 +333,24 @@ def main():
     cont = torch.empty((B, stride), dtype=torch.uint8, device=dev)
     seg = torch.zeros((B, 49), dtype=torch.int32, device=dev)
     rec = torch.empty_like(rgb)
-
-    from llicti_amd import shard
     barrier = shard.barrier
 
-    def enc(m=mode, c=None, s_=None):
-        return codec.encode(rgb, mode=m, out=cont if c is None else c, seg_len=seg if s_ is None else s_)
+    def enc():
+        return codec.encode(rgb, mode=mode, out=cont, seg_len=seg)
 
-    def dec(m=mode, c=None, s_=None):
-        return codec.decode(cont if c is None else c, seg if s_ is None else s_, H, W, mode=m, out=rec)
+    def dec():
+        return codec.decode(cont, seg, H, W, mode=mode, out=rec)
 
     def step():
         enc()
         dec()
 
-    # correctness outside the timed region: lossless, and rank 0's first image bit-exact to the CPU oracle
-    step()
+    # correctness outside the timed region: lossless with the workspace poisoned between encode and decode
+    enc()
+    codec.check()
+    codec.poison_workspace()
+    rec.zero_()
+    dec()
     codec.check()
     assert torch.equal(rec, rgb), "decode(encode(x)) != x"
     seg_h = seg.cpu().numpy()
@@ -272,7 +359,6 @@ def main():
         step()
     torch.cuda.synchronize()
 
-    # separate encode / decode timings (informational)
     def timed(fn, n):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -283,6 +369,7 @@ def main():
     t_enc = timed(enc, max(1, min(3, args.steps)))
     t_dec = timed(dec, max(1, min(3, args.steps)))
 
+    # ---- the timed region: K steps, inputs / outputs resident in HBM
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -293,7 +380,36 @@ def main():
     elapsed = time.perf_counter() - t0
     codec.check()
 
-    # dominant-kernel timing with HIP events on the launch stream, in extra (untimed) profiled steps
+    # ---- the same steps with the PCIe transfers inside (pinned host buffers): never `value`, reported beside it
+    rgb_pin = torch.from_numpy(rgb_h).pin_memory()
+    cont_pin = torch.empty((B, stride), dtype=torch.uint8).pin_memory()
+    seg_pin = torch.empty((B, 49), dtype=torch.int32).pin_memory()
+    rec_pin = torch.empty((B, 3, H, W), dtype=torch.uint8).pin_memory()
+
+    def step_pcie():
+        rgb.copy_(rgb_pin, non_blocking=True)
+        enc()
+        cont_pin.copy_(cont, non_blocking=True)
+        seg_pin.copy_(seg, non_blocking=True)
+        torch.cuda.synchronize()                      # the host owns the containers here
+        cont.copy_(cont_pin, non_blocking=True)
+        seg.copy_(seg_pin, non_blocking=True)
+        dec()
+        rec_pin.copy_(rec, non_blocking=True)
+        torch.cuda.synchronize()
+    step_pcie()
+    n_pcie = max(1, min(args.steps, 5))
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_pcie):
+        step_pcie()
+    barrier()
+    elapsed_pcie = (time.perf_counter() - t0) / n_pcie
+    assert np.array_equal(rec_pin.numpy(), rgb_h)
+    del rgb_pin, cont_pin, seg_pin, rec_pin
+
+    # ---- dominant-kernel timing with HIP events on the launch stream, in extra (untimed) profiled steps
     codec.set_profiling(True)
     cnn_ms, cnn_launches, call_ms = 0.0, 0, 0.0
     for fn in (enc, dec):
@@ -305,81 +421,126 @@ def main():
         call_ms += ms[0]
     codec.set_profiling(False)
 
-    # the other container on the same batch (untimed region; informational): the torchac-compatible AC
-    # container is what bit-exactness with the reference's format is claimed on
-    other = {}
-    extras = (world == 1) and not args.no_extras         # informational legs: N = 1 only (as cpu_baseline)
-    if mode != MODE_AC and extras:
-        cont2 = torch.empty_like(cont)
-        seg2 = torch.zeros_like(seg)
-        enc(MODE_AC, cont2, seg2)
-        dec(MODE_AC, cont2, seg2)
-        codec.check()
-        assert torch.equal(rec, rgb)
-        ta = timed(lambda: enc(MODE_AC, cont2, seg2), 1)
-        tb = timed(lambda: dec(MODE_AC, cont2, seg2), 1)
-        ac_bytes = int(seg2.sum().item())
-        other = {"ac_container": {"enc_mpix_s": round(B * H * W / ta / 1e6, 3), "dec_mpix_s": round(B * H * W / tb / 1e6, 3),
-                                  "encdec_mpix_s": round(B * H * W / (ta + tb) / 1e6, 3),
-                                  "bpp": round(8.0 * ac_bytes / (B * H * W), 4),
-                                  "bpp_delta_rans_minus_ac": round(8.0 * (total_bytes - ac_bytes) / (B * H * W), 4)}}
-        seg_ac_h = seg2.cpu().numpy()
+    # ---- untimed informational legs (rank 0, N = 1 only, like cpu_baseline)
+    extras = (world == 1) and not args.no_extras
+    legs_out = {}
+    cont_ac0 = seg_ac0 = None
+    if extras:
+        legs = Legs(torch, codec, dev)
+        # (1) the reference-format (torchac-compatible) container on the same batch: Delta bpp of the timed container is
+        #     measured against it; its first image is compared with the CPU oracle below
+        r_ac, cont2, seg2 = legs.run(rgb, MODE_AC, reps=1, keep=True)
+        ac_bytes = r_ac["bytes"]
+        seg_ac0 = seg2[0].cpu().numpy()
         cont_ac0 = cont2[0].cpu().numpy()
-    elif mode == MODE_AC:
-        seg_ac_h, cont_ac0 = seg_h, cont[0].cpu().numpy()
-    else:
-        seg_ac_h = cont_ac0 = None
-    tab_roof = nat = None
-    if rank == 0 and extras:
-        nat = natural_like_leg(torch, dev, B, H, W, mode)
-    if rank == 0 and extras:
-        cont2 = seg2 = None
+        r_ac["workload"] = f"{B}x{W}x{H}, reference-format container (45 torchac-algorithm streams per image)"
+        legs_out["ac_container"] = r_ac
+        del cont2, seg2
+        # (2) rANS streams per image: speed against container overhead
+        sweep = []
+        for M in (1, 2, 4, 8, 16, 32):
+            r = legs.run(rgb, MODE_RANS(M), reps=2)
+            sweep.append({"M": M, "encdec_mpix_s": r["encdec_mpix_s"], "enc_mpix_s": r["enc_mpix_s"], "dec_mpix_s": r["dec_mpix_s"],
+                          "bpp_delta_vs_ac_container": round(8.0 * (r["bytes"] - ac_bytes) / (B * H * W), 5)})
+        legs_out["m_sweep"] = {"workload": f"{B}x{W}x{H}, rANS container with M streams per image", "modes": sweep}
+        legs.free()
+        # (3) configs[1]: ONE 768x512 image
+        one = rgb[:1].contiguous()
+        legs_out["single_image"] = {"workload": f"1x{W}x{H} (BASELINE.json configs[1])",
+                                    "rans32": legs.run(one, MODE_RANS(32), reps=5), "rans16": legs.run(one, MODE_RANS(16), reps=5),
+                                    "ac": legs.run(one, MODE_AC, reps=1)}
+        legs.free()
+        # (4) the reference-format container where it has enough streams in flight
+        try:
+            big = torch.from_numpy(make_batch(LARGE_AC_BATCH, H, W, seed0=0)).to(dev)
+            r, cbig, sbig = legs.run(big, MODE_AC, reps=1, keep=True)
+            n0 = int(seg_ac0.sum())
+            assert np.array_equal(cbig[0, :n0].cpu().numpy(), cont_ac0[:n0]), "image 0 coded in a batch of 256 differs from image 0 coded in a batch of 24"
+            r["workload"] = f"{LARGE_AC_BATCH}x{W}x{H} on ONE GPU, reference-format container"
+            legs_out["ac_container_large"] = r
+            r = legs.run(big, MODE_RANS(1), reps=1)
+            r["bpp_delta_vs_ac_container"] = round(r["bpp"] - legs_out["ac_container_large"]["bpp"], 5)
+            r["workload"] = f"{LARGE_AC_BATCH}x{W}x{H} on ONE GPU, rANS container with ONE stream per image"
+            legs_out["rans1_large"] = r
+            del big, cbig, sbig
+        except torch.cuda.OutOfMemoryError as e:      # a smaller card: skip, say so
+            legs_out["ac_container_large"] = {"skipped": repr(e)[:200]}
+        legs.free()
+        # (5) configs[3] end to end: one 3840x2160 image
+        big = torch.from_numpy(make_batch(1, 2160, 3840, seed0=0)).to(dev)
+        legs_out["image_4k"] = {"workload": "1x3840x2160 uniform-noise RGB (BASELINE.json configs[3]) end to end",
+                                "rans32": legs.run(big, MODE_RANS(32), reps=2), "ac": legs.run(big, MODE_AC, reps=1)}
+        del big
+        legs.free()
+        legs_out["natural_like"] = natural_like_leg(torch, dev, B, H, W, mode)
         torch.cuda.empty_cache()
-        tab_roof = table_kernel_roofline(codec, torch)
+        legs_out["roofline_cdf_table"] = table_kernel_roofline(codec, torch)
 
     # whole job: time = MAX over ranks, bytes / pixels = SUM over ranks (the only collectives of the run)
-    agg = shard.aggregate(elapsed, total_bytes, B * H * W, device=dev if (world == 1 or args.backend == "nccl") else "cpu")
+    coll_dev = dev if (world == 1 or args.backend == "nccl") else "cpu"
+    agg = shard.aggregate(elapsed, total_bytes, B * H * W, device=coll_dev)
+    agg_pcie = shard.aggregate(elapsed_pcie, 0, B * H * W, device=coll_dev)
     elapsed = agg["elapsed_s"]
 
+    rc = 0
     if rank == 0:
         pix = agg["pixels"]
         value = pix * args.steps / elapsed / 1e6
         flops = 2.0 * MAC_PER_POSITION * positions_per_image(H, W) * B * 2      # rank 0's launches: encode + decode pass
         achieved = flops / (cnn_ms * 1e-3) / 1e12 if cnn_ms > 0 else 0.0
+        if world == 8 and B == 32 and (H, W) == (512, 768):
+            tag = "; BASELINE.json configs[4] (256 images sharded 32 per GPU)"
+        elif B == 24 and mode != MODE_AC and (H, W) == (512, 768):
+            tag = "; BASELINE.json configs[2]" + ("" if world == 1 else f" per GPU x {world} GPUs")
+        else:
+            tag = ""
         out = {
             "metric": "MPix/s encode+decode", "value": round(value, 3), "unit": "MPix/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{B}x{W}x{H} uniform-noise RGB per GPU, container {args.container}, seed-1337 weights"
-                                   + ("; BASELINE.json configs[2]" if (B == 24 and mode != MODE_AC) else ""),
+            "config": {"workload": f"{B}x{W}x{H} uniform-noise RGB per GPU, container {args.container}, seed-1337 weights" + tag,
                        "batch_per_gpu": B, "height": H, "width": W, "container": args.container,
-                       "sharding": f"images/{world}gpu"},
+                       "sharding": f"images/{world}gpu", "backend": args.backend if world > 1 else None},
+            "rccl_ranks": rccl_ranks,
+            "value_pcie_inclusive": round(agg_pcie["pixels"] / agg_pcie["elapsed_s"] / 1e6, 3),
+            "pcie_note": "same step with H2D of RGB + D2H of containers (encode) and H2D of containers + D2H of RGB (decode) inside "
+                         "the timed region, pinned host buffers, whole container stride copied",
             "enc_mpix_s": round(B * H * W / t_enc / 1e6, 3), "dec_mpix_s": round(B * H * W / t_dec / 1e6, 3),
             "bpp": round(agg["bpp"], 4),
             "roofline": {"bound": "mfma", "kernel": "band_params_kernel<0|1|2> (fp32 MFMA 16x16x4)",
                          "achieved": round(achieved, 3), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": pmc_traffic("band_params_kernel"),
                          "launches": cnn_launches, "kernel_ms_per_step": round(cnn_ms, 3),
                          "call_ms_profiled": round(call_ms, 3),
                          "flop_per_step": flops},
         }
-        out["roofline"]["traffic"] = pmc_traffic()
-        out.update(other)
-        if nat is not None:
-            out["natural_like"] = nat
-        if tab_roof is not None:
-            out["roofline_cdf_table"] = tab_roof
+        if extras:
+            fx, fx_path = _latest_profile_json("bpp_delta_fixtures.json")
+            ac_bpp = legs_out["ac_container"]["bpp"]
+            out["bpp_delta_vs_reference"] = {
+                "timed_container_minus_reference_format_bpp": round(out["bpp"] - ac_bpp, 5),
+                "reference_format_container_bpp": ac_bpp,
+                "oracle_tables_vs_reference_tables": fx,
+                "source": fx_path,
+                "note": "reference-format (AC) container: same format, Delta = the table differences of the fixed-arithmetic spec vs the "
+                        "reference's PyTorch floats (fixtures). rANS container: + per-stream flush of 64 lane states; 0.001 bpp = 49 bytes per "
+                        "768x512 image is below the flush floor of ONE 64-lane stream (see m_sweep, rans1_large)"}
+        out.update(legs_out)
         if not args.no_cpu_baseline and world == 1:
             cb, bl = cpu_baseline(H, W)
             if cont_ac0 is not None:
-                # the same image through the HIP path (AC container) must give the oracle's bytes
-                got = container_to_bytestream_list(cont_ac0, seg_ac_h[0])
+                # the same image through the HIP path (reference-format container) must give the oracle's bytes
+                got = container_to_bytestream_list(cont_ac0, seg_ac0)
                 cb["bitexact_vs_hip"] = bool(got == bl)
+                if not cb["bitexact_vs_hip"]:
+                    print("[bench] FAIL: HIP container of image 0 differs from the CPU oracle's", file=sys.stderr, flush=True)
+                    rc = 3
             out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    return rc
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -18,6 +18,11 @@
  *     synchronise the stream themselves
  *   - one context per GPU / host thread; a context is not thread-safe and its calls must not overlap on different
  *     streams (llicti_decode_images with the AC container fans out over two internal streams and joins back on `stream`)
+ *   - every call makes the context's device current for its own duration and restores the caller's current device
+ *   - calls that BLOCK the host: llicti_create / llicti_destroy / llicti_set_band_weights (device-wide synchronise:
+ *     work in flight may still read the old weights), llicti_check_status and llicti_last_timing (they return
+ *     host-visible results), and the FIRST whole-batch call of a new (B, H, W, mode) (builds and uploads the plan;
+ *     the cache holds 16 plans, the 17th distinct shape synchronises the device and drops them all)
  *   - all images of one call share H x W (32 <= H, W <= 8160: the header stores h4, w4 as uint8,
  *     LLICTI_nets.py:347)
  *
@@ -127,8 +132,8 @@ int llicti_ac_encode_u16cdf(llicti_ctx *ctx, const uint16_t *d_cdf, int Lp, int 
                             int n_streams, long N, uint8_t *d_out, long out_stride, int32_t *d_len, void *stream);
 
 /* K11: the matching DECODER, torchac.decode_int16_normalized_cdf (LLICTI_nets.py:492-493).
- * d_in + s*in_stride holds stream s (4-byte aligned, in_stride a multiple of 4, readable and zero for
- * 16 bytes past d_len[s]). */
+ * d_in + s*in_stride holds stream s (4-byte aligned, in_stride a multiple of 4, d_len[s] <= in_stride); bytes past
+ * d_len[s] are never interpreted: like torchac's reader the decoder shifts in zero bits once the stream is exhausted. */
 int llicti_ac_decode_u16cdf(llicti_ctx *ctx, const uint16_t *d_cdf, int Lp, int row_stride, const uint8_t *d_in,
                             long in_stride, const int32_t *d_len, int n_streams, long N, int16_t *d_sym, void *stream);
 
@@ -136,9 +141,11 @@ int llicti_ac_decode_u16cdf(llicti_ctx *ctx, const uint16_t *d_cdf, int Lp, int 
  * Containers stay in HBM.  Image b's container is the reference's bytestream_list flattened: its 49
  * segments concatenated tightly at d_out + b*out_stride, lengths in d_seg_len[b][49]; segment order
  * [S,h4,w4 u8] | 6 x int16 min/max | int16 padHW | raw DC band u8 CHW | 45 streams, scale 4..0 x band
- * x (Y,Co,Cg)  (LLICTI_nets.py:347-354, :411).  Both calls are asynchronous on `stream` and never
- * synchronise; device-side failures (malformed header, stream overflow) are latched in the context
- * and reported by llicti_check_status. */
+ * x (Y,Co,Cg)  (LLICTI_nets.py:347-354, :411).  Both calls are asynchronous on `stream` (except for the first
+ * call of a new shape, see "calls that BLOCK" above); device-side failures (malformed header or segment lengths,
+ * stream overflow) are latched in the context and reported by llicti_check_status.  A malformed container is a
+ * reported error, never a memory fault: every segment length is validated against in_stride before any byte of the
+ * container is read, and no read leaves [d_in + b*in_stride, d_in + (b+1)*in_stride). */
 
 /* mode: LLICTI_MODE_AC = the reference's container (45 torchac-algorithm streams per image, bit-exact
  * to the oracle / reference format); LLICTI_MODE_RANS(M) = "LLICTI-rANS v1", a NEW container of this

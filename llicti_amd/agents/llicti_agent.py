@@ -16,6 +16,7 @@ import torch
 
 from ..graphs.models.LLICTI_nets import LLICTI
 from ..loggers.rate import RateLogger
+from ..weights import load_reference_state_dict
 
 
 class TrainRLossList:
@@ -74,19 +75,31 @@ class LLICTIAgent:
         self.results = []
         if config.mode in ("test", "validate", "debug", "eval_model"):
             self.load_checkpoint("model_best.pth.tar")
+        self.model_size_estimation()                   # llicti_agent.py:46
 
     def load_checkpoint(self, filename):
         """base.py:51-81: a missing checkpoint is tolerated (the run continues with the seeded init)."""
         path = os.path.join(getattr(self.config, "checkpoint_dir", "") if "checkpoint_dir" in self.config else "", filename)
         try:
             ckpt = torch.load(path, map_location=self.device)
-            sd = ckpt["state_dict"]
-            own = self.model.state_dict()
-            # compressai's extra buffers (scale_table, _offset, _quantized_cdf, ...) are not parameters of the codec
-            self.model.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=False)
+            # strict, as agents/base.py:60: only compressai's known extra buffers (scale_table, _offset, _quantized_cdf, ...)
+            # are dropped; any other mismatch raises instead of silently keeping the seeded init
+            load_reference_state_dict(self.model, ckpt["state_dict"])
             self.logger.info("Checkpoint loaded from '%s'", path)
         except OSError:
             self.logger.info("No checkpoint at '%s' -- running with the seeded default init", path)
+
+    def model_size_estimation(self):
+        """llicti_agent.py:167-192: bytes of parameters and of buffers, logged in MiB.  The reference's own run logs
+        "0.750+0.000=0.750MB" (experiments/.../exp_debug.log:101): 196,596 fp32 parameters, nine 1-element buffers."""
+        mib = float(1024 ** 2)
+        n_par = sum(p.nelement() * p.element_size() for p in self.model.parameters())
+        n_buf = sum(b.nelement() * b.element_size() for b in self.model.buffers())
+        self.size_text = " model param+buffer=total size: {:.3f}+{:.3f}={:.3f}MB".format(n_par / mib, n_buf / mib, (n_par + n_buf) / mib)
+        self.logger.info("------------------TOT----------------------------------------------")
+        self.logger.info(self.size_text)
+        self.logger.info("------------------END----------------------------------------------")
+        return n_par, n_buf
 
     def run(self):
         if self.config.mode == "eval_model":

@@ -20,9 +20,8 @@ def _model(container, checkpoint):
     torch.manual_seed(1337)
     model = LLICTI(default_config(container=container)).to("cuda:0").eval()
     if checkpoint:
-        sd = torch.load(checkpoint, map_location="cuda:0")["state_dict"]
-        own = model.state_dict()
-        model.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=False)
+        from .weights import load_reference_state_dict
+        load_reference_state_dict(model, torch.load(checkpoint, map_location="cuda:0")["state_dict"])
     return model, torch
 
 

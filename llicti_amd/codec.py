@@ -154,20 +154,23 @@ class HipCodec:
                                                _ptr(out), _stream_ptr(self.device)))
         return out
 
-    def ac_encode_tables(self, cdf, sym):
-        """cdf int16/uint16 [S, N, stride] (Lp = stride valid entries unless Lp given), sym int16 [S, N]."""
+    def ac_encode(self, cdf, sym, Lp=None):
+        """torchac seam: cdf int16/uint16 [S, N, stride] with Lp valid entries per row (default: stride), sym int16 [S, N]
+        -> (streams uint8 [S, out_stride], lengths int32 [S])."""
         S, N, stride = cdf.shape
+        Lp = stride if Lp is None else int(Lp)
         out_stride = (2 * N + 32 + 3) // 4 * 4      # slots are written 32 bits at a time
         out = torch.zeros((S, out_stride), dtype=torch.uint8, device=self.device)
         ln = torch.zeros((S,), dtype=torch.int32, device=self.device)
-        _lib.check(self.L.llicti_ac_encode_u16cdf(self.ctx, _ptr(cdf), self._lp, stride, _ptr(sym), S, N, _ptr(out), out_stride,
+        _lib.check(self.L.llicti_ac_encode_u16cdf(self.ctx, _ptr(cdf), Lp, stride, _ptr(sym), S, N, _ptr(out), out_stride,
                                                   _ptr(ln), _stream_ptr(self.device)))
         _lib.check(self.L.llicti_check_status(self.ctx, _stream_ptr(self.device)))
         return out, ln
 
-    def ac_encode(self, cdf, sym, Lp):
-        self._lp = int(Lp)
-        return self.ac_encode_tables(cdf, sym)
+    def poison_workspace(self, value=0xA5):
+        """Overwrite the cached workspace (tests / bench: a decode must not depend on what an earlier call left there)."""
+        if self._ws is not None:
+            self._ws.fill_(value)
 
     def ac_decode(self, cdf, Lp, streams, lens, N):
         S, _, stride = cdf.shape

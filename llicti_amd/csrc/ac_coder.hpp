@@ -158,6 +158,7 @@ __global__ __launch_bounds__(64) void ac_encode_tables_kernel(const uint16_t *__
 // increasing row this is the index torchac's search returns.  8 rows are kept in flight in registers.
 struct DecOut {
     int16_t *sym;            // [n_streams][N] or nullptr
+    const int32_t *len;      // [n_streams] stream lengths in bytes, or nullptr (then the slot is zero padded by the caller)
     int16_t *planes;         // [B][3][H][W] or nullptr
     float *fplanes;
     const int32_t *minmax;   // [B][4]
@@ -228,8 +229,16 @@ __global__ __launch_bounds__(64) void ac_decode_kernel(const uint16_t *__restric
     // readlane.  Every 64 words (~150 symbols) the window is reloaded synchronously: one memory latency per
     // 150 symbols, and no register with a load in flight across loop iterations (those make the compiler
     // emit s_waitcnt vmcnt(0) at every merge point, which would drain the row ring as well).
-    const int in_words = (int)(in_stride >> 2);
-    auto load_win = [&](int w0) -> uint32_t { return bswap32(words[min(w0 + lane, in_words - 1)]); };   // big-endian words, swapped once per reload
+    // Words the stream really has: with a length (torchac seam) everything past it reads as zero bits, whatever the
+    // buffer holds there -- the last word is masked to its valid bytes; without one the slot is zero padded (unpack_kernel).
+    const int len_b = o.len ? max(0, min(o.len[s], (int)in_stride)) : (int)in_stride;
+    const int in_words = max(1, (len_b + 3) >> 2);
+    const uint32_t tail_mask = (len_b & 3) ? ~(0xFFFFFFFFu >> (8 * (len_b & 3))) : 0xFFFFFFFFu;
+    auto load_win = [&](int w0) -> uint32_t {           // big-endian words, swapped once per reload
+        const int wi = min(w0 + lane, in_words - 1);
+        const uint32_t w = bswap32(words[wi]);
+        return (wi == in_words - 1) ? (len_b > 0 ? (w & tail_mask) : 0u) : w;
+    };
     uint32_t *st = ck.state ? ck.state + 8 * s : nullptr;
     int wpos = first ? 3 : (int)st[6];                  // next word to pull (wave-uniform)
     uint32_t win_cur = load_win(first ? 0 : (wpos & ~63));

@@ -55,12 +55,24 @@ __global__ void header_read_kernel(const uint8_t *__restrict__ in, long in_strid
     const long plane = (long)H * W;
     __shared__ int ok;
     if (threadIdx.x == 0) {
-        const int pad = (int)(int16_t)(p[15] | (p[16] << 8));
-        ok = (sl[0] == 3 && sl[1] == 12 && sl[2] == 2 && sl[3] == 3 * h4 * w4 &&
-              p[0] == byte0 && p[1] == h4 && p[2] == w4 && pad == padint);               // LLICTI_nets.py:423-428
+        // every segment length is checked before a single container byte is read: a malformed seg_len must end in
+        // LLICTI_EFORMAT, never in an access outside [in, in + in_stride)
+        long tot = 0;
+        bool segs_ok = in_stride >= 17 + 3L * h4 * w4;
+        for (int k = 0; k < LLICTI_NSEG; ++k) {
+            const int v = sl[k];
+            if (v < 0 || v > in_stride) segs_ok = false;
+            tot += (v < 0) ? 0 : v;
+        }
+        if (tot > in_stride) segs_ok = false;
+        ok = segs_ok && (sl[0] == 3 && sl[1] == 12 && sl[2] == 2 && sl[3] == 3 * h4 * w4);
+        if (ok) {
+            const int pad = (int)(int16_t)(p[15] | (p[16] << 8));
+            ok = (p[0] == byte0 && p[1] == h4 && p[2] == w4 && pad == padint);           // LLICTI_nets.py:423-428
+        }
         if (!ok) atomicExch(&status[0], LLICTI_EFORMAT);
-        int16_t v[6];
-        for (int k = 0; k < 6; ++k) v[k] = (int16_t)(p[3 + 2 * k] | (p[4 + 2 * k] << 8));
+        int16_t v[6] = { 0, -255, -255, 255, 255, 255 };
+        if (ok) for (int k = 0; k < 6; ++k) v[k] = (int16_t)(p[3 + 2 * k] | (p[4 + 2 * k] << 8));
         int32_t *mm = minmax + 4 * b;
         mm[0] = v[1]; mm[1] = v[2]; mm[2] = v[4]; mm[3] = v[5];
         if (v[1] > v[4] || v[2] > v[5] || v[1] < -255 || v[2] < -255 || v[4] > 255 || v[5] > 255) {
@@ -89,10 +101,16 @@ __global__ __launch_bounds__(256) void unpack_kernel(const uint8_t *__restrict__
     const int st = blockIdx.x, b = blockIdx.y;
     const int32_t *sl = seg_len + (long)b * LLICTI_NSEG;
     long src = 0;
-    for (int k = 0; k < 4 + st; ++k) src += sl[k];
+    bool bad = false;
+    for (int k = 0; k < 4 + st; ++k) {          // a negative or oversized EARLIER entry must not move src outside the container
+        const int v = sl[k];
+        if (v < 0 || v > in_stride) bad = true;
+        src += v;
+        if (src < 0 || src > in_stride) { bad = true; src = 0; }
+    }
     int n = sl[4 + st];
     const int cap = slot_cap[(long)st * B + b];
-    if (n < 0 || n + 16 > cap || src + n > in_stride) { if (threadIdx.x == 0) atomicExch(&status[0], LLICTI_EFORMAT); n = 0; }
+    if (bad || n < 0 || n + 16 > cap || src + n > in_stride) { if (threadIdx.x == 0) atomicExch(&status[0], LLICTI_EFORMAT); n = 0; src = 0; }
     const uint8_t *p = in + (long)b * in_stride + src;
     uint8_t *o = slots + slot_off[(long)st * B + b];
     block_copy_bytes(o, p, n);

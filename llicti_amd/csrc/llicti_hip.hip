@@ -89,6 +89,22 @@ struct llicti_ctx {
     bool timing_pending = false;
 };
 
+// Every entry point that touches the device runs under this guard: the context's device becomes current for the
+// call and the caller's current device is restored on return (a HipCodec on cuda:N used while the thread's current
+// device is another one must not launch there, and must not leave the thread's device changed).
+struct DeviceGuard {
+    int prev = -1, dev = -1;
+    explicit DeviceGuard(const llicti_ctx *c) {
+        if (!c) return;
+        dev = c->device;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+    ~DeviceGuard() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 // AC decode: a stage of nc symbols per stream is cut into C chunks (multiples of 64 symbols) so that the Y, Co and Cg
 // streams of a band run as a three-deep pipeline on three HIP streams (see decode_sub)
 static int ac_chunks(long nc) { return nc >= 32768 ? 16 : nc >= 4096 ? 8 : nc >= 1024 ? 4 : nc >= 256 ? 2 : 1; }
@@ -230,12 +246,12 @@ extern "C" int llicti_create(llicti_ctx **out, int device)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(LLICTI_ENODEVICE, "no HIP device: this library has no CPU path");
     if (device < 0 || device >= n) return fail(LLICTI_EINVAL, "create: device %d out of range (%d devices)", device, n);
-    HIPCHK(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(LLICTI_ENODEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
     llicti_ctx *c = new llicti_ctx();
     c->device = device;
+    DeviceGuard guard(c);
     if (const char *e = getenv("LLICTI_PIPELINE")) { c->pipeline = atoi(e) != 0; c->pipeline_s = atoi(e); }     // experiment switch: sub-batch pipelining of decode
     HIPCHK(hipMalloc(&c->d_status, 64));
     HIPCHK(hipMalloc(&c->d_lift_part, (size_t)kLiftMaxParts * 4 * sizeof(int32_t)));
@@ -263,6 +279,9 @@ extern "C" int llicti_create(llicti_ctx **out, int device)
 extern "C" int llicti_destroy(llicti_ctx *c)
 {
     if (!c) return LLICTI_OK;
+    {
+    DeviceGuard guard(c);
+    (void)hipDeviceSynchronize();
     for (int b = 0; b < 3; ++b) if (c->d_pack[b]) hipFree(c->d_pack[b]);
     for (auto &kv : c->plans) {
         PlanDev *pd = kv.second;
@@ -286,6 +305,7 @@ extern "C" int llicti_destroy(llicti_ctx *c)
     if (c->d_lift_part) hipFree(c->d_lift_part);
     for (auto e : c->ev) hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) if (c->ev_call[i]) hipEventDestroy(c->ev_call[i]);
+    }
     delete c;
     return LLICTI_OK;
 }
@@ -298,7 +318,9 @@ extern "C" int llicti_set_band_weights(llicti_ctx *c, int band, int K0, const fl
     if (K0 != K0s[band]) return fail(LLICTI_EINVAL, "set_band_weights: band %d needs K0=%d, got %d", band, K0s[band], K0);
     std::vector<float> pk;
     pack_band(K0, w0, b0, w1, b1, w2, b2, pk);
-    HIPCHK(hipSetDevice(c->device));
+    DeviceGuard guard(c);
+    // blocking by contract (include/llicti_hip.h): work in flight on any stream may still read the old weights
+    HIPCHK(hipDeviceSynchronize());
     if (!c->d_pack[band]) HIPCHK(hipMalloc(&c->d_pack[band], pk.size() * sizeof(float)));
     HIPCHK(hipMemcpy(c->d_pack[band], pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
     c->have[band] = true;
@@ -367,6 +389,7 @@ extern "C" int llicti_lift_u8(llicti_ctx *c, const uint8_t *d_rgb, int B, int H,
                               float *d_fplanes, int32_t *d_minmax, void *stream)
 {
     if (!c || !d_rgb || !d_planes || !d_fplanes || !d_minmax) return fail(LLICTI_EINVAL, "lift: null pointer");
+    DeviceGuard guard(c);
     if (check_dims(B, H, W)) return LLICTI_EINVAL;
     return launch_lift(d_rgb, B, H, W, d_planes, d_fplanes, d_minmax, c->d_lift_part, (hipStream_t)stream);
 }
@@ -374,6 +397,7 @@ extern "C" int llicti_lift_u8(llicti_ctx *c, const uint8_t *d_rgb, int B, int H,
 extern "C" int llicti_unlift_u8(llicti_ctx *c, const int16_t *d_planes, int B, int H, int W, uint8_t *d_rgb, void *stream)
 {
     if (!c || !d_planes || !d_rgb) return fail(LLICTI_EINVAL, "unlift: null pointer");
+    DeviceGuard guard(c);
     if (check_dims(B, H, W)) return LLICTI_EINVAL;
     const long plane = (long)H * W;
     const int gx = (int)std::min<long>((plane + 255) / 256, 1024);
@@ -386,6 +410,7 @@ extern "C" int llicti_band_params_f32(llicti_ctx *c, const float *d_fplanes, int
                                       float *d_params, void *stream)
 {
     if (!c || !d_fplanes || !d_params) return fail(LLICTI_EINVAL, "band_params: null pointer");
+    DeviceGuard guard(c);
     if (check_dims(B, H, W)) return LLICTI_EINVAL;
     if (lvl < 0 || lvl >= LLICTI_NLEVELS || band < 0 || band > 2) return fail(LLICTI_EINVAL, "band_params: bad level/band");
     Geom g = make_geom(B, H, W, lvl);
@@ -395,6 +420,7 @@ extern "C" int llicti_band_params_f32(llicti_ctx *c, const float *d_fplanes, int
 extern "C" int llicti_lift_train_f32(llicti_ctx *c, const uint8_t *d_rgb, int B, int H, int W, float *d_fplanes, void *stream)
 {
     if (!c || !d_rgb || !d_fplanes) return fail(LLICTI_EINVAL, "lift_train: null pointer");
+    DeviceGuard guard(c);
     if (check_dims(B, H, W)) return LLICTI_EINVAL;
     const long plane = (long)H * W;
     const int gx = (int)std::min<long>((plane + 255) / 256, 2048);
@@ -407,6 +433,7 @@ extern "C" int llicti_selfinfo_f32(llicti_ctx *c, const float *d_fplanes, const 
                                    int lvl, int band, float *d_bits, void *stream)
 {
     if (!c || !d_fplanes || !d_params || !d_bits) return fail(LLICTI_EINVAL, "selfinfo: null pointer");
+    DeviceGuard guard(c);
     if (check_dims(B, H, W)) return LLICTI_EINVAL;
     if (lvl < 0 || lvl >= LLICTI_NLEVELS || band < 0 || band > 2) return fail(LLICTI_EINVAL, "selfinfo: bad level/band");
     Geom g = make_geom(B, H, W, lvl);
@@ -446,6 +473,7 @@ extern "C" int llicti_cdf_u16(llicti_ctx *c, const int16_t *d_planes, const floa
                               int B, int H, int W, int lvl, int band, int clr, uint16_t *d_tables, int row_stride, void *stream)
 {
     if (!c || !d_planes || !d_params || !d_minmax || !d_tables) return fail(LLICTI_EINVAL, "cdf_u16: null pointer");
+    DeviceGuard guard(c);
     if (check_dims(B, H, W)) return LLICTI_EINVAL;
     if (lvl < 0 || lvl >= LLICTI_NLEVELS || band < 0 || band > 2 || clr < 0 || clr > 2) return fail(LLICTI_EINVAL, "cdf_u16: bad level/band/clr");
     if (row_stride < 8 || row_stride > 512 || (row_stride & 7)) return fail(LLICTI_EINVAL, "cdf_u16: row_stride must be a multiple of 8 in [8,512]");
@@ -460,6 +488,7 @@ extern "C" int llicti_cdf_pairs_u32(llicti_ctx *c, const int16_t *d_planes, cons
                                     int B, int H, int W, int lvl, int band, uint32_t *d_pairs, void *stream)
 {
     if (!c || !d_planes || !d_params || !d_minmax || !d_pairs) return fail(LLICTI_EINVAL, "cdf_pairs: null pointer");
+    DeviceGuard guard(c);
     if (check_dims(B, H, W)) return LLICTI_EINVAL;
     if (lvl < 0 || lvl >= LLICTI_NLEVELS || band < 0 || band > 2) return fail(LLICTI_EINVAL, "cdf_pairs: bad level/band");
     Geom g = make_geom(B, H, W, lvl);
@@ -470,6 +499,7 @@ extern "C" int llicti_ac_encode_u16cdf(llicti_ctx *c, const uint16_t *d_cdf, int
                                        int n_streams, long N, uint8_t *d_out, long out_stride, int32_t *d_len, void *stream)
 {
     if (!c || !d_cdf || !d_sym || !d_out || !d_len) return fail(LLICTI_EINVAL, "ac_encode: null pointer");
+    DeviceGuard guard(c);
     if (Lp < 2 || Lp > 65536 || row_stride < Lp || n_streams < 1 || N < 1 || out_stride < 8 || (out_stride & 3) || ((uintptr_t)d_out & 3))
         return fail(LLICTI_EINVAL, "ac_encode: bad argument (out_stride and d_out must be multiples of 4)");
     ac_encode_tables_kernel<<<(n_streams + 63) / 64, 64, 0, (hipStream_t)stream>>>(d_cdf, Lp, row_stride, d_sym, n_streams, N, d_out,
@@ -482,13 +512,14 @@ extern "C" int llicti_ac_decode_u16cdf(llicti_ctx *c, const uint16_t *d_cdf, int
                                        long in_stride, const int32_t *d_len, int n_streams, long N, int16_t *d_sym, void *stream)
 {
     if (!c || !d_cdf || !d_in || !d_len || !d_sym) return fail(LLICTI_EINVAL, "ac_decode: null pointer");
+    DeviceGuard guard(c);
     if (Lp < 2 || Lp > 512 || row_stride < Lp || row_stride > 512 || (row_stride & 7) || n_streams < 1 || N < 1 || (in_stride & 3) ||
         ((uintptr_t)d_in & 3) || ((uintptr_t)d_cdf & 15))
         return fail(LLICTI_EINVAL, "ac_decode: bad argument (Lp<=512, row_stride multiple of 8, 4-byte aligned streams, 16-byte aligned tables)");
     DecOut o;
     memset(&o, 0, sizeof o);
     o.sym = d_sym;
-    (void)d_len;
+    o.len = d_len;          // bytes past d_len[s] read as zero bits (torchac's get()), whatever the buffer holds there
     AcChunk ck = { 0, (int)N, (int)N, (int)N, nullptr };
     ac_decode_kernel<<<n_streams, 64, 0, (hipStream_t)stream>>>(d_cdf, Lp, row_stride, d_in, in_stride, ck, o);
     HIPCHK(hipGetLastError());
@@ -573,7 +604,7 @@ extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, 
     const int M = mode_streams(mode);
     if (M < 0) return fail(LLICTI_EINVAL, "encode_images: unknown mode 0x%x", mode);
     for (int b = 0; b < 3; ++b) if (!c->have[b]) return fail(LLICTI_ENOWEIGHTS, "band %d weights not set", b);
-    HIPCHK(hipSetDevice(c->device));
+    DeviceGuard guard(c);
     PlanDev *pd = nullptr;
     if (int rc = get_plan(c, B, H, W, M, &pd)) return rc;
     const Plan &p = pd->p;
@@ -715,7 +746,12 @@ extern "C" int llicti_decode_images(llicti_ctx *c, const uint8_t *d_in, size_t i
     const int M = mode_streams(mode);
     if (M < 0) return fail(LLICTI_EINVAL, "decode_images: unknown mode 0x%x", mode);
     for (int b = 0; b < 3; ++b) if (!c->have[b]) return fail(LLICTI_ENOWEIGHTS, "band %d weights not set", b);
-    HIPCHK(hipSetDevice(c->device));
+    DeviceGuard guard(c);
+    {
+        const Geom g4c = make_geom(B, H, W, 4);
+        if (in_stride < (size_t)(17 + 3 * g4c.h * g4c.w))
+            return fail(LLICTI_EINVAL, "decode_images: in_stride %zu is smaller than the %d header bytes of a %dx%d image", in_stride, 17 + 3 * g4c.h * g4c.w, W, H);
+    }
     const int S = sub_batches(c, B, M);
     const int Bs = B / S;
     PlanDev *pd = nullptr;
@@ -745,6 +781,7 @@ extern "C" int llicti_decode_images(llicti_ctx *c, const uint8_t *d_in, size_t i
 extern "C" int llicti_check_status(llicti_ctx *c, void *stream)
 {
     if (!c) return fail(LLICTI_EINVAL, "null ctx");
+    DeviceGuard guard(c);
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     int32_t st = 0;
     HIPCHK(hipMemcpy(&st, c->d_status, 4, hipMemcpyDeviceToHost));
@@ -775,6 +812,7 @@ extern "C" int llicti_header_dims(const uint8_t *h, int *H, int *W)
 extern "C" int llicti_last_timing(llicti_ctx *c, float ms[4], int *n_launch)
 {
     if (!c || !ms) return fail(LLICTI_EINVAL, "last_timing: null pointer");
+    DeviceGuard guard(c);
     if (c->timing_pending) {
         HIPCHK(hipEventSynchronize(c->ev_call[1]));
         float t = 0;

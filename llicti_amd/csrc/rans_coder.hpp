@@ -354,10 +354,16 @@ __global__ __launch_bounds__(256) void rans_unpack_kernel(const uint8_t *__restr
     const int m = blockIdx.x, b = blockIdx.y;
     const int32_t *sl = seg_len + (long)b * LLICTI_NSEG;
     long src = 0;
-    for (int k = 0; k < 4 + m; ++k) src += sl[k];
+    bool bad = false;
+    for (int k = 0; k < 4 + m; ++k) {           // see unpack_kernel: every earlier entry is validated too
+        const int v = sl[k];
+        if (v < 0 || v > in_stride) bad = true;
+        src += v;
+        if (src < 0 || src > in_stride) { bad = true; src = 0; }
+    }
     int n = sl[4 + m];
     uint8_t *o = slots + rslot_off[b * M + m];
-    if (n < 256 || n > rslot_cap || src + n > in_stride) {
+    if (bad || n < 256 || n > rslot_cap || src + n > in_stride) {
         if (threadIdx.x == 0) atomicExch(&status[0], LLICTI_EFORMAT);
         for (int t = threadIdx.x; t < 256; t += blockDim.x) o[t] = (t & 3) == 2 ? 1 : 0;     // states = 1 << 16: harmless
         n = 256;

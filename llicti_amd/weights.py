@@ -77,3 +77,22 @@ def expected_keys():
         keys += [p + "layers1toL.0.weight", p + "layers1toL.0.bias",
                  p + "layers1toL.2.weight", p + "layers1toL.2.bias"]
     return keys
+
+
+# Buffers compressai's GaussianConditional / EntropyModel register on `conditional_prob_model` in a real checkpoint
+# (compressai==1.1.8: entropy_models.py) that this build's parameter containers do not carry: they are tables of the
+# quantised-CDF coder the reference never uses on this path (it calls torchac with its own get_cdfs tables).
+COMPRESSAI_EXTRA_SUFFIXES = ("._offset", "._quantized_cdf", "._cdf_length", ".scale_table", ".scale_bound")
+
+
+def load_reference_state_dict(model, sd):
+    """Strict load of a reference `state_dict` (agents/base.py:60 loads strictly too): only the known compressai
+    buffers above are dropped; a missing key, an unexpected key (e.g. a `module.` prefix) or a shape mismatch raises
+    instead of silently leaving the seeded default init in place."""
+    kept = {k: v for k, v in sd.items() if not k.endswith(COMPRESSAI_EXTRA_SUFFIXES)}
+    missing = [k for k in expected_keys() if k not in kept]
+    if missing:
+        raise KeyError(f"checkpoint state_dict lacks {len(missing)} of the 24 weight entries of LLICTI (config A), e.g. {missing[:3]}; "
+                       f"first keys present: {list(sd)[:3]}")
+    model.load_state_dict(kept, strict=True)
+    return model

@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """Randomised HIP-vs-oracle parity hunt (GPU box): random shapes, image kinds, weight perturbations, containers.
-usage: tools/fuzz_parity.py [N_CASES] [SEED]   -- stops at the first mismatch with a reproducer line."""
-import os, sys, time
+Test infrastructure (it calls the CPU oracle), hence under tests/; not collected by pytest (minutes of GPU time).
+usage: tests/fuzz_parity.py [N_CASES] [SEED] [SUMMARY.json]   -- stops at the first mismatch with a reproducer line;
+the summary (cases, per-container / per-kind counts, wall time) is what profiles/<round>/fuzz_summary.json holds."""
+import collections, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, torch
 from llicti_amd.codec import HipCodec, MODE_AC, MODE_RANS, container_to_bytestream_list
 from llicti_amd.weights import pack_state_dict
@@ -15,6 +17,8 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 gold = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 base = {w: dict(np.load(os.path.join(gold, f"weights_{w}.npz"))) for w in ("rand1337", "trainedlike")}
 t0 = time.time()
+counts = collections.Counter()
+pixels = 0
 for case in range(N):
     wname = ("rand1337", "trainedlike")[int(rng.integers(0, 2))]
     sd = {k: np.array(v) for k, v in base[wname].items()}
@@ -45,6 +49,8 @@ for case in range(N):
     x = torch.from_numpy(rgb).cuda()
     cont, seg = codec.encode(x, mode=mode)
     codec.check()
+    codec.workspace(B, H, W, mode)
+    codec.poison_workspace()                       # the decode must not find the encoder's planes in the workspace
     rec = codec.decode(cont, seg, H, W, mode=mode)
     codec.check()
     assert torch.equal(rec, x), "ROUND TRIP " + tag
@@ -53,6 +59,14 @@ for case in range(N):
         ref = orc.encode_image(rgb[b], W_o) if M == 0 else orc.encode_image_rans(rgb[b], W_o, M)
         assert container_to_bytestream_list(ch[b], sh[b]) == ref, "BYTES " + tag + f" image {b}"
     codec.close()
+    counts[f"container:{'ac' if M == 0 else 'rans%d' % M}"] += 1
+    counts[f"kind:{kind}"] += 1
+    counts[f"weights:{wname}x{scale}"] += 1
+    pixels += B * H * W
     if case % 10 == 9:
         print(f"{case + 1} cases ok ({time.time() - t0:.0f} s); last: {tag}", flush=True)
 print("fuzz ok:", N, "cases")
+if len(sys.argv) > 3:
+    json.dump({"tool": "tests/fuzz_parity.py", "cases": N, "seed": int(sys.argv[2]), "mismatches": 0, "pixels": pixels,
+               "wall_s": round(time.time() - t0, 1), "checked": "decode(encode(x)) == x on a poisoned workspace; every image's container "
+               "byte-identical to the CPU oracle's", "counts": dict(sorted(counts.items()))}, open(sys.argv[3], "w"), indent=1)

@@ -83,3 +83,35 @@ def test_shard_indices_partition():
     assert a["mpix_s"] == 2.0 and a["bpp"] == 0.002
     with pytest.raises(ValueError):
         shard_indices(4, 2, 2)
+
+
+def test_bench_launches_itself_for_n_gt_1():
+    """`python bench.py --gpus 2 ...` from a bare shell (no WORLD_SIZE): the parent must start the two ranks as CHILD
+    processes under torch.distributed.run, the ranks must rendezvous on 127.0.0.1, and rank 0's line must come back
+    through the parent.  --dry-run keeps the GPU out of it (this box has none): rendezvous, barrier and the MAX / SUM
+    aggregation are the real code path of the N > 1 bench."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["metric"] == "dry_run" and out["value"] is None
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2
+    assert out["elapsed_max_s"] == 2.0 and out["bytes"] == 3000.0          # MAX of (1, 2); SUM of (1000, 2000)
+    assert out["pixels"] == 2 * out["batch_per_gpu"] * 512 * 768
+
+
+def test_bench_defaults_match_baseline_configs():
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.parse_args([])
+    assert a.gpus == 1 and a.batch == 0 and a.container.startswith("rans")
+    # a launcher that started the wrong number of ranks is an error, not a silent single-rank run
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    import subprocess
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "started 3 ranks" in (p.stderr + p.stdout)

@@ -591,3 +591,188 @@ def test_agent_validate_mode(torch_mod, oracle_weights, caplog):
         tot += sum(float(t.astype(np.float64).sum()) for t in orc.forward(pad, W_o)) / pad.size * 3
     assert abs(got - tot / 2) < 1e-4 * (tot / 2)
     assert any("Valid Epoch" in r.message for r in caplog.records)
+
+
+# ------------------------------------------------------------------------------------------------ round 2
+def _decode_poisoned(c, cont, seg, H, W, mode=0):
+    """Decode on a workspace that holds NO trace of the encode: both calls carve planes / fplanes at the same offsets of
+    the same cached workspace, so a decoder reading a not-yet-decoded pixel would otherwise find the right value there."""
+    c.workspace(cont.shape[0], H, W, mode)
+    c.poison_workspace(0xA5)
+    out = c.decode(cont, seg, H, W, mode=mode)
+    c.check()
+    return out
+
+
+@pytest.mark.parametrize("mode_name,B,H,W", [("ac", 3, 128, 192), ("ac", 2, 250, 131), ("rans4", 3, 128, 192),
+                                             ("rans16", 2, 250, 131), ("rans1", 2, 67, 93)])
+def test_decode_on_poisoned_workspace(torch_mod, codecs, mode_name, B, H, W):
+    """Losslessness of the PIPELINED decoders (3-stream AC chunk pipeline with ac_chunks() > 1, rANS next-step
+    prefetch, CNN halo / odd-edge clamps), with B > 1: the workspace is overwritten with 0xA5 between encode and
+    decode, and a second decode runs on a FRESH context that never saw the encoder at all."""
+    from llicti_amd.codec import HipCodec, MODE_RANS
+    torch = torch_mod
+    c = codecs("trainedlike")
+    mode = 0 if mode_name == "ac" else MODE_RANS(int(mode_name[4:]))
+    rgb = np.concatenate([make_batch("smooth", B - 1, H, W, seed0=300), make_batch("noise", 1, H, W, seed0=301)])
+    cont, seg = c.encode(_dev(torch, rgb), mode=mode)
+    c.check()
+    rec = _decode_poisoned(c, cont, seg, H, W, mode)
+    assert np.array_equal(rec.cpu().numpy(), rgb)
+    c2 = HipCodec("cuda:0")
+    try:
+        c2.load_state_dict(load_state_dict("trainedlike"))
+        c2.workspace(B, H, W, mode)
+        c2.poison_workspace(0x5A)
+        rec2 = c2.decode(cont.clone(), seg.clone(), H, W, mode=mode)
+        c2.check()
+        assert np.array_equal(rec2.cpu().numpy(), rgb)
+    finally:
+        c2.close()
+
+
+def test_malformed_segment_lengths_rejected(torch_mod, codecs):
+    """a negative or oversized EARLIER seg_len entry must end in LLICTI_EFORMAT, not in a read outside the
+    container buffer; a too-small in_stride is refused on the host."""
+    from llicti_amd._lib import LlictiError, EFORMAT, EINVAL
+    from llicti_amd.codec import MODE_RANS
+    torch = torch_mod
+    c = codecs("trainedlike")
+    rgb = make_batch("smooth", 2, 64, 96, seed0=61)
+    for mode in (0, MODE_RANS(4)):
+        cont, seg = c.encode(_dev(torch, rgb), mode=mode)
+        c.check()
+        for (k, v) in ((5, -100000), (4, 1 << 30), (6, -1), (3, -(1 << 31)), (10, (1 << 31) - 1), (0, 7)):
+            bad = seg.clone()
+            bad[1, k] = v
+            c.decode(cont, bad, 64, 96, mode=mode)
+            with pytest.raises(LlictiError) as e:
+                c.check()
+            assert e.value.code == EFORMAT, (mode, k, v)
+        with pytest.raises(LlictiError) as e:
+            c.decode(cont[:, :16].contiguous(), seg, 64, 96, mode=mode)
+        assert e.value.code == EINVAL
+        rec = _decode_poisoned(c, cont, seg, 64, 96, mode)        # the context is still usable
+        assert np.array_equal(rec.cpu().numpy(), rgb)
+
+
+def test_ac_decode_seam_ignores_bytes_past_len(torch_mod, codecs):
+    """llicti_ac_decode_u16cdf honours d_len: garbage behind a stream must read as torchac's zero bits."""
+    from oracle import oracle as orc
+    torch = torch_mod
+    c = codecs("rand1337")
+    rng = np.random.default_rng(11)
+    Lp, N, S = 257, 500, 3
+    stride = 264
+    from test_ref_ac import random_rows
+    cdfs = np.full((S, N, stride), 0xFFFF, np.uint16)
+    syms = rng.integers(0, Lp - 1, (S, N)).astype(np.int16)
+    streams = []
+    for s in range(S):
+        cdfs[s, :, :Lp] = random_rows(rng, N, Lp, 3.0)
+        streams.append(orc.ac_encode_tables(cdfs[s, :, :Lp].copy(), syms[s]))
+    in_stride = (max(len(x) for x in streams) + 3) // 4 * 4 + 32
+    buf = rng.integers(0, 256, (S, in_stride)).astype(np.uint8)            # garbage everywhere ...
+    for s, x in enumerate(streams):
+        buf[s, :len(x)] = np.frombuffer(x, np.uint8)                        # ... except the stream itself
+    lens = np.array([len(x) for x in streams], np.int32)
+    dec = c.ac_decode(_dev(torch, cdfs.view(np.int16)), Lp, _dev(torch, buf), _dev(torch, lens), N)
+    assert np.array_equal(dec.cpu().numpy(), syms)
+
+
+def _reference_shaped_checkpoint(path, seed):
+    """What agents/base.py:83-100 saves: epoch / iteration / best_valid_loss / state_dict / optimizer / scheduler / logger
+    states; the state_dict carries compressai's extra buffers on every conditional_prob_model and NON-seed weights."""
+    import torch
+    from llicti_amd.config import default_config
+    from llicti_amd.graphs.models.LLICTI_nets import LLICTI
+    torch.manual_seed(seed)
+    m = LLICTI(default_config())
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(seed + 1)
+    for k in sd:                                             # move the weights away from any default init
+        if k.endswith(".weight") or k.endswith(".bias"):
+            sd[k] = sd[k] * 1.3 + 0.01 * torch.randn(sd[k].shape, generator=g)
+    for b in range(3):
+        p = f"entropymodel.entmdls_scale_band.0.{b}.conditional_prob_model."
+        sd[p + "_offset"] = torch.zeros(64, dtype=torch.int32)
+        sd[p + "_quantized_cdf"] = torch.zeros((64, 40), dtype=torch.int32)
+        sd[p + "_cdf_length"] = torch.zeros(64, dtype=torch.int32)
+        sd[p + "scale_table"] = torch.linspace(0.11, 256, 64)
+    ckpt = {"epoch": 123, "iteration": 45678, "best_valid_loss": 2.7, "state_dict": sd,
+            "optimizer": {"state": {}, "param_groups": [{"lr": 1e-4}]}, "scheduler": {"best": 2.7},
+            "train_logger": {}, "valid_logger": {}, "test_logger": {}}
+    torch.save(ckpt, path)
+    return sd
+
+
+def test_agent_loads_reference_shaped_checkpoint(torch_mod, tmp_path):
+    """a model_best.pth.tar as the reference writes it -> LLICTIAgent(mode='eval_model') -> the bytes the
+    oracle produces for THOSE weights; a checkpoint whose keys do not match raises instead of silently keeping the init."""
+    from llicti_amd.agents.llicti_agent import LLICTIAgent
+    from llicti_amd.config import default_config
+    from llicti_amd.weights import pack_state_dict
+    from oracle import oracle as orc
+    torch = torch_mod
+    sd = _reference_shaped_checkpoint(tmp_path / "model_best.pth.tar", seed=77)
+    cfg = default_config(test_data="synthetic:48x80x2", checkpoint_dir=str(tmp_path))
+    agent = LLICTIAgent(cfg)
+    own = agent.model.state_dict()
+    for k in own:
+        assert torch.equal(own[k].cpu(), sd[k]), k            # the checkpoint's values, not the seeded init
+    W_o = orc.Weights(pack_state_dict({k: v for k, v in sd.items() if k in own}))
+    res = agent.run()
+    assert len(res) == 2 and all(r["max_abs_err"] < 1e-3 for r in res)
+    for i in range(2):
+        rgb = np.random.default_rng(i).integers(0, 256, size=(3, 48, 80), dtype=np.uint8)
+        x = torch.from_numpy(rgb.astype(np.float32) / np.float32(255)).unsqueeze(0).to("cuda:0")
+        bl, _ = agent.model.compress(x)
+        assert bl == orc.encode_image(rgb, W_o), i
+    # cli --checkpoint takes the same file
+    from llicti_amd import cli, fileio
+    src, mid = tmp_path / "in.ppm", tmp_path / "x.llic"
+    fileio.write_image(src, rgb)
+    assert cli.main(["encode", str(src), str(mid), "--checkpoint", str(tmp_path / "model_best.pth.tar")]) == 0
+    assert fileio.read_llic(mid) == orc.encode_image(rgb, W_o)
+    # wrong keys: strict, like agents/base.py:60
+    bad = torch.load(tmp_path / "model_best.pth.tar")
+    bad["state_dict"] = {"module." + k: v for k, v in bad["state_dict"].items()}
+    torch.save(bad, tmp_path / "model_best.pth.tar")
+    with pytest.raises((KeyError, RuntimeError)):
+        LLICTIAgent(cfg)
+
+
+def test_full_size_oracle_parity(torch_mod, codecs, oracle_weights):
+    """BASELINE.json full sizes inside the suite: the 24 x 768x512 batch (configs[2]) in the rANS16 container with 3 of
+    the 24 images compared byte for byte with the oracle (it costs seconds per image), 2 x 768x512 in the AC container
+    (configs[1]'s shape, reference format) against the oracle, and configs[0]'s 256x256 random-RGB image in the AC
+    container; every decode on a poisoned workspace."""
+    from oracle import oracle as orc
+    from llicti_amd.codec import MODE_RANS, container_to_bytestream_list
+    torch = torch_mod
+    c = codecs("rand1337")
+    W_o = oracle_weights("rand1337")
+    H, W = 512, 768
+    rgb = np.stack([np.random.default_rng(i).integers(0, 256, size=(3, H, W), dtype=np.uint8) for i in range(24)])   # bench.py's batch
+    cont, seg = c.encode(_dev(torch, rgb), mode=MODE_RANS(16))
+    c.check()
+    cont_h, seg_h = cont.cpu().numpy(), seg.cpu().numpy()
+    for b in (0, 11, 23):
+        assert container_to_bytestream_list(cont_h[b], seg_h[b]) == orc.encode_image_rans(rgb[b], W_o, 16), b
+    rec = _decode_poisoned(c, cont, seg, H, W, MODE_RANS(16))
+    assert np.array_equal(rec.cpu().numpy(), rgb)
+    cont, seg = c.encode(_dev(torch, rgb[:2]))
+    c.check()
+    cont_h, seg_h = cont.cpu().numpy(), seg.cpu().numpy()
+    for b in range(2):
+        assert container_to_bytestream_list(cont_h[b], seg_h[b]) == orc.encode_image(rgb[b], W_o), b
+    rec = _decode_poisoned(c, cont, seg, H, W, 0)
+    assert np.array_equal(rec.cpu().numpy(), rgb[:2])
+    small = np.random.default_rng(0).integers(0, 256, size=(1, 3, 256, 256), dtype=np.uint8)                         # configs[0]
+    cont, seg = c.encode(_dev(torch, small))
+    c.check()
+    bl = container_to_bytestream_list(cont[0].cpu().numpy(), seg[0].cpu().numpy())
+    assert bl == orc.encode_image(small[0], W_o)
+    assert np.array_equal(orc.decode_image(bl, W_o), small[0])
+    rec = _decode_poisoned(c, cont, seg, 256, 256, 0)
+    assert np.array_equal(rec.cpu().numpy(), small)

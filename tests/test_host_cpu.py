@@ -203,3 +203,48 @@ def test_div255_shortcut_is_exact():
         rem = rn(x - Fr(float(q)) * 255)
         q2 = rn(Fr(float(q)) + Fr(float(rem)) * Fr(float(r255)))
         assert q2 == rn(x / 255), k
+
+
+def test_model_size_line_matches_reference_log():
+    """agents/llicti_agent.py:167-192 prints the one reference-logged number that is reproducible exactly:
+    " model param+buffer=total size: 0.750+0.000=0.750MB" (experiments/.../exp_debug.log:101)."""
+    import logging
+    import torch
+    from llicti_amd.agents.llicti_agent import LLICTIAgent
+    from llicti_amd.config import default_config
+    from llicti_amd.graphs.models.LLICTI_nets import LLICTI
+    a = LLICTIAgent.__new__(LLICTIAgent)              # the constructor needs a GPU; the size estimate does not
+    a.logger = logging.getLogger("Agent")
+    a.model = LLICTI(default_config())
+    n_par, n_buf = a.model_size_estimation()
+    assert n_par == 196596 * 4 and n_buf == 9 * 4
+    assert a.size_text == " model param+buffer=total size: 0.750+0.000=0.750MB"
+
+
+def test_strict_checkpoint_loading():
+    """compressai's known extra buffers are dropped, anything else that does not match raises."""
+    import pytest
+    import torch
+    from llicti_amd.config import default_config
+    from llicti_amd.graphs.models.LLICTI_nets import LLICTI
+    from llicti_amd.weights import load_reference_state_dict
+    torch.manual_seed(5)
+    src = LLICTI(default_config())
+    sd = dict(src.state_dict())
+    p = "entropymodel.entmdls_scale_band.0.1.conditional_prob_model."
+    sd[p + "_offset"] = torch.zeros(3, dtype=torch.int32)
+    sd[p + "scale_table"] = torch.zeros(64)
+    torch.manual_seed(6)
+    dst = LLICTI(default_config())
+    load_reference_state_dict(dst, sd)
+    assert all(torch.equal(a, b) for a, b in zip(src.state_dict().values(), dst.state_dict().values()))
+    with pytest.raises(KeyError):
+        load_reference_state_dict(dst, {"module." + k: v for k, v in sd.items()})
+    short = dict(sd)
+    short.pop("entropymodel.entmdls_scale_band.0.2.layers1toL.2.bias")
+    with pytest.raises(KeyError):
+        load_reference_state_dict(dst, short)
+    extra = dict(sd)
+    extra["entropymodel.something_else.weight"] = torch.zeros(1)
+    with pytest.raises(RuntimeError):
+        load_reference_state_dict(dst, extra)

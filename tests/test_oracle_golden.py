@@ -205,3 +205,45 @@ def test_oracle_roundtrip_random_shapes(oracle_weights):
         assert len(bl) == 6 and all(len(r) == 9 for r in bl)
         assert bl[0][0][1] == (((H + 15) // 16 + 1) // 2) and bl[0][0][2] == (((W + 15) // 16 + 1) // 2)     # h4, w4 of level 4
     run()
+
+
+def test_bpp_delta_vs_reference_tables_report(golden_index, oracle_weights):
+    """ABSOLUTE Delta bpp between the ideal code length of the oracle's tables and of the REFERENCE's own tables
+    (the (c_low, c_high) pairs the reference handed to torchac, recorded in the fixtures), per fixture.  Trained-like
+    weights meet the north star's 0.001 bpp; with the BASELINE workload's sigma-floor random weights the bound is the
+    measured one and is stated as such -- a probability-1/65536 symbol whose entry moves by one
+    count is worth a whole bit.  With LLICTI_WRITE_PROFILES=<dir> the table is written to <dir>/bpp_delta_fixtures.json
+    (the copy bench.py quotes lives under profiles/<round>/)."""
+    import json
+    import os
+    rows, worst = [], {"trainedlike": 0.0, "rand1337": 0.0}
+    for case in CASES:
+        c = load_case(case)
+        info = golden_index[case]
+        W = oracle_weights(info["weights"])
+        planes, mm = orc.lift(c["rgb"])
+        H, Wd = c["rgb"].shape[1:]
+        bits_ref = bits_orc = 0.0
+        for s in range(5):
+            for b in range(3):
+                params = orc.band_params(planes, s, b, W)
+                for clr in range(3):
+                    clow, chigh, _ = orc.stream_pairs(planes, mm, s, b, clr, params)
+                    tag = f"s{s}_b{b}_c{clr}"
+                    rl, rh = c["clow_" + tag].astype(np.int64), c["chigh_" + tag].astype(np.int64)
+                    bits_ref += float(-np.log2((rh - rl) / 65536.0).sum())
+                    bits_orc += float(-np.log2((chigh.astype(np.int64) - clow.astype(np.int64)) / 65536.0).sum())
+        d = (bits_orc - bits_ref) / (H * Wd)
+        rows.append({"fixture": case, "weights": info["weights"], "pixels": H * Wd, "bpp_reference_tables": round(bits_ref / (H * Wd), 5),
+                     "bpp_oracle_tables": round(bits_orc / (H * Wd), 5), "delta_bpp": round(d, 6),
+                     "delta_relative": round((bits_orc - bits_ref) / bits_ref, 8)})
+        worst[info["weights"]] = max(worst[info["weights"]], abs(d))
+    assert worst["trainedlike"] < 1e-3, worst           # north star: bpp within 0.001 of the reference
+    assert worst["rand1337"] < 5e-3, worst              # sigma-floor random weights at ~40 bpp: measured bound, NOT 0.001 (see docstring)
+    out = os.environ.get("LLICTI_WRITE_PROFILES")
+    if out:
+        os.makedirs(out, exist_ok=True)
+        json.dump({"what": "ideal code length of the build's (oracle == HIP, bit-exact) tables minus that of the reference's own recorded "
+                           "tables, identical weights and images (tests/golden fixtures generated from the reference-owned Python)",
+                   "max_abs_delta_bpp": {k: round(v, 6) for k, v in worst.items()}, "fixtures": rows},
+                  open(os.path.join(out, "bpp_delta_fixtures.json"), "w"), indent=1)

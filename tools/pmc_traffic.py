@@ -46,10 +46,18 @@ def per_launch(prefix):
     return d
 
 
-res = {"command": "python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras (one rocprofv3 --pmc pass per counter group)",
-       "band_params_kernel": per_launch("band_params_kernel"),
-       "rans_decode_stage_kernel": per_launch("rans_decode_stage_kernel"),
-       "cdf_pairs_kernel": per_launch("cdf_pairs_kernel"),
-       "lift_kernel": per_launch("lift_kernel")}
-json.dump(res, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
-print(json.dumps(res["band_params_kernel"], indent=1))
+# a third argument merges into an existing pmc_traffic.json (the table kernel's passes are a separate command)
+dst = os.path.join(out, "pmc_traffic.json")
+res = json.load(open(dst)) if (len(sys.argv) > 3 and os.path.exists(dst)) else {}
+res.setdefault("command", {})
+if not isinstance(res["command"], dict):
+    res["command"] = {"bench": res["command"]}
+label = sys.argv[3] if len(sys.argv) > 3 else "bench"
+res["command"][label] = ("python3 tools/bench_table.py" if label == "table" else
+                         "python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras") + " (one rocprofv3 --pmc pass per counter group)"
+for pref in ("band_params_kernel", "rans_decode_stage_kernel", "cdf_pairs_kernel", "lift_kernel", "cdf_table_kernel", "cdf_anchor_kernel",
+             "ac_decode_kernel", "rans_encode_kernel", "ac_encode_pairs_kernel"):
+    if any(k.startswith(pref) for k in agg):
+        res[pref] = per_launch(pref)
+json.dump(res, open(dst, "w"), indent=1)
+print(json.dumps({k: v for k, v in res.items() if k != "command"}, indent=1)[:3000])
