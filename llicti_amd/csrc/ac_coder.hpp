@@ -356,3 +356,160 @@ __global__ __launch_bounds__(64) void ac_decode_kernel(const uint16_t *__restric
     }
     VMCNT_WAIT(0);                                      // no transfer may still target this workgroup's LDS at exit
 }
+
+// ------------------------------------------------------------------------------------------------ anchor decoder
+// Whole-batch AC decode without full tables (cdf.hpp: cdf_anchor_kernel).  Same coder, same state carry between chunk
+// launches, same LDS ring / explicit vmcnt discipline as ac_decode_kernel; what changes is the search:
+//   round 1: lane l holds anchor[l] = entry[8 l]; ballot of (span * anchor >> 16) <= value - low -> bucket L
+//   round 2: the 8 entries 8L .. 8L+7 are EVALUATED here, exactly (numerics spec), one (entry, mixture component) pair
+//            per lane: lane 8e + m computes term m of entry 8L + e, the five terms are summed in the spec's order over
+//            DPP row shifts into lane 8e, integerised, scaled and voted on.  Entry 8L + 8 (c_high when the symbol is the
+//            bucket's last) is the next anchor.
+// Bit-identical to a search over the full row: the entries are the same bits wherever they are computed.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void lds_read_anchor_hidden(uint32_t a_addr, uint32_t c_addr, uint32_t &anc, u32x4 &cmp)
+{
+    asm volatile("ds_read_u16 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(anc), "=&v"(cmp) : "v"(a_addr), "v"(c_addr) : "memory");
+}
+
+__global__ __launch_bounds__(64) void ac_decode_anchor_kernel(const uint8_t *__restrict__ rows, const uint8_t *__restrict__ in,
+                                                              long in_stride, AcChunk ck, DecOut o)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t ring[kDecRing][256];      // kAnchorRow = 208 bytes used per slot
+    const int s = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int N = ck.cnt;
+    const bool first = ck.n0 == 0, last = ck.n0 + ck.cnt >= ck.n_total;
+    const uint32_t *words = reinterpret_cast<const uint32_t *>(in + (long)s * in_stride);
+    int minv, maxv, shift;
+    clr_range(o.minmax + 4 * s, o.clr, minv, maxv, shift);
+    const Grid gr = make_grid(minv, maxv);
+    const uint32_t max_symbol = (uint32_t)(gr.Lp - 2);
+    const float fbase = (float)minv - 0.5f;
+    const uint8_t *tab = rows + (long)s * ck.cap_rows * kAnchorRow;
+    auto dma_row = [&](int n, int slot) {                     // 13 lanes x 16 bytes = one 208-byte row
+        if (lane < kAnchorRow / 16) {
+            const uint8_t *src = tab + (long)min(n, N - 1) * kAnchorRow + 16 * lane;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)&ring[slot][0], 16, 0, 0);
+        }
+    };
+    const int in_words = (int)(in_stride >> 2);
+    auto load_win = [&](int w0) -> uint32_t { return bswap32(words[min(w0 + lane, in_words - 1)]); };
+    uint32_t *st = ck.state + 8 * s;
+    int wpos = first ? 3 : (int)st[6];
+    uint32_t win_cur = load_win(first ? 0 : (wpos & ~63));
+    asm volatile("" : "+v"(win_cur));
+    auto next_word = [&]() -> uint32_t {
+        uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)win_cur, wpos & 63);
+        if (wpos >= in_words) w = 0;
+        ++wpos;
+        if ((wpos & 63) == 0) { win_cur = load_win(wpos); asm volatile("" : "+v"(win_cur)); }
+        return w;
+    };
+#pragma unroll
+    for (int k = 0; k < kDecRing; ++k) dma_row(k, k);
+    uint32_t value = (uint32_t)__builtin_amdgcn_readlane((int)win_cur, 0);
+    const uint32_t w1_ = (uint32_t)__builtin_amdgcn_readlane((int)win_cur, 1), w2_ = (uint32_t)__builtin_amdgcn_readlane((int)win_cur, 2);
+    uint64_t buf = ((uint64_t)w1_ << 32) | w2_;
+    int have = 64;
+    uint32_t low = 0, high = 0xFFFFFFFFu;
+    if (!first) { low = st[0]; high = st[1]; value = st[2]; buf = ((uint64_t)st[3] << 32) | st[4]; have = (int)st[5]; }
+    const bool lane_ok = 8u * (uint32_t)lane <= max_symbol;
+    const int e = lane >> 3, m = lane & 7;
+    const bool head = (m == 0);
+    const uint32_t ring0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)&ring[0][0];
+    const uint32_t a_off = 2u * (uint32_t)lane, c_off = 128u + 16u * (uint32_t)min(m, 4);
+
+    int mysym = 0;
+    auto flush = [&](int n_first, int count) {
+        if (lane < count) {
+            const int n = n_first + lane;
+            const int i = n / o.sg.wc, j = n - i * o.sg.wc;
+            const long off = (long)s * 3 * o.sg.plane + (long)o.clr * o.sg.plane +
+                             ((long)(2 * i + o.sg.oi) << o.sg.lvl) * o.sg.W + ((long)(2 * j + o.sg.oj) << o.sg.lvl);
+            const int v = mysym - shift;
+            o.planes[off] = (int16_t)v;
+            o.fplanes[off] = (float)v / 255.0f;
+        }
+    };
+
+    VMCNT_WAIT(7);
+    uint32_t cur_a;
+    u32x4 cur_c;
+    lds_read_anchor_hidden(ring0 + a_off, ring0 + c_off, cur_a, cur_c);
+    for (int n = 0; n < N; ++n) {
+        const int slot = n & (kDecRing - 1);
+        VMCNT_WAIT(6);
+        uint32_t nxt_a;
+        u32x4 nxt_c;
+        const uint32_t nb = ring0 + 256u * (uint32_t)((n + 1) & (kDecRing - 1));
+        lds_read_anchor_hidden(nb + a_off, nb + c_off, nxt_a, nxt_c);
+        const uint32_t r = high - low, T = value - low;
+        const uint32_t rh = r >> 16, rl = r & 0xFFFFu;
+        // round 1: anchors
+        const uint32_t sc1 = __umul24(rh, cur_a) + ((__umul24(rl, cur_a) + cur_a) >> 16);
+        const bool p1 = (lane == 0) || (lane_ok && sc1 <= T);
+        const int L = __builtin_popcountll(ballot64(p1)) - 1;
+        // round 2: entries 8L + e, term m in lane 8e + m (cdf_entry()'s operations, in its order)
+        const int i = 8 * L + e;
+        const float pt = (i == 0) ? gr.p_first : div255_exact(fbase + (float)i);
+        const float c_mu = __uint_as_float(cur_c.x), c_rs = __uint_as_float(cur_c.y), c_wn = __uint_as_float(cur_c.z);
+        const float t = c_wn * (0.5f * erfc_spec_nobranch(kNegRsqrt2 * ((pt - c_mu) * c_rs)));
+        float acc = t + dpp_row_shl(t, 1);
+        acc = acc + dpp_row_shl(t, 2);
+        acc = acc + dpp_row_shl(t, 3);
+        acc = acc + dpp_row_shl(t, 4);
+        const uint32_t c2 = (uint32_t)((int)__builtin_rintf(acc * gr.scale) + i) & 0xFFFFu;
+        const uint32_t sc2 = __umul24(rh, c2) + ((__umul24(rl, c2) + c2) >> 16);
+        const bool p2 = head && ((e == 0) || ((uint32_t)i <= max_symbol && sc2 <= T));
+        const int es = __builtin_popcountll(ballot64(p2)) - 1;
+        const uint32_t sidx = 8u * (uint32_t)L + (uint32_t)es;
+        const uint32_t low_add = __builtin_amdgcn_readlane(sc2, 8 * es);
+        const uint32_t hi_in = __builtin_amdgcn_readlane(sc2, (8 * (es + 1)) & 63);
+        const uint32_t hi_nx = __builtin_amdgcn_readlane(sc1, (L + 1) & 63);
+        const uint32_t high_add = (sidx == max_symbol) ? r + 1u : (es == 7 ? hi_nx : hi_in);
+        if (lane == (n & 63)) mysym = (int)sidx;
+        if ((n & 63) == 63) flush(ck.n0 + n - 63, 64);
+        dma_row(n + kDecRing, slot);
+        cur_a = nxt_a;
+        cur_c = nxt_c;
+        if (n == N - 1 && last) break;
+        high = (low - 1) + high_add;
+        low = low + low_add;
+        int n1 = __clz((int)(low ^ high));
+        if (n1 > 31) n1 = 31;
+        const uint32_t low1 = low << n1, high1 = (high << n1) | ((1u << n1) - 1u);
+        int n2 = min(__clz((int)~(low1 << 1)), __clz((int)(high1 << 1)));
+        if (n2 > 31) n2 = 31;
+        const int nsh = n1 + n2;
+        if (nsh > 0) {
+            if (nsh < 32) {
+                const uint32_t e3 = n2 > 0 ? 0x80000000u : 0u;
+                low = (low1 << n2) & ~e3;
+                high = ((high1 << n2) | ((1u << n2) - 1u)) | e3;
+                value = ((value << nsh) | (uint32_t)(buf >> (64 - nsh))) ^ e3;
+                buf <<= nsh; have -= nsh;
+                if (have <= 32) { buf |= (uint64_t)next_word() << (32 - have); have += 32; }
+            } else {
+                low = low1; high = high1;
+                if (n1 > 0) {
+                    value = (value << n1) | (uint32_t)(buf >> (64 - n1));
+                    buf <<= n1; have -= n1;
+                    if (have <= 32) { buf |= (uint64_t)next_word() << (32 - have); have += 32; }
+                }
+                low = (low << n2) & 0x7FFFFFFFu;
+                high = ((high << n2) | ((1u << n2) - 1u)) | 0x80000000u;
+                value = ((value << n2) ^ 0x80000000u) | (uint32_t)(buf >> (64 - n2));
+                buf <<= n2; have -= n2;
+                if (have <= 32) { buf |= (uint64_t)next_word() << (32 - have); have += 32; }
+            }
+        }
+    }
+    if (N & 63) flush(ck.n0 + (N & ~63), N & 63);
+    if (!last && lane == 0) {
+        st[0] = low; st[1] = high; st[2] = value; st[3] = (uint32_t)(buf >> 32); st[4] = (uint32_t)buf; st[5] = (uint32_t)have; st[6] = (uint32_t)wpos;
+    }
+    VMCNT_WAIT(0);
+}

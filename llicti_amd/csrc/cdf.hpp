@@ -179,3 +179,73 @@ __global__ __launch_bounds__(64 * kTabWaves) void cdf_table_kernel(const int16_t
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------ anchors (AC decode)
+// The whole-batch AC decoder does not need the full row: it needs to FIND the symbol, and for that every 8th entry
+// (64 "anchors" for Lp <= 512) is enough -- the 8 entries between two anchors are evaluated by the decoding wave itself,
+// on all 64 lanes at once (8 entries x 5 mixture components + 3 idle lanes per entry, ac_decode_anchor_kernel), with
+// the same arithmetic, hence the same bits.  This kernel therefore does 1/8 of the table kernel's erfc work and
+// writes 208 instead of 528 / 1024 bytes per symbol:
+//   row n (kAnchorRow bytes):  [0, 128)   uint16 anchor[l] = entry[min(8 l, Lp - 1)],  l = 0 .. 63
+//                              [128, 208) float4 (mu + cross-channel update, 1 / max(sigma, bound), normalised weight, 0) x 5
+constexpr int kAnchorRow = 208;
+
+__global__ __launch_bounds__(64 * kTabWaves) void cdf_anchor_kernel(const int16_t *__restrict__ planes, const float *__restrict__ params,
+                                                                    const int32_t *__restrict__ minmax, StageGeom s, int clr,
+                                                                    uint8_t *__restrict__ rows, int n0, int cnt, int cap_rows)
+{
+    const int b = blockIdx.y;
+    const int nc = s.hc * s.wc;
+    const int lane = threadIdx.x & 63;
+    const int wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * kTabWaves + (threadIdx.x >> 6)));
+    const int nwaves = gridDim.x * kTabWaves;
+    int minv, maxv, shift;
+    clr_range(minmax + 4 * b, clr, minv, maxv, shift);
+    const Grid gr = make_grid(minv, maxv);
+    const int ec = min(8 * lane, gr.Lp - 1);
+    const float pt = sample_pt(gr, ec);
+    const long img = (long)b * 3 * s.plane;
+    const int mi = min(lane, 4);                         // lanes 0..4 prepare one mixture component each
+    for (int n = n0 + wave0; n < min(nc, n0 + cnt); n += nwaves) {
+        const int i = n / s.wc, j = n - i * s.wc;
+        const float *par = params + ((long)b * s.h * s.w + (long)i * s.w + j) * LLICTI_PARAM_STRIDE;
+        const long off = img + ((long)(2 * i + s.oi) << s.lvl) * s.W + ((long)(2 * j + s.oj) << s.lvl);
+        // component mi, prepared exactly as mix_prepare() does
+        const float sgm = par[5 * clr + mi];
+        float mu = par[16 + 5 * clr + mi];
+        const float wk = par[32 + 5 * clr + mi];
+        if (clr == 1) {
+            const float t = par[48 + mi] * ((float)planes[off] / 255.0f);
+            mu = mu + t;
+        } else if (clr == 2) {
+            const float t1 = par[48 + 5 + mi] * ((float)planes[off] / 255.0f);
+            const float t2 = par[48 + 10 + mi] * ((float)planes[off + s.plane] / 255.0f);
+            const float t = t1 + t2;
+            mu = mu + t;
+        }
+        const float sg = (sgm > kScaleBound) ? sgm : kScaleBound;
+        const float rsig = 1.0f / sg;
+        const float w = (wk > kWeightBound) ? wk : kWeightBound;
+        float ssum = w + dpp_row_shl(w, 1);              // (((w0 + w1) + w2) + w3) + w4 in lane 0
+        ssum = ssum + dpp_row_shl(w, 2);
+        ssum = ssum + dpp_row_shl(w, 3);
+        ssum = ssum + dpp_row_shl(w, 4);
+        ssum = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ssum)));
+        const float wn = w / (1e-9f + ssum);
+        float acc = 0.0f;
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+            const float mu_m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mu), m));
+            const float rs_m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rsig), m));
+            const float wn_m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wn), m));
+            const float z = (pt - mu_m) * rs_m;
+            const float t = wn_m * (0.5f * erfc_spec(kNegRsqrt2 * z));
+            acc = (m == 0) ? t : acc + t;
+        }
+        const float q = __builtin_rintf(acc * gr.scale);
+        const uint32_t v = (uint32_t)((int)q + ec) & 0xFFFFu;
+        uint8_t *row = rows + ((long)b * cap_rows + (n - n0)) * kAnchorRow;
+        reinterpret_cast<uint16_t *>(row)[lane] = (uint16_t)v;
+        if (lane < 5) reinterpret_cast<float4 *>(row + 128)[lane] = make_float4(mu, rsig, wn, 0.0f);
+    }
+}

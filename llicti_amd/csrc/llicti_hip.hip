@@ -192,7 +192,7 @@ static void build_plan(Plan &p, int B, int H, int W, int M)
             p.ac_cap_rows = std::max(p.ac_cap_rows, ac_chunk_rows((long)hcl * wcl));
         }
     }
-    p.off_tables = take((size_t)3 * B * p.ac_cap_rows * 512 * sizeof(uint16_t));     // one chunk buffer per colour channel
+    p.off_tables = take((size_t)3 * B * p.ac_cap_rows * kAnchorRow);                  // one chunk buffer of anchor rows per colour channel
     p.off_acstate = take((size_t)3 * B * 8 * sizeof(uint32_t));
     p.total = o;
 }
@@ -457,6 +457,17 @@ static int launch_cdf_pairs(const int16_t *planes, const float *params, const in
     HIPCHK(hipGetLastError());
     return 0;
 }
+static int launch_cdf_anchors(const int16_t *planes, const float *params, const int32_t *mm, const Geom &g, int band, int clr,
+                              uint8_t *rows, long n0, long cnt, long cap_rows, hipStream_t s)
+{
+    StageGeom sg = make_stage(g, band);
+    const long want = (cnt + kTabWaves - 1) / kTabWaves;
+    const long cap = std::max<long>(1, (256L * 8 * 2) / std::max(1, g.B));
+    cdf_anchor_kernel<<<dim3((unsigned)std::max<long>(1, std::min(want, cap)), g.B), 64 * kTabWaves, 0, s>>>(planes, params, mm, sg, clr, rows,
+                                                                                                   (int)n0, (int)cnt, (int)cap_rows);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 static int launch_cdf_table(const int16_t *planes, const float *params, const int32_t *mm, const Geom &g, int band, int clr,
                             uint16_t *tables, int row_stride, long n0, long cnt, long cap_rows, hipStream_t s)
 {
@@ -661,7 +672,7 @@ static int decode_sub(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in
     int32_t *status = (int32_t *)(ws + p.off_status);
     float *params = (float *)(ws + p.off_params);
     uint8_t *slots = ws + p.off_slots;
-    uint16_t *tables = (uint16_t *)(ws + p.off_tables);
+    uint8_t *tables = ws + p.off_tables;
     uint32_t *acstate = (uint32_t *)(ws + p.off_acstate);
 
     HIPCHK(hipMemsetAsync(status, 0, 64, s));
@@ -684,9 +695,15 @@ static int decode_sub(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in
             StageGeom sg = make_stage(g, band);
             const long nc = (long)sg.hc * sg.wc;
             if (M > 0) {
-                rans_decode_stage_kernel<0><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, planes, fplanes, mm);
-                rans_decode_stage_kernel<1><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, planes, fplanes, mm);
-                rans_decode_stage_kernel<2><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, planes, fplanes, mm);
+                // later_max: the largest symbol count of any LATER stage (rANS v2: which symbol is a lane's last)
+                auto later_max = [&](int clr) {
+                    int mx = 0;
+                    for (int st2 = stage_index(lvl, band, clr) + 1; st2 < LLICTI_NSTREAMS; ++st2) mx = std::max(mx, p.desc[(size_t)st2 * B].n);
+                    return mx;
+                };
+                rans_decode_stage_kernel<0><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, planes, fplanes, mm, later_max(0), status);
+                rans_decode_stage_kernel<1><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, planes, fplanes, mm, later_max(1), status);
+                rans_decode_stage_kernel<2><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, planes, fplanes, mm, later_max(2), status);
             }
             if (M == 0) {
                 // Y, Co, Cg of this band as a pipeline over chunks of the stage: chunk c of Co needs only chunk c
@@ -706,9 +723,8 @@ static int decode_sub(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in
                     for (int clr = 0; clr < 3; ++clr) {
                         hipStream_t qs = (C > 1) ? q[clr] : s;
                         if (C > 1 && clr > 0) HIPCHK(hipStreamWaitEvent(qs, c->ev_ac[clr - 1][ch], 0));
-                        const int row_stride = (clr == 0) ? 264 : 512;      // Y: Lp = 257; Co/Cg: Lp <= 512
-                        uint16_t *tab = tables + (size_t)clr * B * p.ac_cap_rows * 512;
-                        if (int rc = launch_cdf_table(planes, params, mm, g, band, clr, tab, row_stride, n0, cnt, p.ac_cap_rows, qs)) return rc;
+                        uint8_t *tab = tables + (size_t)clr * B * p.ac_cap_rows * kAnchorRow;
+                        if (int rc = launch_cdf_anchors(planes, params, mm, g, band, clr, tab, n0, cnt, p.ac_cap_rows, qs)) return rc;
                         const int st = stage_index(lvl, band, clr);
                         DecOut o;
                         memset(&o, 0, sizeof o);
@@ -716,7 +732,7 @@ static int decode_sub(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in
                         // the B streams of one stage sit in consecutive slots of equal capacity
                         const long in_stride_slots = p.slot_cap[(size_t)st * B];
                         AcChunk ck = { (int)n0, (int)cnt, (int)nc, (int)p.ac_cap_rows, acstate + (size_t)clr * B * 8 };
-                        ac_decode_kernel<<<B, 64, 0, qs>>>(tab, 0, row_stride, slots + p.slot_off[(size_t)st * B], in_stride_slots, ck, o);
+                        ac_decode_anchor_kernel<<<B, 64, 0, qs>>>(tab, slots + p.slot_off[(size_t)st * B], in_stride_slots, ck, o);
                         if (C > 1 && clr < 2) HIPCHK(hipEventRecord(c->ev_ac[clr][ch], qs));
                     }
                 }

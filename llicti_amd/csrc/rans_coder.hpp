@@ -3,12 +3,16 @@
 #pragma once
 
 // ------------------------------------------------------------------------------------------------ rANS container
-// "LLICTI-rANS v1" (new format of this build; BASELINE.json north_star: "torchac replaced by a HIP rANS
+// "LLICTI-rANS v2" (new format of this build; BASELINE.json north_star: "torchac replaced by a HIP rANS
 // coder").  Same CDFs and symbols as the AC container; each image has M independent streams, each a
 // 64-way interleaved rANS coder (32-bit states, 16-bit words, 16-bit probabilities) driven by ONE
 // wavefront: lane l of stream m codes symbol n = 64c + l of every chunk c = m (mod M) of every stage.
 // Words are shared by the 64 lanes in lane order (ballot + mbcnt prefix), so a whole stage decodes in
 // ceil(nc / 64M) wave steps instead of nc serial symbols.
+// v2 "absorbing start": the first symbol a lane's encoder codes (the LAST one its decoder decodes) starts from state
+// x = freq(symbol) instead of 2^16, which makes the coded state 2^16 + c_low -- the 16 bits a rANS state holds at least
+// then carry that symbol instead of nothing (saves one symbol's information per lane: ~95 of ~190 bytes per stream on
+// noise).  The decoder reads no renormalisation word after a lane's last symbol and checks that the state left is freq.
 __device__ __forceinline__ int lanes_below(uint64_t mask)
 {
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -22,6 +26,7 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restr
     uint16_t *w16 = reinterpret_cast<uint16_t *>(slots + rslot_off[sidx]);
     long p = rslot_cap / 2;                         // word cursor, moving backwards from the end of the slot
     uint32_t x = 1u << 16;
+    bool started = false;                           // v2: has this lane coded its first symbol yet?
     int bad = 0;
     for (int st = LLICTI_NSTREAMS - 1; st >= 0; --st) {      // rANS is LIFO: last decoded symbol first
         const StreamDesc d = desc[(long)st * B + b];
@@ -43,12 +48,13 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restr
             if (hi == 0) hi = 0x10000u;
             uint32_t freq = hi - lo;
             if (active && (freq == 0 || hi < lo)) { bad = 1; freq = 1; }
-            const bool emit = active && ((uint64_t)x >= ((uint64_t)freq << 16));
+            const bool emit = active && started && ((uint64_t)x >= ((uint64_t)freq << 16));
             const uint64_t E = ballot64(emit);
             p -= __builtin_popcountll(E);
             if (p < 128) { bad = 2; p = 128; }
             if (emit) { w16[p + lanes_below(E)] = (uint16_t)(x & 0xFFFFu); x >>= 16; }
             if (active) {
+                if (!started) { x = freq; started = true; }          // absorbing start: codes to 2^16 + lo
                 // x < freq << 16 here, so the quotient fits 16 bits: a float reciprocal estimate is off by at most
                 // one, and one signed remainder test repairs it (8 operations instead of a 32-bit division)
                 uint32_t q = (uint32_t)((float)x * __builtin_amdgcn_rcpf((float)freq));
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
                                                                const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
                                                                int rslot_cap, uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos,
                                                                int16_t *__restrict__ planes, float *__restrict__ fplanes,
-                                                               const int32_t *__restrict__ minmax)
+                                                               const int32_t *__restrict__ minmax, int later_max, int32_t *status)
 {
     __shared__ uint32_t sh_res[2][64][2];        // ping-pong by step parity: [0] = c_low, [1] = c_high
     const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M;
@@ -304,11 +310,15 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
         __syncthreads();
         {
             const bool active = chunk0 + lane < nc;
+            // v2: a lane's last symbol (no later slot in this stage, none in any later stage: lane l of stream m is active
+            // in a stage of n symbols iff 64 m + l < n) is followed by no read, and must leave the encoder's start state freq
+            const bool fin = active && (chunk0 + lane + 64 * M >= nc) && (64 * m + lane >= later_max);
             if (active) {
                 const uint32_t vlo = sh_res[k & 1][lane][0], vhi = sh_res[k & 1][lane][1];
                 x = (vhi - vlo) * (x >> 16) + (x & 0xFFFFu) - vlo;
+                if (fin && x != vhi - vlo && wave == 0) atomicExch(&status[0], LLICTI_EFORMAT);
             }
-            const bool need = active && x < 0x10000u;
+            const bool need = active && !fin && x < 0x10000u;
             const uint64_t E = ballot64(need);
             const uint32_t idx = pos + (uint32_t)lanes_below(E);
             const uint32_t rel = idx - wbase;                                   // < 128

@@ -837,7 +837,8 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
     uint16_t *wbuf = (uint16_t *)malloc(sizeof(uint16_t) * (total + 64));
     for (int m = 0; m < M && rc >= 0; ++m) {
         uint32_t x[64];
-        for (int l = 0; l < 64; ++l) x[l] = 1u << 16;
+        int started[64];
+        for (int l = 0; l < 64; ++l) { x[l] = 1u << 16; started[l] = 0; }
         long p = total + 64;                     /* words are written backwards from the end */
         for (int s = ORC_NSTREAM - 1; s >= 0; --s) {
             const long nchunks = (st[s].n + 63) / 64;
@@ -850,6 +851,7 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
                     if (n >= st[s].n) continue;
                     const uint32_t lo = st[s].clow[n], freq = st[s].chigh[n] - lo;
                     if (freq == 0) { rc = -5; break; }
+                    if (!started[l]) continue;   /* v2: the lane's first coded (= last decoded) symbol never emits */
                     if ((uint64_t)x[l] >= ((uint64_t)freq << 16)) { wbuf[--p] = (uint16_t)(x[l] & 0xFFFF); x[l] >>= 16; }
                 }
                 for (int l = 0; l < 64; ++l) {
@@ -857,6 +859,9 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
                     if (n >= st[s].n) continue;
                     const uint32_t lo = st[s].clow[n], freq = st[s].chigh[n] - lo;
                     if (freq == 0) break;
+                    /* v2 "absorbing start": the first symbol a lane codes starts from state freq, so that the coded state
+                     * is 2^16 + c_low: the 16 bits every rANS state carries anyway now hold that symbol, instead of nothing */
+                    if (!started[l]) { x[l] = freq; started[l] = 1; }
                     x[l] = ((x[l] / freq) << 16) + (x[l] % freq) + lo;
                 }
             }
@@ -912,6 +917,24 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
         pos += seg_len[4 + m];
     }
     int Hl, Wl, h, w, padH, padW;
+    /* v2: a lane's LAST symbol (the first one its encoder coded) is followed by no renormalisation read; lane l of
+     * stream m is active in a stage of n symbols iff 64 m + l < n, so "last" needs the largest later stage */
+    long later_max[ORC_NSTREAM + 1];
+    {
+        long nst[ORC_NSTREAM];
+        int si = 0;
+        for (int lvl = ORC_NLEV - 1; lvl >= 0; --lvl) {
+            orc_level_geom(H, W, lvl, &Hl, &Wl, &h, &w, &padH, &padW);
+            for (int band = 0; band < 3; ++band) {
+                int hc, wc;
+                stream_dims(h, w, padH, padW, band, &hc, &wc);
+                for (int clr = 0; clr < 3; ++clr) nst[si++] = (long)hc * wc;
+            }
+        }
+        later_max[ORC_NSTREAM] = 0;
+        for (int k = ORC_NSTREAM - 1; k >= 0; --k) later_max[k] = nst[k] > later_max[k + 1] ? nst[k] : later_max[k + 1];
+    }
+    int stage = 0, bad = 0;
     for (int lvl = ORC_NLEV - 1; lvl >= 0; --lvl) {
         orc_level_geom(H, W, lvl, &Hl, &Wl, &h, &w, &padH, &padW);
         float *params = (float *)malloc(sizeof(float) * (long)h * w * ORC_NPAR);
@@ -922,7 +945,7 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
             stream_dims(h, w, padH, padW, band, &hc, &wc);
             const long n_sym = (long)hc * wc;
             const long nchunks = (n_sym + 63) / 64;
-            for (int clr = 0; clr < 3; ++clr) {
+            for (int clr = 0; clr < 3; ++clr, ++stage) {
                 const int minv = (clr == 0) ? -127 : minmax[clr];
                 const int maxv = (clr == 0) ? 128 : minmax[3 + clr];
                 const int shift = (clr == 0) ? 127 : -minmax[clr];
@@ -949,10 +972,13 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
                         const uint32_t c_high = (lo == max_symbol) ? 0x10000u : cdf_entry(&mx, lo + 1, Lp, minv, maxv);
                         x[m][l] = (c_high - c_low) * (x[m][l] >> 16) + slot - c_low;
                         planes[clr * plane_sz + off] = (int16_t)(lo - shift);
+                        if (q + 64L * M >= n_sym && 64L * m + l >= later_max[stage + 1] && x[m][l] != c_high - c_low)
+                            bad = 1;             /* the lane's last symbol must leave the encoder's start state: freq */
                     }
                     for (int l = 0; l < 64; ++l) {       /* renormalise lane-ascending */
                         const long q = 64 * c + l;
                         if (q >= n_sym) break;
+                        if (q + 64L * M >= n_sym && 64L * m + l >= later_max[stage + 1]) continue;   /* v2: lane finished */
                         if (x[m][l] < (1u << 16)) {
                             uint16_t wv = 0;
                             if (wpos[m] < wcnt[m]) memcpy(&wv, words[m] + 2 * wpos[m], 2);
@@ -967,5 +993,5 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
     }
     orc_unlift(planes, H, W, rgb);
     free(planes); free(x); free(words); free(wpos); free(wcnt);
-    return 0;
+    return bad ? -5 : 0;
 }

@@ -109,7 +109,11 @@ long orc_stream_pairs(const int16_t *planes, int H, int W, const int16_t minmax[
                       const float *params /* [h*w][60] from orc_band_params */,
                       uint32_t *clow, uint32_t *chigh, int16_t *sym);
 
-/* ---- rANS container ("LLICTI-rANS v1", a NEW format of this build: the reference has only torchac) ----
+/* ---- rANS container ("LLICTI-rANS v2", a NEW format of this build: the reference has only torchac) ----
+ * v2 = v1 with the "absorbing start": the FIRST symbol a lane's encoder codes (= the last one its decoder decodes)
+ * starts from state x = freq(symbol) instead of 2^16, so the coded state is 2^16 + c_low; the decoder reads no
+ * renormalisation word after a lane's last symbol and checks that the state it is left with is that symbol's freq.
+ * Saves the information content of one symbol per lane (the 16 bits a rANS state carries at least are no longer empty).
  * Same header segments (byte 0 = 0x80 | lg2(M) << 4 | 5), same CDFs, same symbols; the 45 torchac streams
  * are replaced by M independent 64-way interleaved rANS streams per image (32-bit states, 16-bit words,
  * 16-bit probabilities).  Stage st (decode order) has nc symbols in cropped raster order; symbol n sits in
