@@ -181,6 +181,11 @@ int llicti_header_dims(const uint8_t *h_hdr17, int *H, int *W);
  * HIP events on `stream`: ms[0] = whole call, ms[1] = sum of the band-CNN kernel launches,
  * n_launch = number of band-CNN launches.  Used by bench.py for the roofline figure. */
 int llicti_last_timing(llicti_ctx *ctx, float ms[4], int *n_launch);
+/* Tuning switches that never change a result.  "ac_anchor_min_batch" (default 96): from this many images per call on,
+ * llicti_decode_images decodes the AC container over anchor rows (every 8th table entry from cdf_anchor_kernel, the 8
+ * entries of the located bucket evaluated by the decoding wavefront) instead of full table rows; values above the
+ * default are clamped to it (the workspace is sized for the default). */
+int llicti_set_tuning(llicti_ctx *ctx, const char *key, int value);
 /* enable / disable the per-kernel event timing above (off by default: it adds event records). */
 int llicti_set_profiling(llicti_ctx *ctx, int enable);
 

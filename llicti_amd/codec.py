@@ -226,6 +226,9 @@ class HipCodec:
     def check(self):
         _lib.check(self.L.llicti_check_status(self.ctx, _stream_ptr(self.device)))
 
+    def set_tuning(self, key, value):
+        _lib.check(self.L.llicti_set_tuning(self.ctx, key.encode(), int(value)))
+
     def set_profiling(self, on=True):
         _lib.check(self.L.llicti_set_profiling(self.ctx, int(bool(on))))
 

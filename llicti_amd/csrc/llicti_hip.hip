@@ -58,6 +58,15 @@ struct Plan {                 // workspace carving for (B, H, W)
     size_t off_rinfo, off_rstate, off_rpos;
 };
 
+// AC decode has two table forms.  Few images in flight (latency bound: every stream is one serial wave and the GPU is
+// mostly idle): FULL rows from cdf_table_kernel, because the search over a ready-made row is the shortest instruction
+// sequence on the serial wave (B = 24: 249 ms against 293 ms).  Many images (the SIMDs' issue slots are the bound): ANCHOR
+// rows -- 1/8 of the erfc work and a fifth of the HBM traffic, the bucket's 8 entries evaluated by the decoding wave
+// (B = 256: 475 ms against 641 ms).  The workspace is sized for full rows below kAcAnchorBatch images and for anchor rows
+// from there on; llicti_set_tuning("ac_anchor_min_batch") can only LOWER the switch point (tests run both forms).
+constexpr int kAcAnchorBatch = 96;
+static bool ac_use_anchors(int B, int min_batch = kAcAnchorBatch) { return B >= std::min(min_batch, kAcAnchorBatch); }
+
 constexpr int kMaxSub = 4;
 struct PlanDev {
     Plan p;
@@ -77,6 +86,7 @@ struct llicti_ctx {
     hipEvent_t ev_ac[2][16] = {};      // AC decode pipeline: chunk c of Y / Co done
     hipEvent_t ev_ac_band = nullptr, ev_ac_end[2] = { nullptr, nullptr };
     int pipeline_s = 4;
+    int ac_anchor_min_batch = kAcAnchorBatch;
     bool pipeline = false;     // sub-batch pipelining of decode: measured neutral (co-resident CNN and rANS waves share VALU issue)
     int32_t *d_status = nullptr;      // small persistent status word (for the kernel-level entry points)
     int32_t *d_lift_part = nullptr;   // min/max partials of llicti_lift_u8 (1 MB; calls on one context are not concurrent)
@@ -192,7 +202,9 @@ static void build_plan(Plan &p, int B, int H, int W, int M)
             p.ac_cap_rows = std::max(p.ac_cap_rows, ac_chunk_rows((long)hcl * wcl));
         }
     }
-    p.off_tables = take((size_t)3 * B * p.ac_cap_rows * kAnchorRow);                  // one chunk buffer of anchor rows per colour channel
+    // one chunk buffer per colour channel: full rows (512 x uint16) or anchor rows (kAnchorRow bytes), see ac_use_anchors()
+    p.off_tables = take((size_t)3 * B * p.ac_cap_rows * (ac_use_anchors(B) ? (size_t)kAnchorRow : (size_t)512 * sizeof(uint16_t)));
+    static_assert(kAnchorRow <= 1024, "anchor rows must fit the full-row buffer");
     p.off_acstate = take((size_t)3 * B * 8 * sizeof(uint32_t));
     p.total = o;
 }
@@ -325,6 +337,17 @@ extern "C" int llicti_set_band_weights(llicti_ctx *c, int band, int K0, const fl
     HIPCHK(hipMemcpy(c->d_pack[band], pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
     c->have[band] = true;
     return LLICTI_OK;
+}
+
+extern "C" int llicti_set_tuning(llicti_ctx *c, const char *key, int value)
+{
+    if (!c || !key) return fail(LLICTI_EINVAL, "set_tuning: null argument");
+    if (!strcmp(key, "ac_anchor_min_batch")) {
+        if (value < 1) return fail(LLICTI_EINVAL, "set_tuning: ac_anchor_min_batch must be >= 1");
+        c->ac_anchor_min_batch = value;
+        return LLICTI_OK;
+    }
+    return fail(LLICTI_EINVAL, "set_tuning: unknown key '%s'", key);
 }
 
 extern "C" int llicti_set_profiling(llicti_ctx *c, int enable)
@@ -723,8 +746,11 @@ static int decode_sub(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in
                     for (int clr = 0; clr < 3; ++clr) {
                         hipStream_t qs = (C > 1) ? q[clr] : s;
                         if (C > 1 && clr > 0) HIPCHK(hipStreamWaitEvent(qs, c->ev_ac[clr - 1][ch], 0));
-                        uint8_t *tab = tables + (size_t)clr * B * p.ac_cap_rows * kAnchorRow;
-                        if (int rc = launch_cdf_anchors(planes, params, mm, g, band, clr, tab, n0, cnt, p.ac_cap_rows, qs)) return rc;
+                        const bool anchors = ac_use_anchors(B, c->ac_anchor_min_batch);
+                        const int row_stride = (clr == 0) ? 264 : 512;      // full rows: Y has Lp = 257, Co / Cg Lp <= 512
+                        uint8_t *tab = tables + (size_t)clr * B * p.ac_cap_rows * (anchors ? (size_t)kAnchorRow : (size_t)1024);
+                        if (anchors) { if (int rc = launch_cdf_anchors(planes, params, mm, g, band, clr, tab, n0, cnt, p.ac_cap_rows, qs)) return rc; }
+                        else if (int rc = launch_cdf_table(planes, params, mm, g, band, clr, (uint16_t *)tab, row_stride, n0, cnt, p.ac_cap_rows, qs)) return rc;
                         const int st = stage_index(lvl, band, clr);
                         DecOut o;
                         memset(&o, 0, sizeof o);
@@ -732,7 +758,8 @@ static int decode_sub(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in
                         // the B streams of one stage sit in consecutive slots of equal capacity
                         const long in_stride_slots = p.slot_cap[(size_t)st * B];
                         AcChunk ck = { (int)n0, (int)cnt, (int)nc, (int)p.ac_cap_rows, acstate + (size_t)clr * B * 8 };
-                        ac_decode_anchor_kernel<<<B, 64, 0, qs>>>(tab, slots + p.slot_off[(size_t)st * B], in_stride_slots, ck, o);
+                        if (anchors) ac_decode_anchor_kernel<<<B, 64, 0, qs>>>(tab, slots + p.slot_off[(size_t)st * B], in_stride_slots, ck, o);
+                        else ac_decode_kernel<<<B, 64, 0, qs>>>((const uint16_t *)tab, 0, row_stride, slots + p.slot_off[(size_t)st * B], in_stride_slots, ck, o);
                         if (C > 1 && clr < 2) HIPCHK(hipEventRecord(c->ev_ac[clr][ch], qs));
                     }
                 }

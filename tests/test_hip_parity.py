@@ -604,7 +604,8 @@ def _decode_poisoned(c, cont, seg, H, W, mode=0):
     return out
 
 
-@pytest.mark.parametrize("mode_name,B,H,W", [("ac", 3, 128, 192), ("ac", 2, 250, 131), ("rans4", 3, 128, 192),
+@pytest.mark.parametrize("mode_name,B,H,W", [("ac", 3, 128, 192), ("ac", 2, 250, 131), ("ac_anchors", 3, 128, 192),
+                                             ("ac_anchors", 2, 250, 131), ("rans4", 3, 128, 192),
                                              ("rans16", 2, 250, 131), ("rans1", 2, 67, 93)])
 def test_decode_on_poisoned_workspace(torch_mod, codecs, mode_name, B, H, W):
     """Losslessness of the PIPELINED decoders (3-stream AC chunk pipeline with ac_chunks() > 1, rANS next-step
@@ -613,15 +614,22 @@ def test_decode_on_poisoned_workspace(torch_mod, codecs, mode_name, B, H, W):
     from llicti_amd.codec import HipCodec, MODE_RANS
     torch = torch_mod
     c = codecs("trainedlike")
-    mode = 0 if mode_name == "ac" else MODE_RANS(int(mode_name[4:]))
+    mode = 0 if mode_name.startswith("ac") else MODE_RANS(int(mode_name[4:]))
+    # the AC decoder has two table forms (full rows for few images, anchor rows for many): both are run here
+    anchors = mode_name == "ac_anchors"
     rgb = np.concatenate([make_batch("smooth", B - 1, H, W, seed0=300), make_batch("noise", 1, H, W, seed0=301)])
     cont, seg = c.encode(_dev(torch, rgb), mode=mode)
     c.check()
-    rec = _decode_poisoned(c, cont, seg, H, W, mode)
+    c.set_tuning("ac_anchor_min_batch", 1 if anchors else 96)
+    try:
+        rec = _decode_poisoned(c, cont, seg, H, W, mode)
+    finally:
+        c.set_tuning("ac_anchor_min_batch", 96)
     assert np.array_equal(rec.cpu().numpy(), rgb)
     c2 = HipCodec("cuda:0")
     try:
         c2.load_state_dict(load_state_dict("trainedlike"))
+        c2.set_tuning("ac_anchor_min_batch", 1 if anchors else 96)
         c2.workspace(B, H, W, mode)
         c2.poison_workspace(0x5A)
         rec2 = c2.decode(cont.clone(), seg.clone(), H, W, mode=mode)
@@ -776,3 +784,30 @@ def test_full_size_oracle_parity(torch_mod, codecs, oracle_weights):
     assert np.array_equal(orc.decode_image(bl, W_o), small[0])
     rec = _decode_poisoned(c, cont, seg, 256, 256, 0)
     assert np.array_equal(rec.cpu().numpy(), small)
+
+
+@pytest.mark.parametrize("wname,kind", [("rand1337", "noise"), ("trainedlike", "smooth")])
+def test_ac_anchor_decoder_many_images_and_edges(torch_mod, codecs, oracle_weights, wname, kind):
+    """The anchor form of the AC decoder where it is the default (B >= 96), on small images, plus the degenerate
+    alphabets (Lp = 2, Lp = 512) with the form forced: pixels back exactly, and the streams are the oracle's."""
+    from oracle import oracle as orc
+    from llicti_amd.codec import container_to_bytestream_list
+    torch = torch_mod
+    c = codecs(wname)
+    rgb = make_batch(kind, 100, 40, 56, seed0=500)
+    cont, seg = c.encode(_dev(torch, rgb))
+    c.check()
+    rec = _decode_poisoned(c, cont, seg, 40, 56, 0)
+    assert np.array_equal(rec.cpu().numpy(), rgb)
+    W_o = oracle_weights(wname)
+    for b in (0, 57, 99):
+        assert container_to_bytestream_list(cont[b].cpu().numpy(), seg[b].cpu().numpy()) == orc.encode_image(rgb[b], W_o)
+    edge = np.stack(list(_edge_images().values()))
+    cont, seg = c.encode(_dev(torch, edge))
+    c.check()
+    c.set_tuning("ac_anchor_min_batch", 1)
+    try:
+        rec = _decode_poisoned(c, cont, seg, edge.shape[2], edge.shape[3], 0)
+    finally:
+        c.set_tuning("ac_anchor_min_batch", 96)
+    assert np.array_equal(rec.cpu().numpy(), edge)
