@@ -55,7 +55,7 @@ struct Plan {                 // workspace carving for (B, H, W)
     int M = 0;                          // rANS streams per image (0: AC container only)
     int rslot_cap = 0;
     std::vector<long> rslot_off;        // [B*M] byte offsets into the slots region
-    size_t off_rinfo, off_rstate, off_rpos;
+    size_t off_rinfo, off_rstate, off_rpos, off_rwoff;
 };
 
 // AC decode has two table forms.  Few images in flight (latency bound: every stream is one serial wave and the GPU is
@@ -181,7 +181,7 @@ static void build_plan(Plan &p, int B, int H, int W, int M)
             const long nchunks = (p.desc[(size_t)st * B].n + 63) / 64;
             syms += (nchunks + M - 1) / M * 64;
         }
-        p.rslot_cap = (int)align_up((size_t)(2 * syms + 256 + 64), 64);
+        p.rslot_cap = (int)align_up((size_t)(2 * syms + 288 + 64), 64);      // + compact state header (<= 280 bytes) + zero pad
         p.rslot_off.assign((size_t)B * M, 0);
         for (long i = 0; i < (long)B * M; ++i) p.rslot_off[i] = (long)i * p.rslot_cap;
         slot_pos = std::max<long>(slot_pos, (long)B * M * p.rslot_cap);
@@ -191,6 +191,7 @@ static void build_plan(Plan &p, int B, int H, int W, int M)
     p.off_rinfo = take((size_t)B * 32 * 2 * sizeof(int32_t));
     p.off_rstate = take((size_t)B * 32 * 64 * sizeof(uint32_t));
     p.off_rpos = take((size_t)B * 32 * sizeof(uint32_t));
+    p.off_rwoff = take((size_t)B * 32 * sizeof(uint32_t));
     p.off_slot_len = take((size_t)LLICTI_NSTREAMS * B * sizeof(int32_t));
     int hc0, wc0;
     coded_dims(g0, 1, &hc0, &wc0);
@@ -704,11 +705,12 @@ static int decode_sub(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in
     header_read_kernel<<<B, 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, H, W, g4.h, g4.w, pad_int(H, W), byte0, planes, fplanes, mm, status);
     uint32_t *rstate = (uint32_t *)(ws + p.off_rstate);
     uint32_t *rpos = (uint32_t *)(ws + p.off_rpos);
+    uint32_t *rwoff = (uint32_t *)(ws + p.off_rwoff);
     if (M == 0) {
         unpack_kernel<<<dim3(LLICTI_NSTREAMS, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, B, slots, pd->d_slot_off, pd->d_slot_cap, status);
     } else {
         rans_unpack_kernel<<<dim3(M, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, M, slots, pd->d_rslot_off, p.rslot_cap, status);
-        rans_init_kernel<<<B * M, 64, 0, s>>>(slots, pd->d_rslot_off, rstate, rpos);
+        rans_init_kernel<<<B * M, 64, 0, s>>>(slots, pd->d_rslot_off, d_seg_len, M, rstate, rpos, rwoff, status);
     }
     // 45 dependent stages (LLICTI_nets.py:440-498): CNN of band b needs bands < b of this level, Co needs Y, Cg needs Y, Co
     for (int lvl = LLICTI_NLEVELS - 1; lvl >= 0; --lvl) {
@@ -724,9 +726,9 @@ static int decode_sub(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in
                     for (int st2 = stage_index(lvl, band, clr) + 1; st2 < LLICTI_NSTREAMS; ++st2) mx = std::max(mx, p.desc[(size_t)st2 * B].n);
                     return mx;
                 };
-                rans_decode_stage_kernel<0><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, planes, fplanes, mm, later_max(0), status);
-                rans_decode_stage_kernel<1><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, planes, fplanes, mm, later_max(1), status);
-                rans_decode_stage_kernel<2><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, planes, fplanes, mm, later_max(2), status);
+                rans_decode_stage_kernel<0><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rwoff, planes, fplanes, mm, later_max(0), status);
+                rans_decode_stage_kernel<1><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rwoff, planes, fplanes, mm, later_max(1), status);
+                rans_decode_stage_kernel<2><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rwoff, planes, fplanes, mm, later_max(2), status);
             }
             if (M == 0) {
                 // Y, Co, Cg of this band as a pipeline over chunks of the stage: chunk c of Co needs only chunk c

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restr
             const bool emit = active && started && ((uint64_t)x >= ((uint64_t)freq << 16));
             const uint64_t E = ballot64(emit);
             p -= __builtin_popcountll(E);
-            if (p < 128) { bad = 2; p = 128; }
+            if (p < 144) { bad = 2; p = 144; }                   // room for the state header (<= 140 words)
             if (emit) { w16[p + lanes_below(E)] = (uint16_t)(x & 0xFFFFu); x >>= 16; }
             if (active) {
                 if (!started) { x = freq; started = true; }          // absorbing start: codes to 2^16 + lo
@@ -72,19 +72,64 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restr
             code(k - 3, r3); r3 = fetch(k - 7);
         }
     }
-    p -= 128;                                       // 64 final states, little-endian uint32, lane order
-    w16[p + 2 * lane] = (uint16_t)(x & 0xFFFFu);
-    w16[p + 2 * lane + 1] = (uint16_t)(x >> 16);
+    // v2 compact flush of the 64 final states (x >> 16 is log-uniform in [1, 2^16): its bit length costs 4 bits, its
+    // leading one nothing): 64 nibbles nb = bitlen(x >> 16) - 1 | 64 x uint16 low halves | nb mantissa bits per lane, lane
+    // order, LSB first, zero padded to 16 bits  ->  160 .. 280 bytes instead of 256 (220 on average)
+    __shared__ uint32_t fl_bits[32];
+    if (lane < 32) fl_bits[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t hi16 = x >> 16;
+    const int nb = 31 - __clz((int)hi16);                     // 0 .. 15 (hi16 >= 1)
+    const uint32_t mant = hi16 & ((1u << nb) - 1u);
+    int pre = nb;                                             // inclusive prefix sum over the lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(pre, d); if (lane >= d) pre += t; }
+    const int total_bits = __shfl(pre, 63);
+    const int bpos = pre - nb;
+    if (nb > 0) {
+        atomicOr(&fl_bits[bpos >> 5], mant << (bpos & 31));
+        if ((bpos & 31) + nb > 32) atomicOr(&fl_bits[(bpos >> 5) + 1], mant >> (32 - (bpos & 31)));
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int nw = (total_bits + 15) >> 4;                     // mantissa words (16 bit)
+    p -= 80 + nw;
+    if (p < 0) { bad = 2; p = 0; }
+    const int nb_next = __shfl_down(nb, 1);
+    uint8_t *hdr = reinterpret_cast<uint8_t *>(w16 + p);
+    if ((lane & 1) == 0) hdr[lane >> 1] = (uint8_t)(nb | (nb_next << 4));
+    w16[p + 16 + lane] = (uint16_t)(x & 0xFFFFu);
+    if (lane < nw) w16[p + 80 + lane] = (uint16_t)(fl_bits[lane >> 1] >> (16 * (lane & 1)));
     if (lane == 0) { rinfo[2 * sidx] = (int32_t)(2 * p); rinfo[2 * sidx + 1] = (int32_t)(rslot_cap - 2 * p); }
     if (bad) atomicExch(&status[0], bad == 1 ? LLICTI_EFORMAT : LLICTI_ENOSPACE);
 }
 
+// decode: parse the compact state header of every stream (see rans_encode_kernel) -> 64 states, word cursor 0 and the
+// byte offset of the stream's first 16-bit word
 __global__ __launch_bounds__(64) void rans_init_kernel(const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
-                                                       uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos)
+                                                       const int32_t *__restrict__ seg_len, int M,
+                                                       uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos,
+                                                       uint32_t *__restrict__ rwoff, int32_t *status)
 {
     const int sidx = blockIdx.x, lane = threadIdx.x;
-    rstate[(long)sidx * 64 + lane] = reinterpret_cast<const uint32_t *>(slots + rslot_off[sidx])[lane];
-    if (lane == 0) rpos[sidx] = 0;
+    const int b = sidx / M, m = sidx - b * M;
+    const uint8_t *hdr = slots + rslot_off[sidx];
+    const uint16_t *h16 = reinterpret_cast<const uint16_t *>(hdr);
+    const int n = seg_len[(long)b * LLICTI_NSEG + 4 + m];          // validated >= 160 by rans_unpack_kernel (else a harmless header was written)
+    const int nb = (hdr[lane >> 1] >> (4 * (lane & 1))) & 15;
+    int pre = nb;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(pre, d); if (lane >= d) pre += t; }
+    const int total_bits = __shfl(pre, 63);
+    const int hbytes = 160 + 2 * ((total_bits + 15) >> 4);
+    uint32_t x = 1u << 16;
+    if (hbytes <= max(n, 160)) {
+        const int bpos = pre - nb;
+        const uint32_t win = (uint32_t)h16[80 + (bpos >> 4)] | ((uint32_t)h16[80 + (bpos >> 4) + 1] << 16);   // slot is zero padded past n
+        const uint32_t mant = (win >> (bpos & 15)) & ((1u << nb) - 1u);
+        x = (((1u << nb) | mant) << 16) | (uint32_t)h16[16 + lane];
+    } else if (lane == 0) atomicExch(&status[0], LLICTI_EFORMAT);
+    rstate[(long)sidx * 64 + lane] = x;
+    if (lane == 0) { rpos[sidx] = 0; rwoff[sidx] = (uint32_t)min(hbytes, 280); }
 }
 
 // One stage (level, band, colour channel) of all images.  One workgroup of 4 wavefronts per stream (one per
@@ -165,6 +210,7 @@ template <int CLR>
 __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(const float *__restrict__ params, StageGeom sg, int M,
                                                                const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
                                                                int rslot_cap, uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos,
+                                                               const uint32_t *__restrict__ rwoff,
                                                                int16_t *__restrict__ planes, float *__restrict__ fplanes,
                                                                const int32_t *__restrict__ minmax, int later_max, int32_t *status)
 {
@@ -176,8 +222,9 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
     if (nchunks <= m) return;                    // whole workgroup
     const int K = (nchunks - m + M - 1) / M;
     uint32_t x = rstate[(long)sidx * 64 + lane], pos = rpos[sidx];      // every wave: its own copy
-    const uint16_t *words = reinterpret_cast<const uint16_t *>(slots + rslot_off[sidx] + 256);
-    const uint32_t max_words = (uint32_t)((rslot_cap - 256) / 2);
+    const uint32_t woff = rwoff[sidx];                                  // bytes of the compact state header (160 .. 280, even)
+    const uint16_t *words = reinterpret_cast<const uint16_t *>(slots + rslot_off[sidx] + woff);
+    const uint32_t max_words = ((uint32_t)rslot_cap - woff) / 2;
     constexpr int clr = CLR;                     // compile-time: no branch (hence no register merge, hence no s_waitcnt vmcnt(0)) next to the prefetch loads
     int minv, maxv, shift;
     clr_range(minmax + 4 * b, clr, minv, maxv, shift);
@@ -373,10 +420,10 @@ __global__ __launch_bounds__(256) void rans_unpack_kernel(const uint8_t *__restr
     }
     int n = sl[4 + m];
     uint8_t *o = slots + rslot_off[b * M + m];
-    if (bad || n < 256 || n > rslot_cap || src + n > in_stride) {
+    if (bad || n < 160 || n > rslot_cap || src + n > in_stride) {
         if (threadIdx.x == 0) atomicExch(&status[0], LLICTI_EFORMAT);
-        for (int t = threadIdx.x; t < 256; t += blockDim.x) o[t] = (t & 3) == 2 ? 1 : 0;     // states = 1 << 16: harmless
-        n = 256;
+        for (int t = threadIdx.x; t < 160; t += blockDim.x) o[t] = 0;                       // states = 1 << 16, no mantissa bits: harmless
+        n = 160;
     } else {
         const uint8_t *p = in + (long)b * in_stride + src;
         block_copy_bytes(o, p, n);

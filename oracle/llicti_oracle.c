@@ -867,9 +867,25 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
             }
         }
         const long nwords = total + 64 - p;
-        const long bytes = 256 + 2 * nwords;
+        /* v2 compact state flush: 64 nibbles (bit length of x >> 16, minus 1) | 64 x uint16 low halves | the bits of
+         * x >> 16 below its leading one, lane order, LSB first, padded to 16 bits */
+        uint8_t hdr[160 + 120];
+        memset(hdr, 0, sizeof hdr);
+        long bitpos = 0;
+        for (int l = 0; l < 64; ++l) {
+            const uint32_t hi = x[l] >> 16, lo = x[l] & 0xFFFFu;
+            int nb = 0;
+            while ((hi >> nb) > 1) ++nb;                 /* nb = bit length - 1 (hi >= 1 always) */
+            hdr[l >> 1] |= (uint8_t)(nb << (4 * (l & 1)));
+            hdr[32 + 2 * l] = (uint8_t)(lo & 0xFF); hdr[32 + 2 * l + 1] = (uint8_t)(lo >> 8);
+            const uint32_t mant = hi & ((1u << nb) - 1u);
+            for (int b = 0; b < nb; ++b, ++bitpos)
+                if ((mant >> b) & 1u) hdr[160 + (bitpos >> 3)] |= (uint8_t)(1u << (bitpos & 7));
+        }
+        const long hbytes = 160 + 2 * ((bitpos + 15) / 16);
+        const long bytes = hbytes + 2 * nwords;
         if (pos + bytes > cap) { rc = -1; break; }
-        for (int l = 0; l < 64; ++l) { memcpy(out + pos, &x[l], 4); pos += 4; }
+        memcpy(out + pos, hdr, hbytes); pos += hbytes;
         memcpy(out + pos, wbuf + p, 2 * nwords); pos += 2 * nwords;
         seg_len[4 + m] = (int32_t)bytes;
     }
@@ -910,10 +926,21 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
     long *wpos = (long *)calloc(M, sizeof(long)), *wcnt = (long *)calloc(M, sizeof(long));
     long pos = 17 + seg_len[3];
     for (int m = 0; m < M; ++m) {
-        if (seg_len[4 + m] < 256) { free(planes); free(x); free(words); free(wpos); free(wcnt); return -3; }
-        for (int l = 0; l < 64; ++l) memcpy(&x[m][l], in + pos + 4 * l, 4);
-        words[m] = in + pos + 256;
-        wcnt[m] = (seg_len[4 + m] - 256) / 2;
+        if (seg_len[4 + m] < 160) { free(planes); free(x); free(words); free(wpos); free(wcnt); return -3; }
+        const uint8_t *hd = in + pos;
+        long bitpos = 0, nbits = 0;
+        for (int l = 0; l < 64; ++l) nbits += (hd[l >> 1] >> (4 * (l & 1))) & 15;
+        const long hbytes = 160 + 2 * ((nbits + 15) / 16);
+        if (seg_len[4 + m] < hbytes) { free(planes); free(x); free(words); free(wpos); free(wcnt); return -3; }
+        for (int l = 0; l < 64; ++l) {
+            const int nb = (hd[l >> 1] >> (4 * (l & 1))) & 15;
+            uint32_t mant = 0;
+            for (int b = 0; b < nb; ++b, ++bitpos) mant |= (uint32_t)((hd[160 + (bitpos >> 3)] >> (bitpos & 7)) & 1u) << b;
+            const uint32_t hi = (1u << nb) | mant, lo = (uint32_t)hd[32 + 2 * l] | ((uint32_t)hd[32 + 2 * l + 1] << 8);
+            x[m][l] = (hi << 16) | lo;
+        }
+        words[m] = in + pos + hbytes;
+        wcnt[m] = (seg_len[4 + m] - hbytes) / 2;
         pos += seg_len[4 + m];
     }
     int Hl, Wl, h, w, padH, padW;

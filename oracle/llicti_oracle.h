@@ -118,7 +118,9 @@ long orc_stream_pairs(const int16_t *planes, int H, int W, const int16_t minmax[
  * are replaced by M independent 64-way interleaved rANS streams per image (32-bit states, 16-bit words,
  * 16-bit probabilities).  Stage st (decode order) has nc symbols in cropped raster order; symbol n sits in
  * chunk n/64, lane n%64; chunk c belongs to stream c % M and is that stream's step c / M of the stage.
- * A stream = 64 little-endian uint32 final encoder states followed by the 16-bit words in decode order.
+ * A stream = the 64 final encoder states, compactly (v2: 64 nibbles nb_l = bit length of (x_l >> 16) minus 1 | 64 little-endian
+ * uint16 low halves | the nb_l bits of x_l >> 16 below its leading one, lane order, LSB first, zero padded to 16 bits:
+ * 160 .. 280 bytes instead of 256), followed by the 16-bit words in decode order.
  * seg_len[0..3] header, seg_len[4..4+M-1] streams, rest 0.  Returns total bytes or <0. */
 long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *wts, int M,
                            uint8_t *out, long cap, int32_t seg_len[49]);
