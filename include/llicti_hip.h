@@ -148,10 +148,13 @@ int llicti_ac_decode_u16cdf(llicti_ctx *ctx, const uint16_t *d_cdf, int Lp, int 
  * container is read, and no read leaves [d_in + b*in_stride, d_in + (b+1)*in_stride). */
 
 /* mode: LLICTI_MODE_AC = the reference's container (45 torchac-algorithm streams per image, bit-exact
- * to the oracle / reference format); LLICTI_MODE_RANS(M) = "LLICTI-rANS v1", a NEW container of this
+ * to the oracle / reference format); LLICTI_MODE_RANS(M) = "LLICTI-rANS v2", a NEW container of this
  * build: header byte 0 = 0x80 | lg2(M) << 4 | 5, then M independent 64-way interleaved rANS streams per
  * image (segments 4 .. 4+M-1, the other stream segments empty), same CDFs and symbols, decodable
- * 64*M symbols at a time.  Cost: about 190 bytes per stream over the AC container. */
+ * 64*M symbols at a time.  A stream = compact header of its 64 final coder states (160 .. 280 bytes) + 16-bit words;
+ * every lane's first coded symbol starts from state freq ("absorbing start").  Cost over the ideal code length: about
+ * 60 bytes per stream on noise-like content, 110 on smooth content (M = 1 is within 50 bytes of the AC container, whose
+ * 45 stream terminations cost about 100 bytes themselves).  Format: oracle/llicti_oracle.h, DESIGN.md section 5. */
 #define LLICTI_MODE_AC        0
 #define LLICTI_MODE_RANS(M)  (0x100 | (M))      /* M in {1, 2, 4, 8, 16, 32} */
 

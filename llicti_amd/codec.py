@@ -22,7 +22,7 @@ MODE_AC = 0                      # the reference's container: 45 torchac-algorit
 
 
 def MODE_RANS(M=8):
-    """"LLICTI-rANS v1" container: M independent 64-way interleaved rANS streams per image (include/llicti_hip.h)."""
+    """"LLICTI-rANS v2" container: M independent 64-way interleaved rANS streams per image (include/llicti_hip.h)."""
     return 0x100 | int(M)
 
 

@@ -2,7 +2,7 @@
 """Large-configuration round trips on one MI355X (not part of the test suite: minutes of GPU time, tens of GB):
 BASELINE.json configs[4]'s whole 256-image batch on ONE GPU, a 64-image batch through the AC container, and the
 format's largest image (8160 x 8160)."""
-import os, sys, time
+import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from llicti_amd.codec import HipCodec, MODE_AC, MODE_RANS
@@ -12,24 +12,33 @@ from llicti_amd.graphs.models.LLICTI_nets import LLICTI
 torch.manual_seed(1337)
 codec = HipCodec(torch.device("cuda", 0))
 codec.load_state_dict(LLICTI(default_config()).state_dict())
+results = []
 def run(B, H, W, mode, name):
     g = torch.Generator(device="cuda").manual_seed(B + H)
     rgb = torch.randint(0, 256, (B, 3, H, W), dtype=torch.uint8, device="cuda", generator=g)
     torch.cuda.synchronize(); t0 = time.time()
     cont, seg = codec.encode(rgb, mode=mode)
     codec.check(); torch.cuda.synchronize(); t1 = time.time()
+    codec.poison_workspace()
+    torch.cuda.synchronize(); t1b = time.time()
     rec = codec.decode(cont, seg, H, W, mode=mode)
     codec.check(); torch.cuda.synchronize(); t2 = time.time()
     ok = bool(torch.equal(rec, rgb))
     mp = B * H * W / 1e6
-    print(f"{name}: B={B} {W}x{H} ok={ok} enc {mp/(t1-t0):.1f} MPix/s dec {mp/(t2-t1):.1f} MPix/s bpp {8.0*float(seg.sum())/(B*H*W):.3f} "
+    print(f"{name}: B={B} {W}x{H} ok={ok} enc {mp/(t1-t0):.1f} MPix/s dec {mp/(t2-t1b):.1f} MPix/s bpp {8.0*float(seg.sum())/(B*H*W):.3f} "
           f"workspace {codec._ws.numel()/2**30:.2f} GiB peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
     assert ok
+    results.append({"case": name, "B": B, "W": W, "H": H, "lossless": ok, "enc_mpix_s": round(mp / (t1 - t0), 1), "dec_mpix_s": round(mp / (t2 - t1b), 1),
+                    "bpp": round(8.0 * float(seg.sum()) / (B * H * W), 4), "workspace_GiB": round(codec._ws.numel() / 2**30, 2)})
     del rgb, cont, seg, rec
     codec._ws = None; codec._ws_key = None
     torch.cuda.empty_cache()
-run(256, 512, 768, MODE_RANS(16), "configs[4] batch on one GPU (rans16)")
-run(256, 512, 768, MODE_RANS(16), "same, warm")
+run(256, 512, 768, MODE_RANS(8), "configs[4] batch on one GPU (rans8)")
+run(256, 512, 768, MODE_RANS(8), "same, warm")
+run(256, 512, 768, MODE_RANS(1), "256 images, ONE rANS stream per image")
 run(64, 512, 768, MODE_AC, "AC container")
 run(1, 8160, 8160, MODE_RANS(32), "largest image (rans32)")
 run(2, 2160, 3840, MODE_AC, "two 4K images, AC container")
+if len(sys.argv) > 1:
+    json.dump({"tool": "tools/stress.py", "note": "single runs incl. first-call plan set-up unless marked warm; decode on a poisoned workspace", "runs": results},
+              open(sys.argv[1], "w"), indent=1)
