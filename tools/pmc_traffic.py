@@ -43,6 +43,9 @@ def per_launch(prefix):
         d["wait_any_frac_of_wave_cycles"] = wa / wc
     d["note_mfma_busy_cycles_total"] = mf
     d["note_grbm_gui_active_total"] = gui
+    iv, av, bz = (sum(agg[k].get(c, 0) for k in ks) for c in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES"))
+    if iv:
+        d["valu_insts_per_launch"] = iv / n
     return d
 
 
@@ -55,8 +58,9 @@ if not isinstance(res["command"], dict):
 label = sys.argv[3] if len(sys.argv) > 3 else "bench"
 res["command"][label] = ("python3 tools/bench_table.py" if label == "table" else
                          "python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras") + " (one rocprofv3 --pmc pass per counter group)"
-for pref in ("band_params_kernel", "rans_decode_stage_kernel", "cdf_pairs_kernel", "lift_kernel", "cdf_table_kernel", "cdf_anchor_kernel",
-             "ac_decode_kernel", "rans_encode_kernel", "ac_encode_pairs_kernel"):
+prefs = ("cdf_table_kernel",) if label == "table" else ("band_params_kernel", "rans_decode_stage_kernel", "cdf_pairs_kernel", "lift_kernel", "cdf_table_kernel", "cdf_anchor_kernel",
+             "ac_decode_kernel", "rans_encode_kernel", "ac_encode_pairs_kernel")
+for pref in prefs:
     if any(k.startswith(pref) for k in agg):
         res[pref] = per_launch(pref)
 json.dump(res, open(dst, "w"), indent=1)
