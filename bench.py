@@ -192,6 +192,56 @@ class Legs:
         self.torch.cuda.empty_cache()
 
 
+def overlap_leg(torch, dev, sd, rgb, mode, steps=6):
+    """A server that encodes one batch while it decodes another: two contexts on two HIP streams, encode(batch k) next to
+    decode(containers of batch k - 1).  Same work per step as the timed step (one encode + one decode of a full batch);
+    the rANS stages of the decode are latency bound and leave most of the chip to the other stream's CNN launches.
+    Informational: `value` stays the un-overlapped step."""
+    from llicti_amd.codec import HipCodec
+    B, _, H, W = rgb.shape
+    ce, cd = HipCodec(dev), HipCodec(dev)
+    ce.load_state_dict(sd)
+    cd.load_state_dict(sd)
+    se, sdec = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    stride = ce.max_container_bytes(H, W)
+    cont = [torch.empty((B, stride), dtype=torch.uint8, device=dev) for _ in range(2)]
+    seg = [torch.zeros((B, 49), dtype=torch.int32, device=dev) for _ in range(2)]
+    rec = torch.empty_like(rgb)
+    done = [torch.cuda.Event(), torch.cuda.Event()]
+
+    def enc(k):
+        with torch.cuda.stream(se):
+            ce.encode(rgb, mode=mode, out=cont[k & 1], seg_len=seg[k & 1])
+            done[k & 1].record(se)
+
+    def dec(k):
+        with torch.cuda.stream(sdec):
+            sdec.wait_event(done[k & 1])
+            cd.decode(cont[k & 1], seg[k & 1], H, W, mode=mode, out=rec)
+    torch.cuda.synchronize()
+    enc(0)
+    for k in range(1, 3):                   # warm-up: plans, workspaces
+        enc(k)
+        dec(k - 1)
+    torch.cuda.synchronize()
+    assert torch.equal(rec, rgb)
+    t0 = time.perf_counter()
+    for k in range(3, 3 + steps):
+        enc(k)
+        dec(k - 1)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    with torch.cuda.stream(se):
+        ce.check()
+    with torch.cuda.stream(sdec):
+        cd.check()
+    assert torch.equal(rec, rgb)
+    ce.close()
+    cd.close()
+    return {"workload": f"{B}x{W}x{H}: encode of batch k on one HIP stream next to decode of batch k-1 on another (two contexts)",
+            "encdec_mpix_s": round(B * H * W / dt / 1e6, 2), "ms_per_step": round(dt * 1e3, 3)}
+
+
 def natural_like_leg(torch, dev, B, H, W, mode):
     """uniform noise + sigma-floor random weights is the worst case for alphabet width and far
     from natural statistics, so the same shapes are also run on a SMOOTH set (low-pass noise + gradient, seed-fixed,
@@ -472,6 +522,7 @@ def main(argv=None):
                                 "rans32": legs.run(big, MODE_RANS(32), reps=2), "ac": legs.run(big, MODE_AC, reps=1)}
         del big
         legs.free()
+        legs_out["overlapped_streams"] = overlap_leg(torch, dev, sd, rgb, mode)
         legs_out["natural_like"] = natural_like_leg(torch, dev, B, H, W, mode)
         torch.cuda.empty_cache()
         legs_out["roofline_cdf_table"] = table_kernel_roofline(codec, torch)
