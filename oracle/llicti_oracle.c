@@ -379,7 +379,7 @@ void orc_selfinfo(const float *fplanes, int H, int W, int lvl, int band, const f
     int Hl, Wl, h, w, padH, padW;
     orc_level_geom(H, W, lvl, &Hl, &Wl, &h, &w, &padH, &padW);
     const long plane_sz = (long)H * W;
-    const int oi = BAND_OI[band + 1], oj = BAND_OJ[band + 1];
+
     const float half = (float)(0.5 / 255.0);
     const float kneg = (float)(-0.70710678118654752440);
     const float sbound = (float)(0.11 / 255.0);
