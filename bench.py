@@ -19,7 +19,8 @@ barrier and a MAX / SUM of scalars at the end.
 One JSON line is printed by rank 0.
   value                 pixels of all ranks x K / max-over-ranks time of the K steps, inputs and outputs RESIDENT in HBM
   value_pcie_inclusive  the same steps with H2D of the uint8 RGB, D2H of the containers (encode) and H2D of the containers,
-                        D2H of the RGB (decode) inside the timed region, pinned host buffers (SURVEY.md 8(d)'s wording)
+                        D2H of the RGB (decode) inside the timed region, pinned host buffers (SURVEY.md 8(d)'s wording),
+                        transfers overlapped with compute on their own HIP streams; value_pcie_serial: not overlapped
   roofline              the dominant kernel (fp32-MFMA interpolator CNN): algorithmic FLOP of the launches of one
                         encode+decode / their summed HIP-event durations (events on the launch stream, extra profiled steps)
   roofline_cdf_table    configs[3]: the full-table CDF kernel on one 3840x2160 image, SURVEY 8(d)'s bytes (2 Lp + 60 per symbol)
@@ -455,9 +456,89 @@ def main(argv=None):
     for _ in range(n_pcie):
         step_pcie()
     barrier()
-    elapsed_pcie = (time.perf_counter() - t0) / n_pcie
+    elapsed_pcie_serial = (time.perf_counter() - t0) / n_pcie
     assert np.array_equal(rec_pin.numpy(), rgb_h)
-    del rgb_pin, cont_pin, seg_pin, rec_pin
+
+    # The same four transfers per step, OVERLAPPED with compute: uploads on one HIP stream, downloads on another, double
+    # buffers, events between them; the compute stream runs encode(k), then decode(k - 1) whose containers have meanwhile
+    # made the round trip over the host.  Steady-state throughput of a server fed from and draining to host memory.
+    def pcie_pipeline(n):
+        s_cmp, s_in, s_out = torch.cuda.current_stream(), torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        E = lambda: [torch.cuda.Event(), torch.cuda.Event()]
+        ev_up, ev_rgb_free, ev_enc, ev_d2h, ev_h2d, ev_dec, ev_down = E(), E(), E(), E(), E(), E(), E()
+        rgb_d = [rgb, torch.empty_like(rgb)]
+        cont_d, seg_d = [cont, torch.empty_like(cont)], [seg, torch.empty_like(seg)]
+        cont_i, seg_i = [torch.empty_like(cont), torch.empty_like(cont)], [torch.empty_like(seg), torch.empty_like(seg)]
+        rec_d = [rec, torch.empty_like(rec)]
+        cont_p = [cont_pin, torch.empty_like(cont_pin).pin_memory()]
+        seg_p = [seg_pin, torch.empty_like(seg_pin).pin_memory()]
+        rec_p = [rec_pin, torch.empty_like(rec_pin).pin_memory()]
+
+        def upload(k):
+            b = k & 1
+            with torch.cuda.stream(s_in):
+                s_in.wait_event(ev_rgb_free[b])
+                rgb_d[b].copy_(rgb_pin, non_blocking=True)
+                ev_up[b].record(s_in)
+
+        def encode(k):
+            b = k & 1
+            s_cmp.wait_event(ev_up[b])
+            s_cmp.wait_event(ev_d2h[b])                # cont_d[b] of step k - 2 has left for the host
+            codec.encode(rgb_d[b], mode=mode, out=cont_d[b], seg_len=seg_d[b])
+            ev_enc[b].record(s_cmp)
+            ev_rgb_free[b].record(s_cmp)
+
+        def roundtrip(k):
+            b = k & 1
+            with torch.cuda.stream(s_out):
+                s_out.wait_event(ev_enc[b])
+                cont_p[b].copy_(cont_d[b], non_blocking=True)
+                seg_p[b].copy_(seg_d[b], non_blocking=True)
+                ev_d2h[b].record(s_out)
+            with torch.cuda.stream(s_in):
+                s_in.wait_event(ev_d2h[b])
+                s_in.wait_event(ev_dec[b])             # cont_i[b] of step k - 2 has been decoded
+                cont_i[b].copy_(cont_p[b], non_blocking=True)
+                seg_i[b].copy_(seg_p[b], non_blocking=True)
+                ev_h2d[b].record(s_in)
+
+        def decode(k):
+            b = k & 1
+            s_cmp.wait_event(ev_h2d[b])
+            s_cmp.wait_event(ev_down[b])               # rec_d[b] of step k - 2 has left for the host
+            codec.decode(cont_i[b], seg_i[b], H, W, mode=mode, out=rec_d[b])
+            ev_dec[b].record(s_cmp)
+            with torch.cuda.stream(s_out):
+                s_out.wait_event(ev_dec[b])
+                rec_p[b].copy_(rec_d[b], non_blocking=True)
+                ev_down[b].record(s_out)
+        upload(0)
+        for k in range(n):
+            if k + 1 < n:
+                upload(k + 1)
+            encode(k)
+            roundtrip(k)
+            if k > 0:
+                decode(k - 1)
+        decode(n - 1)
+        torch.cuda.synchronize()
+        return rec_p[(n - 1) & 1]
+    pcie_pipeline(2)                                   # warm-up: second buffers, streams
+    # steady state: the difference of a long and a short pipelined run (both pay the same fill and drain)
+    n_short, n_long = 3, 3 + max(4, min(2 * args.steps, 16))
+    t_pipe = []
+    for n in (n_short, n_long):
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        last = pcie_pipeline(n)
+        barrier()
+        t_pipe.append(time.perf_counter() - t0)
+    elapsed_pcie = max(1e-9, (t_pipe[1] - t_pipe[0]) / (n_long - n_short))
+    codec.check()
+    assert np.array_equal(last.numpy(), rgb_h)
+    del rgb_pin, cont_pin, seg_pin, rec_pin, last
 
     # ---- dominant-kernel timing with HIP events on the launch stream, in extra (untimed) profiled steps
     codec.set_profiling(True)
@@ -531,6 +612,7 @@ def main(argv=None):
     coll_dev = dev if (world == 1 or args.backend == "nccl") else "cpu"
     agg = shard.aggregate(elapsed, total_bytes, B * H * W, device=coll_dev)
     agg_pcie = shard.aggregate(elapsed_pcie, 0, B * H * W, device=coll_dev)
+    agg_pcie_serial = shard.aggregate(elapsed_pcie_serial, 0, B * H * W, device=coll_dev)
     elapsed = agg["elapsed_s"]
 
     rc = 0
@@ -554,8 +636,11 @@ def main(argv=None):
                        "sharding": f"images/{world}gpu", "backend": args.backend if world > 1 else None},
             "rccl_ranks": rccl_ranks,
             "value_pcie_inclusive": round(agg_pcie["pixels"] / agg_pcie["elapsed_s"] / 1e6, 3),
+            "value_pcie_serial": round(agg_pcie_serial["pixels"] / agg_pcie_serial["elapsed_s"] / 1e6, 3),
             "pcie_note": "same step with H2D of RGB + D2H of containers (encode) and H2D of containers + D2H of RGB (decode) inside "
-                         "the timed region, pinned host buffers, whole container stride copied",
+                         "the timed region, pinned host buffers, whole container stride copied; value_pcie_inclusive: transfers on their own "
+                         "HIP streams, double buffered, overlapped with compute (decode of step k-1 behind encode of step k), steady state = (long run - short run) / extra steps; value_pcie_serial: "
+                         "transfer, compute, transfer one after the other",
             "enc_mpix_s": round(B * H * W / t_enc / 1e6, 3), "dec_mpix_s": round(B * H * W / t_dec / 1e6, 3),
             "bpp": round(agg["bpp"], 4),
             "roofline": {"bound": "mfma", "kernel": "band_params_kernel<0|1|2> (fp32 MFMA 16x16x4)",
