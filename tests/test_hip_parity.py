@@ -811,3 +811,34 @@ def test_ac_anchor_decoder_many_images_and_edges(torch_mod, codecs, oracle_weigh
     finally:
         c.set_tuning("ac_anchor_min_batch", 96)
     assert np.array_equal(rec.cpu().numpy(), edge)
+
+
+def test_rans_v2_integrity_check_detects_corruption(torch_mod, codecs, oracle_weights):
+    """rANS v2's absorbing start leaves every lane's LAST symbol with a known state (its freq): a corrupted stream word or
+    a corrupted compact state header ends, with overwhelming probability, in a lane whose final state is wrong -- both
+    decoders (HIP, oracle) report it instead of returning wrong pixels silently; nothing crashes or hangs."""
+    from oracle import oracle as orc
+    from llicti_amd._lib import LlictiError, EFORMAT
+    from llicti_amd.codec import MODE_RANS, container_to_bytestream_list
+    torch = torch_mod
+    c = codecs("trainedlike")
+    W_o = oracle_weights("trainedlike")
+    rgb = make_batch("smooth", 2, 96, 128, seed0=700)
+    mode = MODE_RANS(2)
+    cont, seg = c.encode(_dev(torch, rgb), mode=mode)
+    c.check()
+    seg_h = seg.cpu().numpy()
+    hdr = int(seg_h[1, :4].sum())
+    for where, val in ((hdr + 400, 0x5A), (hdr + 40, 0xFF), (hdr + 3, 0x7F)):        # a stream word | a low half | the length nibbles
+        bad = cont.clone()
+        bad[1, where] ^= val
+        rec = c.decode(bad, seg, 96, 128, mode=mode)
+        with pytest.raises(LlictiError) as e:
+            c.check()
+        assert e.value.code == EFORMAT, where
+        assert np.array_equal(rec[0].cpu().numpy(), rgb[0])                           # the other image of the batch is untouched
+        bl = container_to_bytestream_list(bad[1].cpu().numpy(), seg_h[1])
+        with pytest.raises(Exception):
+            orc.decode_image_rans(bl, W_o)
+    rec = _decode_poisoned(c, cont, seg, 96, 128, mode)
+    assert np.array_equal(rec.cpu().numpy(), rgb)
