@@ -842,3 +842,28 @@ def test_rans_v2_integrity_check_detects_corruption(torch_mod, codecs, oracle_we
             orc.decode_image_rans(bl, W_o)
     rec = _decode_poisoned(c, cont, seg, 96, 128, mode)
     assert np.array_equal(rec.cpu().numpy(), rgb)
+
+
+def test_bench_line_contract(torch_mod):
+    """bench.py's one JSON line carries every field the driver reads (small shape, no informational legs)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "3", "--height", "96", "--width", "128", "--steps", "2",
+                        "--warmup", "1", "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "rccl_ranks", "value_pcie_inclusive", "value_pcie_serial", "bpp"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["unit"] == "MPix/s" and d["value"] > 0 and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(d["ms_per_step"] * d["value"] - 3 * 96 * 128 / 1e3) < 0.02 * 3 * 96 * 128 / 1e3      # value = pixels / time
