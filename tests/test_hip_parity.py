@@ -867,3 +867,18 @@ def test_bench_line_contract(torch_mod):
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert abs(d["ms_per_step"] * d["value"] - 3 * 96 * 128 / 1e3) < 0.02 * 3 * 96 * 128 / 1e3      # value = pixels / time
+
+
+def test_plan_cache_eviction(torch_mod, codecs):
+    """More than 16 distinct (B, H, W, mode) shapes through one context: the plan cache drops everything at the 17th
+    (documented: that call synchronises the device) and every shape still round-trips, including one seen before."""
+    from llicti_amd.codec import MODE_RANS
+    torch = torch_mod
+    c = codecs("trainedlike")
+    shapes = [(1 + (i % 2), 32 + 8 * i, 40 + 4 * i, MODE_RANS(2) if i % 3 else 0) for i in range(20)] + [(1, 32, 40, 0)]
+    for (B, H, W, mode) in shapes:
+        rgb = make_batch("smooth", B, H, W, seed0=900 + H)
+        cont, seg = c.encode(_dev(torch, rgb), mode=mode)
+        c.check()
+        rec = _decode_poisoned(c, cont, seg, H, W, mode)
+        assert np.array_equal(rec.cpu().numpy(), rgb), (B, H, W, mode)
