@@ -43,6 +43,11 @@ constexpr int kParamStride = LLICTI_PARAM_STRIDE;
 #ifndef CNN_STAGGER
 #define CNN_STAGGER 0          // delay waves 4-7 before the first tile (decorrelates the two waves of a SIMD)
 #endif
+#ifndef CNN_REM4X4
+#define CNN_REM4X4 1           // layer 0: channels 80..87 of a head on v_mfma_f32_4x4x1 (16 blocks = 2 x 4 channels x 8 x 4 pixels,
+#endif                         //   one k per instruction) instead of a sixth, half-empty 16-row tile: no padded MACs in layer 0
+static_assert(!CNN_REM4X4 || (CNN_PREFETCH_L0 && CNN_NT == 2), "the 4x4x1 remainder path is written for the prefetching, NT = 2 form");
+constexpr int kMT0 = CNN_REM4X4 ? 5 : 6;        // 16-row tiles of LAYER 0
 
 // One MFMA k-step consumes 4 consecutive k of the canonical K order (llicti_amd/weights.py): the kernel's
 // length-4 axis.  Lane (q = lane>>4, px = lane&15) therefore reads the staged input tile at
@@ -77,7 +82,9 @@ __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make
 
 // Per (band, head) weight pack, in MFMA-fragment order so that the LDS image is lane-linear:
 //   bias0 [6][4][4]            acc init of tile T, lane group q, reg r  = b0[16T + 4r + q]
-//   W0    [6][K0/4][64]        lane l of tile T, k-step t: W0[chan(T, l&15)][4t + (l>>4)]
+//   W0    [kMT0][K0/4][64]     lane l of tile T, k-step t: W0[chan(T, l&15)][4t + (l>>4)]
+//   W0r   [K0/4][8][4]         (CNN_REM4X4) channels 80..87: W0r[t][c][kk] = W0[80 + c][4t + kk]
+//   bias0r[8]                  (CNN_REM4X4) b0[80 + c]
 //   bias1 [6][4][4]
 //   W1    [6][22][64]
 //   bias2 [4][4]               acc init of lane group q, reg r = b2[4q + r]
@@ -85,13 +92,16 @@ __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make
 // chan(T, rho) = 16T + 4(rho&3) + (rho>>2): this row permutation makes the accumulator registers of one
 // layer line up, untouched, as the B operand of the next layer's MFMAs in natural channel order
 // (C/D layout of v_mfma_f32_16x16x4_f32: col = lane&15, row = 4(lane>>4) + reg).
-static constexpr int pack_floats(int K0) { return 96 + kMT * (K0 / 4) * 64 + 96 + kMT * kKS1 * 64 + 16 + kKS1 * 64; }
+static constexpr int rem_floats(int K0) { return CNN_REM4X4 ? K0 * 8 + 8 : 0; }
+static constexpr int pack_floats(int K0) { return 96 + kMT0 * (K0 / 4) * 64 + rem_floats(K0) + 96 + kMT * kKS1 * 64 + 16 + kKS1 * 64; }
 
 template <int K0>
 struct PackOff {
     static constexpr int bias0 = 0;
     static constexpr int w0 = 96;
-    static constexpr int bias1 = w0 + kMT * (K0 / 4) * 64;
+    static constexpr int w0r = w0 + kMT0 * (K0 / 4) * 64;        // [K0/4][8][4]
+    static constexpr int bias0r = w0r + (CNN_REM4X4 ? K0 * 8 : 0);
+    static constexpr int bias1 = w0 + kMT0 * (K0 / 4) * 64 + rem_floats(K0);
     static constexpr int w1 = bias1 + 96;
     static constexpr int bias2 = w1 + kMT * kKS1 * 64;
     static constexpr int w2 = bias2 + 16;
@@ -106,6 +116,9 @@ static constexpr int cnn_lds_bytes(int band)
 __device__ __forceinline__ float relu(float x) { return (x > 0.0f) ? x : 0.0f; }
 __device__ __forceinline__ f32x4 relu4(f32x4 v) { v[0] = relu(v[0]); v[1] = relu(v[1]); v[2] = relu(v[2]); v[3] = relu(v[3]); return v; }
 #define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// 16 blocks of D[4x4] = A[4x1] * B[1x4] + C: A[i] in lane 4b + i, B[j] in lane 4b + j, D[i][j] in lane 4b + j, register i; one
+// fmaf per element (tools/hipchecks/check_mfma4x4.hip)
+#define MFMA1(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
 
 // priority to switch to when the wave's issued-MFMA count passes a quarter mark of the tile inside (before, after]; -1: none
 constexpr int prio_step(int before, int after, int total)
@@ -211,47 +224,117 @@ __global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *_
         // ---- layer 0: [96 x K0] x [K0 x 64 pixels]; bias preloaded into the accumulators
         f32x4 a0[kMT][kNT];
 #pragma unroll
-        for (int T = 0; T < kMT; ++T) {
+        for (int T = 0; T < kMT0; ++T) {
             const f32x4 bv = *reinterpret_cast<const f32x4 *>(lds + PO::bias0 + (T * 4 + q) * 4);
 #pragma unroll
             for (int n = 0; n < kNT; ++n) a0[T][n] = bv;
         }
+#if CNN_REM4X4
+#pragma unroll
+        for (int n = 0; n < kNT; ++n) a0[5][n] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };     // [0], [1] are written after layer 0; [2], [3] never read
+#endif
 #if CNN_PREFETCH_L0
         {
-            float a_c[kMT], b_c[kNT];
+            float a_c[kMT0], b_c[kNT];
+#if CNN_REM4X4
+            // channels 80..87 of the head: block b = lane >> 2 = (cg, pg): channels 80 + 4 cg + i (A, lane & 3 = i) x pixels
+            // 4 pg + j of the wave's 32-pixel row (B, lane & 3 = j); accumulator register i of lane (b, j) = channel
+            // 80 + 4 cg + i at pixel 4 pg + j.  One k per instruction, in k order: the same fmaf chain as the 16x16x4 tiles.
+            const int rsub = lane & 3, rcg = lane >> 5, rpix = 4 * ((lane >> 2) & 7) + rsub;
+            const float *rb_base = lds_cur + ((wave * kNT) >> 1) * kInPitch + rpix;
+            const float *ra_base = lds + PO::w0r + (4 * rcg + rsub) * 4;
+            f32x4 dR = *reinterpret_cast<const f32x4 *>(lds + PO::bias0r + 4 * rcg);
+            f32x4 ar_c;
+            float br_c[4];
+#endif
             {
                 constexpr int U = kKTab<BAND>.s[0].U, S = kKTab<BAND>.s[0].S;
                 const float *bp = lds_cur + U + pix0 + (S == 1 ? q : q_row);
 #pragma unroll
                 for (int n = 0; n < kNT; ++n) b_c[n] = bp[(n >> 1) * kInPitch + 16 * (n & 1)];
 #pragma unroll
-                for (int T = 0; T < kMT; ++T) a_c[T] = lds[PO::w0 + (T * NK0 + 0) * 64 + lane];
+                for (int T = 0; T < kMT0; ++T) a_c[T] = lds[PO::w0 + (T * NK0 + 0) * 64 + lane];
+#if CNN_REM4X4
+                ar_c = *reinterpret_cast<const f32x4 *>(ra_base);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) br_c[kk] = rb_base[U + (S == 1 ? kk : kk * kInPitch)];
+#endif
             }
             static_for<NK0>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
                 if constexpr (CNN_PRIO && prio_step(kMfmaL0 * t / NK0, kMfmaL0 * (t + 1) / NK0, kMfmaTile) >= 0)
                     __builtin_amdgcn_s_setprio(prio_step(kMfmaL0 * t / NK0, kMfmaL0 * (t + 1) / NK0, kMfmaTile));
-                float a_n[kMT], b_n[kNT];
+                float a_n[kMT0], b_n[kNT];
+#if CNN_REM4X4
+                f32x4 ar_n;
+                float br_n[4];
+#endif
                 if constexpr (t + 1 < NK0) {       // next k-step's fragments are in flight while this one's MFMAs run
                     constexpr int U = kKTab<BAND>.s[t + 1].U, S = kKTab<BAND>.s[t + 1].S;
                     const float *bp = lds_cur + U + pix0 + (S == 1 ? q : q_row);
 #pragma unroll
                     for (int n = 0; n < kNT; ++n) b_n[n] = bp[(n >> 1) * kInPitch + 16 * (n & 1)];
 #pragma unroll
-                    for (int T = 0; T < kMT; ++T) a_n[T] = lds[PO::w0 + (T * NK0 + t + 1) * 64 + lane];
-                }
+                    for (int T = 0; T < kMT0; ++T) a_n[T] = lds[PO::w0 + (T * NK0 + t + 1) * 64 + lane];
+#if CNN_REM4X4
+                    ar_n = *reinterpret_cast<const f32x4 *>(ra_base + (t + 1) * 32);
 #pragma unroll
-                for (int T = 0; T < kMT; ++T)
+                    for (int kk = 0; kk < 4; ++kk) br_n[kk] = rb_base[U + (S == 1 ? kk : kk * kInPitch)];
+#endif
+                }
+#if CNN_REM4X4
+                // the four 4x4x1 steps of this k-step form ONE dependent chain (k order is the spec): they are spread between
+                // the ten independent 16x16x4 MFMAs so that none waits for its predecessor
+                // (scheduler fences pin the order: left alone, the machine scheduler clusters the 4x4x1s)
+                a0[0][0] = MFMA4(a_c[0], b_c[0], a0[0][0]); a0[0][1] = MFMA4(a_c[0], b_c[1], a0[0][1]);
+                dR = MFMA1(ar_c[0], br_c[0], dR);
+                __builtin_amdgcn_sched_barrier(0);
+                a0[1][0] = MFMA4(a_c[1], b_c[0], a0[1][0]); a0[1][1] = MFMA4(a_c[1], b_c[1], a0[1][1]);
+                a0[2][0] = MFMA4(a_c[2], b_c[0], a0[2][0]);
+                dR = MFMA1(ar_c[1], br_c[1], dR);
+                __builtin_amdgcn_sched_barrier(0);
+                a0[2][1] = MFMA4(a_c[2], b_c[1], a0[2][1]);
+                a0[3][0] = MFMA4(a_c[3], b_c[0], a0[3][0]); a0[3][1] = MFMA4(a_c[3], b_c[1], a0[3][1]);
+                dR = MFMA1(ar_c[2], br_c[2], dR);
+                __builtin_amdgcn_sched_barrier(0);
+                a0[4][0] = MFMA4(a_c[4], b_c[0], a0[4][0]); a0[4][1] = MFMA4(a_c[4], b_c[1], a0[4][1]);
+                dR = MFMA1(ar_c[3], br_c[3], dR);
+#else
+#pragma unroll
+                for (int T = 0; T < kMT0; ++T)
 #pragma unroll
                     for (int n = 0; n < kNT; ++n) a0[T][n] = MFMA4(a_c[T], b_c[n], a0[T][n]);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (t + 1 < NK0) {
 #pragma unroll
-                    for (int T = 0; T < kMT; ++T) a_c[T] = a_n[T];
+                    for (int T = 0; T < kMT0; ++T) a_c[T] = a_n[T];
 #pragma unroll
                     for (int n = 0; n < kNT; ++n) b_c[n] = b_n[n];
+#if CNN_REM4X4
+                    ar_c = ar_n;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) br_c[kk] = br_n[kk];
+#endif
                 }
             });
+#if CNN_REM4X4
+            // hand the 8 channels to layer 1 in ITS operand layout: k-step 20 + r of layer 1 wants channel 80 + 4 r + q of pixel
+            // 16 n + px in lane (q, px) = register q of lane 32 r + 16 n + px here.  a0[5][n][0..1] are exactly those operands
+            // (a0[5][n][2..3] would be k-steps 22, 23: not used, 88 = 22 x 4).
+            dR = relu4(dR);
+#pragma unroll
+            for (int n = 0; n < kNT; ++n)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int src = 4 * (32 * r + 16 * n + px);
+                    const float t0 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(dR[0])));
+                    const float t1 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(dR[1])));
+                    const float t2 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(dR[2])));
+                    const float t3 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(dR[3])));
+                    a0[5][n][r] = (q == 0) ? t0 : (q == 1) ? t1 : (q == 2) ? t2 : t3;
+                }
+#endif
         }
 #else
         static_for<NK0>([&](auto tc) {
@@ -272,7 +355,7 @@ __global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *_
 #endif
         if constexpr (CNN_STAGE_SITES > 1) stage_next(1);
 #pragma unroll
-        for (int T = 0; T < kMT; ++T)
+        for (int T = 0; T < kMT0; ++T)
 #pragma unroll
             for (int n = 0; n < kNT; ++n) a0[T][n] = relu4(a0[T][n]);
 
@@ -338,7 +421,8 @@ static void pack_band(int K0, const float *w0, const float *b0, const float *w1,
     out.assign((size_t)4 * total, 0.0f);
     for (int hd = 0; hd < 4; ++hd) {
         float *p = out.data() + (size_t)hd * total;
-        float *bias0 = p, *W0 = p + 96, *bias1 = W0 + kMT * NK0 * 64, *W1 = bias1 + 96;
+        float *bias0 = p, *W0 = p + 96, *W0r = W0 + kMT0 * NK0 * 64, *bias0r = W0r + (CNN_REM4X4 ? K0 * 8 : 0);
+        float *bias1 = W0 + kMT0 * NK0 * 64 + rem_floats(K0), *W1 = bias1 + 96;
         float *bias2 = W1 + kMT * kKS1 * 64, *W2 = bias2 + 16;
         for (int T = 0; T < kMT; ++T)
             for (int q = 0; q < 4; ++q)
@@ -351,11 +435,18 @@ static void pack_band(int K0, const float *w0, const float *b0, const float *w1,
             for (int l = 0; l < 64; ++l) {
                 const int rho = l & 15, q = l >> 4;
                 const int cl = 16 * T + 4 * (rho & 3) + (rho >> 2);
-                for (int t = 0; t < NK0; ++t)
-                    W0[(T * NK0 + t) * 64 + l] = (cl < kHead) ? w0[(size_t)(hd * kHead + cl) * K0 + 4 * t + q] : 0.0f;
+                if (T < kMT0)
+                    for (int t = 0; t < NK0; ++t)
+                        W0[(T * NK0 + t) * 64 + l] = (cl < kHead) ? w0[(size_t)(hd * kHead + cl) * K0 + 4 * t + q] : 0.0f;
                 for (int t = 0; t < kKS1; ++t)
                     W1[(T * kKS1 + t) * 64 + l] = (cl < kHead) ? w1[(size_t)(hd * kHead + cl) * kHead + 4 * t + q] : 0.0f;
             }
+        if (CNN_REM4X4) {
+            for (int t = 0; t < NK0; ++t)
+                for (int c = 0; c < 8; ++c)
+                    for (int kk = 0; kk < 4; ++kk) W0r[(t * 8 + c) * 4 + kk] = w0[(size_t)(hd * kHead + 80 + c) * K0 + 4 * t + kk];
+            for (int c = 0; c < 8; ++c) bias0r[c] = b0[hd * kHead + 80 + c];
+        }
         for (int q = 0; q < 4; ++q)
             for (int r = 0; r < 4; ++r) bias2[q * 4 + r] = (4 * q + r < 15) ? b2[hd * 15 + 4 * q + r] : 0.0f;
         for (int l = 0; l < 64; ++l) {
