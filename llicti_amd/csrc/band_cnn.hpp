@@ -43,6 +43,9 @@ constexpr int kParamStride = LLICTI_PARAM_STRIDE;
 #ifndef CNN_STAGGER
 #define CNN_STAGGER 0          // delay waves 4-7 before the first tile (decorrelates the two waves of a SIMD)
 #endif
+#ifndef CNN_PREFETCH_L1
+#define CNN_PREFETCH_L1 8      // layers 1 / 2: weight fragments requested this many k-steps ahead of their MFMAs (0: at the fence window)
+#endif
 #ifndef CNN_REM4X4
 #define CNN_REM4X4 1           // layer 0: channels 80..87 of a head on v_mfma_f32_4x4x1 (16 blocks = 2 x 4 channels x 8 x 4 pixels,
 #endif                         //   one k per instruction) instead of a sixth, half-empty 16-row tile: no padded MACs in layer 0
@@ -367,6 +370,16 @@ __global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *_
 #pragma unroll
             for (int n = 0; n < kNT; ++n) a2[n] = bv;
         }
+#if CNN_PREFETCH_L1 > 0
+        // Layer 1's weight fragments are one linear stream of kMT * kKS1 rows of 64 floats: a ring of D registers keeps the
+        // next D k-steps' fragments in flight (without it the compiler requests a fence window's four fragments and waits
+        // for them on the spot: one exposed LDS latency per 8 MFMAs, and the tile's slowest wave spent 48k cycles on 39k
+        // cycles of MFMA work in these two layers)
+        constexpr int D1 = CNN_PREFETCH_L1;
+        float ring1[D1];
+#pragma unroll
+        for (int i = 0; i < D1; ++i) ring1[i] = lds[PO::w1 + i * 64 + lane];
+#endif
         static_for<kMT>([&](auto Tc) {
             constexpr int T = decltype(Tc)::value;
             if constexpr (CNN_PRIO && prio_step(kMfmaL0 + T * kMfmaT12, kMfmaL0 + (T + 1) * kMfmaT12, kMfmaTile) >= 0)
@@ -379,9 +392,22 @@ __global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *_
 #pragma unroll
                 for (int n = 0; n < kNT; ++n) a1[n] = bv;
             }
+#if CNN_PREFETCH_L1 > 0
+            float a2w[4] = { 0.0f, 0.0f, 0.0f, 0.0f };      // this tile's layer-2 fragments: requested now, used 22 k-steps later
+            static_for<4>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                if constexpr (4 * T + r < kKS1) a2w[r] = lds[PO::w2 + (4 * T + r) * 64 + lane];
+            });
+#endif
             static_for<kKS1>([&](auto ttc) {
                 constexpr int tt = decltype(ttc)::value;
+#if CNN_PREFETCH_L1 > 0
+                constexpr int i = T * kKS1 + tt;
+                const float a = ring1[i % D1];
+                if constexpr (i + D1 < kMT * kKS1) ring1[i % D1] = lds[PO::w1 + (i + D1) * 64 + lane];
+#else
                 const float a = lds[PO::w1 + (T * kKS1 + tt) * 64 + lane];
+#endif
 #pragma unroll
                 for (int n = 0; n < kNT; ++n) a1[n] = MFMA4(a, a0[tt >> 2][n][tt & 3], a1[n]);
 #if CNN_FENCE_L1 > 0
@@ -393,7 +419,11 @@ __global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *_
             static_for<4>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
                 if constexpr (4 * T + r < kKS1) {
+#if CNN_PREFETCH_L1 > 0
+                    const float a = a2w[r];
+#else
                     const float a = lds[PO::w2 + (4 * T + r) * 64 + lane];
+#endif
 #pragma unroll
                     for (int n = 0; n < kNT; ++n) a2[n] = MFMA4(a, a1[n][r], a2[n]);
                 }

@@ -22,7 +22,7 @@ rep("    int cur = 0;\n", "    int cur = 0;\n    unsigned long long TT[4] = {0, 
 # print at the end of the kernel: find the end of the tile loop: the line after 'cur ^= 1;' block closes with '    }\n}'
 i = s.index("        const unsigned long long q4")
 j = s.index("\n    }\n", i)
-s = s[:j + 7] + "    if (ntile >= 64 && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == 8)) printf(\"band %d w%d tiles %d: barrier %llu layer0(+stage0,bias) %llu relu+stage+layers12 %llu store %llu per tile, total %llu\\n\", BAND, wave, ntile, TT[0]/ntile, TT[1]/ntile, TT[2]/ntile, TT[3]/ntile, (TT[0]+TT[1]+TT[2]+TT[3])/ntile);\n" + s[j + 7:]
+s = s[:j + 7] + "    if (ntile >= 64 && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == 5 || wave == 10 || wave == 15)) printf(\"band %d w%d tiles %d: barrier %llu layer0(+stage0,bias) %llu relu+stage+layers12 %llu store %llu per tile, total %llu\\n\", BAND, wave, ntile, TT[0]/ntile, TT[1]/ntile, TT[2]/ntile, TT[3]/ntile, (TT[0]+TT[1]+TT[2]+TT[3])/ntile);\n" + s[j + 7:]
 open(os.path.join(work, "band_cnn.hpp"), "w").write(s)
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unused-value",
                        "-o", os.path.join(root, "build", "lib_stamp_cnn.so"), os.path.join(work, "llicti_hip.hip")])
