@@ -46,6 +46,9 @@ constexpr int kParamStride = LLICTI_PARAM_STRIDE;
 #ifndef CNN_PREFETCH_L1
 #define CNN_PREFETCH_L1 8      // layers 1 / 2: weight fragments requested this many k-steps ahead of their MFMAs (0: at the fence window)
 #endif
+#ifndef CNN_STAGE_FAST
+#define CNN_STAGE_FAST 1       // interior tiles (no clamp can fire): per-lane source offsets of a wave's pieces precomputed once per kernel
+#endif
 #ifndef CNN_REM4X4
 #define CNN_REM4X4 1           // layer 0: channels 80..87 of a head on v_mfma_f32_4x4x1 (16 blocks = 2 x 4 channels x 8 x 4 pixels,
 #endif                         //   one k per instruction) instead of a sixth, half-empty 16-row tile: no padded MACs in layer 0
@@ -165,13 +168,51 @@ __global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *_
     // depend on the lane: piece phase t covers row 4q+t from column 16t (lanes below 48-16t) and the head
     // of row 4q+t+1 (the others).
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    constexpr int kPieces = NPL * (kInPlane / 64);                                   // 45 / 90 / 135
+    constexpr int kMyPieces = (kPieces + kCnnThreads / 64 - 1) / (kCnnThreads / 64);  // pieces a wave stages per tile: 3 / 6 / 9
+#if CNN_STAGE_FAST
+    // For a tile whose whole halo lies inside the band grid (and off the odd edge) no clamp fires, and a lane's source
+    // address is  image base + tile origin (both wave-uniform) + a constant of (wave, piece, lane): those constants are
+    // computed ONCE per kernel (byte offsets, < 2^32), so that staging an interior tile costs no address arithmetic per
+    // piece -- the ~20 vector operations per piece of the general path compete with the MFMAs for the issue port
+    // (deletion experiments: staging is ~6 % of the kernel).  Border tiles take the general path.
+    // lane-dependent part: only the piece's phase t matters (row t or t + 1 of its 4-row group, column within the row)
+    uint32_t lane_t[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int thr = 48 - 16 * t;
+        const bool up = lane >= thr;
+        const int cidx = min(up ? lane - thr : lane + 16 * t, kInCols - 1);
+        lane_t[t] = (uint32_t)((((long)(2 * (t + (up ? 1 : 0))) * g.W + 2 * cidx) << g.lvl) * 4);
+    }
+#endif
     auto stage = [&](int tile, float *dst) {
         const int img = tile / (tiles_x * tiles_y);
         const int trem = tile - img * (tiles_x * tiles_y);
         const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
         const int i0 = ty * kTileH - 2, j0 = tx * kTileW - 2;
         const float *base = fplanes + (long)img * 3 * g.plane;
-        for (int u = wave_u; u < NPL * (kInPlane / 64); u += kCnnThreads / 64) {
+#if CNN_STAGE_FAST
+        // rows i0 .. i0 + kInRows - 1 and columns j0 .. j0 + kInCols - 1 of the band grid, all strictly inside it and below
+        // the last row / column (where lazyDWT's odd-edge pad could apply)
+        if (i0 >= 0 && i0 + kInRows - 1 <= g.h - 2 && j0 >= 0 && j0 + kInCols - 1 <= g.w - 2) {
+            const char *origin = reinterpret_cast<const char *>(base) + (((long)(2 * i0) * g.W + 2 * j0) << g.lvl) * 4;
+#pragma unroll
+            for (int k = 0; k < kMyPieces; ++k) {
+                const int u = wave_u + k * (kCnnThreads / 64);                           // wave-uniform: the rest of the address is scalar work
+                if (u < kPieces) {
+                    const int pl = u / 15, v = u - 15 * pl, q4 = v / 3, t = v - 3 * q4;
+                    const int src = pl / 3, ci = pl - 3 * src;
+                    const long uoff = ((long)ci * g.plane + (((long)(8 * q4 + src_oi(src)) * g.W + src_oj(src)) << g.lvl)) * 4;
+                    const uint32_t lo = (t == 0) ? lane_t[0] : (t == 1) ? lane_t[1] : lane_t[2];
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(origin + uoff + lo),
+                                                     (__attribute__((address_space(3))) void *)(dst + u * 64), 4, 0, 0);
+                }
+            }
+            return;
+        }
+#endif
+        for (int u = wave_u; u < kPieces; u += kCnnThreads / 64) {
             const int pl = u / 15, v = u - 15 * pl, q4 = v / 3, t = v - 3 * q4;       // wave-uniform
             const int src = pl / 3, ci = pl - 3 * src;
             const int thr = 48 - 16 * t;
