@@ -1,4 +1,4 @@
-// rans_coder.hpp -- LLICTI-rANS v1 container: 64-way interleaved rANS encoder and the table-free stage decoder.
+// rans_coder.hpp -- LLICTI-rANS v2 container: 64-way interleaved rANS encoder and the table-free stage decoder.
 // Part of the single translation unit llicti_hip.hip (included in order; not a stand-alone header).
 #pragma once
 

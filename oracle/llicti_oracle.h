@@ -24,8 +24,10 @@
  *
  * PARITY PINNING: pinned against fixtures generated from the reference-owned Python
  * (tests/golden/make_fixtures.py) for everything except the arithmetic coder's byte output:
- * torchac is absent from this image, so the coder is "parity unpinned" (restated from its
- * published algorithm; only self-consistency and hand-computed vectors are checked).
+ * torchac is absent from this image, so the coder is "parity unpinned": restated from its published
+ * algorithm, and checked against an INDEPENDENT second restatement (tests/ref_ac.py, pure Python written from
+ * SURVEY.md Appendix A), against three vectors worked out by hand, and for self-consistency on the reference's own
+ * recorded tables (tests/test_ref_ac.py).
  */
 #ifndef LLICTI_ORACLE_H
 #define LLICTI_ORACLE_H
