@@ -6,7 +6,24 @@
 struct StageGeom {      // one (level, band): band grid, coded crop, full-res addressing
     int B, H, W, lvl, h, w, hc, wc, oi, oj;
     long plane;
+    uint32_t wc_mul;    // n / wc for 0 <= n < 2^31 without a division: t = mulhi(n, wc_mul); q = (t + ((n - t) >> 1)) >> wc_sh
+    int wc_sh;
 };
+// exact unsigned division by an invariant divisor (Granlund / Montgomery, the 33-bit multiplier form): d >= 1
+static void div_magic(uint32_t d, uint32_t *mul, int *sh)
+{
+    int l = 0;
+    while ((1ull << l) < d) ++l;                                   // l = ceil(log2 d)
+    *mul = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    *sh = l > 0 ? l - 1 : 0;
+    if (l == 0) { *mul = 0; *sh = 0; }                              // d == 1: t = 0, q = (0 + (n >> 1)) >> 0 is wrong -> handled by div_wc()
+}
+__device__ __forceinline__ int div_wc(const StageGeom &s, int n)
+{
+    if (s.wc == 1) return n;
+    const uint32_t t = __umulhi((uint32_t)n, s.wc_mul);
+    return (int)((t + (((uint32_t)n - t) >> 1)) >> s.wc_sh);
+}
 static StageGeom make_stage(const Geom &g, int band)
 {
     static const int OI[4] = { 0, 1, 0, 1 }, OJ[4] = { 0, 1, 1, 0 };
@@ -14,6 +31,7 @@ static StageGeom make_stage(const Geom &g, int band)
     s.B = g.B; s.H = g.H; s.W = g.W; s.lvl = g.lvl; s.h = g.h; s.w = g.w; s.plane = g.plane;
     coded_dims(g, band, &s.hc, &s.wc);
     s.oi = OI[band + 1]; s.oj = OJ[band + 1];
+    div_magic((uint32_t)s.wc, &s.wc_mul, &s.wc_sh);
     return s;
 }
 
