@@ -882,3 +882,32 @@ def test_plan_cache_eviction(torch_mod, codecs):
         c.check()
         rec = _decode_poisoned(c, cont, seg, H, W, mode)
         assert np.array_equal(rec.cpu().numpy(), rgb), (B, H, W, mode)
+
+
+def test_integration_md_binding_runs(torch_mod, tmp_path):
+    """INTEGRATION.md section 1 shows the ctypes binding a maintainer of the reference would add.  The code block is
+    executed as written (only the library path is substituted) against this repo's LLICTI module -- whose attribute tree
+    is the reference's -- and must produce the same bytestream_list as the packaged path, and decode it."""
+    import os
+    import re
+    from conftest import ROOT
+    from llicti_amd import _lib
+    from llicti_amd.config import default_config
+    from llicti_amd.graphs.models.LLICTI_nets import LLICTI
+    torch = torch_mod
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"```python\n# graphs/models/llicti_hip_binding.py.*?\n(.*?)```", md, re.S)
+    assert m, "binding code block not found"
+    code = m.group(1).replace('C.CDLL("libllicti_hip.so")', f'C.CDLL({_lib.SO_PATH!r})')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md#binding", "exec"), ns)
+    torch.manual_seed(1337)
+    model = LLICTI(default_config()).to("cuda:0").eval()
+    hip = ns["HipPath"](model, 0)
+    rgb = make_image("smooth", 72, 104, 5)
+    x = torch.from_numpy(rgb.astype(np.float32) / np.float32(255)).unsqueeze(0).to("cuda:0")
+    bl = hip.compress(x)
+    ref, _ = model.compress(x)
+    assert bl == ref
+    x_reco = hip.decompres(bl, torch.device("cuda:0"))
+    assert np.array_equal((x_reco * 255).round().to(torch.uint8).cpu().numpy()[0], rgb)
