@@ -911,3 +911,22 @@ def test_integration_md_binding_runs(torch_mod, tmp_path):
     assert bl == ref
     x_reco = hip.decompres(bl, torch.device("cuda:0"))
     assert np.array_equal((x_reco * 255).round().to(torch.uint8).cpu().numpy()[0], rgb)
+    # section 2 (the torchac seam) and section 3 (LLICTI.forward) in the same namespace, as a maintainer would paste them
+    blocks = re.findall(r"```python\n(.*?)```", md, re.S)
+    seam = next(b for b in blocks if "def encode_int16_normalized_cdf_hip" in b)
+    fwd = next(b for b in blocks if "def forward_hip" in b)
+    exec(compile(seam, "INTEGRATION.md#seam", "exec"), ns)
+    exec(compile(fwd, "INTEGRATION.md#forward", "exec"), ns)
+    import ref_ac
+    g = load_case("smooth_64x48_tl")
+    rows, idx = g["cdfrows_s1_b0_c0"], g["cdfidx_s1_b0_c0"]
+    sym = g["sym_s1_b0_c0"].ravel()[idx].astype(np.int16)
+    cdf_t = torch.from_numpy(rows.view(np.int16).copy()).to("cuda:0").reshape(1, 1, 1, len(sym), rows.shape[1])
+    sym_t = torch.from_numpy(sym).to("cuda:0").reshape(1, 1, 1, len(sym))
+    got = ns["encode_int16_normalized_cdf_hip"](hip.ctx, cdf_t, sym_t)
+    assert got == ref_ac.encode(rows.tolist(), sym.tolist())
+    pad = make_image("smooth", 64, 96, 6)
+    xp = torch.from_numpy(pad.astype(np.float32) / np.float32(255)).unsqueeze(0).to("cuda:0")
+    out = ns["forward_hip"](hip.ctx, xp)
+    mine = model.forward(xp)
+    assert len(out) == 5 and all(torch.equal(a, b) for a, b in zip(out, mine))
