@@ -22,15 +22,17 @@ MODE_AC = 0                      # the reference's container: 45 torchac-algorit
 
 
 def MODE_RANS(M=8):
-    """"LLICTI-rANS v2" container: M independent 64-way interleaved rANS streams per image (include/llicti_hip.h)."""
+    """"LLICTI-rANS v3" container: M independent 64-way interleaved rANS streams per image (include/llicti_hip.h)."""
     return 0x100 | int(M)
 
 
 def mode_of_header(byte0: int) -> int:
     if byte0 == 5:
         return MODE_AC
-    if (byte0 & 0x8F) == 0x85:
+    if (byte0 & 0x8F) == 0x8D:
         return MODE_RANS(1 << ((byte0 >> 4) & 7))
+    if (byte0 & 0x8F) == 0x85:
+        raise ValueError(f"container tag 0x{byte0:02x} is the retired LLICTI-rANS v2 format; this build reads and writes v3 only")
     raise ValueError(f"unknown container tag 0x{byte0:02x}")
 
 

@@ -55,7 +55,7 @@ struct Plan {                 // workspace carving for (B, H, W)
     int M = 0;                          // rANS streams per image (0: AC container only)
     int rslot_cap = 0;
     std::vector<long> rslot_off;        // [B*M] byte offsets into the slots region
-    size_t off_rinfo, off_rstate, off_rpos, off_rwoff;
+    size_t off_rinfo, off_rstate, off_rpos, off_rtail;
 };
 
 // AC decode has two table forms.  Few images in flight (latency bound: every stream is one serial wave and the GPU is
@@ -174,14 +174,14 @@ static void build_plan(Plan &p, int B, int H, int W, int M)
     p.max_container = align_up(container + 64 * 45, 16);
     p.off_pairs = take((size_t)pair_pos * sizeof(uint32_t));
     if (M > 0) {
-        // worst case of one stream: every symbol emits a 16-bit word; chunks are dealt round-robin, so a
+        // worst case of one stream: every symbol emits 16 bits; chunks are dealt round-robin, so a
         // stream gets at most ceil(nchunks / M) chunks of every stage
         long syms = 0;
         for (int st = 0; st < LLICTI_NSTREAMS; ++st) {
             const long nchunks = (p.desc[(size_t)st * B].n + 63) / 64;
             syms += (nchunks + M - 1) / M * 64;
         }
-        p.rslot_cap = (int)align_up((size_t)(2 * syms + 288 + 64), 64);      // + compact state header (<= 280 bytes) + zero pad
+        p.rslot_cap = (int)align_up((size_t)(2 * syms + 4 + 8 + kRansPayBytes + 16 + 64), 64);   // + T, sentinel, 64 x 31-bit states, slack, zero pad
         p.rslot_off.assign((size_t)B * M, 0);
         for (long i = 0; i < (long)B * M; ++i) p.rslot_off[i] = (long)i * p.rslot_cap;
         slot_pos = std::max<long>(slot_pos, (long)B * M * p.rslot_cap);
@@ -191,7 +191,7 @@ static void build_plan(Plan &p, int B, int H, int W, int M)
     p.off_rinfo = take((size_t)B * 32 * 2 * sizeof(int32_t));
     p.off_rstate = take((size_t)B * 32 * 64 * sizeof(uint32_t));
     p.off_rpos = take((size_t)B * 32 * sizeof(uint32_t));
-    p.off_rwoff = take((size_t)B * 32 * sizeof(uint32_t));
+    p.off_rtail = take((size_t)B * 32 * sizeof(uint32_t));
     p.off_slot_len = take((size_t)LLICTI_NSTREAMS * B * sizeof(int32_t));
     int hc0, wc0;
     coded_dims(g0, 1, &hc0, &wc0);
@@ -210,7 +210,7 @@ static void build_plan(Plan &p, int B, int H, int W, int M)
     p.total = o;
 }
 
-// mode: 0 = AC container (torchac-compatible, the reference's format); 0x100 | M = rANS container with M
+// mode: 0 = AC container (torchac-compatible, the reference's format); 0x100 | M = rANS container (v3) with M
 // streams per image, M in {1,2,4,8,16,32}
 static int mode_streams(int mode)
 {
@@ -221,6 +221,8 @@ static int mode_streams(int mode)
     return M;
 }
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+// header byte 0 of the rANS container: 0x80 | lg2(M) << 4 | 0x08 (format v3; the retired v2 had this bit clear) | number of scales
+static int rans_byte0(int M) { return 0x80 | (ilog2(M) << 4) | 0x08 | LLICTI_NLEVELS; }
 
 static int sub_batches_max(int B, int M)
 {
@@ -660,7 +662,7 @@ extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, 
     HIPCHK(hipMemsetAsync(status, 0, 64, s));
     if (int rc = launch_lift(d_rgb, B, H, W, planes, fplanes, mm, (int32_t *)(ws + p.off_lift_part), s)) return rc;
     Geom g4 = make_geom(B, H, W, 4);
-    const int byte0 = M ? (0x80 | (ilog2(M) << 4) | LLICTI_NLEVELS) : LLICTI_NLEVELS;
+    const int byte0 = M ? rans_byte0(M) : LLICTI_NLEVELS;
     header_write_kernel<<<B, 256, 0, s>>>(d_rgb, mm, H, W, g4.h, g4.w, pad_int(H, W), byte0, d_out, (long)out_stride, d_seg_len);
     // the encoder has no dependency between stages: every (level, band) reads only original pixels
     for (int lvl = LLICTI_NLEVELS - 1; lvl >= 0; --lvl) {
@@ -701,16 +703,16 @@ static int decode_sub(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in
 
     HIPCHK(hipMemsetAsync(status, 0, 64, s));
     Geom g4 = make_geom(B, H, W, 4);
-    const int byte0 = M ? (0x80 | (ilog2(M) << 4) | LLICTI_NLEVELS) : LLICTI_NLEVELS;
+    const int byte0 = M ? rans_byte0(M) : LLICTI_NLEVELS;
     header_read_kernel<<<B, 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, H, W, g4.h, g4.w, pad_int(H, W), byte0, planes, fplanes, mm, status);
     uint32_t *rstate = (uint32_t *)(ws + p.off_rstate);
     uint32_t *rpos = (uint32_t *)(ws + p.off_rpos);
-    uint32_t *rwoff = (uint32_t *)(ws + p.off_rwoff);
+    uint32_t *rtail = (uint32_t *)(ws + p.off_rtail);
     if (M == 0) {
         unpack_kernel<<<dim3(LLICTI_NSTREAMS, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, B, slots, pd->d_slot_off, pd->d_slot_cap, status);
     } else {
-        rans_unpack_kernel<<<dim3(M, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, M, slots, pd->d_rslot_off, p.rslot_cap, status);
-        rans_init_kernel<<<B * M, 64, 0, s>>>(slots, pd->d_rslot_off, d_seg_len, M, rstate, rpos, rwoff, status);
+        rans_unpack_kernel<<<dim3(M, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, M, slots, pd->d_rslot_off, p.rslot_cap, rpos, status);
+        rans_init_kernel<<<B * M, 64, 0, s>>>(slots, pd->d_rslot_off, rstate, rpos, rtail, status);
     }
     // 45 dependent stages (LLICTI_nets.py:440-498): CNN of band b needs bands < b of this level, Co needs Y, Cg needs Y, Co
     for (int lvl = LLICTI_NLEVELS - 1; lvl >= 0; --lvl) {
@@ -720,15 +722,11 @@ static int decode_sub(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in
             StageGeom sg = make_stage(g, band);
             const long nc = (long)sg.hc * sg.wc;
             if (M > 0) {
-                // later_max: the largest symbol count of any LATER stage (rANS v2: which symbol is a lane's last)
-                auto later_max = [&](int clr) {
-                    int mx = 0;
-                    for (int st2 = stage_index(lvl, band, clr) + 1; st2 < LLICTI_NSTREAMS; ++st2) mx = std::max(mx, p.desc[(size_t)st2 * B].n);
-                    return mx;
-                };
-                rans_decode_stage_kernel<0><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rwoff, planes, fplanes, mm, later_max(0), status);
-                rans_decode_stage_kernel<1><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rwoff, planes, fplanes, mm, later_max(1), status);
-                rans_decode_stage_kernel<2><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rwoff, planes, fplanes, mm, later_max(2), status);
+                const int last = (lvl == 0 && band == 2) ? 1 : 0;      // the last stage's tail symbols are decoded by rans_tail_kernel
+                rans_decode_stage_kernel<0><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, 0, status);
+                rans_decode_stage_kernel<1><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, 0, status);
+                rans_decode_stage_kernel<2><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status);
+                if (last) rans_tail_kernel<<<B * M, 64, 0, s>>>(params, sg, M, rstate, rpos, rtail, planes, fplanes, mm, status);
             }
             if (M == 0) {
                 // Y, Co, Cg of this band as a pipeline over chunks of the stage: chunk c of Co needs only chunk c
@@ -840,8 +838,10 @@ extern "C" int llicti_check_status(llicti_ctx *c, void *stream)
 extern "C" int llicti_header_dims(const uint8_t *h, int *H, int *W)
 {
     if (!h || !H || !W) return fail(LLICTI_EINVAL, "header_dims: null pointer");
-    if (h[0] != LLICTI_NLEVELS && (h[0] & 0x8F) != (0x80 | LLICTI_NLEVELS))
-        return fail(LLICTI_EFORMAT, "header: byte 0 = 0x%02x is neither %d scales (AC container) nor a rANS container tag", h[0], LLICTI_NLEVELS);
+    if ((h[0] & 0x8F) == (0x80 | LLICTI_NLEVELS))
+        return fail(LLICTI_EFORMAT, "header: byte 0 = 0x%02x is the retired LLICTI-rANS v2 container; this build reads and writes v3 only", h[0]);
+    if (h[0] != LLICTI_NLEVELS && (h[0] & 0x8F) != (0x88 | LLICTI_NLEVELS))
+        return fail(LLICTI_EFORMAT, "header: byte 0 = 0x%02x is neither %d scales (AC container) nor a rANS v3 container tag", h[0], LLICTI_NLEVELS);
     int Hc = h[1], Wc = h[2];
     int pad = (int)(int16_t)(h[15] | (h[16] << 8));
     for (int l = LLICTI_NLEVELS - 1; l >= 0; --l) {     // _get_padHW_lev_list, LLICTI_nets.py:533-542

@@ -1,67 +1,183 @@
-// rans_coder.hpp -- LLICTI-rANS v2 container: 64-way interleaved rANS encoder and the table-free stage decoder.
-// Part of the single translation unit llicti_hip.hip (included in order; not a stand-alone header).
+// rans_coder.hpp -- LLICTI-rANS v3 container: 64-way interleaved, bit-granular rANS encoder, the table-free stage decoder
+// and the tail decoder.  Part of the single translation unit llicti_hip.hip (included in order; not a stand-alone header).
 #pragma once
 
 // ------------------------------------------------------------------------------------------------ rANS container
-// "LLICTI-rANS v2" (new format of this build; BASELINE.json north_star: "torchac replaced by a HIP rANS
-// coder").  Same CDFs and symbols as the AC container; each image has M independent streams, each a
-// 64-way interleaved rANS coder (32-bit states, 16-bit words, 16-bit probabilities) driven by ONE
-// wavefront: lane l of stream m codes symbol n = 64c + l of every chunk c = m (mod M) of every stage.
-// Words are shared by the 64 lanes in lane order (ballot + mbcnt prefix), so a whole stage decodes in
-// ceil(nc / 64M) wave steps instead of nc serial symbols.
-// v2 "absorbing start": the first symbol a lane's encoder codes (the LAST one its decoder decodes) starts from state
-// x = freq(symbol) instead of 2^16, which makes the coded state 2^16 + c_low -- the 16 bits a rANS state holds at least
-// then carry that symbol instead of nothing (saves one symbol's information per lane: ~95 of ~190 bytes per stream on
-// noise).  The decoder reads no renormalisation word after a lane's last symbol and checks that the state left is freq.
+// "LLICTI-rANS v3" (format of this build; BASELINE.json north_star: "torchac replaced by a HIP rANS coder"; spec and CPU
+// restatement: oracle/llicti_oracle.h / .c).  Same CDFs and symbols as the AC container; each image has M independent
+// streams, each a 64-way interleaved rANS coder driven by ONE wavefront: lane l of stream m codes symbol n = 64c + l of
+// every chunk c = m (mod M) of every stage, so a whole stage decodes in ceil(nc / 64M) wave steps.
+// What v3 changes against v2 (16-bit words, states in [2^16, 2^32), ~60 bytes of start / flush overhead per stream):
+//   * states live in [2^31, 2^32) and renormalise BIT by bit (0..16 bits per symbol): x / freq >= 2^15, so the coder loses
+//     ~2^-16 of a symbol's length like the range coder does (v2 lost ~0.005 bpp on smooth content), and a final state is
+//     31 bits flat -- no length field;
+//   * a lane's INITIAL state carries payload instead of nothing: the last T symbols of the stream's last stage are coded by a
+//     single-state "tail" coder whose output (<= 1984 bits) is cut into the 64 x 31 bits the lanes start from.  The decoder
+//     is left with those states after the last stage, reassembles the tail stream and decodes its T symbols serially.
+// Cost over the ideal code length: ~8 bytes per stream (v2: ~60) -- M = 8 is within 0.001 bpp of the AC container.
+// Stream bytes:  u16 T | bit region, read DOWN from a sentinel 1-bit in its last byte | 64 x 31-bit final states.
+constexpr int kRansStateBits = 31;
+constexpr int kRansPayBits = 64 * kRansStateBits;        // 1984
+constexpr int kRansPayBytes = kRansPayBits / 8;          // 248
+constexpr int kRansTailMax = 2047;
+constexpr int kRansMinStream = 2 + 1 + kRansPayBytes;    // T, one byte of bit region (the sentinel), states
+
 __device__ __forceinline__ int lanes_below(uint64_t mask)
 {
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// inclusive prefix sum over the 64 lanes (DPP: row_shr 1, 2, 4, 8 inside each row of 16, then row_bcast 15 / 31)
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);      // lane 15 of rows 0 / 2 -> rows 1 / 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);      // lane 31 -> rows 2, 3
+    return v;
+}
+
+// symbols of stream m in a stage of nc symbols (chunks m, m + M, ...; only the stage's last chunk can be partial)
+__host__ __device__ __forceinline__ int rans_stream_count(int nc, int m, int M)
+{
+    const int nchunks = (nc + 63) >> 6;
+    if (nchunks <= m) return 0;
+    const int K = (nchunks - m + M - 1) / M;
+    const int last = m + (K - 1) * M;
+    return 64 * K - ((last == nchunks - 1 && (nc & 63)) ? 64 - (nc & 63) : 0);
+}
+
+// encoder renormalisation: the smallest n with (x >> n) < freq << 16, x in [2^31, 2^32), 1 <= freq <= 2^16
+__device__ __forceinline__ int rans_emit_bits(uint32_t x, uint32_t freq)
+{
+    if (freq >= 0x10000u) return 0;
+    const int n0 = __clz((int)freq) - 16;                 // 32 - bit length of (freq << 16)
+    return n0 + (((x >> n0) >= (freq << 16)) ? 1 : 0);
+}
+// C(s, x) = (x / freq) << 16 + x % freq + lo for x < freq << 16: the quotient fits 16 bits, so a float reciprocal estimate
+// is off by at most one and one signed remainder test repairs it (8 operations instead of a 32-bit division)
+__device__ __forceinline__ uint32_t rans_push(uint32_t x, uint32_t lo, uint32_t freq)
+{
+    uint32_t q = (uint32_t)((float)x * __builtin_amdgcn_rcpf((float)freq));
+    int32_t r = (int32_t)(x - q * freq);
+    if (r < 0) { q -= 1; r += (int32_t)freq; }
+    else if (r >= (int32_t)freq) { q += 1; r -= (int32_t)freq; }
+    return (q << 16) + (uint32_t)r + lo;
+}
+// n bits (0 <= n <= 32) at bit position pos of a little-endian dword array in LDS
+__device__ __forceinline__ uint32_t lds_get_bits(const uint32_t *buf, int pos, int n)
+{
+    const uint64_t w = (uint64_t)buf[pos >> 5] | ((uint64_t)buf[(pos >> 5) + 1] << 32);
+    return (uint32_t)(w >> (pos & 31)) & (uint32_t)((1ull << n) - 1ull);
+}
+__device__ __forceinline__ void lds_or_bits(uint32_t *buf, int pos, int n, uint32_t v)     // v < 2^n
+{
+    if (n == 0) return;
+    atomicOr(&buf[pos >> 5], v << (pos & 31));
+    if ((pos & 31) + n > 32) atomicOr(&buf[(pos >> 5) + 1], v >> (32 - (pos & 31)));
+}
+
+// One wavefront per stream.  Slot layout (rslot_off is 64-byte aligned): [0,2) unused | [2,4) T | [4, 4 + nbytes) bit region
+// (dword aligned) | 248 bytes of final states; rinfo = (2, 2 + nbytes + 248) for rans_pack_kernel.
 __global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restrict__ pairs, const StreamDesc *__restrict__ desc,
                                                          int B, int M, uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
                                                          int rslot_cap, int32_t *__restrict__ rinfo, int32_t *status)
 {
+    __shared__ uint32_t sh_pay[64];                 // the tail stream / the final states (62 dwords used, 2 of slack)
+    __shared__ uint32_t sh_pairs[64];
+    __shared__ uint32_t sh_win[128];                // staging window of the bit region: dwords [wbase, wbase + 128)
     const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M, lane = threadIdx.x;
-    uint16_t *w16 = reinterpret_cast<uint16_t *>(slots + rslot_off[sidx]);
-    long p = rslot_cap / 2;                         // word cursor, moving backwards from the end of the slot
-    uint32_t x = 1u << 16;
-    bool started = false;                           // v2: has this lane coded its first symbol yet?
+    uint8_t *slot = slots + rslot_off[sidx];
+    uint32_t *out32 = reinterpret_cast<uint32_t *>(slot + 4);
+    const int cap_dw = (rslot_cap - 4 - kRansPayBytes - 8) >> 2;      // dwords the bit region may take
     int bad = 0;
+    sh_pay[lane] = 0;
+    sh_win[lane] = 0; sh_win[64 + lane] = 0;
+    __syncthreads();
+
+    // 1. tail: the stream's last T symbols of the last stage, last symbol first, single state; bits go UP from bit 0 of
+    //    the payload, the final state (32 bits, leading one = highest set bit of the payload) on top.  Every lane runs the
+    //    (wave-uniform) recursion; lane 0 writes.
+    const StreamDesc dl = desc[(long)(LLICTI_NSTREAMS - 1) * B + b];
+    const int cnt = rans_stream_count(dl.n, m, M);
+    int T = 0;
+    {
+        const uint32_t *pl = pairs + dl.pair_off;
+        uint32_t xt = 1u << 31;
+        int tb = 0;
+        bool full = false;
+        for (int q1 = cnt; q1 > 0 && !full; q1 -= 64) {
+            const int q = q1 - 1 - lane;              // lane t holds the t-th symbol from the end of what is left
+            uint32_t raw = 0u;
+            if (q >= 0) raw = pl[64 * (m + (q >> 6) * M) + (q & 63)];
+            sh_pairs[lane] = raw;
+            __syncthreads();
+            const int nblk = min(64, q1);
+            for (int t = 0; t < nblk; ++t) {
+                if (T >= kRansTailMax) { full = true; break; }
+                const uint32_t v = sh_pairs[t];
+                const uint32_t lo = v & 0xFFFFu;
+                uint32_t hi = v >> 16;
+                if (hi == 0) hi = 0x10000u;
+                uint32_t freq = hi - lo;
+                if (freq == 0 || hi < lo) { bad = 1; freq = 1; }
+                const int nb = rans_emit_bits(xt, freq);
+                if (tb + nb + 32 > kRansPayBits) { full = true; break; }
+                if (lane == 0) lds_or_bits(sh_pay, tb, nb, xt & ((1u << nb) - 1u));
+                tb += nb;
+                xt = rans_push(xt >> nb, lo, freq);
+                ++T;
+            }
+            __syncthreads();
+        }
+        if (lane == 0) { lds_or_bits(sh_pay, tb, 16, xt & 0xFFFFu); lds_or_bits(sh_pay, tb + 16, 16, xt >> 16); }
+        __syncthreads();
+    }
+    // 2. the lanes start from the payload
+    uint32_t x = (1u << 31) | lds_get_bits(sh_pay, kRansStateBits * lane, kRansStateBits);
+    const int tail_from = cnt - T;                  // sequence position (64 k + lane) of the first tail symbol
+
+    // 3. main coder, last decoded symbol first; bits go UP from bit 0 of the bit region
+    int bp = 0, wbase = 0;                          // bit cursor; first dword of the staging window
     for (int st = LLICTI_NSTREAMS - 1; st >= 0; --st) {      // rANS is LIFO: last decoded symbol first
         const StreamDesc d = desc[(long)st * B + b];
         const int nchunks = (d.n + 63) >> 6;
         if (nchunks <= m) continue;
         const int K = (nchunks - m + M - 1) / M;
         const uint32_t *pp = pairs + d.pair_off;
+        const int lim = (st == LLICTI_NSTREAMS - 1) ? tail_from : 0x7FFFFFFF;
         // The pair loads do not depend on the coder state: four steps are kept in flight in four registers with
         // FIXED roles (the loop is unrolled by four; a rotating ring r0 = r1 ... makes the compiler copy the
         // newest load, i.e. wait for it with s_waitcnt vmcnt(0) in every step).  Loads are unconditional
         // (clamped address); the raw value is masked only where it is consumed.
         auto fetch = [&](int k) -> uint32_t { return pp[min(64 * (m + max(k, 0) * M) + lane, d.n - 1)]; };
         auto code = [&](int k, uint32_t raw) {
+            if (k < 0) return;                                       // wave-uniform
             const int n = 64 * (m + k * M) + lane;
-            const bool active = k >= 0 && n < d.n;
-            const uint32_t v = active ? raw : 0x00010000u;
+            const bool active = n < d.n && 64 * k + lane < lim;
+            const uint32_t v = active ? raw : 0u;                    // (lo, c_high) = (0, 2^16 stored as 0): freq 2^16, no bits
             const uint32_t lo = v & 0xFFFFu;
             uint32_t hi = v >> 16;
             if (hi == 0) hi = 0x10000u;
             uint32_t freq = hi - lo;
-            if (active && (freq == 0 || hi < lo)) { bad = 1; freq = 1; }
-            const bool emit = active && started && ((uint64_t)x >= ((uint64_t)freq << 16));
-            const uint64_t E = ballot64(emit);
-            p -= __builtin_popcountll(E);
-            if (p < 144) { bad = 2; p = 144; }                   // room for the state header (<= 140 words)
-            if (emit) { w16[p + lanes_below(E)] = (uint16_t)(x & 0xFFFFu); x >>= 16; }
-            if (active) {
-                if (!started) { x = freq; started = true; }          // absorbing start: codes to 2^16 + lo
-                // x < freq << 16 here, so the quotient fits 16 bits: a float reciprocal estimate is off by at most
-                // one, and one signed remainder test repairs it (8 operations instead of a 32-bit division)
-                uint32_t q = (uint32_t)((float)x * __builtin_amdgcn_rcpf((float)freq));
-                int32_t r = (int32_t)(x - q * freq);
-                if (r < 0) { q -= 1; r += (int32_t)freq; }
-                else if (r >= (int32_t)freq) { q += 1; r -= (int32_t)freq; }
-                x = (q << 16) + (uint32_t)r + lo;
+            if (freq == 0 || hi < lo) { bad = 1; freq = 1; }
+            const int nb = rans_emit_bits(x, freq);
+            // the decoder renormalises lane-ascending reading DOWN: lane 63's bits lowest
+            const int incl = wave_incl_scan(nb);
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            lds_or_bits(sh_win, bp + (total - incl) - 32 * wbase, nb, x & ((1u << nb) - 1u));
+            bp += total;
+            if (active) x = rans_push(x >> nb, lo, freq);
+            if (bp - 32 * wbase >= 2048) {                           // the window's lower half is complete
+                __syncthreads();
+                if (wbase + 64 <= cap_dw) out32[wbase + lane] = sh_win[lane]; else bad = 2;
+                const uint32_t up = sh_win[64 + lane];
+                __syncthreads();
+                sh_win[lane] = up; sh_win[64 + lane] = 0;
+                __syncthreads();
+                wbase += 64;
             }
         };
         uint32_t r0 = fetch(K - 1), r1 = fetch(K - 2), r2 = fetch(K - 3), r3 = fetch(K - 4);
@@ -72,78 +188,70 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restr
             code(k - 3, r3); r3 = fetch(k - 7);
         }
     }
-    // v2 compact flush of the 64 final states (x >> 16 is log-uniform in [1, 2^16): its bit length costs 4 bits, its
-    // leading one nothing): 64 nibbles nb = bitlen(x >> 16) - 1 | 64 x uint16 low halves | nb mantissa bits per lane, lane
-    // order, LSB first, zero padded to 16 bits  ->  160 .. 280 bytes instead of 256 (220 on average)
-    __shared__ uint32_t fl_bits[32];
-    if (lane < 32) fl_bits[lane] = 0;
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t hi16 = x >> 16;
-    const int nb = 31 - __clz((int)hi16);                     // 0 .. 15 (hi16 >= 1)
-    const uint32_t mant = hi16 & ((1u << nb) - 1u);
-    int pre = nb;                                             // inclusive prefix sum over the lanes
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(pre, d); if (lane >= d) pre += t; }
-    const int total_bits = __shfl(pre, 63);
-    const int bpos = pre - nb;
-    if (nb > 0) {
-        atomicOr(&fl_bits[bpos >> 5], mant << (bpos & 31));
-        if ((bpos & 31) + nb > 32) atomicOr(&fl_bits[(bpos >> 5) + 1], mant >> (32 - (bpos & 31)));
+    // 4. sentinel, the rest of the window, the 64 final states (31 bits each), T
+    __syncthreads();
+    if (lane == 0) atomicOr(&sh_win[(bp >> 5) - wbase], 1u << (bp & 31));
+    const int nbytes = (bp >> 3) + 1;
+    sh_pay[lane] = 0;
+    __syncthreads();
+    lds_or_bits(sh_pay, kRansStateBits * lane, 16, x & 0xFFFFu);
+    lds_or_bits(sh_pay, kRansStateBits * lane + 16, kRansStateBits - 16, (x >> 16) & 0x7FFFu);
+    __syncthreads();
+    const int ndw = (nbytes >> 2) - wbase;                    // whole window dwords still to write (<= 66); then 0..3 bytes
+    if ((nbytes >> 2) + 1 > cap_dw) bad = 2;
+    else {
+        if (lane < ndw) out32[wbase + lane] = sh_win[lane];
+        if (64 + lane < ndw) out32[wbase + 64 + lane] = sh_win[64 + lane];
+        if (lane < (nbytes & 3)) slot[4 + (nbytes & ~3) + lane] = (uint8_t)(sh_win[ndw] >> (8 * lane));
+        uint8_t *fs = slot + 4 + nbytes;
+        for (int t = lane; t < kRansPayBytes; t += 64) fs[t] = (uint8_t)(sh_pay[t >> 2] >> (8 * (t & 3)));
     }
-    __builtin_amdgcn_wave_barrier();
-    const int nw = (total_bits + 15) >> 4;                     // mantissa words (16 bit)
-    p -= 80 + nw;
-    if (p < 0) { bad = 2; p = 0; }
-    const int nb_next = __shfl_down(nb, 1);
-    uint8_t *hdr = reinterpret_cast<uint8_t *>(w16 + p);
-    if ((lane & 1) == 0) hdr[lane >> 1] = (uint8_t)(nb | (nb_next << 4));
-    w16[p + 16 + lane] = (uint16_t)(x & 0xFFFFu);
-    if (lane < nw) w16[p + 80 + lane] = (uint16_t)(fl_bits[lane >> 1] >> (16 * (lane & 1)));
-    if (lane == 0) { rinfo[2 * sidx] = (int32_t)(2 * p); rinfo[2 * sidx + 1] = (int32_t)(rslot_cap - 2 * p); }
+    if (lane == 0) {
+        slot[2] = (uint8_t)(T & 0xFF); slot[3] = (uint8_t)(T >> 8);
+        rinfo[2 * sidx] = 2; rinfo[2 * sidx + 1] = 2 + nbytes + kRansPayBytes;
+    }
     if (bad) atomicExch(&status[0], bad == 1 ? LLICTI_EFORMAT : LLICTI_ENOSPACE);
 }
 
-// decode: parse the compact state header of every stream (see rans_encode_kernel) -> 64 states, word cursor 0 and the
-// byte offset of the stream's first 16-bit word
+// decode: parse a stream (copied to slot + 2 by rans_unpack_kernel, which also left its validated length in rpos):
+// T, the sentinel (-> bit cursor), the 64 states
 __global__ __launch_bounds__(64) void rans_init_kernel(const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
-                                                       const int32_t *__restrict__ seg_len, int M,
                                                        uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos,
-                                                       uint32_t *__restrict__ rwoff, int32_t *status)
+                                                       uint32_t *__restrict__ rtail, int32_t *status)
 {
     const int sidx = blockIdx.x, lane = threadIdx.x;
-    const int b = sidx / M, m = sidx - b * M;
-    const uint8_t *hdr = slots + rslot_off[sidx];
-    const uint16_t *h16 = reinterpret_cast<const uint16_t *>(hdr);
-    const int n = seg_len[(long)b * LLICTI_NSEG + 4 + m];          // validated >= 160 by rans_unpack_kernel (else a harmless header was written)
-    const int nb = (hdr[lane >> 1] >> (4 * (lane & 1))) & 15;
-    int pre = nb;
+    const uint8_t *slot = slots + rslot_off[sidx];
+    const int n = (int)rpos[sidx];                                 // >= kRansMinStream
+    const int nbytes = n - 2 - kRansPayBytes;
+    int T = slot[2] | (slot[3] << 8);
+    const uint32_t lastb = slot[4 + nbytes - 1];
+    bool bad = false;
+    if (T > kRansTailMax) { bad = true; T = 0; }
+    int cur = 8 * (nbytes - 1);
+    if (lastb == 0) bad = true; else cur += 31 - __clz((int)lastb);
+    const uint8_t *fs = slot + 4 + nbytes;
+    const int bpos = kRansStateBits * lane;
+    uint64_t w = 0;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(pre, d); if (lane >= d) pre += t; }
-    const int total_bits = __shfl(pre, 63);
-    const int hbytes = 160 + 2 * ((total_bits + 15) >> 4);
-    uint32_t x = 1u << 16;
-    if (hbytes <= max(n, 160)) {
-        const int bpos = pre - nb;
-        const uint32_t win = (uint32_t)h16[80 + (bpos >> 4)] | ((uint32_t)h16[80 + (bpos >> 4) + 1] << 16);   // slot is zero padded past n
-        const uint32_t mant = (win >> (bpos & 15)) & ((1u << nb) - 1u);
-        x = (((1u << nb) | mant) << 16) | (uint32_t)h16[16 + lane];
-    } else if (lane == 0) atomicExch(&status[0], LLICTI_EFORMAT);
+    for (int k = 0; k < 5; ++k) w |= (uint64_t)fs[min((bpos >> 3) + k, kRansPayBytes - 1)] << (8 * k);
+    const uint32_t x = (1u << 31) | ((uint32_t)(w >> (bpos & 7)) & 0x7FFFFFFFu);
     rstate[(long)sidx * 64 + lane] = x;
-    if (lane == 0) { rpos[sidx] = 0; rwoff[sidx] = (uint32_t)min(hbytes, 280); }
+    if (lane == 0) { rpos[sidx] = (uint32_t)cur; rtail[sidx] = (uint32_t)T; }
+    if (bad && lane == 0) atomicExch(&status[0], LLICTI_EFORMAT);
 }
 
 // One stage (level, band, colour channel) of all images.  One workgroup of 4 wavefronts per stream (one per
 // SIMD: with the stage VALU-issue bound, the busiest SIMD sets the pace, so waves per workgroup is a multiple
 // of 4).  Every wave keeps its own copy of the 64 rANS states (the update is cheap and identical in all of
-// them), so a step needs ONE barrier.  A wave resolves 16 of the step's 64 symbols, 4 lanes per symbol: lanes
-// 0..2 of a group evaluate mixture components 0..2 of the probed table entry, lane 3 components 3 and 4; the
-// five terms are summed in the spec's order over DPP row shifts, and a ballot hands the comparison to the
-// group's lanes.  The symbol is first located with a CHEAP approximate CDF (Abramowitz-Stegun 7.1.26 erfc on
-// v_rcp / v_exp, ~0.01 table counts of error) by bisection, then PROVEN with the exact spec arithmetic:
-// entry[s] <= slot < entry[s+1] is checked with cdf_entry()'s operations, and if the guess is off the exact
-// search gallops away from it and bisects -- so the result is bit-identical to an exact search whatever the
-// approximation does.  The 64 (c_low, c_high) pairs meet in a ping-pong LDS buffer, after which every wave
-// updates and renormalises its state copy.  No table in HBM.
+// them), so a step needs ONE barrier.  A wave resolves 16 of the step's 64 symbols, 4 lanes per symbol: every lane of a
+// group holds all five mixture components and probes its own table entry.  The symbol is first located with a CHEAP
+// approximate CDF (Abramowitz-Stegun 7.1.26 erfc on v_rcp / v_exp, ~0.01 table counts of error) by 5-ary search, then
+// PROVEN with the exact spec arithmetic: entry[s] <= slot < entry[s+1] is checked with cdf_entry()'s operations, and if
+// the guess is off the exact search gallops away from it and bisects -- so the result is bit-identical to an exact
+// search whatever the approximation does.  The 64 (c_low, c_high) pairs meet in a ping-pong LDS buffer, after which
+// every wave updates its state copy and renormalises it bit-granularly: lane l needs clz(x) bits, a wave prefix sum
+// places them in the stream (read DOWN: the encoder wrote upwards), pulled from a 128-dword register window.
+// No table in HBM.
 constexpr int kRansWaves = 4;
 
 // (((tA0 + tA1) + tA2) + tA3) + tB3 of the 4-lane group starting at this lane (meaningful in the group's first lane)
@@ -216,9 +324,9 @@ template <int CLR>
 __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(const float *__restrict__ params, StageGeom sg, int M,
                                                                const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
                                                                int rslot_cap, uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos,
-                                                               const uint32_t *__restrict__ rwoff,
+                                                               const uint32_t *__restrict__ rtail,
                                                                int16_t *__restrict__ planes, float *__restrict__ fplanes,
-                                                               const int32_t *__restrict__ minmax, int later_max, int32_t *status)
+                                                               const int32_t *__restrict__ minmax, int last_stage, int32_t *status)
 {
     __shared__ uint32_t sh_res[2][64][2];        // ping-pong by step parity: [0] = c_low, [1] = c_high
     const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M;
@@ -227,10 +335,12 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
     const int nchunks = (nc + 63) >> 6;
     if (nchunks <= m) return;                    // whole workgroup
     const int K = (nchunks - m + M - 1) / M;
-    uint32_t x = rstate[(long)sidx * 64 + lane], pos = rpos[sidx];      // every wave: its own copy
-    const uint32_t woff = rwoff[sidx];                                  // bytes of the compact state header (160 .. 280, even)
-    const uint16_t *words = reinterpret_cast<const uint16_t *>(slots + rslot_off[sidx] + woff);
-    const uint32_t max_words = ((uint32_t)rslot_cap - woff) / 2;
+    uint32_t x = rstate[(long)sidx * 64 + lane];                       // every wave: its own copy
+    int bcur = (int)rpos[sidx];                                          // bit cursor in the stream's bit region, moving DOWN
+    const uint32_t *bitw = reinterpret_cast<const uint32_t *>(slots + rslot_off[sidx] + 4);
+    const int max_dw = (rslot_cap - 4) >> 2;
+    // the stream's tail symbols (last stage only) are not in the main stream: sequence position 64 k + lane >= tail_from
+    const int tail_from = last_stage ? rans_stream_count(nc, m, M) - (int)rtail[sidx] : 0x7FFFFFFF;
     constexpr int clr = CLR;                     // compile-time: no branch (hence no register merge, hence no s_waitcnt vmcnt(0)) next to the prefetch loads
     int minv, maxv, shift;
     clr_range(minmax + 4 * b, clr, minv, maxv, shift);
@@ -259,7 +369,7 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
             r.a0A = par[48 + 5 + mA]; r.a1A = par[48 + 10 + mA]; r.a0B = par[48 + 5 + 4]; r.a1B = par[48 + 10 + 4];
             r.y = fplanes[r.off]; r.co = fplanes[r.off + sg.plane];
         }
-        r.on = (k < K) && (64 * (m + k * M) + gsym) < nc;
+        r.on = (k < K) && (64 * (m + k * M) + gsym) < nc && (64 * k + gsym) < tail_from;
         return r;
     };
     // component (sigma, mu, w) -> (mu with the cross-channel update, 1 / max(sigma, bound), max(w, bound)), as mix_prepare()
@@ -273,11 +383,12 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
         cpt.wn = 0.0f;
         return cpt;
     };
-    // Stream words: lane l holds word wbase + l, a second register the 64 after them; a step consumes at most
-    // 64 words, pulled with ds_bpermute instead of a dependent global load.
-    uint32_t wbase = pos & ~63u;
-    auto load_words = [&](uint32_t w0) -> uint32_t { return words[min(w0 + (uint32_t)lane, max_words - 1)]; };
-    uint32_t win0 = load_words(wbase), win1 = load_words(wbase + 64);
+    // Stream bits: register window of 128 dwords below wtop (a multiple of 64): lane l of winA holds dword wtop - 64 + l,
+    // of winB dword wtop - 128 + l; bcur stays in (32 (wtop - 64), 32 wtop] and a step consumes at most 1024 bits, pulled
+    // with ds_bpermute instead of a dependent global load.
+    int wtop = max(64, (((bcur + 31) >> 5) + 63) & ~63);
+    auto load_dw = [&](int d0) -> uint32_t { return bitw[min(max(d0 + lane, 0), max_dw - 1)]; };
+    uint32_t winA = load_dw(wtop - 64), winB = load_dw(wtop - 128);
     Raw cur = fetch(0);
     for (int k = 0; k < K; ++k) {
         const int chunk0 = 64 * (m + k * M);
@@ -383,34 +494,126 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
         }
         __syncthreads();
         {
-            const bool active = chunk0 + lane < nc;
-            // v2: a lane's last symbol (no later slot in this stage, none in any later stage: lane l of stream m is active
-            // in a stage of n symbols iff 64 m + l < n) is followed by no read, and must leave the encoder's start state freq
-            const bool fin = active && (chunk0 + lane + 64 * M >= nc) && (64 * m + lane >= later_max);
+            const bool active = chunk0 + lane < nc && 64 * k + lane < tail_from;
+            int nb = 0;
             if (active) {
                 const uint32_t vlo = sh_res[k & 1][lane][0], vhi = sh_res[k & 1][lane][1];
-                x = (vhi - vlo) * (x >> 16) + (x & 0xFFFFu) - vlo;
-                if (fin && x != vhi - vlo && wave == 0) atomicExch(&status[0], LLICTI_EFORMAT);
+                x = (vhi - vlo) * (x >> 16) + (x & 0xFFFFu) - vlo;            // in [freq << 15, freq << 16)
+                nb = min(__clz((int)x), 16);                                   // > 16 only on a corrupt stream (caught by the end checks)
             }
-            const bool need = active && !fin && x < 0x10000u;
-            const uint64_t E = ballot64(need);
-            const uint32_t idx = pos + (uint32_t)lanes_below(E);
-            const uint32_t rel = idx - wbase;                                   // < 128
-            const uint32_t wa = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (int)(rel & 63u), (int)win0);
-            const uint32_t wb = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (int)(rel & 63u), (int)win1);
-            if (need) {
-                const uint32_t wv = (idx < max_words) ? ((rel < 64u) ? wa : wb) : 0u;
-                x = (x << 16) | wv;
-            }
-            pos += (uint32_t)__builtin_popcountll(E);
-            if (pos - wbase >= 64u) { wbase += 64u; win0 = win1; win1 = load_words(wbase + 64); }
+            const int incl = wave_incl_scan(nb);
+            const int bpos = bcur - incl;                                       // this lane's bits: [bpos, bpos + nb)
+            const int d = bpos >> 5;                                           // wtop - 128 <= d < wtop on a well-formed stream
+            const uint32_t a0 = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (d & 63), (int)winA);
+            const uint32_t b0 = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (d & 63), (int)winB);
+            const uint32_t a1 = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * ((d + 1) & 63), (int)winA);
+            const uint32_t b1 = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * ((d + 1) & 63), (int)winB);
+            const uint32_t w0 = (d >= wtop - 64) ? a0 : b0;
+            const uint32_t w1 = (d + 1 >= wtop - 64) ? a1 : b1;
+            const uint32_t bits = __builtin_amdgcn_alignbit(w1, w0, (uint32_t)(bpos & 31)) & ((1u << nb) - 1u);
+            x = (x << nb) | bits;
+            bcur -= __builtin_amdgcn_readlane(incl, 63);
+            if (bcur <= 32 * (wtop - 64) && wtop > 64) { wtop -= 64; winA = winB; winB = load_dw(wtop - 128); }
         }
         cur = nxt;
     }
     if (wave == 0) {
         rstate[(long)sidx * 64 + lane] = x;
-        if (lane == 0) rpos[sidx] = pos;
+        if (lane == 0) {
+            rpos[sidx] = (uint32_t)max(bcur, 0);
+            if (bcur < 0) atomicExch(&status[0], LLICTI_EFORMAT);              // the stream ran out of bits
+        }
     }
+}
+
+// After the last stage the 64 states of a stream ARE its tail stream (31 bits each, the tail coder's final state on top,
+// its leading one the highest set bit).  One wavefront per stream decodes the T tail symbols serially -- all of the last
+// stage's Cg channel (level 0, band x10) -- with all 64 lanes on one symbol: lane l evaluates entry 8 l exactly (64
+// anchors cover Lp <= 512), a ballot picks the bucket, lanes 0..8 its nine entries, a second ballot the symbol.
+// Checks: the main region was read to its last bit, the tail state ends at 2^31 with no bit left.
+__global__ __launch_bounds__(64) void rans_tail_kernel(const float *__restrict__ params, StageGeom sg, int M,
+                                                       const uint32_t *__restrict__ rstate, const uint32_t *__restrict__ rpos,
+                                                       const uint32_t *__restrict__ rtail,
+                                                       int16_t *__restrict__ planes, float *__restrict__ fplanes,
+                                                       const int32_t *__restrict__ minmax, int32_t *status)
+{
+    __shared__ uint32_t sh_pay[66];
+    const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M, lane = threadIdx.x;
+    const int nc = sg.hc * sg.wc;
+    const int T = (int)rtail[sidx];
+    const int cnt = rans_stream_count(nc, m, M);
+    bool bad = rpos[sidx] != 0 || T > cnt;
+    sh_pay[lane] = 0;
+    if (lane < 2) sh_pay[64 + lane] = 0;
+    __syncthreads();
+    const uint32_t xl = rstate[(long)sidx * 64 + lane] & 0x7FFFFFFFu;
+    lds_or_bits(sh_pay, kRansStateBits * lane, 16, xl & 0xFFFFu);
+    lds_or_bits(sh_pay, kRansStateBits * lane + 16, kRansStateBits - 16, xl >> 16);
+    __syncthreads();
+    const uint64_t nz = ballot64(sh_pay[lane] != 0);
+    int top = -1;
+    if (nz) {
+        const int hd = 63 - __clzll((long long)nz);
+        top = 32 * hd + 31 - __clz((int)sh_pay[hd]);
+    }
+    if (top < 31 || bad) {
+        if (lane == 0) atomicExch(&status[0], LLICTI_EFORMAT);
+        return;                                                                // whole wave
+    }
+    uint32_t xt = lds_get_bits(sh_pay, top - 31, 32);
+    int tc = top - 31;
+    int minv, maxv, shift;
+    clr_range(minmax + 4 * b, 2, minv, maxv, shift);
+    const Grid gr = make_grid(minv, maxv);
+    const int max_symbol = gr.Lp - 2;
+    const long img = (long)b * 3 * sg.plane;
+    auto fetch = [&](int q, float *par, float &y, float &co, long &off) {
+        const int n = min(64 * (m + (q >> 6) * M) + (q & 63), nc - 1);
+        const int i = div_wc(sg, n), j = n - i * sg.wc;
+        const float *src = params + ((long)b * sg.h * sg.w + (long)i * sg.w + j) * LLICTI_PARAM_STRIDE;
+        off = img + ((long)(2 * i + sg.oi) << sg.lvl) * sg.W + ((long)(2 * j + sg.oj) << sg.lvl);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {                                         // only what the Cg channel reads
+            par[10 + k] = src[10 + k]; par[16 + 10 + k] = src[16 + 10 + k]; par[32 + 10 + k] = src[32 + 10 + k];
+            par[48 + 5 + k] = src[48 + 5 + k]; par[48 + 10 + k] = src[48 + 10 + k];
+        }
+        y = fplanes[off]; co = fplanes[off + sg.plane];
+    };
+    float parA[LLICTI_PARAM_STRIDE], parB[LLICTI_PARAM_STRIDE];
+    float yA, coA, yB, coB;
+    long offA, offB;
+    if (T > 0) fetch(cnt - T, parA, yA, coA, offA);
+    for (int q = cnt - T; q < cnt; ++q) {
+        fetch(min(q + 1, cnt - 1), parB, yB, coB, offB);                      // next symbol's row: one step ahead
+        Mix mx;
+        mix_prepare(parA, 2, yA, coA, mx);
+        const uint32_t slot = xt & 0xFFFFu;
+        const int i1 = 8 * lane;
+        const uint32_t e1 = cdf_entry(mx, gr, min(i1, max_symbol));
+        const uint64_t p1 = ballot64(lane == 0 || (i1 <= max_symbol && e1 <= slot));      // entry 0 is the floor of the search
+        const int bkt = __builtin_popcountll(p1) - 1;
+        const int i2 = 8 * bkt + lane;
+        uint32_t e2 = 0x10000u;                                                // past the top symbol: c_high = 2^16 by definition
+        if (lane < 9 && i2 <= max_symbol) e2 = cdf_entry(mx, gr, i2);
+        const uint64_t p2 = ballot64(lane == 0 || (lane < 8 && i2 <= max_symbol && e2 <= slot));
+        const int np = __builtin_popcountll(p2 & 0xFFull);                    // 1 .. 8
+        const uint32_t vlo = (uint32_t)__shfl((int)e2, np - 1), vhi = (uint32_t)__shfl((int)e2, np);
+        const int s = 8 * bkt + np - 1;
+        if (lane == 0) {
+            const int v = s - shift;
+            planes[offA + 2 * sg.plane] = (int16_t)v;
+            fplanes[offA + 2 * sg.plane] = (float)v / 255.0f;
+        }
+        xt = (vhi - vlo) * (xt >> 16) + slot - vlo;
+        const int nb = __clz((int)xt);
+        if (nb > 16 || tc < nb) { bad = true; break; }
+        tc -= nb;
+        xt = (xt << nb) | lds_get_bits(sh_pay, tc, nb);
+#pragma unroll
+        for (int k = 0; k < LLICTI_PARAM_STRIDE; ++k) parA[k] = parB[k];
+        yA = yB; coA = coB; offA = offB;
+    }
+    if ((bad || xt != (1u << 31) || tc != 0) && lane == 0) atomicExch(&status[0], LLICTI_EFORMAT);
 }
 
 __global__ __launch_bounds__(256) void rans_pack_kernel(const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
@@ -433,7 +636,7 @@ __global__ __launch_bounds__(256) void rans_pack_kernel(const uint8_t *__restric
 
 __global__ __launch_bounds__(256) void rans_unpack_kernel(const uint8_t *__restrict__ in, long in_stride, const int32_t *__restrict__ seg_len,
                                                           int M, uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
-                                                          int rslot_cap, int32_t *status)
+                                                          int rslot_cap, uint32_t *__restrict__ rpos, int32_t *status)
 {
     const int m = blockIdx.x, b = blockIdx.y;
     const int32_t *sl = seg_len + (long)b * LLICTI_NSEG;
@@ -446,15 +649,16 @@ __global__ __launch_bounds__(256) void rans_unpack_kernel(const uint8_t *__restr
         if (src < 0 || src > in_stride) { bad = true; src = 0; }
     }
     int n = sl[4 + m];
-    uint8_t *o = slots + rslot_off[b * M + m];
-    if (bad || n < 160 || n > rslot_cap || src + n > in_stride) {
+    uint8_t *o = slots + rslot_off[b * M + m] + 2;               // the bit region (stream offset 2) lands dword aligned
+    if (bad || n < kRansMinStream || n + 2 + 64 > rslot_cap || src + n > in_stride) {
         if (threadIdx.x == 0) atomicExch(&status[0], LLICTI_EFORMAT);
-        for (int t = threadIdx.x; t < 160; t += blockDim.x) o[t] = 0;                       // states = 1 << 16, no mantissa bits: harmless
-        n = 160;
+        n = kRansMinStream;                                        // a harmless stream: T = 0, sentinel only, states 2^31
+        for (int t = threadIdx.x; t < n; t += blockDim.x) o[t] = (t == 2) ? 1 : 0;
     } else {
         const uint8_t *p = in + (long)b * in_stride + src;
         block_copy_bytes(o, p, n);
     }
-    const int padded = min(rslot_cap, n + 64);
+    const int padded = min(rslot_cap - 2, n + 64);
     for (int t = n + threadIdx.x; t < padded; t += blockDim.x) o[t] = 0;
+    if (threadIdx.x == 0) rpos[b * M + m] = (uint32_t)n;         // the length rans_init_kernel parses
 }

@@ -777,8 +777,44 @@ int orc_decode_image(const uint8_t *in, const int32_t seg_len[49], const orc_wei
     return 0;
 }
 
-/* ------------------------------------------------------------------ rANS container (new format, see header) */
+/* ------------------------------------------------------------------ rANS container "LLICTI-rANS v3" (see header) */
 typedef struct { long n; uint32_t *clow, *chigh; } stage_syms_t;
+
+#define RANS_LANES      64
+#define RANS_STATE_BITS 31                              /* a lane state is 2^31 | 31 bits */
+#define RANS_PAY_BITS   (RANS_LANES * RANS_STATE_BITS)  /* 1984: what the 64 initial states carry (the tail stream) */
+#define RANS_TAIL_MAX   2047
+
+static inline void put_bits(uint8_t *buf, long pos, int n, uint32_t v)      /* LSB first */
+{
+    for (int b = 0; b < n; ++b, ++pos)
+        if ((v >> b) & 1u) buf[pos >> 3] |= (uint8_t)(1u << (pos & 7));
+}
+static inline uint32_t get_bits(const uint8_t *buf, long pos, int n)        /* pos >= 0 */
+{
+    uint32_t v = 0;
+    for (int b = 0; b < n; ++b, ++pos) v |= (uint32_t)((buf[pos >> 3] >> (pos & 7)) & 1u) << b;
+    return v;
+}
+/* encoder renormalisation: the smallest n with (x >> n) < freq << 16, for a state x in [2^31, 2^32) */
+static inline int rans_emit_bits(uint32_t x, uint32_t freq)
+{
+    int n = 0;
+    while (((uint64_t)x >> n) >= ((uint64_t)freq << 16)) ++n;
+    return n;
+}
+static inline uint32_t rans_push(uint32_t x, uint32_t lo, uint32_t freq) { return ((x / freq) << 16) + (x % freq) + lo; }
+static inline int clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
+
+/* symbols of stream m in a stage of nc symbols: chunks m, m + M, ...; only the stage's last chunk can be partial */
+static long rans_stream_count(long nc, int m, int M)
+{
+    const long nchunks = (nc + 63) / 64;
+    if (nchunks <= m) return 0;
+    const long K = (nchunks - m + M - 1) / M;
+    const long last = m + (K - 1) * M;
+    return 64 * K - ((last == nchunks - 1 && (nc & 63)) ? 64 - (nc & 63) : 0);
+}
 
 long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *wts, int M,
                            uint8_t *out, long cap, int32_t seg_len[49])
@@ -797,7 +833,7 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
     const int h4 = h, w4 = w;
     if (cap < 17 + 3L * h4 * w4) { free(planes); return -1; }
     for (int i = 0; i < 49; ++i) seg_len[i] = 0;
-    out[pos++] = (uint8_t)(0x80 | (lgM << 4) | ORC_NLEV); out[pos++] = (uint8_t)h4; out[pos++] = (uint8_t)w4;
+    out[pos++] = (uint8_t)(0x88 | (lgM << 4) | ORC_NLEV); out[pos++] = (uint8_t)h4; out[pos++] = (uint8_t)w4;
     seg_len[0] = 3;
     memcpy(out + pos, minmax, 12); pos += 12; seg_len[1] = 12;
     int padint = 0;
@@ -834,71 +870,93 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
     }
     free(planes);
     long rc = 0;
-    uint16_t *wbuf = (uint16_t *)malloc(sizeof(uint16_t) * (total + 64));
+    const long bcap = 2 * total + 64;                    /* <= 16 bits per symbol + sentinel */
+    uint8_t *bits = (uint8_t *)malloc(bcap);
+    const int S = ORC_NSTREAM - 1;                       /* the last stage: the only one the tail may take symbols from */
     for (int m = 0; m < M && rc >= 0; ++m) {
-        uint32_t x[64];
-        int started[64];
-        for (int l = 0; l < 64; ++l) { x[l] = 1u << 16; started[l] = 0; }
-        long p = total + 64;                     /* words are written backwards from the end */
-        for (int s = ORC_NSTREAM - 1; s >= 0; --s) {
+        /* 1. tail: the stream's last T symbols (decode order), single-state coder, pushed last symbol first; its bits
+         *    go UP from bit 0 of the payload, its final state (32 bits, leading one = the payload's highest set bit) on top */
+        uint8_t pay[RANS_PAY_BITS / 8];
+        memset(pay, 0, sizeof pay);
+        const long cnt = rans_stream_count(st[S].n, m, M);
+        uint32_t xt = 1u << 31;
+        long tb = 0, T = 0;
+        while (T < cnt && T < RANS_TAIL_MAX) {
+            const long q = cnt - 1 - T;
+            const long n = 64 * (m + (q / 64) * M) + (q & 63);
+            const uint32_t lo = st[S].clow[n], freq = st[S].chigh[n] - lo;
+            if (freq == 0 || freq > 0x10000u) { rc = -5; break; }
+            const int nb = rans_emit_bits(xt, freq);
+            if (tb + nb + 32 > RANS_PAY_BITS) break;
+            put_bits(pay, tb, nb, xt & ((1u << nb) - 1u));
+            tb += nb;
+            xt = rans_push(xt >> nb, lo, freq);
+            ++T;
+        }
+        if (rc < 0) break;
+        put_bits(pay, tb, 32, xt);
+        /* 2. the 64 lanes start from the payload: lane l = 2^31 | payload bits [31 l, 31 l + 31) */
+        uint32_t x[RANS_LANES];
+        for (int l = 0; l < RANS_LANES; ++l) x[l] = (1u << 31) | get_bits(pay, (long)RANS_STATE_BITS * l, RANS_STATE_BITS);
+        /* 3. main coder, last decoded symbol first; bits go UP from bit 0 of the stream's bit region */
+        memset(bits, 0, bcap);
+        long bp = 0;
+        for (int s = ORC_NSTREAM - 1; s >= 0 && rc >= 0; --s) {
             const long nchunks = (st[s].n + 63) / 64;
             if (nchunks <= m) continue;
             const long K = (nchunks - m + M - 1) / M;
-            for (long k = K - 1; k >= 0; --k) {
+            for (long k = K - 1; k >= 0 && rc >= 0; --k) {
                 const long c = m + k * M;
-                for (int l = 63; l >= 0; --l) {  /* highest lane first: the decoder reads lane-ascending */
+                for (int l = RANS_LANES - 1; l >= 0; --l) {     /* highest lane first: the decoder renormalises lane-ascending, reading DOWN */
                     const long n = 64 * c + l;
                     if (n >= st[s].n) continue;
+                    if (s == S && 64 * k + l >= cnt - T) continue;          /* coded by the tail */
                     const uint32_t lo = st[s].clow[n], freq = st[s].chigh[n] - lo;
-                    if (freq == 0) { rc = -5; break; }
-                    if (!started[l]) continue;   /* v2: the lane's first coded (= last decoded) symbol never emits */
-                    if ((uint64_t)x[l] >= ((uint64_t)freq << 16)) { wbuf[--p] = (uint16_t)(x[l] & 0xFFFF); x[l] >>= 16; }
-                }
-                for (int l = 0; l < 64; ++l) {
-                    const long n = 64 * c + l;
-                    if (n >= st[s].n) continue;
-                    const uint32_t lo = st[s].clow[n], freq = st[s].chigh[n] - lo;
-                    if (freq == 0) break;
-                    /* v2 "absorbing start": the first symbol a lane codes starts from state freq, so that the coded state
-                     * is 2^16 + c_low: the 16 bits every rANS state carries anyway now hold that symbol, instead of nothing */
-                    if (!started[l]) { x[l] = freq; started[l] = 1; }
-                    x[l] = ((x[l] / freq) << 16) + (x[l] % freq) + lo;
+                    if (freq == 0 || freq > 0x10000u) { rc = -5; break; }
+                    const int nb = rans_emit_bits(x[l], freq);
+                    put_bits(bits, bp, nb, x[l] & ((1u << nb) - 1u));
+                    bp += nb;
+                    x[l] = rans_push(x[l] >> nb, lo, freq);
                 }
             }
         }
-        const long nwords = total + 64 - p;
-        /* v2 compact state flush: 64 nibbles (bit length of x >> 16, minus 1) | 64 x uint16 low halves | the bits of
-         * x >> 16 below its leading one, lane order, LSB first, padded to 16 bits */
-        uint8_t hdr[160 + 120];
-        memset(hdr, 0, sizeof hdr);
-        long bitpos = 0;
-        for (int l = 0; l < 64; ++l) {
-            const uint32_t hi = x[l] >> 16, lo = x[l] & 0xFFFFu;
-            int nb = 0;
-            while ((hi >> nb) > 1) ++nb;                 /* nb = bit length - 1 (hi >= 1 always) */
-            hdr[l >> 1] |= (uint8_t)(nb << (4 * (l & 1)));
-            hdr[32 + 2 * l] = (uint8_t)(lo & 0xFF); hdr[32 + 2 * l + 1] = (uint8_t)(lo >> 8);
-            const uint32_t mant = hi & ((1u << nb) - 1u);
-            for (int b = 0; b < nb; ++b, ++bitpos)
-                if ((mant >> b) & 1u) hdr[160 + (bitpos >> 3)] |= (uint8_t)(1u << (bitpos & 7));
-        }
-        const long hbytes = 160 + 2 * ((bitpos + 15) / 16);
-        const long bytes = hbytes + 2 * nwords;
+        if (rc < 0) break;
+        put_bits(bits, bp, 1, 1u);                       /* sentinel: the highest set bit of the region's last byte */
+        const long nbytes = bp / 8 + 1;
+        const long bytes = 2 + nbytes + RANS_PAY_BITS / 8;
         if (pos + bytes > cap) { rc = -1; break; }
-        memcpy(out + pos, hdr, hbytes); pos += hbytes;
-        memcpy(out + pos, wbuf + p, 2 * nwords); pos += 2 * nwords;
+        out[pos] = (uint8_t)(T & 0xFF); out[pos + 1] = (uint8_t)(T >> 8);
+        memcpy(out + pos + 2, bits, nbytes);
+        uint8_t *fs = out + pos + 2 + nbytes;
+        memset(fs, 0, RANS_PAY_BITS / 8);
+        for (int l = 0; l < RANS_LANES; ++l) put_bits(fs, (long)RANS_STATE_BITS * l, RANS_STATE_BITS, x[l] & 0x7FFFFFFFu);
+        pos += bytes;
         seg_len[4 + m] = (int32_t)bytes;
     }
-    free(wbuf);
+    free(bits);
     for (int s = 0; s < ORC_NSTREAM; ++s) { free(st[s].clow); free(st[s].chigh); }
     return rc < 0 ? rc : pos;
+}
+
+/* exact symbol search on the spec's table: largest idx in [0, max_symbol] whose entry is <= slot (idx 0 always qualifies) */
+static inline int rans_find(const mix_t *mx, uint32_t slot, int Lp, int minv, int maxv, uint32_t *c_low, uint32_t *c_high)
+{
+    const int max_symbol = Lp - 2;
+    int lo = 0, hi = max_symbol + 1;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (cdf_entry(mx, mid, Lp, minv, maxv) <= slot) lo = mid; else hi = mid;
+    }
+    *c_low = cdf_entry(mx, lo, Lp, minv, maxv);
+    *c_high = (lo == max_symbol) ? 0x10000u : cdf_entry(mx, lo + 1, Lp, minv, maxv);
+    return lo;
 }
 
 int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const orc_weights *wts,
                           uint8_t *rgb, long rgb_cap, int *H_out, int *W_out)
 {
     if (seg_len[0] != 3 || seg_len[1] != 12 || seg_len[2] != 2) return -3;
-    if ((in[0] & 0x8F) != (0x80 | ORC_NLEV)) return -4;
+    if ((in[0] & 0x8F) != (0x88 | ORC_NLEV)) return -4;          /* 0x85: the retired v2 format */
     const int M = 1 << ((in[0] >> 4) & 7);
     int H, W;
     orc_header_dims(in, seg_len, &H, &W);
@@ -909,6 +967,29 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
     memcpy(minmax, in + 3, 12);
     const int h4 = in[1], w4 = in[2];
     if (seg_len[3] != 3 * h4 * w4) return -3;
+    /* streams: T | bit region (read DOWN from the sentinel) | 64 x 31-bit states */
+    uint32_t (*x)[RANS_LANES] = (uint32_t (*)[RANS_LANES])malloc(sizeof(uint32_t) * RANS_LANES * M);
+    const uint8_t **bitsp = (const uint8_t **)malloc(sizeof(uint8_t *) * M);
+    long *cur = (long *)calloc(M, sizeof(long)), *T = (long *)calloc(M, sizeof(long));
+    int bad = 0;
+    {
+        long pos = 17 + seg_len[3];
+        for (int m = 0; m < M; ++m) {
+            const long len = seg_len[4 + m];
+            if (len < 2 + 1 + RANS_PAY_BITS / 8) { free(x); free(bitsp); free(cur); free(T); return -3; }
+            const uint8_t *sp = in + pos;
+            const int t = sp[0] | (sp[1] << 8);
+            const long nbytes = len - 2 - RANS_PAY_BITS / 8;
+            const uint8_t lastb = sp[2 + nbytes - 1];
+            if (t > RANS_TAIL_MAX || lastb == 0) { free(x); free(bitsp); free(cur); free(T); return -3; }
+            T[m] = t;
+            bitsp[m] = sp + 2;
+            cur[m] = 8 * (nbytes - 1) + (31 - clz32(lastb));          /* position of the sentinel = number of data bits */
+            const uint8_t *fs = sp + 2 + nbytes;
+            for (int l = 0; l < RANS_LANES; ++l) x[m][l] = (1u << 31) | get_bits(fs, (long)RANS_STATE_BITS * l, RANS_STATE_BITS);
+            pos += len;
+        }
+    }
     int16_t *planes = (int16_t *)calloc(3 * plane_sz, sizeof(int16_t));
     const uint8_t *dc = in + 17;
     for (int i = 0; i < h4; ++i)
@@ -920,48 +1001,8 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
             planes[plane_sz + off] = (int16_t)Co;
             planes[2 * plane_sz + off] = (int16_t)Cg;
         }
-    /* stream states and word cursors */
-    uint32_t (*x)[64] = (uint32_t (*)[64])malloc(sizeof(uint32_t) * 64 * M);
-    const uint8_t **words = (const uint8_t **)malloc(sizeof(uint8_t *) * M);
-    long *wpos = (long *)calloc(M, sizeof(long)), *wcnt = (long *)calloc(M, sizeof(long));
-    long pos = 17 + seg_len[3];
-    for (int m = 0; m < M; ++m) {
-        if (seg_len[4 + m] < 160) { free(planes); free(x); free(words); free(wpos); free(wcnt); return -3; }
-        const uint8_t *hd = in + pos;
-        long bitpos = 0, nbits = 0;
-        for (int l = 0; l < 64; ++l) nbits += (hd[l >> 1] >> (4 * (l & 1))) & 15;
-        const long hbytes = 160 + 2 * ((nbits + 15) / 16);
-        if (seg_len[4 + m] < hbytes) { free(planes); free(x); free(words); free(wpos); free(wcnt); return -3; }
-        for (int l = 0; l < 64; ++l) {
-            const int nb = (hd[l >> 1] >> (4 * (l & 1))) & 15;
-            uint32_t mant = 0;
-            for (int b = 0; b < nb; ++b, ++bitpos) mant |= (uint32_t)((hd[160 + (bitpos >> 3)] >> (bitpos & 7)) & 1u) << b;
-            const uint32_t hi = (1u << nb) | mant, lo = (uint32_t)hd[32 + 2 * l] | ((uint32_t)hd[32 + 2 * l + 1] << 8);
-            x[m][l] = (hi << 16) | lo;
-        }
-        words[m] = in + pos + hbytes;
-        wcnt[m] = (seg_len[4 + m] - hbytes) / 2;
-        pos += seg_len[4 + m];
-    }
     int Hl, Wl, h, w, padH, padW;
-    /* v2: a lane's LAST symbol (the first one its encoder coded) is followed by no renormalisation read; lane l of
-     * stream m is active in a stage of n symbols iff 64 m + l < n, so "last" needs the largest later stage */
-    long later_max[ORC_NSTREAM + 1];
-    {
-        long nst[ORC_NSTREAM];
-        int si = 0;
-        for (int lvl = ORC_NLEV - 1; lvl >= 0; --lvl) {
-            orc_level_geom(H, W, lvl, &Hl, &Wl, &h, &w, &padH, &padW);
-            for (int band = 0; band < 3; ++band) {
-                int hc, wc;
-                stream_dims(h, w, padH, padW, band, &hc, &wc);
-                for (int clr = 0; clr < 3; ++clr) nst[si++] = (long)hc * wc;
-            }
-        }
-        later_max[ORC_NSTREAM] = 0;
-        for (int k = ORC_NSTREAM - 1; k >= 0; --k) later_max[k] = nst[k] > later_max[k + 1] ? nst[k] : later_max[k + 1];
-    }
-    int stage = 0, bad = 0;
+    int stage = 0;
     for (int lvl = ORC_NLEV - 1; lvl >= 0; --lvl) {
         orc_level_geom(H, W, lvl, &Hl, &Wl, &h, &w, &padH, &padW);
         float *params = (float *)malloc(sizeof(float) * (long)h * w * ORC_NPAR);
@@ -977,48 +1018,84 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
                 const int maxv = (clr == 0) ? 128 : minmax[3 + clr];
                 const int shift = (clr == 0) ? 127 : -minmax[clr];
                 const int Lp = maxv - minv + 2;
-                const int max_symbol = Lp - 2;
+                const int last_stage = (stage == ORC_NSTREAM - 1);
                 for (long c = 0; c < nchunks; ++c) {
                     const int m = (int)(c % M);
-                    for (int l = 0; l < 64; ++l) {
+                    const long k = c / M;
+                    const long cnt = last_stage ? rans_stream_count(n_sym, m, M) : 0;
+                    int nb[RANS_LANES];
+                    for (int l = 0; l < RANS_LANES; ++l) nb[l] = -1;
+                    for (int l = 0; l < RANS_LANES; ++l) {
                         const long q = 64 * c + l;
                         if (q >= n_sym) break;
+                        if (last_stage && 64 * k + l >= cnt - T[m]) continue;      /* tail symbol: decoded after the stages */
                         int i = (int)(q / wc), j = (int)(q % wc);
                         long off = ((long)(2 * i + BAND_OI[src]) << lvl) * W + ((long)(2 * j + BAND_OJ[src]) << lvl);
                         mix_t mx;
                         mix_prepare(params + ((long)i * w + j) * ORC_NPAR, clr, (float)planes[off] / 255.0f,
                                     (float)planes[plane_sz + off] / 255.0f, &mx);
                         const uint32_t slot = x[m][l] & 0xFFFF;
-                        /* largest idx in [0, max_symbol] whose entry is <= slot (idx 0 always qualifies) */
-                        int lo = 0, hi = max_symbol + 1;
-                        while (hi - lo > 1) {
-                            int mid = (lo + hi) >> 1;
-                            if (cdf_entry(&mx, mid, Lp, minv, maxv) <= slot) lo = mid; else hi = mid;
-                        }
-                        const uint32_t c_low = cdf_entry(&mx, lo, Lp, minv, maxv);
-                        const uint32_t c_high = (lo == max_symbol) ? 0x10000u : cdf_entry(&mx, lo + 1, Lp, minv, maxv);
+                        uint32_t c_low, c_high;
+                        const int s = rans_find(&mx, slot, Lp, minv, maxv, &c_low, &c_high);
                         x[m][l] = (c_high - c_low) * (x[m][l] >> 16) + slot - c_low;
-                        planes[clr * plane_sz + off] = (int16_t)(lo - shift);
-                        if (q + 64L * M >= n_sym && 64L * m + l >= later_max[stage + 1] && x[m][l] != c_high - c_low)
-                            bad = 1;             /* the lane's last symbol must leave the encoder's start state: freq */
+                        planes[clr * plane_sz + off] = (int16_t)(s - shift);
+                        nb[l] = clz32(x[m][l]);
+                        if (nb[l] > 16) { bad = 1; nb[l] = 16; }
                     }
-                    for (int l = 0; l < 64; ++l) {       /* renormalise lane-ascending */
-                        const long q = 64 * c + l;
-                        if (q >= n_sym) break;
-                        if (q + 64L * M >= n_sym && 64L * m + l >= later_max[stage + 1]) continue;   /* v2: lane finished */
-                        if (x[m][l] < (1u << 16)) {
-                            uint16_t wv = 0;
-                            if (wpos[m] < wcnt[m]) memcpy(&wv, words[m] + 2 * wpos[m], 2);
-                            wpos[m]++;
-                            x[m][l] = (x[m][l] << 16) | wv;
-                        }
+                    for (int l = 0; l < RANS_LANES; ++l) {       /* renormalise lane-ascending, reading DOWN */
+                        if (nb[l] < 0) continue;
+                        if (cur[m] < nb[l]) { bad = 1; x[m][l] = (x[m][l] << nb[l]) | (1u << 31); continue; }
+                        cur[m] -= nb[l];
+                        x[m][l] = (x[m][l] << nb[l]) | get_bits(bitsp[m], cur[m], nb[l]);
+                        if (!(x[m][l] >> 31)) { bad = 1; x[m][l] |= 1u << 31; }
                     }
                 }
+            }
+        }
+        if (lvl == 0) {
+            /* tails: what the 64 states of a stream are left with is the tail stream; its final state sits on top */
+            const int band = 2, clr = 2, src = 3;
+            int hc, wc;
+            stream_dims(h, w, padH, padW, band, &hc, &wc);
+            const long n_sym = (long)hc * wc;
+            const int minv = minmax[2], maxv = minmax[5], shift = -minmax[2];
+            const int Lp = maxv - minv + 2;
+            for (int m = 0; m < M; ++m) {
+                if (cur[m] != 0) bad = 1;                        /* every bit of the main region must have been read */
+                uint8_t pay[RANS_PAY_BITS / 8 + 4];
+                memset(pay, 0, sizeof pay);
+                for (int l = 0; l < RANS_LANES; ++l) put_bits(pay, (long)RANS_STATE_BITS * l, RANS_STATE_BITS, x[m][l] & 0x7FFFFFFFu);
+                long top = -1;
+                for (long b = RANS_PAY_BITS - 1; b >= 0; --b)
+                    if ((pay[b >> 3] >> (b & 7)) & 1u) { top = b; break; }
+                if (top < 31) { bad = 1; continue; }
+                uint32_t xt = get_bits(pay, top - 31, 32);
+                long tc = top - 31;
+                const long cnt = rans_stream_count(n_sym, m, M);
+                if (T[m] > cnt) { bad = 1; continue; }
+                for (long q = cnt - T[m]; q < cnt; ++q) {
+                    const long n = 64 * (m + (q / 64) * M) + (q & 63);
+                    int i = (int)(n / wc), j = (int)(n % wc);
+                    long off = ((long)(2 * i + BAND_OI[src]) << lvl) * W + ((long)(2 * j + BAND_OJ[src]) << lvl);
+                    mix_t mx;
+                    mix_prepare(params + ((long)i * w + j) * ORC_NPAR, clr, (float)planes[off] / 255.0f,
+                                (float)planes[plane_sz + off] / 255.0f, &mx);
+                    const uint32_t slot = xt & 0xFFFF;
+                    uint32_t c_low, c_high;
+                    const int s = rans_find(&mx, slot, Lp, minv, maxv, &c_low, &c_high);
+                    xt = (c_high - c_low) * (xt >> 16) + slot - c_low;
+                    planes[clr * plane_sz + off] = (int16_t)(s - shift);
+                    int nb = clz32(xt);
+                    if (nb > 16 || tc < nb) { bad = 1; break; }
+                    tc -= nb;
+                    xt = (xt << nb) | get_bits(pay, tc, nb);
+                }
+                if (xt != (1u << 31) || tc != 0) bad = 1;        /* the tail coder's start state, and no bit left */
             }
         }
         free(params);
     }
     orc_unlift(planes, H, W, rgb);
-    free(planes); free(x); free(words); free(wpos); free(wcnt);
+    free(planes); free(x); free(bitsp); free(cur); free(T);
     return bad ? -5 : 0;
 }

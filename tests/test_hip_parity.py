@@ -262,8 +262,8 @@ def test_golden_headers_and_pixels(torch_mod, codecs, golden_index, case):
                                               ("smooth", 100, 131, "trainedlike", 8), ("noise", 33, 250, "trainedlike", 16),
                                               ("smooth", 256, 256, "trainedlike", 32)])
 def test_rans_container_bitexact(torch_mod, codecs, oracle_weights, kind, H, W, wname, M):
-    """The throughput container: HIP bytes == oracle bytes, both decoders invert it, and it costs about
-    190 bytes per stream over the AC container (same CDFs, same symbols)."""
+    """The throughput container (rANS v3): HIP bytes == oracle bytes, both decoders invert it, and a stream that has symbols
+    costs about 8 bytes over the ideal length (an empty one 251: tiny images with many streams)."""
     from oracle import oracle as orc
     from llicti_amd.codec import MODE_RANS, container_to_bytestream_list
     torch = torch_mod
@@ -813,13 +813,15 @@ def test_ac_anchor_decoder_many_images_and_edges(torch_mod, codecs, oracle_weigh
     assert np.array_equal(rec.cpu().numpy(), edge)
 
 
-def test_rans_v2_integrity_check_detects_corruption(torch_mod, codecs, oracle_weights):
-    """rANS v2's absorbing start leaves every lane's LAST symbol with a known state (its freq): a corrupted stream word or
-    a corrupted compact state header ends, with overwhelming probability, in a lane whose final state is wrong -- both
-    decoders (HIP, oracle) report it instead of returning wrong pixels silently; nothing crashes or hangs."""
+def test_rans_v3_integrity_check_detects_corruption(torch_mod, codecs, oracle_weights):
+    """rANS v3 ends with three known quantities: the main bit region is read to its last bit, and the tail coder (whose
+    stream is what the 64 lane states are left with) returns to its start state 2^31 with no bit left.  A corrupted stream
+    bit, final state or tail count ends, with overwhelming probability, in one of them being wrong -- both decoders (HIP,
+    oracle) report it instead of returning wrong pixels silently; nothing crashes or hangs.  A v2 container (header byte 0
+    without the format bit) is rejected deterministically."""
     from oracle import oracle as orc
     from llicti_amd._lib import LlictiError, EFORMAT
-    from llicti_amd.codec import MODE_RANS, container_to_bytestream_list
+    from llicti_amd.codec import MODE_RANS, container_to_bytestream_list, header_dims, mode_of_header
     torch = torch_mod
     c = codecs("trainedlike")
     W_o = oracle_weights("trainedlike")
@@ -829,7 +831,9 @@ def test_rans_v2_integrity_check_detects_corruption(torch_mod, codecs, oracle_we
     c.check()
     seg_h = seg.cpu().numpy()
     hdr = int(seg_h[1, :4].sum())
-    for where, val in ((hdr + 400, 0x5A), (hdr + 40, 0xFF), (hdr + 3, 0x7F)):        # a stream word | a low half | the length nibbles
+    s0 = int(seg_h[1, 4])
+    # a bit of the bit region | a final state | the tail count | the sentinel byte
+    for where, val in ((hdr + 2 + 400, 0x10), (hdr + s0 - 100, 0x04), (hdr, 0x01), (hdr + s0 - 249, 0xFF)):
         bad = cont.clone()
         bad[1, where] ^= val
         rec = c.decode(bad, seg, 96, 128, mode=mode)
@@ -840,6 +844,17 @@ def test_rans_v2_integrity_check_detects_corruption(torch_mod, codecs, oracle_we
         bl = container_to_bytestream_list(bad[1].cpu().numpy(), seg_h[1])
         with pytest.raises(Exception):
             orc.decode_image_rans(bl, W_o)
+    # the retired v2 tag: same bytes, format bit cleared
+    v2 = cont.clone()
+    v2[:, 0] &= 0xF7
+    c.decode(v2, seg, 96, 128, mode=mode)
+    with pytest.raises(LlictiError) as e:
+        c.check()
+    assert e.value.code == EFORMAT
+    with pytest.raises(LlictiError):
+        header_dims(bytes(v2[0, :17].cpu().numpy()))
+    with pytest.raises(ValueError):
+        mode_of_header(int(v2[0, 0]))
     rec = _decode_poisoned(c, cont, seg, 96, 128, mode)
     assert np.array_equal(rec.cpu().numpy(), rgb)
 
