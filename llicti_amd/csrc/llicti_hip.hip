@@ -181,7 +181,7 @@ static void build_plan(Plan &p, int B, int H, int W, int M)
             const long nchunks = (p.desc[(size_t)st * B].n + 63) / 64;
             syms += (nchunks + M - 1) / M * 64;
         }
-        p.rslot_cap = (int)align_up((size_t)(2 * syms + 4 + 8 + kRansPayBytes + 16 + 64), 64);   // + T, sentinel, 64 x 31-bit states, slack, zero pad
+        p.rslot_cap = (int)align_up((size_t)(2 * syms + 4 + 8 + kRansPayBytes + 16 + 64), 64);   // + T, 64 x 31-bit states, slack, zero pad
         p.rslot_off.assign((size_t)B * M, 0);
         for (long i = 0; i < (long)B * M; ++i) p.rslot_off[i] = (long)i * p.rslot_cap;
         slot_pos = std::max<long>(slot_pos, (long)B * M * p.rslot_cap);

@@ -15,12 +15,12 @@
 //     single-state "tail" coder whose output (<= 1984 bits) is cut into the 64 x 31 bits the lanes start from.  The decoder
 //     is left with those states after the last stage, reassembles the tail stream and decodes its T symbols serially.
 // Cost over the ideal code length: ~8 bytes per stream (v2: ~60) -- M = 8 is within 0.001 bpp of the AC container.
-// Stream bytes:  u16 T | bit region, read DOWN from a sentinel 1-bit in its last byte | 64 x 31-bit final states.
+// Stream bytes:  u16 (T | pad << 11) | bit region, read DOWN from its top minus pad unused bits | 64 x 31-bit final states.
 constexpr int kRansStateBits = 31;
 constexpr int kRansPayBits = 64 * kRansStateBits;        // 1984
 constexpr int kRansPayBytes = kRansPayBits / 8;          // 248
 constexpr int kRansTailMax = 2047;
-constexpr int kRansMinStream = 2 + 1 + kRansPayBytes;    // T, one byte of bit region (the sentinel), states
+constexpr int kRansMinStream = 2 + kRansPayBytes;        // T | pad, (empty bit region), states
 
 __device__ __forceinline__ int lanes_below(uint64_t mask)
 {
@@ -123,7 +123,8 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restr
                 if (hi == 0) hi = 0x10000u;
                 uint32_t freq = hi - lo;
                 if (freq == 0 || hi < lo) { bad = 1; freq = 1; }
-                const int nb = rans_emit_bits(xt, freq);
+                if (T == 0) xt = freq << 15;            // absorbing start: the first pushed symbol codes to 2^31 + c_low, no bits
+                const int nb = (T == 0) ? 0 : rans_emit_bits(xt, freq);      // (the closed form needs x >= 2^31)
                 if (tb + nb + 32 > kRansPayBits) { full = true; break; }
                 if (lane == 0) lds_or_bits(sh_pay, tb, nb, xt & ((1u << nb) - 1u));
                 tb += nb;
@@ -188,10 +189,9 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restr
             code(k - 3, r3); r3 = fetch(k - 7);
         }
     }
-    // 4. sentinel, the rest of the window, the 64 final states (31 bits each), T
+    // 4. the rest of the window, the 64 final states (31 bits each), T | pad
     __syncthreads();
-    if (lane == 0) atomicOr(&sh_win[(bp >> 5) - wbase], 1u << (bp & 31));
-    const int nbytes = (bp >> 3) + 1;
+    const int nbytes = (bp + 7) >> 3;
     sh_pay[lane] = 0;
     __syncthreads();
     lds_or_bits(sh_pay, kRansStateBits * lane, 16, x & 0xFFFFu);
@@ -207,14 +207,15 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restr
         for (int t = lane; t < kRansPayBytes; t += 64) fs[t] = (uint8_t)(sh_pay[t >> 2] >> (8 * (t & 3)));
     }
     if (lane == 0) {
-        slot[2] = (uint8_t)(T & 0xFF); slot[3] = (uint8_t)(T >> 8);
+        const int t16 = T | ((8 * nbytes - bp) << 11);               // pad: unused (zero) bits on top of the region's last byte
+        slot[2] = (uint8_t)(t16 & 0xFF); slot[3] = (uint8_t)(t16 >> 8);
         rinfo[2 * sidx] = 2; rinfo[2 * sidx + 1] = 2 + nbytes + kRansPayBytes;
     }
     if (bad) atomicExch(&status[0], bad == 1 ? LLICTI_EFORMAT : LLICTI_ENOSPACE);
 }
 
 // decode: parse a stream (copied to slot + 2 by rans_unpack_kernel, which also left its validated length in rpos):
-// T, the sentinel (-> bit cursor), the 64 states
+// T and pad (-> bit cursor), the 64 states
 __global__ __launch_bounds__(64) void rans_init_kernel(const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
                                                        uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos,
                                                        uint32_t *__restrict__ rtail, int32_t *status)
@@ -223,12 +224,12 @@ __global__ __launch_bounds__(64) void rans_init_kernel(const uint8_t *__restrict
     const uint8_t *slot = slots + rslot_off[sidx];
     const int n = (int)rpos[sidx];                                 // >= kRansMinStream
     const int nbytes = n - 2 - kRansPayBytes;
-    int T = slot[2] | (slot[3] << 8);
-    const uint32_t lastb = slot[4 + nbytes - 1];
+    const int t16 = slot[2] | (slot[3] << 8);
+    int T = t16 & 0x7FF;
+    const int pad = (t16 >> 11) & 7;
     bool bad = false;
-    if (T > kRansTailMax) { bad = true; T = 0; }
-    int cur = 8 * (nbytes - 1);
-    if (lastb == 0) bad = true; else cur += 31 - __clz((int)lastb);
+    if ((t16 >> 14) || (nbytes == 0 && pad)) { bad = true; T = 0; }
+    const int cur = bad ? 0 : 8 * nbytes - pad;
     const uint8_t *fs = slot + 4 + nbytes;
     const int bpos = kRansStateBits * lane;
     uint64_t w = 0;
@@ -530,7 +531,8 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
 // its leading one the highest set bit).  One wavefront per stream decodes the T tail symbols serially -- all of the last
 // stage's Cg channel (level 0, band x10) -- with all 64 lanes on one symbol: lane l evaluates entry 8 l exactly (64
 // anchors cover Lp <= 512), a ballot picks the bucket, lanes 0..8 its nine entries, a second ballot the symbol.
-// Checks: the main region was read to its last bit, the tail state ends at 2^31 with no bit left.
+// Checks: the main region was read to its last bit, the tail state ends at its start state (freq << 15 of the symbol the
+// tail encoder began with; 2^31 when T = 0) with no bit left.
 __global__ __launch_bounds__(64) void rans_tail_kernel(const float *__restrict__ params, StageGeom sg, int M,
                                                        const uint32_t *__restrict__ rstate, const uint32_t *__restrict__ rpos,
                                                        const uint32_t *__restrict__ rtail,
@@ -605,6 +607,7 @@ __global__ __launch_bounds__(64) void rans_tail_kernel(const float *__restrict__
             fplanes[offA + 2 * sg.plane] = (float)v / 255.0f;
         }
         xt = (vhi - vlo) * (xt >> 16) + slot - vlo;
+        if (q == cnt - 1) { bad = bad || xt != (vhi - vlo) << 15; break; }    // the encoder's first symbol: absorbing start, no bits
         const int nb = __clz((int)xt);
         if (nb > 16 || tc < nb) { bad = true; break; }
         tc -= nb;
@@ -613,7 +616,8 @@ __global__ __launch_bounds__(64) void rans_tail_kernel(const float *__restrict__
         for (int k = 0; k < LLICTI_PARAM_STRIDE; ++k) parA[k] = parB[k];
         yA = yB; coA = coB; offA = offB;
     }
-    if ((bad || xt != (1u << 31) || tc != 0) && lane == 0) atomicExch(&status[0], LLICTI_EFORMAT);
+    if (T == 0) bad = bad || xt != (1u << 31);
+    if ((bad || tc != 0) && lane == 0) atomicExch(&status[0], LLICTI_EFORMAT);
 }
 
 __global__ __launch_bounds__(256) void rans_pack_kernel(const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
@@ -652,8 +656,8 @@ __global__ __launch_bounds__(256) void rans_unpack_kernel(const uint8_t *__restr
     uint8_t *o = slots + rslot_off[b * M + m] + 2;               // the bit region (stream offset 2) lands dword aligned
     if (bad || n < kRansMinStream || n + 2 + 64 > rslot_cap || src + n > in_stride) {
         if (threadIdx.x == 0) atomicExch(&status[0], LLICTI_EFORMAT);
-        n = kRansMinStream;                                        // a harmless stream: T = 0, sentinel only, states 2^31
-        for (int t = threadIdx.x; t < n; t += blockDim.x) o[t] = (t == 2) ? 1 : 0;
+        n = kRansMinStream;                                        // a harmless stream: T = 0, no bits, states 2^31
+        for (int t = threadIdx.x; t < n; t += blockDim.x) o[t] = 0;
     } else {
         const uint8_t *p = in + (long)b * in_stride + src;
         block_copy_bytes(o, p, n);

@@ -886,6 +886,7 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
             const long n = 64 * (m + (q / 64) * M) + (q & 63);
             const uint32_t lo = st[S].clow[n], freq = st[S].chigh[n] - lo;
             if (freq == 0 || freq > 0x10000u) { rc = -5; break; }
+            if (T == 0) xt = freq << 15;          /* absorbing start: the first pushed symbol codes to 2^31 + c_low, no bits */
             const int nb = rans_emit_bits(xt, freq);
             if (tb + nb + 32 > RANS_PAY_BITS) break;
             put_bits(pay, tb, nb, xt & ((1u << nb) - 1u));
@@ -921,11 +922,12 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
             }
         }
         if (rc < 0) break;
-        put_bits(bits, bp, 1, 1u);                       /* sentinel: the highest set bit of the region's last byte */
-        const long nbytes = bp / 8 + 1;
+        const long nbytes = (bp + 7) / 8;
+        const long padb = 8 * nbytes - bp;               /* unused (zero) bits on top of the region's last byte */
         const long bytes = 2 + nbytes + RANS_PAY_BITS / 8;
         if (pos + bytes > cap) { rc = -1; break; }
-        out[pos] = (uint8_t)(T & 0xFF); out[pos + 1] = (uint8_t)(T >> 8);
+        const long t16 = T | (padb << 11);
+        out[pos] = (uint8_t)(t16 & 0xFF); out[pos + 1] = (uint8_t)(t16 >> 8);
         memcpy(out + pos + 2, bits, nbytes);
         uint8_t *fs = out + pos + 2 + nbytes;
         memset(fs, 0, RANS_PAY_BITS / 8);
@@ -976,15 +978,15 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
         long pos = 17 + seg_len[3];
         for (int m = 0; m < M; ++m) {
             const long len = seg_len[4 + m];
-            if (len < 2 + 1 + RANS_PAY_BITS / 8) { free(x); free(bitsp); free(cur); free(T); return -3; }
+            if (len < 2 + RANS_PAY_BITS / 8) { free(x); free(bitsp); free(cur); free(T); return -3; }
             const uint8_t *sp = in + pos;
-            const int t = sp[0] | (sp[1] << 8);
+            const int t16 = sp[0] | (sp[1] << 8);
+            const int padb = (t16 >> 11) & 7;
             const long nbytes = len - 2 - RANS_PAY_BITS / 8;
-            const uint8_t lastb = sp[2 + nbytes - 1];
-            if (t > RANS_TAIL_MAX || lastb == 0) { free(x); free(bitsp); free(cur); free(T); return -3; }
-            T[m] = t;
+            if ((t16 >> 14) || (nbytes == 0 && padb)) { free(x); free(bitsp); free(cur); free(T); return -3; }
+            T[m] = t16 & 0x7FF;
             bitsp[m] = sp + 2;
-            cur[m] = 8 * (nbytes - 1) + (31 - clz32(lastb));          /* position of the sentinel = number of data bits */
+            cur[m] = 8 * nbytes - padb;                               /* number of data bits */
             const uint8_t *fs = sp + 2 + nbytes;
             for (int l = 0; l < RANS_LANES; ++l) x[m][l] = (1u << 31) | get_bits(fs, (long)RANS_STATE_BITS * l, RANS_STATE_BITS);
             pos += len;
@@ -1073,6 +1075,7 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
                 long tc = top - 31;
                 const long cnt = rans_stream_count(n_sym, m, M);
                 if (T[m] > cnt) { bad = 1; continue; }
+                uint32_t f_last = 0;
                 for (long q = cnt - T[m]; q < cnt; ++q) {
                     const long n = 64 * (m + (q / 64) * M) + (q & 63);
                     int i = (int)(n / wc), j = (int)(n % wc);
@@ -1085,12 +1088,14 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
                     const int s = rans_find(&mx, slot, Lp, minv, maxv, &c_low, &c_high);
                     xt = (c_high - c_low) * (xt >> 16) + slot - c_low;
                     planes[clr * plane_sz + off] = (int16_t)(s - shift);
+                    f_last = c_high - c_low;
+                    if (q == cnt - 1) break;                     /* the encoder's first symbol: absorbing start, no bits */
                     int nb = clz32(xt);
                     if (nb > 16 || tc < nb) { bad = 1; break; }
                     tc -= nb;
                     xt = (xt << nb) | get_bits(pay, tc, nb);
                 }
-                if (xt != (1u << 31) || tc != 0) bad = 1;        /* the tail coder's start state, and no bit left */
+                if (xt != (T[m] ? f_last << 15 : 1u << 31) || tc != 0) bad = 1;   /* the tail coder's start state, and no bit left */
             }
         }
         free(params);

@@ -832,7 +832,7 @@ def test_rans_v3_integrity_check_detects_corruption(torch_mod, codecs, oracle_we
     seg_h = seg.cpu().numpy()
     hdr = int(seg_h[1, :4].sum())
     s0 = int(seg_h[1, 4])
-    # a bit of the bit region | a final state | the tail count | the sentinel byte
+    # a bit of the bit region | a final state | the tail count | the last byte of the bit region
     for where, val in ((hdr + 2 + 400, 0x10), (hdr + s0 - 100, 0x04), (hdr, 0x01), (hdr + s0 - 249, 0xFF)):
         bad = cont.clone()
         bad[1, where] ^= val
