@@ -148,13 +148,16 @@ int llicti_ac_decode_u16cdf(llicti_ctx *ctx, const uint16_t *d_cdf, int Lp, int 
  * container is read, and no read leaves [d_in + b*in_stride, d_in + (b+1)*in_stride). */
 
 /* mode: LLICTI_MODE_AC = the reference's container (45 torchac-algorithm streams per image, bit-exact
- * to the oracle / reference format); LLICTI_MODE_RANS(M) = "LLICTI-rANS v2", a NEW container of this
- * build: header byte 0 = 0x80 | lg2(M) << 4 | 5, then M independent 64-way interleaved rANS streams per
- * image (segments 4 .. 4+M-1, the other stream segments empty), same CDFs and symbols, decodable
- * 64*M symbols at a time.  A stream = compact header of its 64 final coder states (160 .. 280 bytes) + 16-bit words;
- * every lane's first coded symbol starts from state freq ("absorbing start").  Cost over the ideal code length: about
- * 60 bytes per stream on noise-like content, 110 on smooth content (M = 1 is within 50 bytes of the AC container, whose
- * 45 stream terminations cost about 100 bytes themselves).  Format: oracle/llicti_oracle.h, DESIGN.md section 5. */
+ * to the oracle / reference format); LLICTI_MODE_RANS(M) = "LLICTI-rANS v3", a NEW container of this
+ * build (BASELINE.json north_star: "torchac replaced by a HIP rANS coder"): header byte 0 = 0x88 | lg2(M) << 4 | 5
+ * (bit 3 = format v3; the retired v2 tag 0x80 | lg2(M) << 4 | 5 is rejected with LLICTI_EFORMAT), then M independent
+ * 64-way interleaved rANS streams per image (segments 4 .. 4+M-1, the other stream segments empty), same CDFs and
+ * symbols, decodable 64*M symbols at a time.  States live in [2^31, 2^32) and renormalise bit by bit (the coder loses
+ * ~2^-16 of a symbol's length, like the range coder); a stream = u16 (T | pad << 11) | bit region | 64 x 31-bit final
+ * states, and the 64 INITIAL states carry the last T symbols of the stream's last stage, coded by a single-state tail
+ * coder.  Cost over the ideal code length: about 6 bytes per stream that has symbols -- M = 8 is within 0.0005 bpp of the AC
+ * container on 768x512 images (whose 45 stream terminations cost about 25 bytes).  Format: oracle/llicti_oracle.h,
+ * DESIGN.md section 5. */
 #define LLICTI_MODE_AC        0
 #define LLICTI_MODE_RANS(M)  (0x100 | (M))      /* M in {1, 2, 4, 8, 16, 32} */
 
@@ -184,6 +187,20 @@ int llicti_header_dims(const uint8_t *h_hdr17, int *H, int *W);
  * HIP events on `stream`: ms[0] = whole call, ms[1] = sum of the band-CNN kernel launches,
  * n_launch = number of band-CNN launches.  Used by bench.py for the roofline figure. */
 int llicti_last_timing(llicti_ctx *ctx, float ms[4], int *n_launch);
+/* Where the last whole-batch call spent its device time (profiling on): summed event durations per kernel group --
+ * cat_ms[LLICTI_PROF_CNN] band-CNN launches, [RANS_STAGE] rans_decode_stage_kernel, [RANS_TAIL] rans_tail_kernel,
+ * [PAIRS] cdf_pairs_kernel, [RANS_ENC] rans_encode + pack, [AC] the range-coder / table kernels of the reference-format
+ * container, [MISC] lift / unlift / header / unpack / init -- and the duration of every band-CNN launch in launch order
+ * (scale 4..0 x band 0..2; up to cnn_cap entries, their number in *n_cnn).  Synchronises like llicti_last_timing. */
+#define LLICTI_NPROF 7
+#define LLICTI_PROF_CNN 0
+#define LLICTI_PROF_RANS_STAGE 1
+#define LLICTI_PROF_RANS_TAIL 2
+#define LLICTI_PROF_PAIRS 3
+#define LLICTI_PROF_RANS_ENC 4
+#define LLICTI_PROF_AC 5
+#define LLICTI_PROF_MISC 6
+int llicti_last_timing_detail(llicti_ctx *ctx, float cat_ms[LLICTI_NPROF], float *cnn_launch_ms, int cnn_cap, int *n_cnn);
 /* Tuning switches that never change a result.  "ac_anchor_min_batch" (default 96): from this many images per call on,
  * llicti_decode_images decodes the AC container over anchor rows (every 8th table entry from cdf_anchor_kernel, the 8
  * entries of the located bucket evaluated by the decoding wavefront) instead of full table rows; values above the

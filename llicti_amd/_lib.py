@@ -64,6 +64,7 @@ _SIGS = {
     "llicti_check_status": (_i, [_vp, _vp]),
     "llicti_header_dims": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "llicti_last_timing": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(_i)]),
+    "llicti_last_timing_detail": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, C.POINTER(_i)]),
     "llicti_set_profiling": (_i, [_vp, _i]),
     "llicti_set_tuning": (_i, [_vp, C.c_char_p, _i]),
 }

@@ -234,6 +234,16 @@ class HipCodec:
     def set_profiling(self, on=True):
         _lib.check(self.L.llicti_set_profiling(self.ctx, int(bool(on))))
 
+    PROF_CATS = ("cnn", "rans_stage", "rans_tail", "cdf_pairs", "rans_encode", "ac", "misc")
+
+    def last_timing_detail(self):
+        """-> ({kernel group: ms}, [ms of every band-CNN launch, scale 4..0 x band 0..2]) of the last whole-batch call."""
+        cat = (C.c_float * len(self.PROF_CATS))()
+        per = (C.c_float * 64)()
+        n = C.c_int()
+        _lib.check(self.L.llicti_last_timing_detail(self.ctx, cat, per, 64, C.byref(n)))
+        return dict(zip(self.PROF_CATS, [float(v) for v in cat])), [float(per[i]) for i in range(min(n.value, 64))]
+
     def last_timing(self):
         ms = (C.c_float * 4)()
         n = C.c_int()

@@ -20,6 +20,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <map>
+#include <memory>
 #include <string>
 #include <tuple>
 #include <type_traits>
@@ -68,13 +69,27 @@ constexpr int kAcAnchorBatch = 96;
 static bool ac_use_anchors(int B, int min_batch = kAcAnchorBatch) { return B >= std::min(min_batch, kAcAnchorBatch); }
 
 constexpr int kMaxSub = 4;
-struct PlanDev {
+struct PlanDev {                  // owns its device arrays: a plan that fails half-way through get_plan() frees what it took
     Plan p;
     StreamDesc *d_desc = nullptr;
     long *d_slot_off = nullptr;
     int32_t *d_slot_cap = nullptr;
     long *d_rslot_off = nullptr;
+    PlanDev() = default;
+    PlanDev(const PlanDev &) = delete;
+    PlanDev &operator=(const PlanDev &) = delete;
+    ~PlanDev()
+    {
+        if (d_desc) (void)hipFree(d_desc);
+        if (d_slot_off) (void)hipFree(d_slot_off);
+        if (d_slot_cap) (void)hipFree(d_slot_cap);
+        if (d_rslot_off) (void)hipFree(d_rslot_off);
+    }
 };
+
+// profiling spans (llicti_set_profiling): what a pair of events brackets
+enum ProfCat { PROF_CNN = 0, PROF_RANS_STAGE, PROF_RANS_TAIL, PROF_PAIRS, PROF_RANS_ENC, PROF_AC, PROF_MISC, PROF_NCAT };
+static_assert(PROF_NCAT == LLICTI_NPROF, "include/llicti_hip.h: LLICTI_NPROF");
 
 struct llicti_ctx {
     int device = 0;
@@ -90,13 +105,44 @@ struct llicti_ctx {
     bool pipeline = false;     // sub-batch pipelining of decode: measured neutral (co-resident CNN and rANS waves share VALU issue)
     int32_t *d_status = nullptr;      // small persistent status word (for the kernel-level entry points)
     int32_t *d_lift_part = nullptr;   // min/max partials of llicti_lift_u8 (1 MB; calls on one context are not concurrent)
+    int n_cu = 256;                   // compute units of the device (grid sizing of the persistent kernels)
     bool profiling = false;
-    std::vector<hipEvent_t> ev;       // pairs around band-CNN launches
-    int ev_used = 0;
+    std::vector<hipEvent_t> ev;       // event pairs of the profiling spans of the current call
+    std::vector<int> ev_cat;          // category of pair i
+    int ev_used = 0;                  // events used (2 per span)
     hipEvent_t ev_call[2] = { nullptr, nullptr };
     float last_ms[4] = { 0, 0, 0, 0 };
+    float last_cat_ms[PROF_NCAT] = {};
+    std::vector<float> last_cnn_ms;   // per band-CNN launch, launch order
     int last_launches = 0;
     bool timing_pending = false;
+};
+
+// One profiling span: events on `s` before and after the launches it brackets (no-op unless profiling is on).
+// A failed event call only loses the measurement.
+struct ProfSpan {
+    llicti_ctx *c;
+    hipStream_t s;
+    hipEvent_t e1 = nullptr;
+    ProfSpan(llicti_ctx *c_, int cat, hipStream_t s_) : c(c_), s(s_)
+    {
+        if (!c->profiling) return;
+        if ((int)c->ev.size() < c->ev_used + 2) {
+            hipEvent_t a = nullptr, b = nullptr;
+            if (hipEventCreate(&a) != hipSuccess) return;
+            if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return; }
+            c->ev.push_back(a);
+            c->ev.push_back(b);
+            c->ev_cat.push_back(cat);
+        }
+        c->ev_cat[c->ev_used / 2] = cat;
+        if (hipEventRecord(c->ev[c->ev_used], s) != hipSuccess) return;
+        e1 = c->ev[c->ev_used + 1];
+        c->ev_used += 2;
+    }
+    ~ProfSpan() { if (e1) (void)hipEventRecord(e1, s); }
+    ProfSpan(const ProfSpan &) = delete;
+    ProfSpan &operator=(const ProfSpan &) = delete;
 };
 
 // Every entry point that touches the device runs under this guard: the context's device becomes current for the
@@ -266,6 +312,7 @@ extern "C" int llicti_create(llicti_ctx **out, int device)
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(LLICTI_ENODEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
     llicti_ctx *c = new llicti_ctx();
     c->device = device;
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     DeviceGuard guard(c);
     if (const char *e = getenv("LLICTI_PIPELINE")) { c->pipeline = atoi(e) != 0; c->pipeline_s = atoi(e); }     // experiment switch: sub-batch pipelining of decode
     HIPCHK(hipMalloc(&c->d_status, 64));
@@ -298,14 +345,7 @@ extern "C" int llicti_destroy(llicti_ctx *c)
     DeviceGuard guard(c);
     (void)hipDeviceSynchronize();
     for (int b = 0; b < 3; ++b) if (c->d_pack[b]) hipFree(c->d_pack[b]);
-    for (auto &kv : c->plans) {
-        PlanDev *pd = kv.second;
-        if (pd->d_desc) hipFree(pd->d_desc);
-        if (pd->d_slot_off) hipFree(pd->d_slot_off);
-        if (pd->d_slot_cap) hipFree(pd->d_slot_cap);
-        if (pd->d_rslot_off) hipFree(pd->d_rslot_off);
-        delete pd;
-    }
+    for (auto &kv : c->plans) delete kv.second;
     for (int i = 0; i < kMaxSub; ++i) {
         if (c->sub[i]) hipStreamDestroy(c->sub[i]);
         if (c->ev_join[i]) hipEventDestroy(c->ev_join[i]);
@@ -385,28 +425,15 @@ static int launch_band_params(llicti_ctx *c, const float *fplanes, const Geom &g
     const int n_tiles = (int)n_tiles_l;
     const int lds_bytes = cnn_lds_bytes(band);
     const int wg_per_cu = std::max(1, std::min(4, (160 * 1024) / lds_bytes));
-    int gx = std::min(n_tiles, 256 * wg_per_cu / 4);    // 4 heads in grid.y; persistent loop over tiles
+    int gx = std::min(n_tiles, c->n_cu * wg_per_cu / 4);    // 4 heads in grid.y; persistent loop over tiles
     if (gx < 1) gx = 1;
     dim3 grid((unsigned)gx, 4);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->profiling) {
-        if ((int)c->ev.size() < c->ev_used + 2) {
-            hipEvent_t a, b;
-            HIPCHK(hipEventCreate(&a));
-            HIPCHK(hipEventCreate(&b));
-            c->ev.push_back(a);
-            c->ev.push_back(b);
-        }
-        e0 = c->ev[c->ev_used]; e1 = c->ev[c->ev_used + 1];
-        c->ev_used += 2;
-        HIPCHK(hipEventRecord(e0, s));
-    }
+    ProfSpan span(c, PROF_CNN, s);
     switch (band) {
     case 0: band_params_kernel<0><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[0], params, tiles_x, tiles_y, n_tiles); break;
     case 1: band_params_kernel<1><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[1], params, tiles_x, tiles_y, n_tiles); break;
     default: band_params_kernel<2><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[2], params, tiles_x, tiles_y, n_tiles); break;
     }
-    if (c->profiling) HIPCHK(hipEventRecord(e1, s));
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -571,15 +598,10 @@ static int get_plan(llicti_ctx *c, int B, int H, int W, int M, PlanDev **out)
     if (it != c->plans.end()) { *out = it->second; return 0; }
     if (c->plans.size() >= 16) {      // bounded cache: drop everything (plans are cheap to rebuild)
         HIPCHK(hipDeviceSynchronize());
-        for (auto &kv : c->plans) {
-            PlanDev *pd = kv.second;
-            hipFree(pd->d_desc); hipFree(pd->d_slot_off); hipFree(pd->d_slot_cap);
-            if (pd->d_rslot_off) hipFree(pd->d_rslot_off);
-            delete pd;
-        }
+        for (auto &kv : c->plans) delete kv.second;
         c->plans.clear();
     }
-    PlanDev *pd = new PlanDev();
+    std::unique_ptr<PlanDev> pd(new PlanDev());       // an early return below (HIPCHK) frees the plan and what it allocated
     build_plan(pd->p, B, H, W, M);
     if (M > 0) {
         HIPCHK(hipMalloc(&pd->d_rslot_off, (size_t)B * M * sizeof(long)));
@@ -592,8 +614,8 @@ static int get_plan(llicti_ctx *c, int B, int H, int W, int M, PlanDev **out)
     HIPCHK(hipMemcpy(pd->d_desc, pd->p.desc.data(), n * sizeof(StreamDesc), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(pd->d_slot_off, pd->p.slot_off.data(), n * sizeof(long), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(pd->d_slot_cap, pd->p.slot_cap.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
-    c->plans[key] = pd;
-    *out = pd;
+    *out = pd.get();
+    c->plans[key] = pd.release();
     return 0;
 }
 
@@ -622,15 +644,22 @@ static int pad_int(int H, int W)
     return v;
 }
 
-static void begin_call(llicti_ctx *c, hipStream_t s)
-{
-    c->ev_used = 0;
-    if (c->profiling) hipEventRecord(c->ev_call[0], s);
-}
-static void end_call(llicti_ctx *c, hipStream_t s)
-{
-    if (c->profiling) { hipEventRecord(c->ev_call[1], s); c->timing_pending = true; }
-}
+// The profiled extent of one whole-batch call: the closing event is recorded on EVERY way out (an early error return
+// included), so llicti_last_timing never waits on an event of a call that did not record it.
+struct CallScope {
+    llicti_ctx *c;
+    hipStream_t s;
+    bool on;
+    CallScope(llicti_ctx *c_, hipStream_t s_) : c(c_), s(s_), on(c_->profiling)
+    {
+        c->ev_used = 0;
+        c->timing_pending = false;
+        if (on) on = hipEventRecord(c->ev_call[0], s) == hipSuccess;
+    }
+    ~CallScope() { if (on && hipEventRecord(c->ev_call[1], s) == hipSuccess) c->timing_pending = true; }
+    CallScope(const CallScope &) = delete;
+    CallScope &operator=(const CallScope &) = delete;
+};
 
 extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, int H, int W, int mode,
                                     void *d_workspace, size_t workspace_bytes,
@@ -658,33 +687,38 @@ extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, 
     uint8_t *slots = ws + p.off_slots;
     int32_t *slot_len = (int32_t *)(ws + p.off_slot_len);
 
-    begin_call(c, s);
+    CallScope call(c, s);
     HIPCHK(hipMemsetAsync(status, 0, 64, s));
-    if (int rc = launch_lift(d_rgb, B, H, W, planes, fplanes, mm, (int32_t *)(ws + p.off_lift_part), s)) return rc;
     Geom g4 = make_geom(B, H, W, 4);
     const int byte0 = M ? rans_byte0(M) : LLICTI_NLEVELS;
-    header_write_kernel<<<B, 256, 0, s>>>(d_rgb, mm, H, W, g4.h, g4.w, pad_int(H, W), byte0, d_out, (long)out_stride, d_seg_len);
+    {
+        ProfSpan span(c, PROF_MISC, s);
+        if (int rc = launch_lift(d_rgb, B, H, W, planes, fplanes, mm, (int32_t *)(ws + p.off_lift_part), s)) return rc;
+        header_write_kernel<<<B, 256, 0, s>>>(d_rgb, mm, H, W, g4.h, g4.w, pad_int(H, W), byte0, d_out, (long)out_stride, d_seg_len);
+    }
     // the encoder has no dependency between stages: every (level, band) reads only original pixels
     for (int lvl = LLICTI_NLEVELS - 1; lvl >= 0; --lvl) {
         Geom g = make_geom(B, H, W, lvl);
         for (int band = 0; band < 3; ++band) {
             if (int rc = launch_band_params(c, fplanes, g, band, params, s)) return rc;
+            ProfSpan span(c, PROF_PAIRS, s);
             if (int rc = launch_cdf_pairs(planes, params, mm, g, band, pairs + p.pair_base[lvl * 3 + band], s)) return rc;
         }
     }
     const int hdr_bytes = 17 + 3 * g4.h * g4.w;
     if (M == 0) {
+        ProfSpan span(c, PROF_AC, s);
         const int n_streams = LLICTI_NSTREAMS * B;
         ac_encode_pairs_kernel<<<n_streams, 64, 0, s>>>(pairs, pd->d_desc, n_streams, slots, slot_len, status);
         pack_kernel<<<dim3(LLICTI_NSTREAMS, B), 256, 0, s>>>(slots, pd->d_slot_off, slot_len, B, hdr_bytes, d_out, (long)out_stride, d_seg_len, status);
     } else {
+        ProfSpan span(c, PROF_RANS_ENC, s);
         int32_t *rinfo = (int32_t *)(ws + p.off_rinfo);
         rans_encode_kernel<<<B * M, 64, 0, s>>>(pairs, pd->d_desc, B, M, slots, pd->d_rslot_off, p.rslot_cap, rinfo, status);
         rans_pack_kernel<<<dim3(M, B), 256, 0, s>>>(slots, pd->d_rslot_off, rinfo, M, hdr_bytes, d_out, (long)out_stride, d_seg_len, status);
     }
     latch_status_kernel<<<1, 1, 0, s>>>(status, c->d_status);
     HIPCHK(hipGetLastError());
-    end_call(c, s);
     return LLICTI_OK;
 }
 
@@ -704,15 +738,18 @@ static int decode_sub(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in
     HIPCHK(hipMemsetAsync(status, 0, 64, s));
     Geom g4 = make_geom(B, H, W, 4);
     const int byte0 = M ? rans_byte0(M) : LLICTI_NLEVELS;
-    header_read_kernel<<<B, 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, H, W, g4.h, g4.w, pad_int(H, W), byte0, planes, fplanes, mm, status);
     uint32_t *rstate = (uint32_t *)(ws + p.off_rstate);
     uint32_t *rpos = (uint32_t *)(ws + p.off_rpos);
     uint32_t *rtail = (uint32_t *)(ws + p.off_rtail);
-    if (M == 0) {
-        unpack_kernel<<<dim3(LLICTI_NSTREAMS, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, B, slots, pd->d_slot_off, pd->d_slot_cap, status);
-    } else {
-        rans_unpack_kernel<<<dim3(M, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, M, slots, pd->d_rslot_off, p.rslot_cap, rpos, status);
-        rans_init_kernel<<<B * M, 64, 0, s>>>(slots, pd->d_rslot_off, rstate, rpos, rtail, status);
+    {
+        ProfSpan span(c, PROF_MISC, s);
+        header_read_kernel<<<B, 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, H, W, g4.h, g4.w, pad_int(H, W), byte0, planes, fplanes, mm, status);
+        if (M == 0) {
+            unpack_kernel<<<dim3(LLICTI_NSTREAMS, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, B, slots, pd->d_slot_off, pd->d_slot_cap, status);
+        } else {
+            rans_unpack_kernel<<<dim3(M, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, M, slots, pd->d_rslot_off, p.rslot_cap, rpos, status);
+            rans_init_kernel<<<B * M, 64, 0, s>>>(slots, pd->d_rslot_off, rstate, rpos, rtail, status);
+        }
     }
     // 45 dependent stages (LLICTI_nets.py:440-498): CNN of band b needs bands < b of this level, Co needs Y, Cg needs Y, Co
     for (int lvl = LLICTI_NLEVELS - 1; lvl >= 0; --lvl) {
@@ -723,10 +760,16 @@ static int decode_sub(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in
             const long nc = (long)sg.hc * sg.wc;
             if (M > 0) {
                 const int last = (lvl == 0 && band == 2) ? 1 : 0;      // the last stage's tail symbols are decoded by rans_tail_kernel
+                {
+                ProfSpan span(c, PROF_RANS_STAGE, s);
                 rans_decode_stage_kernel<0><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, 0, status);
                 rans_decode_stage_kernel<1><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, 0, status);
                 rans_decode_stage_kernel<2><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status);
-                if (last) rans_tail_kernel<<<B * M, 64, 0, s>>>(params, sg, M, rstate, rpos, rtail, planes, fplanes, mm, status);
+                }
+                if (last) {
+                    ProfSpan span(c, PROF_RANS_TAIL, s);
+                    rans_tail_kernel<<<B * M, 64, 0, s>>>(params, sg, M, rstate, rpos, rtail, planes, fplanes, mm, status);
+                }
             }
             if (M == 0) {
                 // Y, Co, Cg of this band as a pipeline over chunks of the stage: chunk c of Co needs only chunk c
@@ -746,6 +789,7 @@ static int decode_sub(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in
                     for (int clr = 0; clr < 3; ++clr) {
                         hipStream_t qs = (C > 1) ? q[clr] : s;
                         if (C > 1 && clr > 0) HIPCHK(hipStreamWaitEvent(qs, c->ev_ac[clr - 1][ch], 0));
+                        ProfSpan span(c, PROF_AC, qs);
                         const bool anchors = ac_use_anchors(B, c->ac_anchor_min_batch);
                         const int row_stride = (clr == 0) ? 264 : 512;      // full rows: Y has Lp = 257, Co / Cg Lp <= 512
                         uint8_t *tab = tables + (size_t)clr * B * p.ac_cap_rows * (anchors ? (size_t)kAnchorRow : (size_t)1024);
@@ -774,7 +818,10 @@ static int decode_sub(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in
     }
     const long plane = (long)H * W;
     const int gx = (int)std::min<long>((plane + 255) / 256, 1024);
-    unlift_kernel<<<dim3(gx, B), 256, 0, s>>>(planes, plane, d_rgb);
+    {
+        ProfSpan span(c, PROF_MISC, s);
+        unlift_kernel<<<dim3(gx, B), 256, 0, s>>>(planes, plane, d_rgb);
+    }
     latch_status_kernel<<<1, 1, 0, s>>>(status, c->d_status);
     HIPCHK(hipGetLastError());
     return 0;
@@ -806,7 +853,7 @@ extern "C" int llicti_decode_images(llicti_ctx *c, const uint8_t *d_in, size_t i
     uint8_t *ws = (uint8_t *)d_workspace;
     const size_t plane3 = (size_t)3 * H * W;
 
-    begin_call(c, s);
+    CallScope call(c, s);
     if (S > 1) HIPCHK(hipEventRecord(c->ev_fork, s));
     for (int k = 0; k < S; ++k) {
         hipStream_t sk = (k == 0) ? s : c->sub[k];
@@ -817,7 +864,6 @@ extern "C" int llicti_decode_images(llicti_ctx *c, const uint8_t *d_in, size_t i
         if (k > 0) HIPCHK(hipEventRecord(c->ev_join[k], sk));
     }
     for (int k = 1; k < S; ++k) HIPCHK(hipStreamWaitEvent(s, c->ev_join[k], 0));
-    end_call(c, s);
     return LLICTI_OK;
 }
 
@@ -863,17 +909,33 @@ extern "C" int llicti_last_timing(llicti_ctx *c, float ms[4], int *n_launch)
         float t = 0;
         HIPCHK(hipEventElapsedTime(&t, c->ev_call[0], c->ev_call[1]));
         c->last_ms[0] = t;
-        float sum = 0;
+        for (int k = 0; k < PROF_NCAT; ++k) c->last_cat_ms[k] = 0;
+        c->last_cnn_ms.clear();
         for (int i = 0; i + 1 < c->ev_used; i += 2) {
             float k = 0;
+            HIPCHK(hipEventSynchronize(c->ev[i + 1]));       // spans of the AC decode pipeline sit on the internal streams
             HIPCHK(hipEventElapsedTime(&k, c->ev[i], c->ev[i + 1]));
-            sum += k;
+            const int cat = c->ev_cat[i / 2];
+            c->last_cat_ms[cat] += k;
+            if (cat == PROF_CNN) c->last_cnn_ms.push_back(k);
         }
-        c->last_ms[1] = sum;
-        c->last_launches = c->ev_used / 2;
+        c->last_ms[1] = c->last_cat_ms[PROF_CNN];
+        c->last_launches = (int)c->last_cnn_ms.size();
         c->timing_pending = false;
     }
     for (int i = 0; i < 4; ++i) ms[i] = c->last_ms[i];
     if (n_launch) *n_launch = c->last_launches;
+    return LLICTI_OK;
+}
+
+extern "C" int llicti_last_timing_detail(llicti_ctx *c, float cat_ms[LLICTI_NPROF], float *cnn_launch_ms, int cnn_cap, int *n_cnn)
+{
+    if (!c || !cat_ms) return fail(LLICTI_EINVAL, "last_timing_detail: null pointer");
+    float ms[4];
+    if (int rc = llicti_last_timing(c, ms, nullptr)) return rc;
+    for (int k = 0; k < LLICTI_NPROF; ++k) cat_ms[k] = c->last_cat_ms[k];
+    const int n = (int)c->last_cnn_ms.size();
+    if (cnn_launch_ms) for (int i = 0; i < std::min(n, cnn_cap); ++i) cnn_launch_ms[i] = c->last_cnn_ms[i];
+    if (n_cnn) *n_cnn = n;
     return LLICTI_OK;
 }

@@ -750,25 +750,47 @@ def test_agent_loads_reference_shaped_checkpoint(torch_mod, tmp_path):
         LLICTIAgent(cfg)
 
 
+def _bench_container_mode():
+    """The container bench.py TIMES (bench.DEFAULT_CONTAINER), as a codec mode."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    from llicti_amd.codec import MODE_RANS
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    name = bench.DEFAULT_CONTAINER
+    return name, (0 if name == "ac" else MODE_RANS(int(name[4:])))
+
+
 def test_full_size_oracle_parity(torch_mod, codecs, oracle_weights):
-    """BASELINE.json full sizes inside the suite: the 24 x 768x512 batch (configs[2]) in the rANS16 container with 3 of
-    the 24 images compared byte for byte with the oracle (it costs seconds per image), 2 x 768x512 in the AC container
+    """BASELINE.json full sizes inside the suite: the 24 x 768x512 batch (configs[2]) in the container bench.py TIMES
+    (bench.DEFAULT_CONTAINER) with 3 of the 24 images compared byte for byte with the oracle (it costs seconds per image)
+    and the whole batch within the north star's 0.001 bpp of the reference-format container; 2 x 768x512 in the AC container
     (configs[1]'s shape, reference format) against the oracle, and configs[0]'s 256x256 random-RGB image in the AC
     container; every decode on a poisoned workspace."""
     from oracle import oracle as orc
-    from llicti_amd.codec import MODE_RANS, container_to_bytestream_list
+    from llicti_amd.codec import container_to_bytestream_list
     torch = torch_mod
     c = codecs("rand1337")
     W_o = oracle_weights("rand1337")
     H, W = 512, 768
+    name, mode = _bench_container_mode()
     rgb = np.stack([np.random.default_rng(i).integers(0, 256, size=(3, H, W), dtype=np.uint8) for i in range(24)])   # bench.py's batch
-    cont, seg = c.encode(_dev(torch, rgb), mode=MODE_RANS(16))
+    cont, seg = c.encode(_dev(torch, rgb), mode=mode)
     c.check()
     cont_h, seg_h = cont.cpu().numpy(), seg.cpu().numpy()
     for b in (0, 11, 23):
-        assert container_to_bytestream_list(cont_h[b], seg_h[b]) == orc.encode_image_rans(rgb[b], W_o, 16), b
-    rec = _decode_poisoned(c, cont, seg, H, W, MODE_RANS(16))
+        ref = orc.encode_image(rgb[b], W_o) if mode == 0 else orc.encode_image_rans(rgb[b], W_o, mode & 0xFF)
+        assert container_to_bytestream_list(cont_h[b], seg_h[b]) == ref, (name, b)
+    rec = _decode_poisoned(c, cont, seg, H, W, mode)
     assert np.array_equal(rec.cpu().numpy(), rgb)
+    n_timed = int(seg_h.sum())
+    cont_a, seg_a = c.encode(_dev(torch, rgb))
+    c.check()
+    dbpp = 8.0 * (n_timed - int(seg_a.sum().item())) / (24 * H * W)
+    assert abs(dbpp) <= 0.001, f"timed container {name}: {dbpp:+.5f} bpp against the reference-format container"
+    del cont_a, seg_a
     cont, seg = c.encode(_dev(torch, rgb[:2]))
     c.check()
     cont_h, seg_h = cont.cpu().numpy(), seg.cpu().numpy()
@@ -784,6 +806,43 @@ def test_full_size_oracle_parity(torch_mod, codecs, oracle_weights):
     assert np.array_equal(orc.decode_image(bl, W_o), small[0])
     rec = _decode_poisoned(c, cont, seg, 256, 256, 0)
     assert np.array_equal(rec.cpu().numpy(), small)
+
+
+def test_configs4_per_gpu_batch_oracle_parity(torch_mod, codecs, oracle_weights):
+    """BASELINE.json configs[4]: 256 images over 8 GPUs = 32 x 768x512 per GPU.  Rank 7's batch (bench.py seeds rank * B ...)
+    in the timed container: one image against the oracle byte for byte, the batch lossless on a poisoned workspace."""
+    from oracle import oracle as orc
+    from llicti_amd.codec import container_to_bytestream_list
+    torch = torch_mod
+    c = codecs("rand1337")
+    W_o = oracle_weights("rand1337")
+    H, W, B, rank = 512, 768, 32, 7
+    name, mode = _bench_container_mode()
+    rgb = np.stack([np.random.default_rng(rank * B + i).integers(0, 256, size=(3, H, W), dtype=np.uint8) for i in range(B)])
+    cont, seg = c.encode(_dev(torch, rgb), mode=mode)
+    c.check()
+    b = 29
+    ref = orc.encode_image(rgb[b], W_o) if mode == 0 else orc.encode_image_rans(rgb[b], W_o, mode & 0xFF)
+    assert container_to_bytestream_list(cont[b].cpu().numpy(), seg[b].cpu().numpy()) == ref, name
+    rec = _decode_poisoned(c, cont, seg, H, W, mode)
+    assert np.array_equal(rec.cpu().numpy(), rgb)
+
+
+def test_4k_image_oracle_parity(torch_mod, codecs, oracle_weights):
+    """BASELINE.json configs[3] against the oracle: one 3840x2160 uniform-noise image (bench.py's image_4k leg) in the rANS32
+    container, HIP bytes == oracle bytes (about a minute of CPU: the oracle evaluates 24.9 M symbols), lossless."""
+    from oracle import oracle as orc
+    from llicti_amd.codec import MODE_RANS, container_to_bytestream_list
+    torch = torch_mod
+    c = codecs("rand1337")
+    W_o = oracle_weights("rand1337")
+    rgb = np.random.default_rng(0).integers(0, 256, size=(1, 3, 2160, 3840), dtype=np.uint8)
+    cont, seg = c.encode(_dev(torch, rgb), mode=MODE_RANS(32))
+    c.check()
+    got = container_to_bytestream_list(cont[0].cpu().numpy(), seg[0].cpu().numpy())
+    assert got == orc.encode_image_rans(rgb[0], W_o, 32)
+    rec = _decode_poisoned(c, cont, seg, 2160, 3840, MODE_RANS(32))
+    assert np.array_equal(rec.cpu().numpy(), rgb)
 
 
 @pytest.mark.parametrize("wname,kind", [("rand1337", "noise"), ("trainedlike", "smooth")])
@@ -868,19 +927,29 @@ def test_bench_line_contract(torch_mod):
     from conftest import ROOT
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "3", "--height", "96", "--width", "128", "--steps", "2",
-                        "--warmup", "1", "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+                        "--warmup", "1", "--no-extras"], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "rccl_ranks", "value_pcie_inclusive", "value_pcie_serial", "bpp"):
+              "dtype", "data", "config", "roofline", "rccl_ranks", "value_pcie_inclusive", "value_pcie_serial", "bpp",
+              "cpu_baseline", "bpp_delta_vs_reference", "meets_north_star", "north_star_check"):
         assert k in d, k
+    assert d["meets_north_star"] is False                       # not the north star's 768x512 shape: never claimed on another one
+    assert abs(d["bpp_delta_vs_reference"]["timed_container_minus_reference_format_bpp"]) < 0.2      # 3 tiny images, 8 streams each
+    cb = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] == "port" and cb["bitexact_vs_hip"] is True and cb["timed_container_bitexact_vs_hip"] is True
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
     assert d["unit"] == "MPix/s" and d["value"] > 0 and d["dtype"] == "f32" and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert 0 < r["whole_path_frac"] <= r["frac"] and set(r["kernel_ms"]) == {"encode", "decode"}
+    assert {"cnn", "rans_stage", "rans_tail", "misc"} <= set(r["kernel_ms"]["decode"]) and {"cnn", "cdf_pairs", "rans_encode"} <= set(r["kernel_ms"]["encode"])
+    assert len(r["cnn_tflops_per_level"]) == 5
     assert abs(d["ms_per_step"] * d["value"] - 3 * 96 * 128 / 1e3) < 0.02 * 3 * 96 * 128 / 1e3      # value = pixels / time
 
 
