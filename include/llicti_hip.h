@@ -180,6 +180,13 @@ int llicti_decode_images(llicti_ctx *ctx, const uint8_t *d_in, size_t in_stride,
  * last check (LLICTI_OK, LLICTI_EFORMAT, LLICTI_ENOSPACE). */
 int llicti_check_status(llicti_ctx *ctx, void *stream);
 
+/* Per-image status of the last llicti_decode_images call: h_status[b] = LLICTI_OK or LLICTI_EFORMAT for image b (a batch with one
+ * malformed container decodes the others correctly; the bad image's pixels are deterministic garbage).  Synchronises `stream`. */
+int llicti_image_status(llicti_ctx *ctx, int32_t *h_status, int n, void *stream);
+
+/* Host-side self-test of arithmetic helpers that have no device dependency (the magic division of the stage geometry). */
+int llicti_selftest(void);
+
 /* Image size from a container's first 17 header bytes (host memory). */
 int llicti_header_dims(const uint8_t *h_hdr17, int *H, int *W);
 

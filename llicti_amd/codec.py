@@ -228,6 +228,12 @@ class HipCodec:
     def check(self):
         _lib.check(self.L.llicti_check_status(self.ctx, _stream_ptr(self.device)))
 
+    def image_status(self, B):
+        """Per-image status of the last decode: numpy int32 [B], 0 = ok, EFORMAT = that image's container was malformed."""
+        out = np.zeros(B, dtype=np.int32)
+        _lib.check(self.L.llicti_image_status(self.ctx, _ptr(out), B, _stream_ptr(self.device)))
+        return out
+
     def set_tuning(self, key, value):
         _lib.check(self.L.llicti_set_tuning(self.ctx, key.encode(), int(value)))
 

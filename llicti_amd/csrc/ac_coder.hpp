@@ -237,6 +237,7 @@ __global__ __launch_bounds__(64) void ac_decode_kernel(const uint16_t *__restric
     auto load_win = [&](int w0) -> uint32_t {           // big-endian words, swapped once per reload
         const int wi = min(w0 + lane, in_words - 1);
         const uint32_t w = bswap32(words[wi]);
+        if (w0 + lane >= in_words) return 0u;           // past the stream: zero bits (also for the first three words of a stream of <= 8 bytes)
         return (wi == in_words - 1) ? (len_b > 0 ? (w & tail_mask) : 0u) : w;
     };
     uint32_t *st = ck.state ? ck.state + 8 * s : nullptr;
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(64) void ac_decode_kernel(const uint16_t *__restric
             const int n = n_first + lane;
             if (o.sym) o.sym[(long)s * ck.n_total + n] = (int16_t)mysym;
             if (o.planes) {
-                const int i = n / o.sg.wc, j = n - i * o.sg.wc;
+                const int i = div_wc(o.sg, n), j = n - i * o.sg.wc;
                 const long off = (long)s * 3 * o.sg.plane + (long)o.clr * o.sg.plane +
                                  ((long)(2 * i + o.sg.oi) << o.sg.lvl) * o.sg.W + ((long)(2 * j + o.sg.oj) << o.sg.lvl);
                 const int v = mysym - shift;                       // _convert_int16cpu_to_float32gpu, LLICTI_nets.py:559-568
@@ -395,8 +396,17 @@ __global__ __launch_bounds__(64) void ac_decode_anchor_kernel(const uint8_t *__r
                                              (__attribute__((address_space(3))) void *)&ring[slot][0], 16, 0, 0);
         }
     };
-    const int in_words = (int)(in_stride >> 2);
-    auto load_win = [&](int w0) -> uint32_t { return bswap32(words[min(w0 + lane, in_words - 1)]); };
+    // words the stream really has (o.len: the lengths unpack_kernel validated): everything past them reads as zero bits, whatever
+    // the slot holds there -- a desynchronised decode of a malformed container must not depend on stale workspace bytes
+    const int len_b = o.len ? max(0, min(o.len[s], (int)in_stride)) : (int)in_stride;
+    const int in_words = max(1, (len_b + 3) >> 2);
+    const uint32_t tail_mask = (len_b & 3) ? ~(0xFFFFFFFFu >> (8 * (len_b & 3))) : 0xFFFFFFFFu;
+    auto load_win = [&](int w0) -> uint32_t {
+        const int wi = min(w0 + lane, in_words - 1);
+        const uint32_t w = bswap32(words[wi]);
+        if (w0 + lane >= in_words) return 0u;
+        return (wi == in_words - 1) ? (len_b > 0 ? (w & tail_mask) : 0u) : w;
+    };
     uint32_t *st = ck.state + 8 * s;
     int wpos = first ? 3 : (int)st[6];
     uint32_t win_cur = load_win(first ? 0 : (wpos & ~63));
@@ -426,7 +436,7 @@ __global__ __launch_bounds__(64) void ac_decode_anchor_kernel(const uint8_t *__r
     auto flush = [&](int n_first, int count) {
         if (lane < count) {
             const int n = n_first + lane;
-            const int i = n / o.sg.wc, j = n - i * o.sg.wc;
+            const int i = div_wc(o.sg, n), j = n - i * o.sg.wc;
             const long off = (long)s * 3 * o.sg.plane + (long)o.clr * o.sg.plane +
                              ((long)(2 * i + o.sg.oi) << o.sg.lvl) * o.sg.W + ((long)(2 * j + o.sg.oj) << o.sg.lvl);
             const int v = mysym - shift;

@@ -6,23 +6,43 @@
 struct StageGeom {      // one (level, band): band grid, coded crop, full-res addressing
     int B, H, W, lvl, h, w, hc, wc, oi, oj;
     long plane;
-    uint32_t wc_mul;    // n / wc for 0 <= n < 2^31 without a division: t = mulhi(n, wc_mul); q = (t + ((n - t) >> 1)) >> wc_sh
+    uint32_t wc_mul;    // n / wc for 0 <= n < 2^31 without a division: div_by_magic(n, wc_mul, wc_sh)
     int wc_sh;
 };
-// exact unsigned division by an invariant divisor (Granlund / Montgomery, the 33-bit multiplier form): d >= 1
+// exact unsigned division by an invariant divisor (Granlund / Montgomery, the 33-bit multiplier form), 1 <= d < 2^31,
+// 0 <= n < 2^31: l = ceil(log2 d), mul = floor(2^32 (2^l - d) / d) + 1, t = mulhi(n, mul), q = (t + ((n - t) >> 1)) >> (l - 1).
+// d == 1 has no 33-bit form with a non-negative shift: it is encoded as (mul, sh) = (0, -1) and div_by_magic() returns n.
 static void div_magic(uint32_t d, uint32_t *mul, int *sh)
 {
     int l = 0;
     while ((1ull << l) < d) ++l;                                   // l = ceil(log2 d)
+    if (l == 0) { *mul = 0; *sh = -1; return; }                     // d == 1
     *mul = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
-    *sh = l > 0 ? l - 1 : 0;
-    if (l == 0) { *mul = 0; *sh = 0; }                              // d == 1: t = 0, q = (0 + (n >> 1)) >> 0 is wrong -> handled by div_wc()
+    *sh = l - 1;
 }
-__device__ __forceinline__ int div_wc(const StageGeom &s, int n)
+__host__ __device__ __forceinline__ uint32_t div_by_magic(uint32_t n, uint32_t mul, int sh)
 {
-    if (s.wc == 1) return n;
-    const uint32_t t = __umulhi((uint32_t)n, s.wc_mul);
-    return (int)((t + (((uint32_t)n - t) >> 1)) >> s.wc_sh);
+    if (sh < 0) return n;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t t = __umulhi(n, mul);
+#else
+    const uint32_t t = (uint32_t)(((uint64_t)n * mul) >> 32);
+#endif
+    return (t + ((n - t) >> 1)) >> sh;
+}
+__device__ __forceinline__ int div_wc(const StageGeom &s, int n) { return (int)div_by_magic((uint32_t)n, s.wc_mul, s.wc_sh); }
+// host self-test (llicti_selftest): every divisor of the format's range against '/', at the values where a magic division breaks first
+static int selftest_div_magic()
+{
+    for (uint32_t d = 1; d <= 8192; ++d) {
+        uint32_t mul; int sh;
+        div_magic(d, &mul, &sh);
+        const uint32_t probes[] = { 0u, 1u, d - 1, d, d + 1, 2 * d - 1, 2 * d, 4080u * 4080u - 1, 4080u * 4080u, (1u << 24) - 1, (1u << 24) + d,
+                                    0x7FFFFFFFu / d * d - 1, 0x7FFFFFFFu / d * d, 0x7FFFFFFFu };
+        for (uint32_t n : probes) if ((n >> 31) == 0 && div_by_magic(n, mul, sh) != n / d) return (int)d;
+        for (uint32_t k = 0; k < 4096; ++k) { const uint32_t n = k * 524287u + d; if ((n >> 31) == 0 && div_by_magic(n, mul, sh) != n / d) return (int)d; }
+    }
+    return 0;
 }
 static StageGeom make_stage(const Geom &g, int band)
 {

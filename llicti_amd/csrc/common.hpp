@@ -78,6 +78,14 @@ __device__ __forceinline__ int src_oi(int s) { return s & 1; }
 __device__ __forceinline__ int src_oj(int s) { return ((s + 1) >> 1) & 1; }
 
 
+// Device-side failures are latched twice: status[0] for the whole call (llicti_check_status) and status[16 + b] for image b
+// (llicti_image_status), so that a caller can drop just the bad image of a batch.
+__device__ __forceinline__ void flag_image(int32_t *status, int b, int code)
+{
+    atomicExch(&status[0], code);
+    atomicExch(&status[16 + b], code);
+}
+
 // wave-wide vote as a 64-bit lane mask, straight from the comparison (HIP's __ballot(int) first materialises the
 // predicate as 0/1 in a VGPR and compares it again: two extra vector operations per vote)
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }

@@ -70,22 +70,23 @@ __global__ void header_read_kernel(const uint8_t *__restrict__ in, long in_strid
             const int pad = (int)(int16_t)(p[15] | (p[16] << 8));
             ok = (p[0] == byte0 && p[1] == h4 && p[2] == w4 && pad == padint);           // LLICTI_nets.py:423-428
         }
-        if (!ok) atomicExch(&status[0], LLICTI_EFORMAT);
+        if (!ok) flag_image(status, b, LLICTI_EFORMAT);
         int16_t v[6] = { 0, -255, -255, 255, 255, 255 };
         if (ok) for (int k = 0; k < 6; ++k) v[k] = (int16_t)(p[3 + 2 * k] | (p[4 + 2 * k] << 8));
         int32_t *mm = minmax + 4 * b;
         mm[0] = v[1]; mm[1] = v[2]; mm[2] = v[4]; mm[3] = v[5];
         if (v[1] > v[4] || v[2] > v[5] || v[1] < -255 || v[2] < -255 || v[4] > 255 || v[5] > 255) {
-            atomicExch(&status[0], LLICTI_EFORMAT);
+            flag_image(status, b, LLICTI_EFORMAT);
             mm[0] = mm[1] = -255; mm[2] = mm[3] = 255;
         }
     }
     __syncthreads();
-    if (!ok) return;
+    // a rejected header still gets a DC band (mid grey): the 45 stages run for every image of the batch, and what they write
+    // must not depend on what an earlier call left in the shared workspace (the image is flagged: llicti_image_status)
     const uint8_t *dc = p + 17;
     for (int t = threadIdx.x; t < h4 * w4; t += blockDim.x) {                              // :429-430, :443-444
         const int i = t / w4, j = t - i * w4;
-        const int R = dc[t], G = dc[h4 * w4 + t], Bl = dc[2 * h4 * w4 + t];
+        const int R = ok ? dc[t] : 128, G = ok ? dc[h4 * w4 + t] : 128, Bl = ok ? dc[2 * h4 * w4 + t] : 128;
         const int Co = R - Bl, tt = Bl + (Co >> 1), Cg = G - tt, Y = tt + (Cg >> 1) - 127;
         const long off = (long)b * 3 * plane + (long)(32 * i) * W + 32 * j;
         planes[off] = (int16_t)Y; planes[off + plane] = (int16_t)Co; planes[off + 2 * plane] = (int16_t)Cg;
@@ -96,7 +97,7 @@ __global__ void header_read_kernel(const uint8_t *__restrict__ in, long in_strid
 // decode: copy stream st of image b into its 4-byte aligned, zero padded slot
 __global__ __launch_bounds__(256) void unpack_kernel(const uint8_t *__restrict__ in, long in_stride, const int32_t *__restrict__ seg_len,
                                                      int B, uint8_t *__restrict__ slots, const long *__restrict__ slot_off,
-                                                     const int32_t *__restrict__ slot_cap, int32_t *status)
+                                                     const int32_t *__restrict__ slot_cap, int32_t *__restrict__ slot_len, int32_t *status)
 {
     const int st = blockIdx.x, b = blockIdx.y;
     const int32_t *sl = seg_len + (long)b * LLICTI_NSEG;
@@ -110,10 +111,11 @@ __global__ __launch_bounds__(256) void unpack_kernel(const uint8_t *__restrict__
     }
     int n = sl[4 + st];
     const int cap = slot_cap[(long)st * B + b];
-    if (bad || n < 0 || n + 16 > cap || src + n > in_stride) { if (threadIdx.x == 0) atomicExch(&status[0], LLICTI_EFORMAT); n = 0; src = 0; }
+    if (bad || n < 0 || n + 16 > cap || src + n > in_stride) { if (threadIdx.x == 0) flag_image(status, b, LLICTI_EFORMAT); n = 0; src = 0; }
     const uint8_t *p = in + (long)b * in_stride + src;
     uint8_t *o = slots + slot_off[(long)st * B + b];
     block_copy_bytes(o, p, n);
     const int padded = min(cap, ((n + 3) & ~3) + 16);
     for (int t = n + threadIdx.x; t < padded; t += blockDim.x) o[t] = 0;
+    if (threadIdx.x == 0) slot_len[(long)st * B + b] = n;       // the decoders read nothing past it
 }

@@ -69,6 +69,7 @@ constexpr int kAcAnchorBatch = 96;
 static bool ac_use_anchors(int B, int min_batch = kAcAnchorBatch) { return B >= std::min(min_batch, kAcAnchorBatch); }
 
 constexpr int kMaxSub = 4;
+constexpr int kStatusHead = 16;       // status words in front of the per-image ones (common.hpp: image_status())
 struct PlanDev {                  // owns its device arrays: a plan that fails half-way through get_plan() frees what it took
     Plan p;
     StreamDesc *d_desc = nullptr;
@@ -102,6 +103,8 @@ struct llicti_ctx {
     hipEvent_t ev_ac_band = nullptr, ev_ac_end[2] = { nullptr, nullptr };
     int pipeline_s = 4;
     int ac_anchor_min_batch = kAcAnchorBatch;
+    const int32_t *img_status = nullptr;   // per-image status words of the last llicti_decode_images call (in its workspace)
+    int img_status_n = 0;
     bool pipeline = false;     // sub-batch pipelining of decode: measured neutral (co-resident CNN and rANS waves share VALU issue)
     int32_t *d_status = nullptr;      // small persistent status word (for the kernel-level entry points)
     int32_t *d_lift_part = nullptr;   // min/max partials of llicti_lift_u8 (1 MB; calls on one context are not concurrent)
@@ -176,7 +179,7 @@ static void build_plan(Plan &p, int B, int H, int W, int M)
     const size_t plane = (size_t)H * W;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
-    p.off_status = take(64);
+    p.off_status = take(kStatusHead * sizeof(int32_t) + (size_t)B * sizeof(int32_t));   // [0]: the call's status; [kStatusHead + b]: image b's
     p.off_minmax = take((size_t)B * 4 * sizeof(int32_t));
     p.off_lift_part = take((size_t)kLiftMaxParts * 4 * sizeof(int32_t));
     p.off_planes = take((size_t)B * 3 * plane * sizeof(int16_t));
@@ -688,7 +691,7 @@ extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, 
     int32_t *slot_len = (int32_t *)(ws + p.off_slot_len);
 
     CallScope call(c, s);
-    HIPCHK(hipMemsetAsync(status, 0, 64, s));
+    HIPCHK(hipMemsetAsync(status, 0, (kStatusHead + (size_t)B) * sizeof(int32_t), s));
     Geom g4 = make_geom(B, H, W, 4);
     const int byte0 = M ? rans_byte0(M) : LLICTI_NLEVELS;
     {
@@ -734,8 +737,9 @@ static int decode_sub(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in
     uint8_t *slots = ws + p.off_slots;
     uint8_t *tables = ws + p.off_tables;
     uint32_t *acstate = (uint32_t *)(ws + p.off_acstate);
+    int32_t *slot_len = (int32_t *)(ws + p.off_slot_len);
 
-    HIPCHK(hipMemsetAsync(status, 0, 64, s));
+    HIPCHK(hipMemsetAsync(status, 0, (kStatusHead + (size_t)B) * sizeof(int32_t), s));
     Geom g4 = make_geom(B, H, W, 4);
     const int byte0 = M ? rans_byte0(M) : LLICTI_NLEVELS;
     uint32_t *rstate = (uint32_t *)(ws + p.off_rstate);
@@ -745,10 +749,10 @@ static int decode_sub(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in
         ProfSpan span(c, PROF_MISC, s);
         header_read_kernel<<<B, 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, H, W, g4.h, g4.w, pad_int(H, W), byte0, planes, fplanes, mm, status);
         if (M == 0) {
-            unpack_kernel<<<dim3(LLICTI_NSTREAMS, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, B, slots, pd->d_slot_off, pd->d_slot_cap, status);
+            unpack_kernel<<<dim3(LLICTI_NSTREAMS, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, B, slots, pd->d_slot_off, pd->d_slot_cap, slot_len, status);
         } else {
             rans_unpack_kernel<<<dim3(M, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, M, slots, pd->d_rslot_off, p.rslot_cap, rpos, status);
-            rans_init_kernel<<<B * M, 64, 0, s>>>(slots, pd->d_rslot_off, rstate, rpos, rtail, status);
+            rans_init_kernel<<<B * M, 64, 0, s>>>(slots, pd->d_rslot_off, M, rstate, rpos, rtail, status);
         }
     }
     // 45 dependent stages (LLICTI_nets.py:440-498): CNN of band b needs bands < b of this level, Co needs Y, Cg needs Y, Co
@@ -799,6 +803,7 @@ static int decode_sub(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in
                         DecOut o;
                         memset(&o, 0, sizeof o);
                         o.planes = planes; o.fplanes = fplanes; o.minmax = mm; o.sg = sg; o.clr = clr;
+                        o.len = slot_len + (size_t)st * B;
                         // the B streams of one stage sit in consecutive slots of equal capacity
                         const long in_stride_slots = p.slot_cap[(size_t)st * B];
                         AcChunk ck = { (int)n0, (int)cnt, (int)nc, (int)p.ac_cap_rows, acstate + (size_t)clr * B * 8 };
@@ -854,6 +859,8 @@ extern "C" int llicti_decode_images(llicti_ctx *c, const uint8_t *d_in, size_t i
     const size_t plane3 = (size_t)3 * H * W;
 
     CallScope call(c, s);
+    c->img_status = (S == 1) ? (const int32_t *)(ws + pd->p.off_status) + kStatusHead : nullptr;
+    c->img_status_n = (S == 1) ? B : 0;
     if (S > 1) HIPCHK(hipEventRecord(c->ev_fork, s));
     for (int k = 0; k < S; ++k) {
         hipStream_t sk = (k == 0) ? s : c->sub[k];
@@ -937,5 +944,21 @@ extern "C" int llicti_last_timing_detail(llicti_ctx *c, float cat_ms[LLICTI_NPRO
     const int n = (int)c->last_cnn_ms.size();
     if (cnn_launch_ms) for (int i = 0; i < std::min(n, cnn_cap); ++i) cnn_launch_ms[i] = c->last_cnn_ms[i];
     if (n_cnn) *n_cnn = n;
+    return LLICTI_OK;
+}
+
+extern "C" int llicti_image_status(llicti_ctx *c, int32_t *h_status, int n, void *stream)
+{
+    if (!c || !h_status || n < 1) return fail(LLICTI_EINVAL, "image_status: bad argument");
+    DeviceGuard guard(c);
+    if (!c->img_status || n > c->img_status_n) return fail(LLICTI_EINVAL, "image_status: the last decode held %d images (per-image status is not kept for pipelined decodes)", c->img_status_n);
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    HIPCHK(hipMemcpy(h_status, c->img_status, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return LLICTI_OK;
+}
+
+extern "C" int llicti_selftest(void)
+{
+    if (int d = selftest_div_magic()) return fail(LLICTI_EINVAL, "selftest: magic division by %d differs from '/'", d);
     return LLICTI_OK;
 }

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restr
 // decode: parse a stream (copied to slot + 2 by rans_unpack_kernel, which also left its validated length in rpos):
 // T and pad (-> bit cursor), the 64 states
 __global__ __launch_bounds__(64) void rans_init_kernel(const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
-                                                       uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos,
+                                                       int M, uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos,
                                                        uint32_t *__restrict__ rtail, int32_t *status)
 {
     const int sidx = blockIdx.x, lane = threadIdx.x;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(64) void rans_init_kernel(const uint8_t *__restrict
     const uint32_t x = (1u << 31) | ((uint32_t)(w >> (bpos & 7)) & 0x7FFFFFFFu);
     rstate[(long)sidx * 64 + lane] = x;
     if (lane == 0) { rpos[sidx] = (uint32_t)cur; rtail[sidx] = (uint32_t)T; }
-    if (bad && lane == 0) atomicExch(&status[0], LLICTI_EFORMAT);
+    if (bad && lane == 0) flag_image(status, sidx / M, LLICTI_EFORMAT);
 }
 
 // One stage (level, band, colour channel) of all images.  One workgroup of 4 wavefronts per stream (one per
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
         rstate[(long)sidx * 64 + lane] = x;
         if (lane == 0) {
             rpos[sidx] = (uint32_t)max(bcur, 0);
-            if (bcur < 0) atomicExch(&status[0], LLICTI_EFORMAT);              // the stream ran out of bits
+            if (bcur < 0) flag_image(status, b, LLICTI_EFORMAT);               // the stream ran out of bits
         }
     }
 }
@@ -542,9 +542,9 @@ __global__ __launch_bounds__(64) void rans_tail_kernel(const float *__restrict__
     __shared__ uint32_t sh_pay[66];
     const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M, lane = threadIdx.x;
     const int nc = sg.hc * sg.wc;
-    const int T = (int)rtail[sidx];
     const int cnt = rans_stream_count(nc, m, M);
-    bool bad = rpos[sidx] != 0 || T > cnt;
+    bool bad = rpos[sidx] != 0 || (int)rtail[sidx] > cnt;
+    const int T = min((int)rtail[sidx], cnt);
     sh_pay[lane] = 0;
     if (lane < 2) sh_pay[64 + lane] = 0;
     __syncthreads();
@@ -558,12 +558,11 @@ __global__ __launch_bounds__(64) void rans_tail_kernel(const float *__restrict__
         const int hd = 63 - __clzll((long long)nz);
         top = 32 * hd + 31 - __clz((int)sh_pay[hd]);
     }
-    if (top < 31 || bad) {
-        if (lane == 0) atomicExch(&status[0], LLICTI_EFORMAT);
-        return;                                                                // whole wave
-    }
-    uint32_t xt = lds_get_bits(sh_pay, top - 31, 32);
-    int tc = top - 31;
+    // a malformed stream still gets its T tail pixels written (from whatever state there is): the output of a flagged image
+    // must not depend on what the workspace held
+    if (top < 31) bad = true;
+    uint32_t xt = (top >= 31) ? lds_get_bits(sh_pay, top - 31, 32) : (1u << 31);
+    int tc = (top >= 31) ? top - 31 : 0;
     int minv, maxv, shift;
     clr_range(minmax + 4 * b, 2, minv, maxv, shift);
     const Grid gr = make_grid(minv, maxv);
@@ -608,16 +607,16 @@ __global__ __launch_bounds__(64) void rans_tail_kernel(const float *__restrict__
         }
         xt = (vhi - vlo) * (xt >> 16) + slot - vlo;
         if (q == cnt - 1) { bad = bad || xt != (vhi - vlo) << 15; break; }    // the encoder's first symbol: absorbing start, no bits
-        const int nb = __clz((int)xt);
-        if (nb > 16 || tc < nb) { bad = true; break; }
+        int nb = __clz((int)xt);
+        if (nb > 16 || tc < nb) { bad = true; nb = min(nb, min(tc, 16)); }      // corrupt: keep going on what is there
         tc -= nb;
-        xt = (xt << nb) | lds_get_bits(sh_pay, tc, nb);
+        xt = ((xt << nb) | lds_get_bits(sh_pay, tc, nb)) | (1u << 31);
 #pragma unroll
         for (int k = 0; k < LLICTI_PARAM_STRIDE; ++k) parA[k] = parB[k];
         yA = yB; coA = coB; offA = offB;
     }
     if (T == 0) bad = bad || xt != (1u << 31);
-    if ((bad || tc != 0) && lane == 0) atomicExch(&status[0], LLICTI_EFORMAT);
+    if ((bad || tc != 0) && lane == 0) flag_image(status, b, LLICTI_EFORMAT);
 }
 
 __global__ __launch_bounds__(256) void rans_pack_kernel(const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
@@ -655,7 +654,7 @@ __global__ __launch_bounds__(256) void rans_unpack_kernel(const uint8_t *__restr
     int n = sl[4 + m];
     uint8_t *o = slots + rslot_off[b * M + m] + 2;               // the bit region (stream offset 2) lands dword aligned
     if (bad || n < kRansMinStream || n + 2 + 64 > rslot_cap || src + n > in_stride) {
-        if (threadIdx.x == 0) atomicExch(&status[0], LLICTI_EFORMAT);
+        if (threadIdx.x == 0) flag_image(status, b, LLICTI_EFORMAT);
         n = kRansMinStream;                                        // a harmless stream: T = 0, no bits, states 2^31
         for (int t = threadIdx.x; t < n; t += blockDim.x) o[t] = 0;
     } else {

@@ -688,6 +688,62 @@ def test_ac_decode_seam_ignores_bytes_past_len(torch_mod, codecs):
     assert np.array_equal(dec.cpu().numpy(), syms)
 
 
+@pytest.mark.parametrize("N", [1, 2, 3, 5])
+def test_ac_decode_seam_short_streams(torch_mod, codecs, N):
+    """Streams of a few bytes (1 .. 3 symbols give 1 .. 8 bytes): the decoder's first three words must read as zero bits past
+    d_len[s] too, whatever the buffer holds there (torchac's get() semantics)."""
+    from oracle import oracle as orc
+    torch = torch_mod
+    c = codecs("rand1337")
+    rng = np.random.default_rng(100 + N)
+    Lp, S, stride = 257, 16, 264
+    from test_ref_ac import random_rows
+    cdfs = np.full((S, N, stride), 0xFFFF, np.uint16)
+    syms = rng.integers(0, Lp - 1, (S, N)).astype(np.int16)
+    streams = []
+    for s in range(S):
+        cdfs[s, :, :Lp] = random_rows(rng, N, Lp, 3.0)
+        streams.append(orc.ac_encode_tables(cdfs[s, :, :Lp].copy(), syms[s]))
+        assert np.array_equal(orc.ac_decode_tables(cdfs[s, :, :Lp].copy(), streams[-1], N), syms[s])
+    assert min(len(x) for x in streams) <= 8
+    in_stride = 64
+    buf = np.full((S, in_stride), 0xFF, np.uint8)                           # all-ones garbage: the worst case for a zero-bit tail
+    for s, x in enumerate(streams):
+        buf[s, :len(x)] = np.frombuffer(x, np.uint8)
+    lens = np.array([len(x) for x in streams], np.int32)
+    dec = c.ac_decode(_dev(torch, cdfs.view(np.int16)), Lp, _dev(torch, buf), _dev(torch, lens), N)
+    assert np.array_equal(dec.cpu().numpy(), syms)
+
+
+def test_malformed_header_is_deterministic_and_per_image(torch_mod, codecs):
+    """One image of a batch with a header that does not match the call: the call reports EFORMAT, llicti_image_status names
+    the image, the OTHER images decode correctly, and the bad image's pixels do not depend on what the workspace held."""
+    from llicti_amd._lib import LlictiError, EFORMAT
+    from llicti_amd.codec import MODE_RANS
+    torch = torch_mod
+    c = codecs("trainedlike")
+    rgb = make_batch("smooth", 3, 64, 96, seed0=900)
+    for mode in (0, MODE_RANS(2)):
+        cont, seg = c.encode(_dev(torch, rgb), mode=mode)
+        c.check()
+        bad = cont.clone()
+        bad[1, 1] ^= 0x01                                                   # h4 of image 1
+        outs = []
+        for poison in (0xA5, 0x3C):
+            c.poison_workspace(poison)
+            rec = c.decode(bad, seg, 64, 96, mode=mode)
+            with pytest.raises(LlictiError) as e:
+                c.check()
+            assert e.value.code == EFORMAT
+            st = c.image_status(3)
+            assert st[0] == 0 and st[2] == 0 and st[1] == EFORMAT, st
+            outs.append(rec.cpu().numpy())
+        assert np.array_equal(outs[0][0], rgb[0]) and np.array_equal(outs[0][2], rgb[2])
+        assert np.array_equal(outs[0][1], outs[1][1])                       # garbage, but the same garbage
+        rec = _decode_poisoned(c, cont, seg, 64, 96, mode)
+        assert np.array_equal(rec.cpu().numpy(), rgb) and not c.image_status(3).any()
+
+
 def _reference_shaped_checkpoint(path, seed):
     """What agents/base.py:83-100 saves: epoch / iteration / best_valid_loss / state_dict / optimizer / scheduler / logger
     states; the state_dict carries compressai's extra buffers on every conditional_prob_model and NON-seed weights."""
@@ -900,6 +956,7 @@ def test_rans_v3_integrity_check_detects_corruption(torch_mod, codecs, oracle_we
             c.check()
         assert e.value.code == EFORMAT, where
         assert np.array_equal(rec[0].cpu().numpy(), rgb[0])                           # the other image of the batch is untouched
+        assert list(c.image_status(2)) == [0, EFORMAT]                               # ... and the status names the bad one
         bl = container_to_bytestream_list(bad[1].cpu().numpy(), seg_h[1])
         with pytest.raises(Exception):
             orc.decode_image_rans(bl, W_o)
@@ -951,6 +1008,39 @@ def test_bench_line_contract(torch_mod):
     assert {"cnn", "rans_stage", "rans_tail", "misc"} <= set(r["kernel_ms"]["decode"]) and {"cnn", "cdf_pairs", "rans_encode"} <= set(r["kernel_ms"]["encode"])
     assert len(r["cnn_tflops_per_level"]) == 5
     assert abs(d["ms_per_step"] * d["value"] - 3 * 96 * 128 / 1e3) < 0.02 * 3 * 96 * 128 / 1e3      # value = pixels / time
+
+
+def _run_bench(args, timeout=900):
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_two_ranks_aggregate(torch_mod):
+    """The N > 1 path of bench.py on the GPU: `--gpus 2` from a bare shell (the parent launches the ranks as children).  With two
+    GPUs visible: RCCL, one rank per GPU.  On a one-GPU box: gloo with --allow-shared-gpu (a rehearsal, marked as such in the
+    line; without the flag the run must refuse).  Either way `value` is SUM pixels / MAX time over the ranks and every rank
+    leaves through destroy_process_group (a clean exit code)."""
+    torch = torch_mod
+    two = torch.cuda.device_count() >= 2
+    common = ["--gpus", "2", "--batch", "2", "--height", "96", "--width", "128", "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline"]
+    if not two:
+        p, d = _run_bench(common + ["--backend", "gloo"])
+        assert p.returncode != 0 and d is None and "allow-shared-gpu" in p.stderr
+    p, d = _run_bench(common + (["--backend", "nccl"] if two else ["--backend", "gloo", "--allow-shared-gpu"]))
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "destroy_process_group() was not called" not in p.stderr
+    assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "weak"
+    assert d["backend"] == ("nccl" if two else "gloo") and d["shared_gpu"] is (not two) and d["distinct_devices"] == (2 if two else 1)
+    assert abs(d["ms_per_step"] * d["value"] - 2 * 2 * 96 * 128 / 1e3) < 0.02 * 2 * 2 * 96 * 128 / 1e3      # both ranks' pixels over the slower rank's time
+    assert d["meets_north_star"] is False and d["config"]["sharding"] == "images/2gpu"
 
 
 def test_plan_cache_eviction(torch_mod, codecs):

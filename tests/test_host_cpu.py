@@ -24,6 +24,13 @@ def test_library_exports_every_header_symbol():
     assert b"gfx950" in _lib.lib().llicti_version()
 
 
+def test_magic_division_selftest():
+    """The stage geometry's division by an invariant width (div_magic / div_by_magic, used by every decoder to turn a symbol
+    index into a row and a column) against '/': every divisor 1 .. 8192, boundary and pseudo-random dividends below 2^31."""
+    from llicti_amd import _lib
+    assert _lib.lib().llicti_selftest() == 0, _lib.lib().llicti_last_error()
+
+
 def test_no_gpu_fails_loudly():
     import torch
     if torch.cuda.is_available():
