@@ -109,6 +109,12 @@ struct llicti_ctx {
     int32_t *d_status = nullptr;      // small persistent status word (for the kernel-level entry points)
     int32_t *d_lift_part = nullptr;   // min/max partials of llicti_lift_u8 (1 MB; calls on one context are not concurrent)
     int n_cu = 256;                   // compute units of the device (grid sizing of the persistent kernels)
+    int cnn_cus = 256;                // compute units the band CNN may fill (= n_cu, less inside a CU-partitioned decode)
+    // experiment (LLICTI_CUMASK=<R>): decode as sub-batches whose CNN launches run on streams masked to n_cu - R compute units and
+    // whose rANS stages run on streams masked to the other R, so that one sub-batch's stages overlap another's CNN
+    int cumask_rans = 0;
+    hipStream_t cu_cnn[kMaxSub] = {}, cu_rans[kMaxSub] = {};
+    hipEvent_t ev_cr[kMaxSub][2] = {};
     bool profiling = false;
     std::vector<hipEvent_t> ev;       // event pairs of the profiling spans of the current call
     std::vector<int> ev_cat;          // category of pair i
@@ -316,6 +322,7 @@ extern "C" int llicti_create(llicti_ctx **out, int device)
     llicti_ctx *c = new llicti_ctx();
     c->device = device;
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->cnn_cus = c->n_cu;
     DeviceGuard guard(c);
     if (const char *e = getenv("LLICTI_PIPELINE")) { c->pipeline = atoi(e) != 0; c->pipeline_s = atoi(e); }     // experiment switch: sub-batch pipelining of decode
     HIPCHK(hipMalloc(&c->d_status, 64));
@@ -329,9 +336,23 @@ extern "C" int llicti_create(llicti_ctx **out, int device)
         HIPCHK(hipEventCreateWithFlags(&c->ev_ac_end[k], hipEventDisableTiming));
     }
     HIPCHK(hipEventCreateWithFlags(&c->ev_ac_band, hipEventDisableTiming));
-    for (int i = 1; i < kMaxSub; ++i) {
-        HIPCHK(hipStreamCreateWithFlags(&c->sub[i], hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+    for (int i = 1; i < kMaxSub; ++i) HIPCHK(hipStreamCreateWithFlags(&c->sub[i], hipStreamNonBlocking));
+    for (int i = 0; i < kMaxSub; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+    if (const char *e = getenv("LLICTI_CUMASK")) {
+        const int R = atoi(e);
+        if (R >= 8 && R <= c->n_cu - 8 && c->n_cu <= 256) {
+            uint32_t mr[8] = {}, mc[8] = {};
+            for (int i = 0; i < c->n_cu; ++i) (i < R ? mr : mc)[i >> 5] |= 1u << (i & 31);
+            const int nsub = (c->pipeline && c->pipeline_s >= 4) ? 4 : 2;      // only the queues the decode will use
+            for (int k = 0; k < nsub; ++k) {
+                HIPCHK(hipExtStreamCreateWithCUMask(&c->cu_cnn[k], 8, mc));
+                HIPCHK(hipExtStreamCreateWithCUMask(&c->cu_rans[k], 8, mr));
+                HIPCHK(hipEventCreateWithFlags(&c->ev_cr[k][0], hipEventDisableTiming));
+                HIPCHK(hipEventCreateWithFlags(&c->ev_cr[k][1], hipEventDisableTiming));
+            }
+            c->cumask_rans = R;
+            if (!c->pipeline) { c->pipeline = true; c->pipeline_s = 2; }
+        }
     }
     // the band CNN stages a whole head (up to 86 KB) in LDS
     HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(0)));
@@ -352,6 +373,9 @@ extern "C" int llicti_destroy(llicti_ctx *c)
     for (int i = 0; i < kMaxSub; ++i) {
         if (c->sub[i]) hipStreamDestroy(c->sub[i]);
         if (c->ev_join[i]) hipEventDestroy(c->ev_join[i]);
+        if (c->cu_cnn[i]) hipStreamDestroy(c->cu_cnn[i]);
+        if (c->cu_rans[i]) hipStreamDestroy(c->cu_rans[i]);
+        for (int j = 0; j < 2; ++j) if (c->ev_cr[i][j]) hipEventDestroy(c->ev_cr[i][j]);
     }
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     for (int k = 0; k < 2; ++k) {
@@ -428,7 +452,7 @@ static int launch_band_params(llicti_ctx *c, const float *fplanes, const Geom &g
     const int n_tiles = (int)n_tiles_l;
     const int lds_bytes = cnn_lds_bytes(band);
     const int wg_per_cu = std::max(1, std::min(4, (160 * 1024) / lds_bytes));
-    int gx = std::min(n_tiles, c->n_cu * wg_per_cu / 4);    // 4 heads in grid.y; persistent loop over tiles
+    int gx = std::min(n_tiles, c->cnn_cus * wg_per_cu / 4);    // 4 heads in grid.y; persistent loop over tiles
     if (gx < 1) gx = 1;
     dim3 grid((unsigned)gx, 4);
     ProfSpan span(c, PROF_CNN, s);
@@ -725,9 +749,11 @@ extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, 
     return LLICTI_OK;
 }
 
+// sr: the stream the rANS stages run on (== s, or a CU-masked stream chained to s with the two events evcr)
 static int decode_sub(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in_stride, const int32_t *d_seg_len,
-                      int B, int H, int W, int M, uint8_t *ws, uint8_t *d_rgb, hipStream_t s)
+                      int B, int H, int W, int M, uint8_t *ws, uint8_t *d_rgb, hipStream_t s, hipStream_t sr = nullptr, hipEvent_t *evcr = nullptr)
 {
+    if (!sr) sr = s;
     const Plan &p = pd->p;
     int16_t *planes = (int16_t *)(ws + p.off_planes);
     float *fplanes = (float *)(ws + p.off_fplanes);
@@ -764,16 +790,18 @@ static int decode_sub(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in
             const long nc = (long)sg.hc * sg.wc;
             if (M > 0) {
                 const int last = (lvl == 0 && band == 2) ? 1 : 0;      // the last stage's tail symbols are decoded by rans_tail_kernel
+                if (sr != s) { HIPCHK(hipEventRecord(evcr[0], s)); HIPCHK(hipStreamWaitEvent(sr, evcr[0], 0)); }
                 {
-                ProfSpan span(c, PROF_RANS_STAGE, s);
-                rans_decode_stage_kernel<0><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, 0, status);
-                rans_decode_stage_kernel<1><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, 0, status);
-                rans_decode_stage_kernel<2><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status);
+                ProfSpan span(c, PROF_RANS_STAGE, sr);
+                rans_decode_stage_kernel<0><<<B * M, 64 * kRansWaves, 0, sr>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, 0, status);
+                rans_decode_stage_kernel<1><<<B * M, 64 * kRansWaves, 0, sr>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, 0, status);
+                rans_decode_stage_kernel<2><<<B * M, 64 * kRansWaves, 0, sr>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status);
                 }
                 if (last) {
-                    ProfSpan span(c, PROF_RANS_TAIL, s);
-                    rans_tail_kernel<<<B * M, 64, 0, s>>>(params, sg, M, rstate, rpos, rtail, planes, fplanes, mm, status);
+                    ProfSpan span(c, PROF_RANS_TAIL, sr);
+                    rans_tail_kernel<<<B * M, 64, 0, sr>>>(params, sg, M, rstate, rpos, rtail, planes, fplanes, mm, status);
                 }
+                if (sr != s) { HIPCHK(hipEventRecord(evcr[1], sr)); HIPCHK(hipStreamWaitEvent(s, evcr[1], 0)); }
             }
             if (M == 0) {
                 // Y, Co, Cg of this band as a pipeline over chunks of the stage: chunk c of Co needs only chunk c
@@ -862,15 +890,19 @@ extern "C" int llicti_decode_images(llicti_ctx *c, const uint8_t *d_in, size_t i
     c->img_status = (S == 1) ? (const int32_t *)(ws + pd->p.off_status) + kStatusHead : nullptr;
     c->img_status_n = (S == 1) ? B : 0;
     if (S > 1) HIPCHK(hipEventRecord(c->ev_fork, s));
+    const bool masked = S > 1 && c->cumask_rans > 0;
+    struct CusScope { llicti_ctx *c; ~CusScope() { c->cnn_cus = c->n_cu; } } cus_scope{ c };
+    if (masked) c->cnn_cus = c->n_cu - c->cumask_rans;
     for (int k = 0; k < S; ++k) {
-        hipStream_t sk = (k == 0) ? s : c->sub[k];
-        if (k > 0) HIPCHK(hipStreamWaitEvent(sk, c->ev_fork, 0));
+        hipStream_t sk = masked ? c->cu_cnn[k] : (k == 0) ? s : c->sub[k];
+        if (sk != s) HIPCHK(hipStreamWaitEvent(sk, c->ev_fork, 0));
         if (int rc = decode_sub(c, pd, d_in + (size_t)k * Bs * in_stride, in_stride, d_seg_len + (size_t)k * Bs * LLICTI_NSEG,
-                                Bs, H, W, M, ws + (size_t)k * sub_total, d_rgb + (size_t)k * Bs * plane3, sk))
+                                Bs, H, W, M, ws + (size_t)k * sub_total, d_rgb + (size_t)k * Bs * plane3, sk,
+                                masked ? c->cu_rans[k] : nullptr, masked ? c->ev_cr[k] : nullptr))
             return rc;
-        if (k > 0) HIPCHK(hipEventRecord(c->ev_join[k], sk));
+        if (sk != s) HIPCHK(hipEventRecord(c->ev_join[k], sk));
     }
-    for (int k = 1; k < S; ++k) HIPCHK(hipStreamWaitEvent(s, c->ev_join[k], 0));
+    for (int k = 0; k < S; ++k) if (masked || k > 0) HIPCHK(hipStreamWaitEvent(s, c->ev_join[k], 0));
     return LLICTI_OK;
 }
 
