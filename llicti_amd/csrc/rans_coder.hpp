@@ -529,8 +529,9 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
 
 // After the last stage the 64 states of a stream ARE its tail stream (31 bits each, the tail coder's final state on top,
 // its leading one the highest set bit).  One wavefront per stream decodes the T tail symbols serially -- all of the last
-// stage's Cg channel (level 0, band x10) -- with all 64 lanes on one symbol: lane l evaluates entry 8 l exactly (64
-// anchors cover Lp <= 512), a ballot picks the bucket, lanes 0..8 its nine entries, a second ballot the symbol.
+// stage's Cg channel (level 0, band x10) -- with all 64 lanes on one symbol: the approximate mixture at the 64 anchors 8 l
+// (Lp <= 512) picks a bucket, then 12 x 5 lanes evaluate the 12 exact table entries around it, one mixture component per
+// lane, and a ballot proves the symbol (an exact 13-ary search takes over when the hint is wrong).
 // Checks: the main region was read to its last bit, the tail state ends at its start state (freq << 15 of the symbol the
 // tail encoder began with; 2^31 when T = 0) with no bit left.
 __global__ __launch_bounds__(64) void rans_tail_kernel(const float *__restrict__ params, StageGeom sg, int M,
@@ -568,42 +569,99 @@ __global__ __launch_bounds__(64) void rans_tail_kernel(const float *__restrict__
     const Grid gr = make_grid(minv, maxv);
     const int max_symbol = gr.Lp - 2;
     const long img = (long)b * 3 * sg.plane;
-    auto fetch = [&](int q, float *par, float &y, float &co, long &off) {
+    // lane = 5 e + mc: mixture component mc of window entry e (e = 0 .. 11; lanes 60 .. 63 idle along).  A lane prepares and
+    // evaluates ONE component (one division for 1 / sigma, one for the weight, one erfc per exact entry); the five terms of an
+    // entry meet over ds_bpermute in the spec's order.
+    const int mc = lane % 5, we = lane / 5;
+    struct Row { float sg, mu, wk, bb, dd, y, co; long off; };
+    auto fetch = [&](int q) -> Row {
+        Row r;
         const int n = min(64 * (m + (q >> 6) * M) + (q & 63), nc - 1);
         const int i = div_wc(sg, n), j = n - i * sg.wc;
         const float *src = params + ((long)b * sg.h * sg.w + (long)i * sg.w + j) * LLICTI_PARAM_STRIDE;
-        off = img + ((long)(2 * i + sg.oi) << sg.lvl) * sg.W + ((long)(2 * j + sg.oj) << sg.lvl);
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {                                         // only what the Cg channel reads
-            par[10 + k] = src[10 + k]; par[16 + 10 + k] = src[16 + 10 + k]; par[32 + 10 + k] = src[32 + 10 + k];
-            par[48 + 5 + k] = src[48 + 5 + k]; par[48 + 10 + k] = src[48 + 10 + k];
-        }
-        y = fplanes[off]; co = fplanes[off + sg.plane];
+        r.off = img + ((long)(2 * i + sg.oi) << sg.lvl) * sg.W + ((long)(2 * j + sg.oj) << sg.lvl);
+        r.sg = src[10 + mc]; r.mu = src[16 + 10 + mc]; r.wk = src[32 + 10 + mc];          // the Cg channel's sigma, mu, weight ...
+        r.bb = src[48 + 5 + mc]; r.dd = src[48 + 10 + mc];                                    // ... and its cross-channel factors
+        r.y = fplanes[r.off]; r.co = fplanes[r.off + sg.plane];
+        return r;
     };
-    float parA[LLICTI_PARAM_STRIDE], parB[LLICTI_PARAM_STRIDE];
-    float yA, coA, yB, coB;
-    long offA, offB;
-    if (T > 0) fetch(cnt - T, parA, yA, coA, offA);
+    Row cur = fetch(max(cnt - T, 0));
     for (int q = cnt - T; q < cnt; ++q) {
-        fetch(min(q + 1, cnt - 1), parB, yB, coB, offB);                      // next symbol's row: one step ahead
-        Mix mx;
-        mix_prepare(parA, 2, yA, coA, mx);
+        const Row nxt = fetch(min(q + 1, cnt - 1));                           // next symbol's row: one step ahead
+        // component mc, exactly as mix_prepare() does
+        const float t1 = cur.bb * cur.y;
+        const float t2 = cur.dd * cur.co;
+        const float tt = t1 + t2;
+        const float mu = cur.mu + tt;
+        const float rsig = 1.0f / ((cur.sg > kScaleBound) ? cur.sg : kScaleBound);
+        const float w = (cur.wk > kWeightBound) ? cur.wk : kWeightBound;
+        float wk5[5], mu5[5], rs5[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) wk5[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w), k));
+        const float ssum = (((wk5[0] + wk5[1]) + wk5[2]) + wk5[3]) + wk5[4];
+        const float wn = w / (1e-9f + ssum);
         const uint32_t slot = xt & 0xFFFFu;
-        const int i1 = 8 * lane;
-        const uint32_t e1 = cdf_entry(mx, gr, min(i1, max_symbol));
-        const uint64_t p1 = ballot64(lane == 0 || (i1 <= max_symbol && e1 <= slot));      // entry 0 is the floor of the search
-        const int bkt = __builtin_popcountll(p1) - 1;
-        const int i2 = 8 * bkt + lane;
-        uint32_t e2 = 0x10000u;                                                // past the top symbol: c_high = 2^16 by definition
-        if (lane < 9 && i2 <= max_symbol) e2 = cdf_entry(mx, gr, i2);
-        const uint64_t p2 = ballot64(lane == 0 || (lane < 8 && i2 <= max_symbol && e2 <= slot));
-        const int np = __builtin_popcountll(p2 & 0xFFull);                    // 1 .. 8
-        const uint32_t vlo = (uint32_t)__shfl((int)e2, np - 1), vhi = (uint32_t)__shfl((int)e2, np);
-        const int s = 8 * bkt + np - 1;
+        // exact entry idx (uniform in the lane's group of five): valid in every lane of the group
+        auto entry_at = [&](int idx) -> uint32_t {
+            const float pt = sample_pt(gr, min(idx, gr.Lp - 1));
+            const float term = wn * (0.5f * erfc_spec_nobranch(kNegRsqrt2 * ((pt - mu) * rsig)));
+            const int g0 = 4 * 5 * min(we, 11);
+            const float a0 = __int_as_float(__builtin_amdgcn_ds_bpermute(g0, __float_as_int(term)));
+            const float a1 = __int_as_float(__builtin_amdgcn_ds_bpermute(g0 + 4, __float_as_int(term)));
+            const float a2 = __int_as_float(__builtin_amdgcn_ds_bpermute(g0 + 8, __float_as_int(term)));
+            const float a3 = __int_as_float(__builtin_amdgcn_ds_bpermute(g0 + 12, __float_as_int(term)));
+            const float a4 = __int_as_float(__builtin_amdgcn_ds_bpermute(g0 + 16, __float_as_int(term)));
+            const float acc = (((a0 + a1) + a2) + a3) + a4;
+            const float qf = __builtin_rintf(acc * gr.scale);
+            return (idx <= max_symbol) ? ((uint32_t)((int)qf + idx) & 0xFFFFu) : 0x10000u;      // past the top symbol: c_high = 2^16
+        };
+        // 1. hint: the approximate mixture (all five components in every lane) at the 64 anchors 8 l
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            mu5[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mu), k));
+            rs5[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rsig), k));
+            wk5[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wn), k));
+        }
+        int wb;
+        {
+            const int i1 = min(8 * lane, max_symbol);
+            const float pt1 = sample_pt(gr, i1);
+            float sum = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) { Comp ck; ck.mu = mu5[k]; ck.rsig = rs5[k]; ck.wn = wk5[k]; sum += term_fast(comp_fast(ck), pt1); }
+            const int e1 = (int)__builtin_rintf(sum * gr.scale) + i1;
+            const uint64_t p1 = ballot64(lane == 0 || (8 * lane <= max_symbol && e1 <= (int)slot));
+            wb = max(8 * (__builtin_popcountll(p1) - 1) - 2, 0);
+        }
+        // 2. proof: the 12 exact entries wb .. wb + 11; the symbol is the last one <= slot, its successor must be in the window too
+        uint32_t ent = entry_at(wb + we);
+        uint64_t pw = ballot64(mc == 0 && we < 12 && wb + we <= max_symbol && (ent <= slot || wb + we == 0));
+        int np = __builtin_popcountll(pw);
+        if (np == 0 || np == 12) {
+            // the hint was wrong (only absurd mixtures get here): exact 13-ary search from scratch, then the window at the result
+            int lo = 0, hi = max_symbol + 1;
+            while (hi - lo > 1) {
+                const int stp = (hi - lo + 12) / 13;
+                const int pi = min(lo + stp * (min(we, 11) + 1), hi - 1);
+                const uint32_t e = entry_at(pi);
+                const uint64_t pb = ballot64(mc == 0 && we < 12 && e <= slot);
+                const int k = __builtin_popcountll(pb);                        // probes are ordered: the passes form a prefix
+                const int nlo = (k > 0) ? min(lo + stp * k, hi - 1) : lo;
+                const int nhi = (k < 12) ? min(lo + stp * (k + 1), hi - 1) : hi;
+                lo = nlo; hi = (k < 12) ? nhi : hi;
+                if (k == 12 && nlo == hi - 1) hi = nlo + 1;
+            }
+            wb = lo;
+            ent = entry_at(wb + we);
+            np = 1;
+        }
+        const uint32_t vlo = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * 5 * (np - 1), (int)ent);
+        const uint32_t vhi = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * 5 * np, (int)ent);
+        const int s = wb + np - 1;
         if (lane == 0) {
             const int v = s - shift;
-            planes[offA + 2 * sg.plane] = (int16_t)v;
-            fplanes[offA + 2 * sg.plane] = (float)v / 255.0f;
+            planes[cur.off + 2 * sg.plane] = (int16_t)v;
+            fplanes[cur.off + 2 * sg.plane] = (float)v / 255.0f;
         }
         xt = (vhi - vlo) * (xt >> 16) + slot - vlo;
         if (q == cnt - 1) { bad = bad || xt != (vhi - vlo) << 15; break; }    // the encoder's first symbol: absorbing start, no bits
@@ -611,9 +669,7 @@ __global__ __launch_bounds__(64) void rans_tail_kernel(const float *__restrict__
         if (nb > 16 || tc < nb) { bad = true; nb = min(nb, min(tc, 16)); }      // corrupt: keep going on what is there
         tc -= nb;
         xt = ((xt << nb) | lds_get_bits(sh_pay, tc, nb)) | (1u << 31);
-#pragma unroll
-        for (int k = 0; k < LLICTI_PARAM_STRIDE; ++k) parA[k] = parB[k];
-        yA = yB; coA = coB; offA = offB;
+        cur = nxt;
     }
     if (T == 0) bad = bad || xt != (1u << 31);
     if ((bad || tc != 0) && lane == 0) flag_image(status, b, LLICTI_EFORMAT);
