@@ -20,13 +20,21 @@ constexpr int kKS1 = 22;           // k-steps of the 88-deep layers (88 / 4)
 #define CNN_NT 2
 #endif
 constexpr int kNT = CNN_NT;                    // pixel tiles (16 positions each) per wavefront
-constexpr int kCnnThreads = 64 * (32 / CNN_NT);    // NT=4: 8 wavefronts (2 per SIMD); NT=2: 16 wavefronts (4 per SIMD)
-constexpr int kTileH = 16;         // band-grid positions per workgroup tile: 16 rows x 32 columns,
-constexpr int kTileW = 32;         //   wave w owns rows 2w, 2w+1 (two 16-column pixel tiles each)
-constexpr int kInRows = kTileH + 4;    // taps reach rows i-2 .. i+2 and columns j-2 .. j+2
-constexpr int kInCols = kTileW + 4;
+static_assert(CNN_NT == 2, "one wavefront per tile row (two 16-column pixel tiles)");
+// Workgroup tile = TH rows x 32 columns of band-grid positions, one wavefront per row.  TH = 16 (16 wavefronts, 4 per SIMD) is the
+// throughput form; TH = 4 (4 wavefronts, one per SIMD, a quarter of the work per workgroup) is the LATENCY form for launches whose
+// 16-row tiles would leave most of the chip idle (coarse levels, single images): 4x the workgroups, each done in ~a third of the time.
+constexpr int kTileHMax = 16, kTileHSmall = 4;
+constexpr int kTileW = 32;
+constexpr int kInCols = kTileW + 4;    // taps reach rows i-2 .. i+2 and columns j-2 .. j+2
 constexpr int kInPitch = 48;       // = 16 (mod 32): B-fragment reads that stride by one row stay bank-conflict free
-constexpr int kInPlane = kInRows * kInPitch;
+template <int TH> struct CnnGeo {
+    static_assert(TH % 4 == 0 && TH >= 4 && TH <= 16, "tile rows: a whole number of 4-row groups");
+    static constexpr int kThreads = 64 * TH;
+    static constexpr int kInRows = TH + 4;
+    static constexpr int kInPlane = kInRows * kInPitch;      // floats of one staged plane: (TH + 4) / 4 row groups of three 64-float pieces
+    static constexpr int kPP = kInPlane / 64;                // pieces per plane: 15 (TH = 16), 6 (TH = 4)
+};
 constexpr int kParamStride = LLICTI_PARAM_STRIDE;
 #ifndef CNN_PREFETCH_L0
 #define CNN_PREFETCH_L0 1      // software-pipeline the layer-0 fragments one k-step ahead
@@ -60,7 +68,7 @@ constexpr int kMT0 = CNN_REM4X4 ? 5 : 6;        // 16-row tiles of LAYER 0
 // U + q*S + pixel offset with U, S compile-time constants of the k-step.
 struct KStep { int U, S; };
 struct KTab { KStep s[30]; int n; };
-constexpr KTab make_ktab(int band)
+constexpr KTab make_ktab(int band, int kInPlane)
 {
     KTab t{};
     int k = 0;
@@ -79,7 +87,7 @@ constexpr KTab make_ktab(int band)
     t.n = k;
     return t;
 }
-template <int BAND> inline constexpr KTab kKTab = make_ktab(BAND);
+template <int BAND, int TH> inline constexpr KTab kKTab = make_ktab(BAND, CnnGeo<TH>::kInPlane);
 
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
@@ -113,10 +121,10 @@ struct PackOff {
     static constexpr int w2 = bias2 + 16;
     static constexpr int total = w2 + kKS1 * 64;
 };
-static constexpr int cnn_lds_bytes(int band)
+static constexpr int cnn_lds_bytes(int band, int TH = kTileHMax)
 {
     const int K0 = band == 0 ? 48 : band == 1 ? 72 : 120;
-    return (pack_floats(K0) + 2 * 3 * (band + 1) * kInPlane) * 4;     // weights + double-buffered input tile
+    return (pack_floats(K0) + 2 * 3 * (band + 1) * (TH + 4) * kInPitch) * 4;     // weights + double-buffered input tile
 }
 
 __device__ __forceinline__ float relu(float x) { return (x > 0.0f) ? x : 0.0f; }
@@ -133,17 +141,19 @@ constexpr int prio_step(int before, int after, int total)
     return -1;
 }
 
-template <int BAND>
-__global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *__restrict__ fplanes, Geom g,
+template <int BAND, int TH = kTileHMax>
+__global__ __launch_bounds__(CnnGeo<TH>::kThreads) void band_params_kernel(const float *__restrict__ fplanes, Geom g,
                                                                   const float *__restrict__ wpack,
                                                                   float *__restrict__ params, int tiles_x, int tiles_y, int n_tiles)
 {
+    using GEO = CnnGeo<TH>;
+    constexpr int kCnnThreads = GEO::kThreads, kTileH = TH, kInRows = GEO::kInRows, kInPlane = GEO::kInPlane, kPP = GEO::kPP;
     constexpr int K0 = (BAND == 0) ? 48 : (BAND == 1) ? 72 : 120;
     constexpr int NK0 = K0 / 4;
     constexpr int NPL = 3 * (BAND + 1);          // staged input planes: (x00 | x11 | x01) x (Y, Co, Cg)
     constexpr int kMfmaL0 = kMT * NK0 * kNT, kMfmaT12 = (kKS1 + 4) * kNT, kMfmaTile = kMfmaL0 + kMT * kMfmaT12;   // MFMAs of a wave per tile (approx.)
     using PO = PackOff<K0>;
-    static_assert(kKTab<BAND>.n == NK0, "k-step table");
+    static_assert(kKTab<BAND, TH>.n == NK0, "k-step table");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *lds_in = lds + PO::total;
 
@@ -168,7 +178,7 @@ __global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *_
     // depend on the lane: piece phase t covers row 4q+t from column 16t (lanes below 48-16t) and the head
     // of row 4q+t+1 (the others).
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    constexpr int kPieces = NPL * (kInPlane / 64);                                   // 45 / 90 / 135
+    constexpr int kPieces = NPL * kPP;                                               // TH = 16: 45 / 90 / 135
     constexpr int kMyPieces = (kPieces + kCnnThreads / 64 - 1) / (kCnnThreads / 64);  // pieces a wave stages per tile: 3 / 6 / 9
 #if CNN_STAGE_FAST
     // For a tile whose whole halo lies inside the band grid (and off the odd edge) no clamp fires, and a lane's source
@@ -201,7 +211,7 @@ __global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *_
             for (int k = 0; k < kMyPieces; ++k) {
                 const int u = wave_u + k * (kCnnThreads / 64);                           // wave-uniform: the rest of the address is scalar work
                 if (u < kPieces) {
-                    const int pl = u / 15, v = u - 15 * pl, q4 = v / 3, t = v - 3 * q4;
+                    const int pl = u / kPP, v = u - kPP * pl, q4 = v / 3, t = v - 3 * q4;
                     const int src = pl / 3, ci = pl - 3 * src;
                     const long uoff = ((long)ci * g.plane + (((long)(8 * q4 + src_oi(src)) * g.W + src_oj(src)) << g.lvl)) * 4;
                     const uint32_t lo = (t == 0) ? lane_t[0] : (t == 1) ? lane_t[1] : lane_t[2];
@@ -213,7 +223,7 @@ __global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *_
         }
 #endif
         for (int u = wave_u; u < kPieces; u += kCnnThreads / 64) {
-            const int pl = u / 15, v = u - 15 * pl, q4 = v / 3, t = v - 3 * q4;       // wave-uniform
+            const int pl = u / kPP, v = u - kPP * pl, q4 = v / 3, t = v - 3 * q4;       // wave-uniform
             const int src = pl / 3, ci = pl - 3 * src;
             const int thr = 48 - 16 * t;
             const bool up = lane >= thr;
@@ -230,10 +240,10 @@ __global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *_
                                              (__attribute__((address_space(3))) void *)(dst + u * 64), 4, 0, 0);
         }
     };
-    static_assert(kInPitch == 48 && kInRows % 4 == 0 && kInPlane / 64 == 15, "piece decomposition assumes pitch 48, 20 rows");
+    static_assert(kInPitch == 48 && kInRows % 4 == 0 && kPP * 64 == kInPlane && kPP == 3 * (kInRows / 4), "piece decomposition assumes pitch 48 and whole 4-row groups");
     static_assert(kInPlane % 64 == 0, "tile plane must be a whole number of 64-float pieces");
 
-    const int stage_site = (__builtin_amdgcn_readfirstlane(wave) / (kCnnThreads / 256)) % CNN_STAGE_SITES;
+    const int stage_site = (__builtin_amdgcn_readfirstlane(wave) / (kCnnThreads >= 256 ? kCnnThreads / 256 : 1)) % CNN_STAGE_SITES;
     int cur = 0;
     if ((int)blockIdx.x < n_tiles) stage(blockIdx.x, lds_in);
 #if CNN_STAGGER
@@ -292,7 +302,7 @@ __global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *_
             float br_c[4];
 #endif
             {
-                constexpr int U = kKTab<BAND>.s[0].U, S = kKTab<BAND>.s[0].S;
+                constexpr int U = kKTab<BAND, TH>.s[0].U, S = kKTab<BAND, TH>.s[0].S;
                 const float *bp = lds_cur + U + pix0 + (S == 1 ? q : q_row);
 #pragma unroll
                 for (int n = 0; n < kNT; ++n) b_c[n] = bp[(n >> 1) * kInPitch + 16 * (n & 1)];
@@ -314,7 +324,7 @@ __global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *_
                 float br_n[4];
 #endif
                 if constexpr (t + 1 < NK0) {       // next k-step's fragments are in flight while this one's MFMAs run
-                    constexpr int U = kKTab<BAND>.s[t + 1].U, S = kKTab<BAND>.s[t + 1].S;
+                    constexpr int U = kKTab<BAND, TH>.s[t + 1].U, S = kKTab<BAND, TH>.s[t + 1].S;
                     const float *bp = lds_cur + U + pix0 + (S == 1 ? q : q_row);
 #pragma unroll
                     for (int n = 0; n < kNT; ++n) b_n[n] = bp[(n >> 1) * kInPitch + 16 * (n & 1)];
@@ -383,7 +393,7 @@ __global__ __launch_bounds__(kCnnThreads) void band_params_kernel(const float *_
 #else
         static_for<NK0>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
-            constexpr int U = kKTab<BAND>.s[t].U, S = kKTab<BAND>.s[t].S;
+            constexpr int U = kKTab<BAND, TH>.s[t].U, S = kKTab<BAND, TH>.s[t].S;
             const float *bp = lds_cur + U + pix0 + (S == 1 ? q : q_row);
             float bf[kNT];
 #pragma unroll

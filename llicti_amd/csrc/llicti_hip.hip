@@ -110,6 +110,7 @@ struct llicti_ctx {
     int32_t *d_lift_part = nullptr;   // min/max partials of llicti_lift_u8 (1 MB; calls on one context are not concurrent)
     int n_cu = 256;                   // compute units of the device (grid sizing of the persistent kernels)
     int cnn_cus = 256;                // compute units the band CNN may fill (= n_cu, less inside a CU-partitioned decode)
+    int cnn_tile_rows = 0;            // llicti_set_tuning("cnn_tile_rows"): 0 = choose per launch, 16 / 4 = force (tests, A/B)
     // experiment (LLICTI_CUMASK=<R>): decode as sub-batches whose CNN launches run on streams masked to n_cu - R compute units and
     // whose rANS stages run on streams masked to the other R, so that one sub-batch's stages overlap another's CNN
     int cumask_rans = 0;
@@ -358,6 +359,9 @@ extern "C" int llicti_create(llicti_ctx **out, int device)
     HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(0)));
     HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(1)));
     HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(2)));
+    HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<0, kTileHSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(0, kTileHSmall)));
+    HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<1, kTileHSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(1, kTileHSmall)));
+    HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<2, kTileHSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(2, kTileHSmall)));
     *out = c;
     return LLICTI_OK;
 }
@@ -417,6 +421,11 @@ extern "C" int llicti_set_tuning(llicti_ctx *c, const char *key, int value)
         c->ac_anchor_min_batch = value;
         return LLICTI_OK;
     }
+    if (!strcmp(key, "cnn_tile_rows")) {
+        if (value != 0 && value != kTileHMax && value != kTileHSmall) return fail(LLICTI_EINVAL, "set_tuning: cnn_tile_rows must be 0 (automatic), %d or %d", kTileHMax, kTileHSmall);
+        c->cnn_tile_rows = value;
+        return LLICTI_OK;
+    }
     return fail(LLICTI_EINVAL, "set_tuning: unknown key '%s'", key);
 }
 
@@ -446,20 +455,31 @@ static int launch_lift(const uint8_t *d_rgb, int B, int H, int W, int16_t *plane
 static int launch_band_params(llicti_ctx *c, const float *fplanes, const Geom &g, int band, float *params, hipStream_t s)
 {
     if (!c->have[band]) return fail(LLICTI_ENOWEIGHTS, "band %d weights not set", band);
-    const int tiles_x = (g.w + kTileW - 1) / kTileW, tiles_y = (g.h + kTileH - 1) / kTileH;
+    // Tile height: 16 rows while those tiles alone give every compute unit a workgroup (4 heads x tiles >= CUs); otherwise 4 rows
+    // (a quarter of the work per workgroup, 4x the workgroups): coarse levels and single images.  Either form computes each
+    // position with the same fmaf chains: the results do not depend on it (test_band_params_bitexact_and_golden runs both).
+    const int tiles_x = (g.w + kTileW - 1) / kTileW;
+    const long tiles16 = (long)g.B * tiles_x * ((g.h + kTileHMax - 1) / kTileHMax);
+    const bool small = c->cnn_tile_rows ? c->cnn_tile_rows == kTileHSmall : 4 * tiles16 < c->cnn_cus;
+    const int TH = small ? kTileHSmall : kTileHMax;
+    const int tiles_y = (g.h + TH - 1) / TH;
     const long n_tiles_l = (long)g.B * tiles_x * tiles_y;
     if (n_tiles_l > 0x7FFFFFFFL) return fail(LLICTI_EINVAL, "band_params: too many tiles");
     const int n_tiles = (int)n_tiles_l;
-    const int lds_bytes = cnn_lds_bytes(band);
+    const int lds_bytes = cnn_lds_bytes(band, TH);
+    const int kCnnThreads = 64 * TH;
     const int wg_per_cu = std::max(1, std::min(4, (160 * 1024) / lds_bytes));
     int gx = std::min(n_tiles, c->cnn_cus * wg_per_cu / 4);    // 4 heads in grid.y; persistent loop over tiles
     if (gx < 1) gx = 1;
     dim3 grid((unsigned)gx, 4);
     ProfSpan span(c, PROF_CNN, s);
-    switch (band) {
+    switch (band + (small ? 3 : 0)) {
     case 0: band_params_kernel<0><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[0], params, tiles_x, tiles_y, n_tiles); break;
     case 1: band_params_kernel<1><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[1], params, tiles_x, tiles_y, n_tiles); break;
-    default: band_params_kernel<2><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[2], params, tiles_x, tiles_y, n_tiles); break;
+    case 2: band_params_kernel<2><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[2], params, tiles_x, tiles_y, n_tiles); break;
+    case 3: band_params_kernel<0, kTileHSmall><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[0], params, tiles_x, tiles_y, n_tiles); break;
+    case 4: band_params_kernel<1, kTileHSmall><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[1], params, tiles_x, tiles_y, n_tiles); break;
+    default: band_params_kernel<2, kTileHSmall><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[2], params, tiles_x, tiles_y, n_tiles); break;
     }
     HIPCHK(hipGetLastError());
     return 0;

@@ -68,15 +68,20 @@ def test_band_params_bitexact_and_golden(torch_mod, codecs, golden_index, oracle
     rgb = g["rgb"]
     planes, fplanes, mm = c.lift(_dev(torch, rgb[None]))
     p_host = planes[0].cpu().numpy()
-    for lvl in range(5):
-        for band in range(3):
-            got = np.ascontiguousarray(c.params60(c.band_params(fplanes, lvl, band))[0].cpu().numpy())
-            ref = orc.band_params(p_host, lvl, band, W_o)
-            assert got.shape == ref.shape
-            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (lvl, band, np.abs(got - ref).max())
-            key = f"params_s{lvl}_b{band}"
-            if key in g.files:
-                assert np.abs(got - np.transpose(g[key], (1, 2, 0))).max() < PARAM_TOL
+    try:
+        for rows in (16, 4, 0):                    # both tile forms of the kernel (throughput / latency), then the automatic choice
+            c.set_tuning("cnn_tile_rows", rows)
+            for lvl in range(5):
+                for band in range(3):
+                    got = np.ascontiguousarray(c.params60(c.band_params(fplanes, lvl, band))[0].cpu().numpy())
+                    ref = orc.band_params(p_host, lvl, band, W_o)
+                    assert got.shape == ref.shape
+                    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (rows, lvl, band, np.abs(got - ref).max())
+                    key = f"params_s{lvl}_b{band}"
+                    if key in g.files:
+                        assert np.abs(got - np.transpose(g[key], (1, 2, 0))).max() < PARAM_TOL
+    finally:
+        c.set_tuning("cnn_tile_rows", 0)
 
 
 @pytest.mark.parametrize("case", ["smooth_67x93_tl", "noise_33x64_tl", "noise_32x32_rand"])
