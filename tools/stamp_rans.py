@@ -20,8 +20,8 @@ rep("                // 1. hint: 5-ary search on the approximate table.  Every l
 rep("                // 2. proof with the exact spec arithmetic: entries glo and glo + 1 in one round (independent chains);\n", "                unsigned long long s2 = __builtin_amdgcn_s_memtime(); T[1] += s2 - s1;\n")
 rep("                    const uint32_t e = group_cdf_entry(A, B, gr, probe);\n", "                    const uint32_t e = group_cdf_entry(A, B, gr, probe); ++nprobe;\n")
 rep("                if (!have_lo) vlo = group_cdf_entry(A, B, gr, 0);\n", "                if (!have_lo) vlo = group_cdf_entry(A, B, gr, 0);\n                unsigned long long s3 = __builtin_amdgcn_s_memtime(); T[2] += s3 - s2;\n")
-rep("        __syncthreads();\n        {\n            const bool active = chunk0 + lane < nc;\n",
-    "        unsigned long long s4 = __builtin_amdgcn_s_memtime();\n        __syncthreads();\n        unsigned long long s5 = __builtin_amdgcn_s_memtime(); T[3] += s5 - s4;\n        {\n            const bool active = chunk0 + lane < nc;\n")
+rep("        __syncthreads();\n        {\n            const bool active = chunk0 + lane < nc && 64 * k + lane < tail_from;\n",
+    "        unsigned long long s4 = __builtin_amdgcn_s_memtime();\n        __syncthreads();\n        unsigned long long s5 = __builtin_amdgcn_s_memtime(); T[3] += s5 - s4;\n        {\n            const bool active = chunk0 + lane < nc && 64 * k + lane < tail_from;\n")
 rep("        cur = nxt;\n    }\n", "        cur = nxt;\n        unsigned long long s6 = __builtin_amdgcn_s_memtime(); T[4] += s6 - s5; T[5] += s6 - s0;\n    }\n    if (K >= 90 && blockIdx.x == 5 && (lane & 3) == 0) { int mx = nprobe; for (int o = 32; o >= 4; o >>= 1) mx = max(mx, __shfl_xor(mx, o)); if (lane == 0) printf(\"w%d K=%d prol %llu hint %llu proof %llu bar %llu upd %llu total %llu | exact probes/step: lane0 %.2f max-group %.2f\\n\", wave, K, T[0]/K, T[1]/K, T[2]/K, T[3]/K, T[4]/K, T[5]/K, (float)nprobe / K, (float)mx / K); }\n")
 open(os.path.join(work, "rans_coder.hpp"), "w").write(s)
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unused-value",
