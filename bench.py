@@ -63,6 +63,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed informational legs (profiling runs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--no-ac-leg", action="store_true",
+                    help="profiling runs: skip the (untimed) reference-format container of the batch; the line then has no bpp_delta_vs_reference / meets_north_star")
     ap.add_argument("--allow-shared-gpu", action="store_true",
                     help="let several ranks share one GPU when the node has fewer GPUs than --gpus (rehearsal only: the line is marked shared_gpu)")
     ap.add_argument("--dry-run", action="store_true",
@@ -587,7 +589,7 @@ def main(argv=None):
     legs_out = {}
     cont_ac0 = seg_ac0 = None
     ac_bytes = None
-    if rank == 0:
+    if rank == 0 and not args.no_ac_leg:
         r_ac, cont2, seg2 = Legs(torch, codec, dev).run(rgb, MODE_AC, reps=1, keep=True)
         ac_bytes = r_ac["bytes"]
         seg_ac0 = seg2[0].cpu().numpy()
@@ -598,7 +600,7 @@ def main(argv=None):
         codec._ws = None
         codec._ws_key = None
     # ---- untimed informational legs (rank 0, N = 1 only, like cpu_baseline)
-    extras = (world == 1) and not args.no_extras
+    extras = (world == 1) and not args.no_extras and not args.no_ac_leg
     if extras:
         legs = Legs(torch, codec, dev)
         # (2) rANS streams per image: speed against container overhead
