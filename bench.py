@@ -704,8 +704,12 @@ def main(argv=None):
                         "reference's PyTorch floats (fixtures). rANS v3 container: same tables and symbols, about 6 bytes per stream over the ideal "
                         "code length (0.001 bpp = 49 bytes per 768x512 image; the AC container's 45 terminations cost about 25) -- see m_sweep"}
             dbpp = out["bpp_delta_vs_reference"]["timed_container_minus_reference_format_bpp"]
-            out["meets_north_star"] = bool(value / world >= NORTH_STAR_MPIX_S and abs(dbpp) <= NORTH_STAR_DBPP and (H, W) == (512, 768) and not shared_gpu)
-            out["north_star_check"] = {"mpix_s_per_gpu": round(value / world, 3), "min_mpix_s": NORTH_STAR_MPIX_S, "delta_bpp": dbpp, "max_abs_delta_bpp": NORTH_STAR_DBPP,
+            # + what the build's tables cost against the reference's own PyTorch tables on full-size images of this workload (committed
+            #   measurement: tests/golden/ref_ideal_bits.json vs the oracle, profiles/<round>/bpp_delta_fixtures.json "full_size")
+            tab = abs((fx or {}).get("full_size", {}).get("max_abs_delta_bpp", 0.0))
+            out["meets_north_star"] = bool(value / world >= NORTH_STAR_MPIX_S and abs(dbpp) + tab <= NORTH_STAR_DBPP and (H, W) == (512, 768) and not shared_gpu)
+            out["north_star_check"] = {"mpix_s_per_gpu": round(value / world, 3), "min_mpix_s": NORTH_STAR_MPIX_S, "delta_bpp": dbpp,
+                                       "tables_vs_reference_tables_full_size_abs_delta_bpp": tab, "max_abs_delta_bpp": NORTH_STAR_DBPP,
                                        "lossless": True, "what": "timed container vs the reference-format container on the same batch (same tables, same symbols); "
                                                                  "decode(encode(x)) == x asserted on a poisoned workspace; image 0 of both containers == CPU oracle bytes (cpu_baseline)"}
         out.update(legs_out)

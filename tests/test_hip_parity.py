@@ -291,6 +291,33 @@ def test_rans_container_bitexact(torch_mod, codecs, oracle_weights, kind, H, W, 
     assert np.array_equal(rec.cpu().numpy(), rgb)
 
 
+def test_rans_v3_known_answer_hip(torch_mod, codecs):
+    """The committed known-answer vectors of the rANS v3 container (tests/golden/rans_v3_vectors.npz, frozen by
+    test_rans_v3_known_answer on the CPU): the HIP encoder reproduces the stored bytes, the HIP decoder turns the stored bytes
+    back into the fixture's pixels -- without the oracle in the loop."""
+    import os
+    from conftest import GOLDEN
+    from llicti_amd.codec import MODE_RANS
+    torch = torch_mod
+    vec = np.load(os.path.join(GOLDEN, "rans_v3_vectors.npz"))
+    for case, wname in [("smooth_67x93_tl", "trainedlike"), ("noise_32x32_rand", "rand1337"), ("noise_33x64_tl", "trainedlike")]:
+        c = codecs(wname)
+        rgb = load_case(case)["rgb"]
+        H, W = rgb.shape[1:]
+        for M in (1, 4):
+            want, lens = vec[f"{case}_M{M}_bytes"], vec[f"{case}_M{M}_seglen"]
+            seg_want = np.concatenate([lens[:4], lens[9:]]).astype(np.int32)        # bytestream_list rows of 9 -> the 49 segments
+            cont, seg = c.encode(_dev(torch, rgb[None]), mode=MODE_RANS(M))
+            c.check()
+            n = int(seg.sum().item())
+            assert np.array_equal(seg[0].cpu().numpy(), seg_want), (case, M)
+            assert n == want.size and np.array_equal(cont[0, :n].cpu().numpy(), want), (case, M)
+            cont2 = torch.zeros_like(cont)
+            cont2[0, :n] = _dev(torch, want)
+            rec = _decode_poisoned(c, cont2, _dev(torch, seg_want[None]), H, W, MODE_RANS(M))
+            assert np.array_equal(rec[0].cpu().numpy(), rgb), (case, M)
+
+
 def test_rans_kodak_batch_roundtrip(torch_mod, codecs):
     from llicti_amd.codec import MODE_RANS
     torch = torch_mod

@@ -155,6 +155,35 @@ def test_rans_container_oracle_roundtrip(M, oracle_weights):
         assert n_r - n_ac <= 8          # one stream: no more than the 45 range-coder terminations it replaces, give or take
 
 
+def test_rans_v3_known_answer(oracle_weights):
+    """The rANS v3 container is a format of this build (no reference counterpart to pin it to), so it is frozen by known-answer
+    vectors: tests/golden/rans_v3_vectors.npz holds the container bytes for three fixture images x M in {1, 4}
+    (make_rans_v3_vectors.py).  The oracle must reproduce them byte for byte -- a changed byte is a changed format and needs a new
+    version bit -- and decode them back to the fixture's pixels; the GPU suite holds the HIP path to the oracle."""
+    import hashlib
+    import os
+    from conftest import GOLDEN
+    vec = np.load(os.path.join(GOLDEN, "rans_v3_vectors.npz"))
+    for case, wname in [("smooth_67x93_tl", "trainedlike"), ("noise_32x32_rand", "rand1337"), ("noise_33x64_tl", "trainedlike")]:
+        rgb = load_case(case)["rgb"]
+        W = oracle_weights(wname)
+        for M in (1, 4):
+            want = vec[f"{case}_M{M}_bytes"].tobytes()
+            assert hashlib.sha256(want).digest() == vec[f"{case}_M{M}_sha256"].tobytes()
+            bl = orc.encode_image_rans(rgb, W, M)
+            got = b"".join(s for row in bl for s in row)
+            assert got == want, (case, M)
+            assert [len(s) for row in bl for s in row] == list(vec[f"{case}_M{M}_seglen"])
+            assert got[0] == (0x88 | ({1: 0, 4: 2}[M] << 4) | 5)
+            # rebuild the list from the stored bytes alone and decode it
+            lens, pos, flat = list(vec[f"{case}_M{M}_seglen"]), 0, []
+            for n in lens:
+                flat.append(want[pos:pos + n])
+                pos += n
+            bl2 = [flat[9 * r: 9 * r + 9] for r in range(6)]
+            assert np.array_equal(orc.decode_image_rans(bl2, W), rgb)
+
+
 @pytest.mark.parametrize("case,wname", [("fwd_smooth_64x96_tl", "trainedlike"), ("fwd_noise_32x64_rand", "rand1337")])
 def test_forward_selfinfo_vs_reference(case, wname, oracle_weights):
     """Training / validation likelihood path against the reference's LLICTI.forward output
@@ -242,11 +271,37 @@ def test_bpp_delta_vs_reference_tables_report(golden_index, oracle_weights):
                      "delta_relative": round((bits_orc - bits_ref) / bits_ref, 8)})
         worst[info["weights"]] = max(worst[info["weights"]], abs(d))
     assert worst["trainedlike"] < 1e-3, worst           # north star: bpp within 0.001 of the reference
-    assert worst["rand1337"] < 5e-3, worst              # sigma-floor random weights at ~40 bpp: measured bound, NOT 0.001 (see docstring)
+    assert worst["rand1337"] < 5e-3, worst              # sigma-floor random weights at ~40 bpp on 1-6 kpixel images: small-sample noise (see below)
+    # The same difference at FULL SIZE (tests/golden/ref_ideal_bits.json, make_fixture_ideal_bits.py: the reference-owned code on image 0 of
+    # bench.py's batch and on configs[0]'s 256x256 image, seed-1337 weights; only the 45 per-stream ideal bit counts are stored): on the
+    # headline workload the tables are within 0.0001 bpp of the reference's -- the north star's 0.001 with an order of magnitude to spare.
+    from conftest import GOLDEN
+    full = json.load(open(os.path.join(GOLDEN, "ref_ideal_bits.json")))
+    W = oracle_weights("rand1337")
+    full_rows = []
+    for name, r in full.items():
+        H, Wd = r["H"], r["W"]
+        rgb = np.random.default_rng(r["seed"]).integers(0, 256, size=(3, H, Wd), dtype=np.uint8)
+        planes, mm = orc.lift(rgb)
+        bits = []
+        for lvl in range(4, -1, -1):
+            for b in range(3):
+                params = orc.band_params(planes, lvl, b, W)
+                for clr in range(3):
+                    clow, chigh, _ = orc.stream_pairs(planes, mm, lvl, b, clr, params)
+                    bits.append(float(np.log2(65536.0 / (chigh.astype(np.int64) - clow.astype(np.int64))).sum()))
+        d = (sum(bits) - r["ideal_bits"]) / (H * Wd)
+        full_rows.append({"image": name, "weights": "rand1337", "pixels": H * Wd, "bpp_reference_tables": round((r["ideal_bits"] + 8 * r["header_bytes"]) / (H * Wd), 6),
+                          "bpp_oracle_tables": round((sum(bits) + 8 * r["header_bytes"]) / (H * Wd), 6), "delta_bpp": round(d, 7),
+                          "max_abs_delta_bits_of_a_stream": round(max(abs(a - c) for a, c in zip(bits, r["ideal_bits_per_stream"])), 2)})
+        assert abs(d) < 1e-4, (name, d)
     out = os.environ.get("LLICTI_WRITE_PROFILES")
     if out:
         os.makedirs(out, exist_ok=True)
         json.dump({"what": "ideal code length of the build's (oracle == HIP, bit-exact) tables minus that of the reference's own recorded "
                            "tables, identical weights and images (tests/golden fixtures generated from the reference-owned Python)",
-                   "max_abs_delta_bpp": {k: round(v, 6) for k, v in worst.items()}, "fixtures": rows},
+                   "max_abs_delta_bpp": {k: round(v, 6) for k, v in worst.items()}, "fixtures": rows,
+                   "full_size": {"what": "the same difference on full-size images of the bench workload (seed-1337 weights): the small fixtures' "
+                                         "+0.0007 .. +0.002 bpp is small-sample noise (one probability-1/65536 symbol = 1e-3 bpp on 1 kpixel)",
+                                 "max_abs_delta_bpp": max(abs(r["delta_bpp"]) for r in full_rows), "images": full_rows}},
                   open(os.path.join(out, "bpp_delta_fixtures.json"), "w"), indent=1)
