@@ -614,7 +614,7 @@ def main(argv=None):
         # (3) configs[1]: ONE 768x512 image
         one = rgb[:1].contiguous()
         legs_out["single_image"] = {"workload": f"1x{W}x{H} (BASELINE.json configs[1])",
-                                    "rans32": legs.run(one, MODE_RANS(32), reps=5), "rans16": legs.run(one, MODE_RANS(16), reps=5),
+                                    "rans128": legs.run(one, MODE_RANS(128), reps=5), "rans32": legs.run(one, MODE_RANS(32), reps=5), "rans16": legs.run(one, MODE_RANS(16), reps=5),
                                     "ac": legs.run(one, MODE_AC, reps=1)}
         legs.free()
         # (4) the reference-format container where it has enough streams in flight
@@ -636,7 +636,7 @@ def main(argv=None):
         # (5) configs[3] end to end: one 3840x2160 image
         big = torch.from_numpy(make_batch(1, 2160, 3840, seed0=0)).to(dev)
         legs_out["image_4k"] = {"workload": "1x3840x2160 uniform-noise RGB (BASELINE.json configs[3]) end to end",
-                                "rans32": legs.run(big, MODE_RANS(32), reps=2), "ac": legs.run(big, MODE_AC, reps=1)}
+                                "rans128": legs.run(big, MODE_RANS(128), reps=2), "rans32": legs.run(big, MODE_RANS(32), reps=2), "ac": legs.run(big, MODE_AC, reps=1)}
         del big
         legs.free()
         legs_out["overlapped_streams"] = overlap_leg(torch, dev, sd, rgb, mode)

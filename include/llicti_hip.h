@@ -159,7 +159,8 @@ int llicti_ac_decode_u16cdf(llicti_ctx *ctx, const uint16_t *d_cdf, int Lp, int 
  * container on 768x512 images (whose 45 stream terminations cost about 25 bytes).  Format: oracle/llicti_oracle.h,
  * DESIGN.md section 5. */
 #define LLICTI_MODE_AC        0
-#define LLICTI_MODE_RANS(M)  (0x100 | (M))      /* M in {1, 2, 4, 8, 16, 32} */
+#define LLICTI_MODE_RANS(M)  (0x100 | (M))      /* M in {1, 2, 4, 8, 16, 32}: one stream per segment; {64, 128}: latency modes for single / large
+                                                  images, M / 32 streams per segment behind a table of their u32 lengths (+6 bytes per stream) */
 
 /* Bytes of device workspace the two calls below need for B images of H x W in `mode`. */
 size_t llicti_workspace_bytes(int B, int H, int W, int mode);
@@ -208,7 +209,9 @@ int llicti_last_timing(llicti_ctx *ctx, float ms[4], int *n_launch);
 #define LLICTI_PROF_AC 5
 #define LLICTI_PROF_MISC 6
 int llicti_last_timing_detail(llicti_ctx *ctx, float cat_ms[LLICTI_NPROF], float *cnn_launch_ms, int cnn_cap, int *n_cnn);
-/* Tuning switches that never change a result.  "ac_anchor_min_batch" (default 96): from this many images per call on,
+/* Tuning switches that never change a result.  "cnn_tile_rows" (0 = per launch, 16, 4): force the band CNN's 16-row throughput tiles
+ * or its 4-row latency tiles (default: 4 rows whenever the 16-row tiles could not give every compute unit a workgroup).
+ * "ac_anchor_min_batch" (default 96): from this many images per call on,
  * llicti_decode_images decodes the AC container over anchor rows (every 8th table entry from cdf_anchor_kernel, the 8
  * entries of the located bucket evaluated by the decoding wavefront) instead of full table rows; values above the
  * default are clamped to it (the workspace is sized for the default). */

@@ -69,6 +69,7 @@ constexpr int kAcAnchorBatch = 96;
 static bool ac_use_anchors(int B, int min_batch = kAcAnchorBatch) { return B >= std::min(min_batch, kAcAnchorBatch); }
 
 constexpr int kMaxSub = 4;
+constexpr int kRansMaxStreams = 128;   // rANS streams per image: <= 32 one per segment, 64 / 128 grouped (rans_group())
 constexpr int kStatusHead = 16;       // status words in front of the per-image ones (common.hpp: image_status())
 struct PlanDev {                  // owns its device arrays: a plan that fails half-way through get_plan() frees what it took
     Plan p;
@@ -241,13 +242,18 @@ static void build_plan(Plan &p, int B, int H, int W, int M)
         p.rslot_off.assign((size_t)B * M, 0);
         for (long i = 0; i < (long)B * M; ++i) p.rslot_off[i] = (long)i * p.rslot_cap;
         slot_pos = std::max<long>(slot_pos, (long)B * M * p.rslot_cap);
-        p.max_container = std::max(p.max_container, align_up((size_t)(17 + 3 * g4.h * g4.w) + (size_t)M * p.rslot_cap, 16));
+        // container bound: the streams together hold every symbol once (<= 16 bits each, whole chunks), plus per stream T | pad, the
+        // 64 final states, a table entry (M > 32) and the byte the bit region rounds up to
+        long all_syms = 0;
+        for (int st = 0; st < LLICTI_NSTREAMS; ++st) all_syms += (p.desc[(size_t)st * B].n + 63) / 64 * 64;
+        p.max_container = std::max(p.max_container, align_up((size_t)(17 + 3 * g4.h * g4.w) + (size_t)(2 * all_syms) + (size_t)M * (kRansMinStream + 4 + 4) + 64, 16));
     }
     p.off_slots = take((size_t)slot_pos);
-    p.off_rinfo = take((size_t)B * 32 * 2 * sizeof(int32_t));
-    p.off_rstate = take((size_t)B * 32 * 64 * sizeof(uint32_t));
-    p.off_rpos = take((size_t)B * 32 * sizeof(uint32_t));
-    p.off_rtail = take((size_t)B * 32 * sizeof(uint32_t));
+    const size_t ns = (size_t)B * std::max(M, 32);
+    p.off_rinfo = take(ns * 2 * sizeof(int32_t));
+    p.off_rstate = take(ns * 64 * sizeof(uint32_t));
+    p.off_rpos = take(ns * sizeof(uint32_t));
+    p.off_rtail = take(ns * sizeof(uint32_t));
     p.off_slot_len = take((size_t)LLICTI_NSTREAMS * B * sizeof(int32_t));
     int hc0, wc0;
     coded_dims(g0, 1, &hc0, &wc0);
@@ -267,13 +273,13 @@ static void build_plan(Plan &p, int B, int H, int W, int M)
 }
 
 // mode: 0 = AC container (torchac-compatible, the reference's format); 0x100 | M = rANS container (v3) with M
-// streams per image, M in {1,2,4,8,16,32}
+// streams per image, M in {1,2,4,8,16,32} (one per container segment) or {64,128} (latency modes: 2 / 4 streams per segment)
 static int mode_streams(int mode)
 {
     if (mode == 0) return 0;
     if ((mode & ~0xFF) != 0x100) return -1;
     const int M = mode & 0xFF;
-    if (M < 1 || M > 32 || (M & (M - 1))) return -1;
+    if (M < 1 || M > kRansMaxStreams || (M & (M - 1))) return -1;
     return M;
 }
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
@@ -306,9 +312,10 @@ extern "C" size_t llicti_workspace_bytes(int B, int H, int W, int mode)
 extern "C" size_t llicti_max_container_bytes(int H, int W)
 {
     if (check_dims(1, H, W)) return 0;
-    Plan p;
-    build_plan(p, 1, H, W, 32);     // covers every mode
-    return p.max_container;
+    Plan p, q;
+    build_plan(p, 1, H, W, 32);     // covers the AC container and M <= 32 ...
+    build_plan(q, 1, H, W, kRansMaxStreams);     // ... and the many-stream latency modes (more per-stream slack)
+    return std::max(p.max_container, q.max_container);
 }
 
 extern "C" int llicti_create(llicti_ctx **out, int device)

@@ -675,12 +675,17 @@ __global__ __launch_bounds__(64) void rans_tail_kernel(const float *__restrict__
     if ((bad || tc != 0) && lane == 0) flag_image(status, b, LLICTI_EFORMAT);
 }
 
+// M <= 32: stream m is segment 4 + m of the container.  M = 64 / 128 (latency modes for single / large images; the reference's list
+// has 45 stream slots): G = M / 32 streams share segment 4 + m / G = G little-endian u32 stream lengths, then the G streams.
+__host__ __device__ __forceinline__ int rans_group(int M) { return M > 32 ? M / 32 : 1; }
+
 __global__ __launch_bounds__(256) void rans_pack_kernel(const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
                                                         const int32_t *__restrict__ rinfo, int M, int hdr_bytes,
                                                         uint8_t *__restrict__ out, long out_stride, int32_t *__restrict__ seg_len, int32_t *status)
 {
     const int m = blockIdx.x, b = blockIdx.y;
-    long dst = hdr_bytes;
+    const int G = rans_group(M), sg = m / G;
+    long dst = hdr_bytes + (G > 1 ? 4L * G * (sg + 1) : 0);
     for (int k = 0; k < m; ++k) dst += rinfo[2 * (b * M + k) + 1];
     const int n = rinfo[2 * (b * M + m) + 1];
     if (dst + n > out_stride) { if (threadIdx.x == 0) atomicExch(&status[0], LLICTI_ENOSPACE); return; }
@@ -688,8 +693,19 @@ __global__ __launch_bounds__(256) void rans_pack_kernel(const uint8_t *__restric
     uint8_t *o = out + (long)b * out_stride + dst;
     block_copy_bytes(o, src, n);
     if (threadIdx.x == 0) {
-        seg_len[(long)b * LLICTI_NSEG + 4 + m] = n;
-        if (m == 0) for (int k = 4 + M; k < LLICTI_NSEG; ++k) seg_len[(long)b * LLICTI_NSEG + k] = 0;
+        if (G == 1) seg_len[(long)b * LLICTI_NSEG + 4 + m] = n;
+        else if (m % G == 0) {                                  // the segment's length table and total
+            uint8_t *tab = o - 4 * G;
+            int tot = 4 * G;
+            for (int k = 0; k < G; ++k) {
+                const int len = rinfo[2 * (b * M + m + k) + 1];
+                tab[4 * k] = (uint8_t)(len & 0xFF); tab[4 * k + 1] = (uint8_t)((len >> 8) & 0xFF);
+                tab[4 * k + 2] = (uint8_t)((len >> 16) & 0xFF); tab[4 * k + 3] = (uint8_t)((len >> 24) & 0xFF);
+                tot += len;
+            }
+            seg_len[(long)b * LLICTI_NSEG + 4 + sg] = tot;
+        }
+        if (m == 0) for (int k = 4 + M / G; k < LLICTI_NSEG; ++k) seg_len[(long)b * LLICTI_NSEG + k] = 0;
     }
 }
 
@@ -698,16 +714,35 @@ __global__ __launch_bounds__(256) void rans_unpack_kernel(const uint8_t *__restr
                                                           int rslot_cap, uint32_t *__restrict__ rpos, int32_t *status)
 {
     const int m = blockIdx.x, b = blockIdx.y;
+    const int G = rans_group(M), sg = m / G;
     const int32_t *sl = seg_len + (long)b * LLICTI_NSEG;
     long src = 0;
     bool bad = false;
-    for (int k = 0; k < 4 + m; ++k) {           // see unpack_kernel: every earlier entry is validated too
+    for (int k = 0; k < 4 + sg; ++k) {          // see unpack_kernel: every earlier entry is validated too
         const int v = sl[k];
         if (v < 0 || v > in_stride) bad = true;
         src += v;
         if (src < 0 || src > in_stride) { bad = true; src = 0; }
     }
-    int n = sl[4 + m];
+    int n = sl[4 + sg];
+    if (G > 1) {
+        // the segment's table: G stream lengths, each a whole stream, together exactly the segment
+        const int seg_n = n;
+        if (bad || seg_n < 4 * G || src + seg_n > in_stride) { bad = true; n = 0; }
+        else {
+            const uint8_t *tab = in + (long)b * in_stride + src;
+            long off = 4L * G, tot = 4L * G;
+            for (int k = 0; k < G; ++k) {
+                const long len = (long)tab[4 * k] | ((long)tab[4 * k + 1] << 8) | ((long)tab[4 * k + 2] << 16) | ((long)tab[4 * k + 3] << 24);
+                if (len < kRansMinStream || len > seg_n) bad = true;
+                if (k < m % G) off += len;
+                if (k == m % G) n = (int)min(len, (long)seg_n);
+                tot += len;
+            }
+            if (tot != seg_n) bad = true;
+            src += off;
+        }
+    }
     uint8_t *o = slots + rslot_off[b * M + m] + 2;               // the bit region (stream offset 2) lands dword aligned
     if (bad || n < kRansMinStream || n + 2 + 64 > rslot_cap || src + n > in_stride) {
         if (threadIdx.x == 0) flag_image(status, b, LLICTI_EFORMAT);

@@ -822,7 +822,8 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
     if (H < 32 || W < 32 || H > 8160 || W > 8160) return -2;
     int lgM = 0;
     while ((1 << lgM) < M) ++lgM;
-    if ((1 << lgM) != M || M > 32) return -2;
+    if ((1 << lgM) != M || M > 128) return -2;
+    const int G = M > 32 ? M / 32 : 1;                  /* streams per segment (the reference's list has 45 stream slots: 32 are used) */
     const long plane_sz = (long)H * W;
     int16_t *planes = (int16_t *)malloc(sizeof(int16_t) * 3 * plane_sz);
     int16_t minmax[6];
@@ -925,7 +926,13 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
         const long nbytes = (bp + 7) / 8;
         const long padb = 8 * nbytes - bp;               /* unused (zero) bits on top of the region's last byte */
         const long bytes = 2 + nbytes + RANS_PAY_BITS / 8;
-        if (pos + bytes > cap) { rc = -1; break; }
+        if (pos + bytes + 4 * G > cap) { rc = -1; break; }
+        if (G > 1) {
+            /* M = 64 / 128: segment m / G = G little-endian u32 stream lengths, then its G streams */
+            if (m % G == 0) { memset(out + pos, 0, 4 * G); pos += 4 * G; seg_len[4 + m / G] = 4 * G; }
+            uint8_t *tab = out + pos - seg_len[4 + m / G] + 4 * (m % G);
+            tab[0] = (uint8_t)(bytes & 0xFF); tab[1] = (uint8_t)((bytes >> 8) & 0xFF); tab[2] = (uint8_t)((bytes >> 16) & 0xFF); tab[3] = (uint8_t)(bytes >> 24);
+        }
         const long t16 = T | (padb << 11);
         out[pos] = (uint8_t)(t16 & 0xFF); out[pos + 1] = (uint8_t)(t16 >> 8);
         memcpy(out + pos + 2, bits, nbytes);
@@ -933,7 +940,7 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
         memset(fs, 0, RANS_PAY_BITS / 8);
         for (int l = 0; l < RANS_LANES; ++l) put_bits(fs, (long)RANS_STATE_BITS * l, RANS_STATE_BITS, x[l] & 0x7FFFFFFFu);
         pos += bytes;
-        seg_len[4 + m] = (int32_t)bytes;
+        seg_len[4 + m / G] += (int32_t)bytes;
     }
     free(bits);
     for (int s = 0; s < ORC_NSTREAM; ++s) { free(st[s].clow); free(st[s].chigh); }
@@ -960,6 +967,7 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
     if (seg_len[0] != 3 || seg_len[1] != 12 || seg_len[2] != 2) return -3;
     if ((in[0] & 0x8F) != (0x88 | ORC_NLEV)) return -4;          /* 0x85: the retired v2 format */
     const int M = 1 << ((in[0] >> 4) & 7);
+    const int G = M > 32 ? M / 32 : 1;
     int H, W;
     orc_header_dims(in, seg_len, &H, &W);
     *H_out = H; *W_out = W;
@@ -976,8 +984,22 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
     int bad = 0;
     {
         long pos = 17 + seg_len[3];
+        long seg_left = 0;
         for (int m = 0; m < M; ++m) {
-            const long len = seg_len[4 + m];
+            long len = seg_len[4 + m / G];
+            if (G > 1) {
+                if (m % G == 0) {
+                    seg_left = len - 4 * G;
+                    if (seg_left < 0) { free(x); free(bitsp); free(cur); free(T); return -3; }
+                    pos += 4 * G;
+                }
+                const uint8_t *seg0 = in + 17 + seg_len[3];           /* the segment's table of G stream lengths */
+                for (int sgi = 0; sgi < m / G; ++sgi) seg0 += seg_len[4 + sgi];
+                const uint8_t *tab = seg0 + 4 * (m % G);
+                len = (long)tab[0] | ((long)tab[1] << 8) | ((long)tab[2] << 16) | ((long)tab[3] << 24);
+                seg_left -= len;
+                if (seg_left < 0 || (m % G == G - 1 && seg_left != 0)) { free(x); free(bitsp); free(cur); free(T); return -3; }
+            }
             if (len < 2 + RANS_PAY_BITS / 8) { free(x); free(bitsp); free(cur); free(T); return -3; }
             const uint8_t *sp = in + pos;
             const int t16 = sp[0] | (sp[1] << 8);

@@ -265,7 +265,8 @@ def test_golden_headers_and_pixels(torch_mod, codecs, golden_index, case):
 
 @pytest.mark.parametrize("kind,H,W,wname,M", [("smooth", 67, 93, "trainedlike", 1), ("noise", 64, 48, "rand1337", 4),
                                               ("smooth", 100, 131, "trainedlike", 8), ("noise", 33, 250, "trainedlike", 16),
-                                              ("smooth", 256, 256, "trainedlike", 32)])
+                                              ("smooth", 256, 256, "trainedlike", 32), ("noise", 256, 384, "rand1337", 64),
+                                              ("smooth", 512, 768, "trainedlike", 128)])
 def test_rans_container_bitexact(torch_mod, codecs, oracle_weights, kind, H, W, wname, M):
     """The throughput container (rANS v3): HIP bytes == oracle bytes, both decoders invert it, and a stream that has symbols
     costs about 8 bytes over the ideal length (an empty one 251: tiny images with many streams)."""
@@ -286,6 +287,7 @@ def test_rans_container_bitexact(torch_mod, codecs, oracle_weights, kind, H, W, 
         n_ac = sum(len(x) for row in orc.encode_image(rgb[b], W_o) for x in row)
         n_rans = sum(len(x) for row in bl for x in row)
         assert -64 <= n_rans - n_ac <= 260 * M + 64
+        assert sum(1 for row in bl[1:] for x in row if len(x)) == min(M, 32)      # M = 64 / 128: 2 / 4 streams per segment
     rec = c.decode(cont, seg, H, W, mode=MODE_RANS(M))
     c.check()
     assert np.array_equal(rec.cpu().numpy(), rgb)
