@@ -44,7 +44,19 @@ sys.path.insert(0, ROOT)
 MAC_PER_POSITION = 193248            # 84,480 layer-0 + 92,928 mid + 15,840 out
 PEAK_FP32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_HBM_GBS = 8000.0
-DEFAULT_CONTAINER = "rans8"          # rANS v3, 8 streams per image: the fastest mode within 0.001 bpp of the reference-format container (m_sweep)
+DEFAULT_CONTAINER = "auto"           # rANS v3 with default_streams(batch) streams per image, see below
+MAX_STREAMS_IN_BUDGET = 10           # a v3 stream costs ~6 bytes: 10 per 768x512 image are +0.0007 bpp over the reference-format container (m_sweep)
+
+
+def default_streams(B, n_cu=256):
+    """Streams per image of the timed container: as many as keep ONE decoder workgroup per stream on its own compute unit
+    (B * M <= CUs: a second workgroup on a CU slows both by 1.4x, so more streams than that buy nothing) and stay inside the north
+    star's 0.001 bpp (<= 10 per 768x512 image).  24 images on a 256-CU MI355X: 10; 32 images (configs[4] per GPU): 8."""
+    return max(1, min(MAX_STREAMS_IN_BUDGET, n_cu // max(1, B)))
+
+
+def default_container(B, n_cu=256):
+    return f"rans{default_streams(B, n_cu)}"
 NORTH_STAR_MPIX_S = 200.0            # BASELINE.json north_star: >= 200 MPix/s encode+decode on 768x512 at 1 MI355X ...
 NORTH_STAR_DBPP = 0.001              # ... with bpp within 0.001 of the reference
 MAC_PER_BAND = (352 * 48 + 30976 + 5280, 352 * 72 + 30976 + 5280, 352 * 120 + 30976 + 5280)   # layer 0 (K = 48 / 72 / 120) + 4 x 88 x 88 + 4 x 15 x 88
@@ -59,7 +71,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default: 24; 32 at --gpus 8 = BASELINE.json configs[4])")
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=768)
-    ap.add_argument("--container", default=DEFAULT_CONTAINER, help="rans<M> (M streams per image) or ac (torchac-compatible)")
+    ap.add_argument("--container", default=DEFAULT_CONTAINER, help="auto (rANS v3, streams per image from the batch size: default_streams()), rans<M> (M streams per image) or ac (torchac-compatible)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed informational legs (profiling runs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
@@ -396,6 +408,8 @@ def main(argv=None):
 
     def mode_of(name):
         return MODE_AC if name == "ac" else MODE_RANS(int(name[4:]))
+    if args.container == "auto":
+        args.container = default_container(B, torch.cuda.get_device_properties(dev).multi_processor_count)
     mode = mode_of(args.container)
     torch.manual_seed(1337)
     sd = LLICTI(default_config()).state_dict()                # seed-1337 default init, identical on every rank
@@ -605,7 +619,7 @@ def main(argv=None):
         legs = Legs(torch, codec, dev)
         # (2) rANS streams per image: speed against container overhead
         sweep = []
-        for M in (1, 2, 4, 8, 16, 32):
+        for M in (1, 2, 4, 8, 10, 12, 16, 32):
             r = legs.run(rgb, MODE_RANS(M), reps=2)
             sweep.append({"M": M, "encdec_mpix_s": r["encdec_mpix_s"], "enc_mpix_s": r["enc_mpix_s"], "dec_mpix_s": r["dec_mpix_s"],
                           "bpp_delta_vs_ac_container": round(8.0 * (r["bytes"] - ac_bytes) / (B * H * W), 5)})

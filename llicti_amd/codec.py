@@ -22,16 +22,29 @@ MODE_AC = 0                      # the reference's container: 45 torchac-algorit
 
 
 def MODE_RANS(M=8):
-    """"LLICTI-rANS v3" container: M independent 64-way interleaved rANS streams per image (include/llicti_hip.h)."""
+    """"LLICTI-rANS v3" container: M independent 64-way interleaved rANS streams per image, M in 1 .. 32, 64, 128
+    (include/llicti_hip.h)."""
     return 0x100 | int(M)
+
+
+def rans_tag(M):
+    """Header byte 0 of a rANS v3 container with M streams per image."""
+    lat = 1 if M > 32 else 0
+    v = ({64: 0, 128: 1}[M] if lat else M - 1)
+    return 0x88 | (lat << 6) | (((v >> 3) & 3) << 4) | (v & 7)
 
 
 def mode_of_header(byte0: int) -> int:
     if byte0 == 5:
         return MODE_AC
-    if (byte0 & 0x8F) == 0x8D:
-        return MODE_RANS(1 << ((byte0 >> 4) & 7))
-    if (byte0 & 0x8F) == 0x85:
+    if (byte0 & 0x88) == 0x88:          # rANS v3: bit 6 = latency mode, bits 5,4,2,1,0 = v; M = v + 1, or 64 << v in latency mode
+        v = (((byte0 >> 4) & 3) << 3) | (byte0 & 7)
+        if (byte0 >> 6) & 1:
+            if v > 1:
+                raise ValueError(f"unknown container tag 0x{byte0:02x}")
+            return MODE_RANS(64 << v)
+        return MODE_RANS(v + 1)
+    if (byte0 & 0x88) == 0x80:
         raise ValueError(f"container tag 0x{byte0:02x} is the retired LLICTI-rANS v2 format; this build reads and writes v3 only")
     raise ValueError(f"unknown container tag 0x{byte0:02x}")
 

@@ -273,18 +273,31 @@ static void build_plan(Plan &p, int B, int H, int W, int M)
 }
 
 // mode: 0 = AC container (torchac-compatible, the reference's format); 0x100 | M = rANS container (v3) with M
-// streams per image, M in {1,2,4,8,16,32} (one per container segment) or {64,128} (latency modes: 2 / 4 streams per segment)
+// streams per image, M in 1 .. 32 (one per container segment) or {64, 128} (latency modes: 2 / 4 streams per segment)
 static int mode_streams(int mode)
 {
     if (mode == 0) return 0;
     if ((mode & ~0xFF) != 0x100) return -1;
     const int M = mode & 0xFF;
-    if (M < 1 || M > kRansMaxStreams || (M & (M - 1))) return -1;
+    if (M < 1 || (M > 32 && M != 64 && M != 128)) return -1;
     return M;
 }
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
-// header byte 0 of the rANS container: 0x80 | lg2(M) << 4 | 0x08 (format v3; the retired v2 had this bit clear) | number of scales
-static int rans_byte0(int M) { return 0x80 | (ilog2(M) << 4) | 0x08 | LLICTI_NLEVELS; }
+// Header byte 0 of the rANS v3 container (the AC container stores the number of scales, 5, there): bit 7 = rANS, bit 3 = format v3 (the
+// retired v2 had it clear), bit 6 = latency mode, bits 5,4,2,1,0 = a 5-bit value v:  M = v + 1 (1 .. 32 streams, one per segment), or
+// with bit 6 set M = 64 << v (v = 0, 1: 64 / 128 streams, M / 32 per segment).
+static int rans_byte0(int M)
+{
+    const int lat = M > 32 ? 1 : 0, v = lat ? (M == 64 ? 0 : 1) : M - 1;
+    return 0x88 | (lat << 6) | (((v >> 3) & 3) << 4) | (v & 7);
+}
+static int rans_streams_of_byte0(int b0)      // 0: not a v3 tag
+{
+    if ((b0 & 0x88) != 0x88) return 0;
+    const int v = (((b0 >> 4) & 3) << 3) | (b0 & 7);
+    if ((b0 >> 6) & 1) return v == 0 ? 64 : v == 1 ? 128 : 0;
+    return v + 1;
+}
 
 static int sub_batches_max(int B, int M)
 {
@@ -950,9 +963,9 @@ extern "C" int llicti_check_status(llicti_ctx *c, void *stream)
 extern "C" int llicti_header_dims(const uint8_t *h, int *H, int *W)
 {
     if (!h || !H || !W) return fail(LLICTI_EINVAL, "header_dims: null pointer");
-    if ((h[0] & 0x8F) == (0x80 | LLICTI_NLEVELS))
+    if ((h[0] & 0x88) == 0x80)
         return fail(LLICTI_EFORMAT, "header: byte 0 = 0x%02x is the retired LLICTI-rANS v2 container; this build reads and writes v3 only", h[0]);
-    if (h[0] != LLICTI_NLEVELS && (h[0] & 0x8F) != (0x88 | LLICTI_NLEVELS))
+    if (h[0] != LLICTI_NLEVELS && rans_streams_of_byte0(h[0]) == 0)
         return fail(LLICTI_EFORMAT, "header: byte 0 = 0x%02x is neither %d scales (AC container) nor a rANS v3 container tag", h[0], LLICTI_NLEVELS);
     int Hc = h[1], Wc = h[2];
     int pad = (int)(int16_t)(h[15] | (h[16] << 8));

@@ -820,9 +820,7 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
                            uint8_t *out, long cap, int32_t seg_len[49])
 {
     if (H < 32 || W < 32 || H > 8160 || W > 8160) return -2;
-    int lgM = 0;
-    while ((1 << lgM) < M) ++lgM;
-    if ((1 << lgM) != M || M > 128) return -2;
+    if (M < 1 || (M > 32 && M != 64 && M != 128)) return -2;
     const int G = M > 32 ? M / 32 : 1;                  /* streams per segment (the reference's list has 45 stream slots: 32 are used) */
     const long plane_sz = (long)H * W;
     int16_t *planes = (int16_t *)malloc(sizeof(int16_t) * 3 * plane_sz);
@@ -834,7 +832,11 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
     const int h4 = h, w4 = w;
     if (cap < 17 + 3L * h4 * w4) { free(planes); return -1; }
     for (int i = 0; i < 49; ++i) seg_len[i] = 0;
-    out[pos++] = (uint8_t)(0x88 | (lgM << 4) | ORC_NLEV); out[pos++] = (uint8_t)h4; out[pos++] = (uint8_t)w4;
+    {   /* byte 0: bit 7 rANS, bit 3 format v3, bit 6 latency mode, bits 5,4,2,1,0 = v: M = v + 1 (<= 32), or 64 << v with bit 6 */
+        const int lat = M > 32, v = lat ? (M == 64 ? 0 : 1) : M - 1;
+        out[pos++] = (uint8_t)(0x88 | (lat << 6) | (((v >> 3) & 3) << 4) | (v & 7));
+    }
+    out[pos++] = (uint8_t)h4; out[pos++] = (uint8_t)w4;
     seg_len[0] = 3;
     memcpy(out + pos, minmax, 12); pos += 12; seg_len[1] = 12;
     int padint = 0;
@@ -965,8 +967,10 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
                           uint8_t *rgb, long rgb_cap, int *H_out, int *W_out)
 {
     if (seg_len[0] != 3 || seg_len[1] != 12 || seg_len[2] != 2) return -3;
-    if ((in[0] & 0x8F) != (0x88 | ORC_NLEV)) return -4;          /* 0x85: the retired v2 format */
-    const int M = 1 << ((in[0] >> 4) & 7);
+    if ((in[0] & 0x88) != 0x88) return -4;                        /* bit 3 clear: the retired v2 format */
+    const int tagv = (((in[0] >> 4) & 3) << 3) | (in[0] & 7);
+    const int M = ((in[0] >> 6) & 1) ? (tagv == 0 ? 64 : tagv == 1 ? 128 : 0) : tagv + 1;
+    if (M == 0) return -4;
     const int G = M > 32 ? M / 32 : 1;
     int H, W;
     orc_header_dims(in, seg_len, &H, &W);

@@ -112,7 +112,9 @@ long orc_stream_pairs(const int16_t *planes, int H, int W, const int16_t minmax[
                       uint32_t *clow, uint32_t *chigh, int16_t *sym);
 
 /* ---- rANS container ("LLICTI-rANS v3", a NEW format of this build: the reference has only torchac) ----
- * Same header segments except byte 0 = 0x88 | lg2(M) << 4 | 5 (bit 3: format v3; v2's 0x80 | lg2(M) << 4 | 5 is rejected),
+ * Same header segments except byte 0: bit 7 = rANS, bit 3 = format v3 (v2 had it clear and is rejected), bit 6 = latency mode, bits
+ * 5,4,2,1,0 = v with M = v + 1 streams (1 .. 32) or, in latency mode, M = 64 << v (64 / 128: M / 32 streams per segment behind a table
+ * of their u32 lengths),
  * same CDFs, same symbols; the 45 torchac streams are replaced by M independent 64-way interleaved rANS streams per image
  * (seg_len[4 .. 4+M-1], the rest 0).  Stage st (decode order) has nc symbols in cropped raster order; symbol n sits in chunk
  * n/64, lane n%64; chunk c belongs to stream c % M and is that stream's step c / M of the stage.

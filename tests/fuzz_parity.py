@@ -40,7 +40,7 @@ for case in range(N):
         else:
             imgs.append(np.random.default_rng(seed).choice(np.array([0, 255], np.uint8), size=(3, H, W)))
     rgb = np.stack(imgs)
-    M = int(rng.choice([0, 1, 2, 4, 8, 16, 32, 64, 128]))
+    M = int(rng.choice([0, 1, 2, 3, 4, 8, 10, 11, 16, 32, 64, 128]))
     mode = MODE_AC if M == 0 else MODE_RANS(M)
     tag = f"case {case}: {wname} x{scale} {kind} B={B} {W}x{H} M={M}"
     codec = HipCodec("cuda:0")

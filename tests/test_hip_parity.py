@@ -266,6 +266,7 @@ def test_golden_headers_and_pixels(torch_mod, codecs, golden_index, case):
 @pytest.mark.parametrize("kind,H,W,wname,M", [("smooth", 67, 93, "trainedlike", 1), ("noise", 64, 48, "rand1337", 4),
                                               ("smooth", 100, 131, "trainedlike", 8), ("noise", 33, 250, "trainedlike", 16),
                                               ("smooth", 256, 256, "trainedlike", 32), ("noise", 256, 384, "rand1337", 64),
+                                              ("noise", 128, 192, "rand1337", 10), ("smooth", 150, 131, "trainedlike", 11),
                                               ("smooth", 512, 768, "trainedlike", 128)])
 def test_rans_container_bitexact(torch_mod, codecs, oracle_weights, kind, H, W, wname, M):
     """The throughput container (rANS v3): HIP bytes == oracle bytes, both decoders invert it, and a stream that has symbols
@@ -840,8 +841,8 @@ def test_agent_loads_reference_shaped_checkpoint(torch_mod, tmp_path):
         LLICTIAgent(cfg)
 
 
-def _bench_container_mode():
-    """The container bench.py TIMES (bench.DEFAULT_CONTAINER), as a codec mode."""
+def _bench_container_mode(B=24):
+    """The container bench.py TIMES for a batch of B images per GPU (bench.default_container), as a codec mode."""
     import importlib.util
     import os
     from conftest import ROOT
@@ -849,13 +850,14 @@ def _bench_container_mode():
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    name = bench.DEFAULT_CONTAINER
+    import torch
+    name = bench.default_container(B, torch.cuda.get_device_properties(0).multi_processor_count)
     return name, (0 if name == "ac" else MODE_RANS(int(name[4:])))
 
 
 def test_full_size_oracle_parity(torch_mod, codecs, oracle_weights):
     """BASELINE.json full sizes inside the suite: the 24 x 768x512 batch (configs[2]) in the container bench.py TIMES
-    (bench.DEFAULT_CONTAINER) with 3 of the 24 images compared byte for byte with the oracle (it costs seconds per image)
+    (bench.default_container(24)) with 3 of the 24 images compared byte for byte with the oracle (it costs seconds per image)
     and the whole batch within the north star's 0.001 bpp of the reference-format container; 2 x 768x512 in the AC container
     (configs[1]'s shape, reference format) against the oracle, and configs[0]'s 256x256 random-RGB image in the AC
     container; every decode on a poisoned workspace."""
@@ -907,7 +909,7 @@ def test_configs4_per_gpu_batch_oracle_parity(torch_mod, codecs, oracle_weights)
     c = codecs("rand1337")
     W_o = oracle_weights("rand1337")
     H, W, B, rank = 512, 768, 32, 7
-    name, mode = _bench_container_mode()
+    name, mode = _bench_container_mode(B)
     rgb = np.stack([np.random.default_rng(rank * B + i).integers(0, 256, size=(3, H, W), dtype=np.uint8) for i in range(B)])
     cont, seg = c.encode(_dev(torch, rgb), mode=mode)
     c.check()
@@ -994,9 +996,9 @@ def test_rans_v3_integrity_check_detects_corruption(torch_mod, codecs, oracle_we
         bl = container_to_bytestream_list(bad[1].cpu().numpy(), seg_h[1])
         with pytest.raises(Exception):
             orc.decode_image_rans(bl, W_o)
-    # the retired v2 tag: same bytes, format bit cleared
+    # the retired v2 tag (0x80 | lg2(M) << 4 | 5): the format bit clear
     v2 = cont.clone()
-    v2[:, 0] &= 0xF7
+    v2[:, 0] = 0x95
     c.decode(v2, seg, 96, 128, mode=mode)
     with pytest.raises(LlictiError) as e:
         c.check()

@@ -75,7 +75,9 @@ def test_workspace_and_container_bounds():
     # worst case of a 16-bit-precision coder: 2 bytes per symbol + termination / stream flush, 1,178,496 symbols
     assert 2 * 1178496 < L.llicti_max_container_bytes(512, 768) < 2 * 1178496 + 256 * 1024
     assert L.llicti_workspace_bytes(1, 512, 768, 0x100 | 8) > 0
-    assert L.llicti_workspace_bytes(1, 512, 768, 0x100 | 3) == 0     # M must be a power of two <= 32
+    assert L.llicti_workspace_bytes(1, 512, 768, 0x100 | 3) > 0 and L.llicti_workspace_bytes(1, 512, 768, 0x100 | 128) > 0
+    assert L.llicti_workspace_bytes(1, 512, 768, 0x100 | 33) == 0    # M in 1 .. 32, 64 or 128
+    assert L.llicti_workspace_bytes(1, 512, 768, 0x100 | 96) == 0
     assert L.llicti_workspace_bytes(1, 512, 768, 7) == 0
 
 
