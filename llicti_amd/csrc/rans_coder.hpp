@@ -648,8 +648,7 @@ __global__ __launch_bounds__(64) void rans_tail_kernel(const float *__restrict__
                 const int k = __builtin_popcountll(pb);                        // probes are ordered: the passes form a prefix
                 const int nlo = (k > 0) ? min(lo + stp * k, hi - 1) : lo;
                 const int nhi = (k < 12) ? min(lo + stp * (k + 1), hi - 1) : hi;
-                lo = nlo; hi = (k < 12) ? nhi : hi;
-                if (k == 12 && nlo == hi - 1) hi = nlo + 1;
+                lo = nlo; hi = nhi;
             }
             wb = lo;
             ent = entry_at(wb + we);
