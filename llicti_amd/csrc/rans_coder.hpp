@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restr
     if (lane == 0) {
         const int t16 = T | ((8 * nbytes - bp) << 11);               // pad: unused (zero) bits on top of the region's last byte
         slot[2] = (uint8_t)(t16 & 0xFF); slot[3] = (uint8_t)(t16 >> 8);
-        rinfo[2 * sidx] = 2; rinfo[2 * sidx + 1] = 2 + nbytes + kRansPayBytes;
+        rinfo[2 * sidx] = 2; rinfo[2 * sidx + 1] = (bad == 2) ? 0 : 2 + nbytes + kRansPayBytes;      // overflowed slot (never with the plan's sizing): nothing to pack, ENOSPACE is latched
     }
     if (bad) atomicExch(&status[0], bad == 1 ? LLICTI_EFORMAT : LLICTI_ENOSPACE);
 }
