@@ -406,8 +406,7 @@ def main(argv=None):
     from llicti_amd.graphs.models.LLICTI_nets import LLICTI
     from llicti_amd import shard
 
-    def mode_of(name):
-        return MODE_AC if name == "ac" else MODE_RANS(int(name[4:]))
+    from llicti_amd.codec import mode_of_name as mode_of
     if args.container == "auto":
         args.container = default_container(B, torch.cuda.get_device_properties(dev).multi_processor_count)
     mode = mode_of(args.container)
@@ -623,6 +622,10 @@ def main(argv=None):
             r = legs.run(rgb, MODE_RANS(M), reps=2)
             sweep.append({"M": M, "encdec_mpix_s": r["encdec_mpix_s"], "enc_mpix_s": r["enc_mpix_s"], "dec_mpix_s": r["dec_mpix_s"],
                           "bpp_delta_vs_ac_container": round(8.0 * (r["bytes"] - ac_bytes) / (B * H * W), 5)})
+        for M in (4, 5, 6, 8, 10):                  # wide streams: 128 lanes each, two decoder workgroups' worth of wavefronts per stream
+            r = legs.run(rgb, MODE_RANS(M, wide=True), reps=2)
+            sweep.append({"M": M, "wide": True, "encdec_mpix_s": r["encdec_mpix_s"], "enc_mpix_s": r["enc_mpix_s"], "dec_mpix_s": r["dec_mpix_s"],
+                          "bpp_delta_vs_ac_container": round(8.0 * (r["bytes"] - ac_bytes) / (B * H * W), 5)})
         legs_out["m_sweep"] = {"workload": f"{B}x{W}x{H}, rANS container with M streams per image", "modes": sweep}
         legs.free()
         # (3) configs[1]: ONE 768x512 image
@@ -739,7 +742,7 @@ def main(argv=None):
             if mode != MODE_AC:
                 # ... and so must image 0 of the TIMED container (the oracle's restatement of the rANS v3 format)
                 from oracle import oracle as orc
-                ref_r = orc.encode_image_rans(rgb_h[0], cpu_weights(), mode & 0xFF)
+                ref_r = orc.encode_image_rans(rgb_h[0], cpu_weights(), mode & 0xFF, (mode & ~0xFF) == 0x300)
                 got_r = container_to_bytestream_list(cont[0].cpu().numpy(), seg_h[0])
                 cb["timed_container_bitexact_vs_hip"] = bool(got_r == ref_r)
                 if not cb["timed_container_bitexact_vs_hip"]:

@@ -162,6 +162,8 @@ int llicti_ac_decode_u16cdf(llicti_ctx *ctx, const uint16_t *d_cdf, int Lp, int 
 #define LLICTI_MODE_AC        0
 #define LLICTI_MODE_RANS(M)  (0x100 | (M))      /* M in 1 .. 32: one stream per segment; {64, 128}: latency modes for single / large
                                                   images, M / 32 streams per segment behind a table of their u32 lengths (+6 bytes per stream) */
+#define LLICTI_MODE_RANS_WIDE(M) (0x300 | (M))  /* M in 1 .. 30 WIDE streams: 128 lanes per stream (two 64-symbol chunks per coder step, 128 x
+                                                  31-bit states, up to 127 tail symbols), header byte 0 = bit 6 set with v = M + 1 */
 
 /* Bytes of device workspace the two calls below need for B images of H x W in `mode`. */
 size_t llicti_workspace_bytes(int B, int H, int W, int mode);

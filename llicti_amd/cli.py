@@ -1,4 +1,4 @@
-"""python -m llicti_amd.cli encode IN.(png|ppm|jpg) OUT.llic [--container ac|rans<M>] [--checkpoint model_best.pth.tar]
+"""python -m llicti_amd.cli encode IN.(png|ppm|jpg) OUT.llic [--container ac|rans<M>|wrans<M>] [--checkpoint model_best.pth.tar]
    python -m llicti_amd.cli decode IN.llic OUT.(png|ppm)
    python -m llicti_amd.cli info   IN.llic
 
@@ -35,12 +35,12 @@ def main(argv=None):
     a = ap.parse_args(argv)
     from . import fileio
     if a.cmd == "info":
-        from .codec import header_dims, mode_of_header
+        from .codec import header_dims, mode_of_header, name_of_mode
         bl = fileio.read_llic(a.src)
         H, W = header_dims(bl[0][0] + bl[0][1] + bl[0][2])
         n = sum(len(s) for r in bl for s in r)
         mode = mode_of_header(bl[0][0][0])
-        print(f"{a.src}: {W}x{H} RGB, container {'ac' if mode == 0 else 'rans%d' % (mode & 0xFF)}, {n} bytes, {8.0 * n / (H * W):.4f} bpp")
+        print(f"{a.src}: {W}x{H} RGB, container {name_of_mode(mode)}, {n} bytes, {8.0 * n / (H * W):.4f} bpp")
         return 0
     if a.cmd == "encode":
         rgb = fileio.read_image(a.src)

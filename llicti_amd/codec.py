@@ -21,32 +21,47 @@ NSEG = 49
 MODE_AC = 0                      # the reference's container: 45 torchac-algorithm streams per image
 
 
-def MODE_RANS(M=8):
-    """"LLICTI-rANS v3" container: M independent 64-way interleaved rANS streams per image, M in 1 .. 32, 64, 128
+def MODE_RANS(M=8, wide=False):
+    """"LLICTI-rANS v3" container: M independent interleaved rANS streams per image.  64 lanes per stream with M in
+    1 .. 32, 64, 128; wide=True: 128 lanes per stream (two 64-symbol chunks per coder step), M in 1 .. 30
     (include/llicti_hip.h)."""
-    return 0x100 | int(M)
+    return (0x300 if wide else 0x100) | int(M)
 
 
-def rans_tag(M):
+def rans_tag(M, wide=False):
     """Header byte 0 of a rANS v3 container with M streams per image."""
-    lat = 1 if M > 32 else 0
-    v = ({64: 0, 128: 1}[M] if lat else M - 1)
-    return 0x88 | (lat << 6) | (((v >> 3) & 3) << 4) | (v & 7)
+    ext = 1 if (M > 32 or wide) else 0
+    v = M + 1 if wide else ({64: 0, 128: 1}[M] if ext else M - 1)
+    return 0x88 | (ext << 6) | (((v >> 3) & 3) << 4) | (v & 7)
 
 
 def mode_of_header(byte0: int) -> int:
     if byte0 == 5:
         return MODE_AC
-    if (byte0 & 0x88) == 0x88:          # rANS v3: bit 6 = latency mode, bits 5,4,2,1,0 = v; M = v + 1, or 64 << v in latency mode
+    if (byte0 & 0x88) == 0x88:          # rANS v3: bits 5,4,2,1,0 = v; bit 6 clear: M = v + 1; set: v = 0, 1 -> 64, 128 streams, v >= 2 -> v - 1 wide streams
         v = (((byte0 >> 4) & 3) << 3) | (byte0 & 7)
         if (byte0 >> 6) & 1:
-            if v > 1:
-                raise ValueError(f"unknown container tag 0x{byte0:02x}")
-            return MODE_RANS(64 << v)
+            return MODE_RANS(64 << v) if v <= 1 else MODE_RANS(v - 1, wide=True)
         return MODE_RANS(v + 1)
     if (byte0 & 0x88) == 0x80:
         raise ValueError(f"container tag 0x{byte0:02x} is the retired LLICTI-rANS v2 format; this build reads and writes v3 only")
     raise ValueError(f"unknown container tag 0x{byte0:02x}")
+
+
+def mode_of_name(name: str) -> int:
+    """"ac" | "rans<M>" | "wrans<M>" (wide streams) -> mode."""
+    name = str(name).lower()
+    if name == "ac":
+        return MODE_AC
+    if name.startswith("wrans"):
+        return MODE_RANS(int(name[5:]), wide=True)
+    if name.startswith("rans"):
+        return MODE_RANS(int(name[4:] or 8))
+    raise ValueError(f"unknown container {name!r}: ac, rans<M> or wrans<M>")
+
+
+def name_of_mode(mode: int) -> str:
+    return "ac" if mode == MODE_AC else ("wrans%d" if (mode & ~0xFF) == 0x300 else "rans%d") % (mode & 0xFF)
 
 
 def _ptr(t):

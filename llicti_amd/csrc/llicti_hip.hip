@@ -54,6 +54,7 @@ struct Plan {                 // workspace carving for (B, H, W)
     std::vector<long> pair_base;        // per (lvl, band): first pair of [clr][B][nc]
     size_t max_container;
     int M = 0;                          // rANS streams per image (0: AC container only)
+    int Q = 1;                          // 64-lane sub-chunks per stream step (2: wide streams of 128 lanes)
     int rslot_cap = 0;
     std::vector<long> rslot_off;        // [B*M] byte offsets into the slots region
     size_t off_rinfo, off_rstate, off_rpos, off_rtail;
@@ -181,9 +182,11 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static int stage_index(int lvl, int band, int clr) { return (LLICTI_NLEVELS - 1 - lvl) * 9 + band * 3 + clr; }   // scale 4..0
 
-static void build_plan(Plan &p, int B, int H, int W, int M)
+// ME: streams per image, | 0x100 for wide (128-lane) streams -- what mode_streams() returns and the plan cache is keyed on
+static void build_plan(Plan &p, int B, int H, int W, int ME)
 {
-    p.B = B; p.H = H; p.W = W; p.M = M;
+    const int M = ME & 0xFF, Q = (ME >> 8) ? 2 : 1;
+    p.B = B; p.H = H; p.W = W; p.M = M; p.Q = Q;
     const size_t plane = (size_t)H * W;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
@@ -234,11 +237,13 @@ static void build_plan(Plan &p, int B, int H, int W, int M)
         // worst case of one stream: every symbol emits 16 bits; chunks are dealt round-robin, so a
         // stream gets at most ceil(nchunks / M) chunks of every stage
         long syms = 0;
+        const int L = 64 * Q;
         for (int st = 0; st < LLICTI_NSTREAMS; ++st) {
-            const long nchunks = (p.desc[(size_t)st * B].n + 63) / 64;
-            syms += (nchunks + M - 1) / M * 64;
+            const long nchunks = (p.desc[(size_t)st * B].n + L - 1) / L;
+            syms += (nchunks + M - 1) / M * L;
         }
-        p.rslot_cap = (int)align_up((size_t)(2 * syms + 4 + 8 + kRansPayBytes + 16 + 64), 64);   // + T, 64 x 31-bit states, slack, zero pad
+        const int pay_bytes = Q == 2 ? RansGeo<2>::kPayBytes : RansGeo<1>::kPayBytes;
+        p.rslot_cap = (int)align_up((size_t)(2 * syms + 4 + 8 + pay_bytes + 16 + 64), 64);   // + T, the 31-bit states, slack, zero pad
         p.rslot_off.assign((size_t)B * M, 0);
         for (long i = 0; i < (long)B * M; ++i) p.rslot_off[i] = (long)i * p.rslot_cap;
         slot_pos = std::max<long>(slot_pos, (long)B * M * p.rslot_cap);
@@ -246,12 +251,12 @@ static void build_plan(Plan &p, int B, int H, int W, int M)
         // 64 final states, a table entry (M > 32) and the byte the bit region rounds up to
         long all_syms = 0;
         for (int st = 0; st < LLICTI_NSTREAMS; ++st) all_syms += (p.desc[(size_t)st * B].n + 63) / 64 * 64;
-        p.max_container = std::max(p.max_container, align_up((size_t)(17 + 3 * g4.h * g4.w) + (size_t)(2 * all_syms) + (size_t)M * (kRansMinStream + 4 + 4) + 64, 16));
+        p.max_container = std::max(p.max_container, align_up((size_t)(17 + 3 * g4.h * g4.w) + (size_t)(2 * all_syms) + (size_t)M * (2 + pay_bytes + 4 + 4) + 64, 16));
     }
     p.off_slots = take((size_t)slot_pos);
     const size_t ns = (size_t)B * std::max(M, 32);
     p.off_rinfo = take(ns * 2 * sizeof(int32_t));
-    p.off_rstate = take(ns * 64 * sizeof(uint32_t));
+    p.off_rstate = take(ns * 64 * Q * sizeof(uint32_t));
     p.off_rpos = take(ns * sizeof(uint32_t));
     p.off_rtail = take(ns * sizeof(uint32_t));
     p.off_slot_len = take((size_t)LLICTI_NSTREAMS * B * sizeof(int32_t));
@@ -274,28 +279,30 @@ static void build_plan(Plan &p, int B, int H, int W, int M)
 
 // mode: 0 = AC container (torchac-compatible, the reference's format); 0x100 | M = rANS container (v3) with M
 // streams per image, M in 1 .. 32 (one per container segment) or {64, 128} (latency modes: 2 / 4 streams per segment)
-static int mode_streams(int mode)
+static int mode_streams(int mode)      // -> M, | 0x100 for wide streams (LLICTI_MODE_RANS_WIDE); 0: AC container; -1: unknown
 {
     if (mode == 0) return 0;
-    if ((mode & ~0xFF) != 0x100) return -1;
     const int M = mode & 0xFF;
+    if ((mode & ~0xFF) == 0x300) return (M >= 1 && M <= 30) ? (M | 0x100) : -1;
+    if ((mode & ~0xFF) != 0x100) return -1;
     if (M < 1 || (M > 32 && M != 64 && M != 128)) return -1;
     return M;
 }
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 // Header byte 0 of the rANS v3 container (the AC container stores the number of scales, 5, there): bit 7 = rANS, bit 3 = format v3 (the
 // retired v2 had it clear), bit 6 = latency mode, bits 5,4,2,1,0 = a 5-bit value v:  M = v + 1 (1 .. 32 streams, one per segment), or
-// with bit 6 set M = 64 << v (v = 0, 1: 64 / 128 streams, M / 32 per segment).
-static int rans_byte0(int M)
+// with bit 6 set M = 64 << v (v = 0, 1: 64 / 128 streams, M / 32 per segment)
+// ... and v = M + 1 (2 .. 31) with bit 6 set: M wide streams of 128 lanes.
+static int rans_byte0(int M, int Q)
 {
-    const int lat = M > 32 ? 1 : 0, v = lat ? (M == 64 ? 0 : 1) : M - 1;
-    return 0x88 | (lat << 6) | (((v >> 3) & 3) << 4) | (v & 7);
+    const int ext = (M > 32 || Q == 2) ? 1 : 0, v = Q == 2 ? M + 1 : M > 32 ? (M == 64 ? 0 : 1) : M - 1;
+    return 0x88 | (ext << 6) | (((v >> 3) & 3) << 4) | (v & 7);
 }
-static int rans_streams_of_byte0(int b0)      // 0: not a v3 tag
+static int rans_streams_of_byte0(int b0)      // -> M (| 0x100 for wide streams); 0: not a v3 tag
 {
     if ((b0 & 0x88) != 0x88) return 0;
     const int v = (((b0 >> 4) & 3) << 3) | (b0 & 7);
-    if ((b0 >> 6) & 1) return v == 0 ? 64 : v == 1 ? 128 : 0;
+    if ((b0 >> 6) & 1) return v == 0 ? 64 : v == 1 ? 128 : ((v - 1) | 0x100);
     return v + 1;
 }
 
@@ -309,15 +316,15 @@ static int sub_batches_max(int B, int M)
 
 extern "C" size_t llicti_workspace_bytes(int B, int H, int W, int mode)
 {
-    const int M = mode_streams(mode);
-    if (check_dims(B, H, W) || M < 0) return 0;
+    const int ME = mode_streams(mode);
+    if (check_dims(B, H, W) || ME < 0) return 0;
     Plan p;
-    build_plan(p, B, H, W, M);
+    build_plan(p, B, H, W, ME);
     size_t need = p.total;
-    const int S = sub_batches_max(B, M);
+    const int S = sub_batches_max(B, ME & 0xFF);
     if (S > 1) {
         Plan q;
-        build_plan(q, B / S, H, W, M);
+        build_plan(q, B / S, H, W, ME);
         need = std::max(need, (size_t)S * align_up(q.total, 256));
     }
     return need;
@@ -328,7 +335,9 @@ extern "C" size_t llicti_max_container_bytes(int H, int W)
     Plan p, q;
     build_plan(p, 1, H, W, 32);     // covers the AC container and M <= 32 ...
     build_plan(q, 1, H, W, kRansMaxStreams);     // ... and the many-stream latency modes (more per-stream slack)
-    return std::max(p.max_container, q.max_container);
+    Plan w;
+    build_plan(w, 1, H, W, 30 | 0x100);          // ... and wide streams (larger state blocks)
+    return std::max(std::max(p.max_container, q.max_container), w.max_container);
 }
 
 extern "C" int llicti_create(llicti_ctx **out, int device)
@@ -734,12 +743,13 @@ extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, 
 {
     if (!c || !d_rgb || !d_workspace || !d_out || !d_seg_len) return fail(LLICTI_EINVAL, "encode_images: null pointer");
     if (check_dims(B, H, W)) return LLICTI_EINVAL;
-    const int M = mode_streams(mode);
-    if (M < 0) return fail(LLICTI_EINVAL, "encode_images: unknown mode 0x%x", mode);
+    const int ME = mode_streams(mode);
+    if (ME < 0) return fail(LLICTI_EINVAL, "encode_images: unknown mode 0x%x", mode);
+    const int M = ME & 0xFF, Q = (ME >> 8) ? 2 : 1;
     for (int b = 0; b < 3; ++b) if (!c->have[b]) return fail(LLICTI_ENOWEIGHTS, "band %d weights not set", b);
     DeviceGuard guard(c);
     PlanDev *pd = nullptr;
-    if (int rc = get_plan(c, B, H, W, M, &pd)) return rc;
+    if (int rc = get_plan(c, B, H, W, ME, &pd)) return rc;
     const Plan &p = pd->p;
     if (workspace_bytes < p.total) return fail(LLICTI_ENOSPACE, "encode_images: workspace %zu < %zu", workspace_bytes, p.total);
     if (out_stride < p.max_container) return fail(LLICTI_ENOSPACE, "encode_images: out_stride %zu < %zu", out_stride, p.max_container);
@@ -757,7 +767,7 @@ extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, 
     CallScope call(c, s);
     HIPCHK(hipMemsetAsync(status, 0, (kStatusHead + (size_t)B) * sizeof(int32_t), s));
     Geom g4 = make_geom(B, H, W, 4);
-    const int byte0 = M ? rans_byte0(M) : LLICTI_NLEVELS;
+    const int byte0 = M ? rans_byte0(M, Q) : LLICTI_NLEVELS;
     {
         ProfSpan span(c, PROF_MISC, s);
         if (int rc = launch_lift(d_rgb, B, H, W, planes, fplanes, mm, (int32_t *)(ws + p.off_lift_part), s)) return rc;
@@ -781,7 +791,8 @@ extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, 
     } else {
         ProfSpan span(c, PROF_RANS_ENC, s);
         int32_t *rinfo = (int32_t *)(ws + p.off_rinfo);
-        rans_encode_kernel<<<B * M, 64, 0, s>>>(pairs, pd->d_desc, B, M, slots, pd->d_rslot_off, p.rslot_cap, rinfo, status);
+        if (Q == 2) rans_encode_kernel<2><<<B * M, 64, 0, s>>>(pairs, pd->d_desc, B, M, slots, pd->d_rslot_off, p.rslot_cap, rinfo, status);
+        else rans_encode_kernel<1><<<B * M, 64, 0, s>>>(pairs, pd->d_desc, B, M, slots, pd->d_rslot_off, p.rslot_cap, rinfo, status);
         rans_pack_kernel<<<dim3(M, B), 256, 0, s>>>(slots, pd->d_rslot_off, rinfo, M, hdr_bytes, d_out, (long)out_stride, d_seg_len, status);
     }
     latch_status_kernel<<<1, 1, 0, s>>>(status, c->d_status);
@@ -794,6 +805,7 @@ static int decode_sub(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in
                       int B, int H, int W, int M, uint8_t *ws, uint8_t *d_rgb, hipStream_t s, hipStream_t sr = nullptr, hipEvent_t *evcr = nullptr)
 {
     if (!sr) sr = s;
+    const int Q = pd->p.Q;
     const Plan &p = pd->p;
     int16_t *planes = (int16_t *)(ws + p.off_planes);
     float *fplanes = (float *)(ws + p.off_fplanes);
@@ -807,7 +819,7 @@ static int decode_sub(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in
 
     HIPCHK(hipMemsetAsync(status, 0, (kStatusHead + (size_t)B) * sizeof(int32_t), s));
     Geom g4 = make_geom(B, H, W, 4);
-    const int byte0 = M ? rans_byte0(M) : LLICTI_NLEVELS;
+    const int byte0 = M ? rans_byte0(M, Q) : LLICTI_NLEVELS;
     uint32_t *rstate = (uint32_t *)(ws + p.off_rstate);
     uint32_t *rpos = (uint32_t *)(ws + p.off_rpos);
     uint32_t *rtail = (uint32_t *)(ws + p.off_rtail);
@@ -817,8 +829,10 @@ static int decode_sub(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in
         if (M == 0) {
             unpack_kernel<<<dim3(LLICTI_NSTREAMS, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, B, slots, pd->d_slot_off, pd->d_slot_cap, slot_len, status);
         } else {
-            rans_unpack_kernel<<<dim3(M, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, M, slots, pd->d_rslot_off, p.rslot_cap, rpos, status);
-            rans_init_kernel<<<B * M, 64, 0, s>>>(slots, pd->d_rslot_off, M, rstate, rpos, rtail, status);
+            rans_unpack_kernel<<<dim3(M, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, M, Q == 2 ? RansGeo<2>::kMinStream : RansGeo<1>::kMinStream,
+                                                          slots, pd->d_rslot_off, p.rslot_cap, rpos, status);
+            if (Q == 2) rans_init_kernel<2><<<B * M, 64, 0, s>>>(slots, pd->d_rslot_off, M, rstate, rpos, rtail, status);
+            else rans_init_kernel<1><<<B * M, 64, 0, s>>>(slots, pd->d_rslot_off, M, rstate, rpos, rtail, status);
         }
     }
     // 45 dependent stages (LLICTI_nets.py:440-498): CNN of band b needs bands < b of this level, Co needs Y, Cg needs Y, Co
@@ -833,13 +847,20 @@ static int decode_sub(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in
                 if (sr != s) { HIPCHK(hipEventRecord(evcr[0], s)); HIPCHK(hipStreamWaitEvent(sr, evcr[0], 0)); }
                 {
                 ProfSpan span(c, PROF_RANS_STAGE, sr);
-                rans_decode_stage_kernel<0><<<B * M, 64 * kRansWaves, 0, sr>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, 0, status);
-                rans_decode_stage_kernel<1><<<B * M, 64 * kRansWaves, 0, sr>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, 0, status);
-                rans_decode_stage_kernel<2><<<B * M, 64 * kRansWaves, 0, sr>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status);
+                if (Q == 2) {
+                    rans_decode_stage_kernel<0, 2><<<B * M, 128 * kRansWaves, 0, sr>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, 0, status);
+                    rans_decode_stage_kernel<1, 2><<<B * M, 128 * kRansWaves, 0, sr>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, 0, status);
+                    rans_decode_stage_kernel<2, 2><<<B * M, 128 * kRansWaves, 0, sr>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status);
+                } else {
+                    rans_decode_stage_kernel<0, 1><<<B * M, 64 * kRansWaves, 0, sr>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, 0, status);
+                    rans_decode_stage_kernel<1, 1><<<B * M, 64 * kRansWaves, 0, sr>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, 0, status);
+                    rans_decode_stage_kernel<2, 1><<<B * M, 64 * kRansWaves, 0, sr>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status);
+                }
                 }
                 if (last) {
                     ProfSpan span(c, PROF_RANS_TAIL, sr);
-                    rans_tail_kernel<<<B * M, 64, 0, sr>>>(params, sg, M, rstate, rpos, rtail, planes, fplanes, mm, status);
+                    if (Q == 2) rans_tail_kernel<2><<<B * M, 64, 0, sr>>>(params, sg, M, rstate, rpos, rtail, planes, fplanes, mm, status);
+                    else rans_tail_kernel<1><<<B * M, 64, 0, sr>>>(params, sg, M, rstate, rpos, rtail, planes, fplanes, mm, status);
                 }
                 if (sr != s) { HIPCHK(hipEventRecord(evcr[1], sr)); HIPCHK(hipStreamWaitEvent(s, evcr[1], 0)); }
             }
@@ -906,8 +927,9 @@ extern "C" int llicti_decode_images(llicti_ctx *c, const uint8_t *d_in, size_t i
 {
     if (!c || !d_in || !d_seg_len || !d_workspace || !d_rgb) return fail(LLICTI_EINVAL, "decode_images: null pointer");
     if (check_dims(B, H, W)) return LLICTI_EINVAL;
-    const int M = mode_streams(mode);
-    if (M < 0) return fail(LLICTI_EINVAL, "decode_images: unknown mode 0x%x", mode);
+    const int ME = mode_streams(mode);
+    if (ME < 0) return fail(LLICTI_EINVAL, "decode_images: unknown mode 0x%x", mode);
+    const int M = ME & 0xFF;
     for (int b = 0; b < 3; ++b) if (!c->have[b]) return fail(LLICTI_ENOWEIGHTS, "band %d weights not set", b);
     DeviceGuard guard(c);
     {
@@ -918,7 +940,7 @@ extern "C" int llicti_decode_images(llicti_ctx *c, const uint8_t *d_in, size_t i
     const int S = sub_batches(c, B, M);
     const int Bs = B / S;
     PlanDev *pd = nullptr;
-    if (int rc = get_plan(c, Bs, H, W, M, &pd)) return rc;
+    if (int rc = get_plan(c, Bs, H, W, ME, &pd)) return rc;
     const size_t sub_total = align_up(pd->p.total, 256);
     if (workspace_bytes < (size_t)S * sub_total)
         return fail(LLICTI_ENOSPACE, "decode_images: workspace %zu < %zu", workspace_bytes, (size_t)S * sub_total);

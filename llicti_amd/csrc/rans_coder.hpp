@@ -17,10 +17,17 @@
 // Cost over the ideal code length: ~8 bytes per stream (v2: ~60) -- M = 8 is within 0.001 bpp of the AC container.
 // Stream bytes:  u16 (T | pad << 11) | bit region, read DOWN from its top minus pad unused bits | 64 x 31-bit final states.
 constexpr int kRansStateBits = 31;
-constexpr int kRansPayBits = 64 * kRansStateBits;        // 1984
-constexpr int kRansPayBytes = kRansPayBits / 8;          // 248
 constexpr int kRansTailMax = 2047;
-constexpr int kRansMinStream = 2 + kRansPayBytes;        // T | pad, (empty bit region), states
+// A stream has 64 Q lanes: Q = 1, or Q = 2 ("wide" streams: two 64-symbol sub-chunks per step, decoded by eight wavefronts -- two per
+// SIMD, which raises a CU's throughput by 1.44x -- at the price of a tail twice as long).  Symbol n of a stage sits in chunk n / 64Q.
+template <int Q> struct RansGeo {
+    static constexpr int kLanes = 64 * Q;
+    static constexpr int kPayBits = kLanes * kRansStateBits;      // 1984 / 3968: what the initial states carry (the tail stream)
+    static constexpr int kPayBytes = kPayBits / 8;                // 248 / 496
+    static constexpr int kPayDw = (kPayBits + 31) / 32;           // 62 / 124
+    static constexpr int kMinStream = 2 + kPayBytes;              // T | pad, (empty bit region), states
+};
+constexpr int kRansPayBytesMax = RansGeo<2>::kPayBytes;
 
 __device__ __forceinline__ int lanes_below(uint64_t mask)
 {
@@ -39,14 +46,14 @@ __device__ __forceinline__ int wave_incl_scan(int v)
     return v;
 }
 
-// symbols of stream m in a stage of nc symbols (chunks m, m + M, ...; only the stage's last chunk can be partial)
-__host__ __device__ __forceinline__ int rans_stream_count(int nc, int m, int M)
+// symbols of stream m in a stage of nc symbols (chunks of L symbols m, m + M, ...; only the stage's last chunk can be partial)
+__host__ __device__ __forceinline__ int rans_stream_count(int nc, int m, int M, int L)
 {
-    const int nchunks = (nc + 63) >> 6;
+    const int nchunks = (nc + L - 1) / L;
     if (nchunks <= m) return 0;
     const int K = (nchunks - m + M - 1) / M;
     const int last = m + (K - 1) * M;
-    return 64 * K - ((last == nchunks - 1 && (nc & 63)) ? 64 - (nc & 63) : 0);
+    return L * K - ((last == nchunks - 1 && (nc % L)) ? L - (nc % L) : 0);
 }
 
 // encoder renormalisation: the smallest n with (x >> n) < freq << 16, x in [2^31, 2^32), 1 <= freq <= 2^16
@@ -80,20 +87,24 @@ __device__ __forceinline__ void lds_or_bits(uint32_t *buf, int pos, int n, uint3
 }
 
 // One wavefront per stream.  Slot layout (rslot_off is 64-byte aligned): [0,2) unused | [2,4) T | [4, 4 + nbytes) bit region
-// (dword aligned) | 248 bytes of final states; rinfo = (2, 2 + nbytes + 248) for rans_pack_kernel.
+// (dword aligned) | 248 Q bytes of final states; rinfo = (2, 2 + nbytes + 248 Q) for rans_pack_kernel.
+template <int Q>
 __global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restrict__ pairs, const StreamDesc *__restrict__ desc,
                                                          int B, int M, uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
                                                          int rslot_cap, int32_t *__restrict__ rinfo, int32_t *status)
 {
-    __shared__ uint32_t sh_pay[64];                 // the tail stream / the final states (62 dwords used, 2 of slack)
+    using GEO = RansGeo<Q>;
+    constexpr int L = GEO::kLanes;
+    __shared__ uint32_t sh_pay[64 * Q];             // the tail stream / the final states (62 Q dwords used, the rest slack)
     __shared__ uint32_t sh_pairs[64];
     __shared__ uint32_t sh_win[128];                // staging window of the bit region: dwords [wbase, wbase + 128)
     const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M, lane = threadIdx.x;
     uint8_t *slot = slots + rslot_off[sidx];
     uint32_t *out32 = reinterpret_cast<uint32_t *>(slot + 4);
-    const int cap_dw = (rslot_cap - 4 - kRansPayBytes - 8) >> 2;      // dwords the bit region may take
+    const int cap_dw = (rslot_cap - 4 - GEO::kPayBytes - 8) >> 2;      // dwords the bit region may take
     int bad = 0;
-    sh_pay[lane] = 0;
+#pragma unroll
+    for (int qq = 0; qq < Q; ++qq) sh_pay[64 * qq + lane] = 0;
     sh_win[lane] = 0; sh_win[64 + lane] = 0;
     __syncthreads();
 
@@ -101,7 +112,7 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restr
     //    the payload, the final state (32 bits, leading one = highest set bit of the payload) on top.  Every lane runs the
     //    (wave-uniform) recursion; lane 0 writes.
     const StreamDesc dl = desc[(long)(LLICTI_NSTREAMS - 1) * B + b];
-    const int cnt = rans_stream_count(dl.n, m, M);
+    const int cnt = rans_stream_count(dl.n, m, M, L);
     int T = 0;
     {
         const uint32_t *pl = pairs + dl.pair_off;
@@ -111,7 +122,7 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restr
         for (int q1 = cnt; q1 > 0 && !full; q1 -= 64) {
             const int q = q1 - 1 - lane;              // lane t holds the t-th symbol from the end of what is left
             uint32_t raw = 0u;
-            if (q >= 0) raw = pl[64 * (m + (q >> 6) * M) + (q & 63)];
+            if (q >= 0) raw = pl[L * (m + (q / L) * M) + (q % L)];
             sh_pairs[lane] = raw;
             __syncthreads();
             const int nblk = min(64, q1);
@@ -125,7 +136,7 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restr
                 if (freq == 0 || hi < lo) { bad = 1; freq = 1; }
                 if (T == 0) xt = freq << 15;            // absorbing start: the first pushed symbol codes to 2^31 + c_low, no bits
                 const int nb = (T == 0) ? 0 : rans_emit_bits(xt, freq);      // (the closed form needs x >= 2^31)
-                if (tb + nb + 32 > kRansPayBits) { full = true; break; }
+                if (tb + nb + 32 > GEO::kPayBits) { full = true; break; }
                 if (lane == 0) lds_or_bits(sh_pay, tb, nb, xt & ((1u << nb) - 1u));
                 tb += nb;
                 xt = rans_push(xt >> nb, lo, freq);
@@ -136,15 +147,17 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restr
         if (lane == 0) { lds_or_bits(sh_pay, tb, 16, xt & 0xFFFFu); lds_or_bits(sh_pay, tb + 16, 16, xt >> 16); }
         __syncthreads();
     }
-    // 2. the lanes start from the payload
-    uint32_t x = (1u << 31) | lds_get_bits(sh_pay, kRansStateBits * lane, kRansStateBits);
-    const int tail_from = cnt - T;                  // sequence position (64 k + lane) of the first tail symbol
+    // 2. the lanes start from the payload (lane l of sub-chunk qq = stream lane 64 qq + l)
+    uint32_t x[Q];
+#pragma unroll
+    for (int qq = 0; qq < Q; ++qq) x[qq] = (1u << 31) | lds_get_bits(sh_pay, kRansStateBits * (64 * qq + lane), kRansStateBits);
+    const int tail_from = cnt - T;                  // sequence position (L k + stream lane) of the first tail symbol
 
     // 3. main coder, last decoded symbol first; bits go UP from bit 0 of the bit region
     int bp = 0, wbase = 0;                          // bit cursor; first dword of the staging window
     for (int st = LLICTI_NSTREAMS - 1; st >= 0; --st) {      // rANS is LIFO: last decoded symbol first
         const StreamDesc d = desc[(long)st * B + b];
-        const int nchunks = (d.n + 63) >> 6;
+        const int nchunks = (d.n + L - 1) / L;
         if (nchunks <= m) continue;
         const int K = (nchunks - m + M - 1) / M;
         const uint32_t *pp = pairs + d.pair_off;
@@ -153,11 +166,11 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restr
         // FIXED roles (the loop is unrolled by four; a rotating ring r0 = r1 ... makes the compiler copy the
         // newest load, i.e. wait for it with s_waitcnt vmcnt(0) in every step).  Loads are unconditional
         // (clamped address); the raw value is masked only where it is consumed.
-        auto fetch = [&](int k) -> uint32_t { return pp[min(64 * (m + max(k, 0) * M) + lane, d.n - 1)]; };
-        auto code = [&](int k, uint32_t raw) {
+        auto fetch = [&](int k, int qq) -> uint32_t { return pp[min(L * (m + max(k, 0) * M) + 64 * qq + lane, d.n - 1)]; };
+        auto code = [&](int k, int qq, uint32_t raw, uint32_t &x) {
             if (k < 0) return;                                       // wave-uniform
-            const int n = 64 * (m + k * M) + lane;
-            const bool active = n < d.n && 64 * k + lane < lim;
+            const int n = L * (m + k * M) + 64 * qq + lane;
+            const bool active = n < d.n && L * k + 64 * qq + lane < lim;
             const uint32_t v = active ? raw : 0u;                    // (lo, c_high) = (0, 2^16 stored as 0): freq 2^16, no bits
             const uint32_t lo = v & 0xFFFFu;
             uint32_t hi = v >> 16;
@@ -165,7 +178,7 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restr
             uint32_t freq = hi - lo;
             if (freq == 0 || hi < lo) { bad = 1; freq = 1; }
             const int nb = rans_emit_bits(x, freq);
-            // the decoder renormalises lane-ascending reading DOWN: lane 63's bits lowest
+            // the decoder renormalises stream-lane-ascending reading DOWN: the highest lane's bits lowest (sub-chunk Q - 1 is coded first)
             const int incl = wave_incl_scan(nb);
             const int total = __builtin_amdgcn_readlane(incl, 63);
             lds_or_bits(sh_win, bp + (total - incl) - 32 * wbase, nb, x & ((1u << nb) - 1u));
@@ -181,21 +194,31 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restr
                 wbase += 64;
             }
         };
-        uint32_t r0 = fetch(K - 1), r1 = fetch(K - 2), r2 = fetch(K - 3), r3 = fetch(K - 4);
+        uint32_t r0[Q], r1[Q], r2[Q], r3[Q];
+#pragma unroll
+        for (int qq = 0; qq < Q; ++qq) { r0[qq] = fetch(K - 1, qq); r1[qq] = fetch(K - 2, qq); r2[qq] = fetch(K - 3, qq); r3[qq] = fetch(K - 4, qq); }
         for (int k = K - 1; k >= 0; k -= 4) {                 // steps k, k-1, k-2, k-3 (those below 0 are no-ops)
-            code(k, r0);     r0 = fetch(k - 4);
-            code(k - 1, r1); r1 = fetch(k - 5);
-            code(k - 2, r2); r2 = fetch(k - 6);
-            code(k - 3, r3); r3 = fetch(k - 7);
+#pragma unroll
+            for (int qq = Q - 1; qq >= 0; --qq) { code(k, qq, r0[qq], x[qq]);     r0[qq] = fetch(k - 4, qq); }
+#pragma unroll
+            for (int qq = Q - 1; qq >= 0; --qq) { code(k - 1, qq, r1[qq], x[qq]); r1[qq] = fetch(k - 5, qq); }
+#pragma unroll
+            for (int qq = Q - 1; qq >= 0; --qq) { code(k - 2, qq, r2[qq], x[qq]); r2[qq] = fetch(k - 6, qq); }
+#pragma unroll
+            for (int qq = Q - 1; qq >= 0; --qq) { code(k - 3, qq, r3[qq], x[qq]); r3[qq] = fetch(k - 7, qq); }
         }
     }
-    // 4. the rest of the window, the 64 final states (31 bits each), T | pad
+    // 4. the rest of the window, the 64 Q final states (31 bits each), T | pad
     __syncthreads();
     const int nbytes = (bp + 7) >> 3;
-    sh_pay[lane] = 0;
+#pragma unroll
+    for (int qq = 0; qq < Q; ++qq) sh_pay[64 * qq + lane] = 0;
     __syncthreads();
-    lds_or_bits(sh_pay, kRansStateBits * lane, 16, x & 0xFFFFu);
-    lds_or_bits(sh_pay, kRansStateBits * lane + 16, kRansStateBits - 16, (x >> 16) & 0x7FFFu);
+#pragma unroll
+    for (int qq = 0; qq < Q; ++qq) {
+        lds_or_bits(sh_pay, kRansStateBits * (64 * qq + lane), 16, x[qq] & 0xFFFFu);
+        lds_or_bits(sh_pay, kRansStateBits * (64 * qq + lane) + 16, kRansStateBits - 16, (x[qq] >> 16) & 0x7FFFu);
+    }
     __syncthreads();
     const int ndw = (nbytes >> 2) - wbase;                    // whole window dwords still to write (<= 66); then 0..3 bytes
     if ((nbytes >> 2) + 1 > cap_dw) bad = 2;
@@ -204,26 +227,28 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restr
         if (64 + lane < ndw) out32[wbase + 64 + lane] = sh_win[64 + lane];
         if (lane < (nbytes & 3)) slot[4 + (nbytes & ~3) + lane] = (uint8_t)(sh_win[ndw] >> (8 * lane));
         uint8_t *fs = slot + 4 + nbytes;
-        for (int t = lane; t < kRansPayBytes; t += 64) fs[t] = (uint8_t)(sh_pay[t >> 2] >> (8 * (t & 3)));
+        for (int t = lane; t < GEO::kPayBytes; t += 64) fs[t] = (uint8_t)(sh_pay[t >> 2] >> (8 * (t & 3)));
     }
     if (lane == 0) {
         const int t16 = T | ((8 * nbytes - bp) << 11);               // pad: unused (zero) bits on top of the region's last byte
         slot[2] = (uint8_t)(t16 & 0xFF); slot[3] = (uint8_t)(t16 >> 8);
-        rinfo[2 * sidx] = 2; rinfo[2 * sidx + 1] = (bad == 2) ? 0 : 2 + nbytes + kRansPayBytes;      // overflowed slot (never with the plan's sizing): nothing to pack, ENOSPACE is latched
+        rinfo[2 * sidx] = 2; rinfo[2 * sidx + 1] = (bad == 2) ? 0 : 2 + nbytes + GEO::kPayBytes;      // overflowed slot (never with the plan's sizing): nothing to pack, ENOSPACE is latched
     }
     if (bad) atomicExch(&status[0], bad == 1 ? LLICTI_EFORMAT : LLICTI_ENOSPACE);
 }
 
 // decode: parse a stream (copied to slot + 2 by rans_unpack_kernel, which also left its validated length in rpos):
 // T and pad (-> bit cursor), the 64 states
+template <int Q>
 __global__ __launch_bounds__(64) void rans_init_kernel(const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
                                                        int M, uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos,
                                                        uint32_t *__restrict__ rtail, int32_t *status)
 {
+    using GEO = RansGeo<Q>;
     const int sidx = blockIdx.x, lane = threadIdx.x;
     const uint8_t *slot = slots + rslot_off[sidx];
-    const int n = (int)rpos[sidx];                                 // >= kRansMinStream
-    const int nbytes = n - 2 - kRansPayBytes;
+    const int n = (int)rpos[sidx];                                 // >= GEO::kMinStream
+    const int nbytes = n - 2 - GEO::kPayBytes;
     const int t16 = slot[2] | (slot[3] << 8);
     int T = t16 & 0x7FF;
     const int pad = (t16 >> 11) & 7;
@@ -231,12 +256,14 @@ __global__ __launch_bounds__(64) void rans_init_kernel(const uint8_t *__restrict
     if ((t16 >> 14) || (nbytes == 0 && pad)) { bad = true; T = 0; }
     const int cur = bad ? 0 : 8 * nbytes - pad;
     const uint8_t *fs = slot + 4 + nbytes;
-    const int bpos = kRansStateBits * lane;
-    uint64_t w = 0;
 #pragma unroll
-    for (int k = 0; k < 5; ++k) w |= (uint64_t)fs[min((bpos >> 3) + k, kRansPayBytes - 1)] << (8 * k);
-    const uint32_t x = (1u << 31) | ((uint32_t)(w >> (bpos & 7)) & 0x7FFFFFFFu);
-    rstate[(long)sidx * 64 + lane] = x;
+    for (int qq = 0; qq < Q; ++qq) {
+        const int bpos = kRansStateBits * (64 * qq + lane);
+        uint64_t w = 0;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) w |= (uint64_t)fs[min((bpos >> 3) + k, GEO::kPayBytes - 1)] << (8 * k);
+        rstate[((long)sidx * Q + qq) * 64 + lane] = (1u << 31) | ((uint32_t)(w >> (bpos & 7)) & 0x7FFFFFFFu);
+    }
     if (lane == 0) { rpos[sidx] = (uint32_t)cur; rtail[sidx] = (uint32_t)T; }
     if (bad && lane == 0) flag_image(status, sidx / M, LLICTI_EFORMAT);
 }
@@ -321,27 +348,30 @@ __device__ __forceinline__ int group_cdf_entry_fast(const CompFast &A, const Com
     return (int)__builtin_rintf(dpp_sum5(term_fast(A, pt), term_fast(B, pt)) * scale) + i;
 }
 
-template <int CLR>
-__global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(const float *__restrict__ params, StageGeom sg, int M,
+template <int CLR, int Q>
+__global__ __launch_bounds__(64 * kRansWaves * Q) void rans_decode_stage_kernel(const float *__restrict__ params, StageGeom sg, int M,
                                                                const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
                                                                int rslot_cap, uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos,
                                                                const uint32_t *__restrict__ rtail,
                                                                int16_t *__restrict__ planes, float *__restrict__ fplanes,
                                                                const int32_t *__restrict__ minmax, int last_stage, int32_t *status)
 {
-    __shared__ uint32_t sh_res[2][64][2];        // ping-pong by step parity: [0] = c_low, [1] = c_high
+    constexpr int L = 64 * Q;                    // lanes of a stream = symbols of a chunk; Q = 2: eight wavefronts, two state registers each
+    __shared__ uint32_t sh_res[2][L][2];         // ping-pong by step parity: [0] = c_low, [1] = c_high
     const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nc = sg.hc * sg.wc;
-    const int nchunks = (nc + 63) >> 6;
+    const int nchunks = (nc + L - 1) / L;
     if (nchunks <= m) return;                    // whole workgroup
     const int K = (nchunks - m + M - 1) / M;
-    uint32_t x = rstate[(long)sidx * 64 + lane];                       // every wave: its own copy
+    uint32_t x[Q];                                                      // every wave: its own copy of the stream's 64 Q states
+#pragma unroll
+    for (int qq = 0; qq < Q; ++qq) x[qq] = rstate[((long)sidx * Q + qq) * 64 + lane];
     int bcur = (int)rpos[sidx];                                          // bit cursor in the stream's bit region, moving DOWN
     const uint32_t *bitw = reinterpret_cast<const uint32_t *>(slots + rslot_off[sidx] + 4);
     const int max_dw = (rslot_cap - 4) >> 2;
-    // the stream's tail symbols (last stage only) are not in the main stream: sequence position 64 k + lane >= tail_from
-    const int tail_from = last_stage ? rans_stream_count(nc, m, M) - (int)rtail[sidx] : 0x7FFFFFFF;
+    // the stream's tail symbols (last stage only) are not in the main stream: sequence position L k + stream lane >= tail_from
+    const int tail_from = last_stage ? rans_stream_count(nc, m, M, L) - (int)rtail[sidx] : 0x7FFFFFFF;
     constexpr int clr = CLR;                     // compile-time: no branch (hence no register merge, hence no s_waitcnt vmcnt(0)) next to the prefetch loads
     int minv, maxv, shift;
     clr_range(minmax + 4 * b, clr, minv, maxv, shift);
@@ -350,7 +380,7 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
     const float fbase = (float)minv - 0.5f;
     const long img = (long)b * 3 * sg.plane;
     const int mA = lane & 3;                                            // component A of this lane; component B is 4 (read from lane 3 only)
-    const int gsym = 16 * wave + (lane >> 2);                           // symbol (lane of the stream) this 4-lane group resolves
+    const int gsym = 16 * wave + (lane >> 2);                           // symbol (lane of the stream, 0 .. L - 1) this 4-lane group resolves
     const int gbit = lane & ~3;                                         // ballot bit of the group's first lane
     const bool head = (mA == 0);
     // Raw CNN outputs / prior-channel pixels of this group's symbol in step k: requested one step ahead, so the
@@ -358,7 +388,7 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
     struct Raw { float sgA, muA, wkA, a0A, a1A, sgB, muB, wkB, a0B, a1B, y, co; long off; bool on; };
     auto fetch = [&](int k) -> Raw {
         Raw r;
-        const int n = min(64 * (m + k * M) + gsym, nc - 1);          // clamped: the loads are unconditional
+        const int n = min(L * (m + k * M) + gsym, nc - 1);           // clamped: the loads are unconditional
         const int i = div_wc(sg, n), j = n - i * sg.wc;          // multiply-shift: a runtime division costs ~25 of the step's ~900 instructions
         const float *par = params + ((long)b * sg.h * sg.w + (long)i * sg.w + j) * LLICTI_PARAM_STRIDE;
         r.off = img + ((long)(2 * i + sg.oi) << sg.lvl) * sg.W + ((long)(2 * j + sg.oj) << sg.lvl);
@@ -370,7 +400,7 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
             r.a0A = par[48 + 5 + mA]; r.a1A = par[48 + 10 + mA]; r.a0B = par[48 + 5 + 4]; r.a1B = par[48 + 10 + 4];
             r.y = fplanes[r.off]; r.co = fplanes[r.off + sg.plane];
         }
-        r.on = (k < K) && (64 * (m + k * M) + gsym) < nc && (64 * k + gsym) < tail_from;
+        r.on = (k < K) && (L * (m + k * M) + gsym) < nc && (L * k + gsym) < tail_from;
         return r;
     };
     // component (sigma, mu, w) -> (mu with the cross-channel update, 1 / max(sigma, bound), max(w, bound)), as mix_prepare()
@@ -385,17 +415,18 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
         return cpt;
     };
     // Stream bits: register window of 128 dwords below wtop (a multiple of 64): lane l of winA holds dword wtop - 64 + l,
-    // of winB dword wtop - 128 + l; bcur stays in (32 (wtop - 64), 32 wtop] and a step consumes at most 1024 bits, pulled
-    // with ds_bpermute instead of a dependent global load.
+    // of winB dword wtop - 128 + l; bcur stays in (32 (wtop - 64), 32 wtop] and a step consumes at most 1024 Q <= 2048 bits (so no
+    // field starts below dword wtop - 128), pulled with ds_bpermute instead of a dependent global load.
     int wtop = max(64, (((bcur + 31) >> 5) + 63) & ~63);
     auto load_dw = [&](int d0) -> uint32_t { return bitw[min(max(d0 + lane, 0), max_dw - 1)]; };
     uint32_t winA = load_dw(wtop - 64), winB = load_dw(wtop - 128);
     Raw cur = fetch(0);
     for (int k = 0; k < K; ++k) {
-        const int chunk0 = 64 * (m + k * M);
+        const int chunk0 = L * (m + k * M);
         const Raw nxt = fetch(min(k + 1, K - 1));
-        // slot of this group's symbol = low half of the state in lane gsym of this wave's copy
-        const uint32_t slot = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * gsym, (int)x) & 0xFFFFu;
+        // slot of this group's symbol = low half of the state in stream lane gsym of this wave's copy (waves 4 .. 7: the second register)
+        const uint32_t xs = (Q == 1 || wave < kRansWaves) ? x[0] : x[Q - 1];
+        const uint32_t slot = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (gsym & 63), (int)xs) & 0xFFFFu;
         {
             if (cur.on) {                        // uniform within the group
                 const long off = cur.off;
@@ -495,31 +526,38 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
         }
         __syncthreads();
         {
-            const bool active = chunk0 + lane < nc && 64 * k + lane < tail_from;
-            int nb = 0;
-            if (active) {
-                const uint32_t vlo = sh_res[k & 1][lane][0], vhi = sh_res[k & 1][lane][1];
-                x = (vhi - vlo) * (x >> 16) + (x & 0xFFFFu) - vlo;            // in [freq << 15, freq << 16)
-                nb = min(__clz((int)x), 16);                                   // > 16 only on a corrupt stream (caught by the end checks)
+            int below = 0;                                                         // bits of the lower sub-chunks of this step
+#pragma unroll
+            for (int qq = 0; qq < Q; ++qq) {
+                const int sl = 64 * qq + lane;                                     // stream lane
+                const bool active = chunk0 + sl < nc && L * k + sl < tail_from;
+                int nb = 0;
+                if (active) {
+                    const uint32_t vlo = sh_res[k & 1][sl][0], vhi = sh_res[k & 1][sl][1];
+                    x[qq] = (vhi - vlo) * (x[qq] >> 16) + (x[qq] & 0xFFFFu) - vlo;  // in [freq << 15, freq << 16)
+                    nb = min(__clz((int)x[qq]), 16);                               // > 16 only on a corrupt stream (caught by the end checks)
+                }
+                const int incl = wave_incl_scan(nb);
+                const int bpos = bcur - below - incl;                              // this lane's bits: [bpos, bpos + nb)
+                const int d = bpos >> 5;                                           // wtop - 128 <= d < wtop on a well-formed stream
+                const uint32_t a0 = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (d & 63), (int)winA);
+                const uint32_t b0 = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (d & 63), (int)winB);
+                const uint32_t a1 = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * ((d + 1) & 63), (int)winA);
+                const uint32_t b1 = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * ((d + 1) & 63), (int)winB);
+                const uint32_t w0 = (d >= wtop - 64) ? a0 : b0;
+                const uint32_t w1 = (d + 1 >= wtop - 64) ? a1 : b1;
+                const uint32_t bits = __builtin_amdgcn_alignbit(w1, w0, (uint32_t)(bpos & 31)) & ((1u << nb) - 1u);
+                x[qq] = (x[qq] << nb) | bits;
+                below += __builtin_amdgcn_readlane(incl, 63);
             }
-            const int incl = wave_incl_scan(nb);
-            const int bpos = bcur - incl;                                       // this lane's bits: [bpos, bpos + nb)
-            const int d = bpos >> 5;                                           // wtop - 128 <= d < wtop on a well-formed stream
-            const uint32_t a0 = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (d & 63), (int)winA);
-            const uint32_t b0 = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (d & 63), (int)winB);
-            const uint32_t a1 = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * ((d + 1) & 63), (int)winA);
-            const uint32_t b1 = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * ((d + 1) & 63), (int)winB);
-            const uint32_t w0 = (d >= wtop - 64) ? a0 : b0;
-            const uint32_t w1 = (d + 1 >= wtop - 64) ? a1 : b1;
-            const uint32_t bits = __builtin_amdgcn_alignbit(w1, w0, (uint32_t)(bpos & 31)) & ((1u << nb) - 1u);
-            x = (x << nb) | bits;
-            bcur -= __builtin_amdgcn_readlane(incl, 63);
+            bcur -= below;
             if (bcur <= 32 * (wtop - 64) && wtop > 64) { wtop -= 64; winA = winB; winB = load_dw(wtop - 128); }
         }
         cur = nxt;
     }
     if (wave == 0) {
-        rstate[(long)sidx * 64 + lane] = x;
+#pragma unroll
+        for (int qq = 0; qq < Q; ++qq) rstate[((long)sidx * Q + qq) * 64 + lane] = x[qq];
         if (lane == 0) {
             rpos[sidx] = (uint32_t)max(bcur, 0);
             if (bcur < 0) flag_image(status, b, LLICTI_EFORMAT);               // the stream ran out of bits
@@ -534,30 +572,39 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
 // lane, and a ballot proves the symbol (an exact 13-ary search takes over when the hint is wrong).
 // Checks: the main region was read to its last bit, the tail state ends at its start state (freq << 15 of the symbol the
 // tail encoder began with; 2^31 when T = 0) with no bit left.
+template <int Q>
 __global__ __launch_bounds__(64) void rans_tail_kernel(const float *__restrict__ params, StageGeom sg, int M,
                                                        const uint32_t *__restrict__ rstate, const uint32_t *__restrict__ rpos,
                                                        const uint32_t *__restrict__ rtail,
                                                        int16_t *__restrict__ planes, float *__restrict__ fplanes,
                                                        const int32_t *__restrict__ minmax, int32_t *status)
 {
-    __shared__ uint32_t sh_pay[66];
+    constexpr int L = 64 * Q;
+    __shared__ uint32_t sh_pay[64 * Q + 2];
     const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M, lane = threadIdx.x;
     const int nc = sg.hc * sg.wc;
-    const int cnt = rans_stream_count(nc, m, M);
+    const int cnt = rans_stream_count(nc, m, M, L);
     bool bad = rpos[sidx] != 0 || (int)rtail[sidx] > cnt;
     const int T = min((int)rtail[sidx], cnt);
-    sh_pay[lane] = 0;
-    if (lane < 2) sh_pay[64 + lane] = 0;
+#pragma unroll
+    for (int qq = 0; qq < Q; ++qq) sh_pay[64 * qq + lane] = 0;
+    if (lane < 2) sh_pay[64 * Q + lane] = 0;
     __syncthreads();
-    const uint32_t xl = rstate[(long)sidx * 64 + lane] & 0x7FFFFFFFu;
-    lds_or_bits(sh_pay, kRansStateBits * lane, 16, xl & 0xFFFFu);
-    lds_or_bits(sh_pay, kRansStateBits * lane + 16, kRansStateBits - 16, xl >> 16);
+#pragma unroll
+    for (int qq = 0; qq < Q; ++qq) {
+        const uint32_t xl = rstate[((long)sidx * Q + qq) * 64 + lane] & 0x7FFFFFFFu;
+        lds_or_bits(sh_pay, kRansStateBits * (64 * qq + lane), 16, xl & 0xFFFFu);
+        lds_or_bits(sh_pay, kRansStateBits * (64 * qq + lane) + 16, kRansStateBits - 16, xl >> 16);
+    }
     __syncthreads();
-    const uint64_t nz = ballot64(sh_pay[lane] != 0);
-    int top = -1;
-    if (nz) {
-        const int hd = 63 - __clzll((long long)nz);
-        top = 32 * hd + 31 - __clz((int)sh_pay[hd]);
+    int top = -1;                                                              // the payload's highest set bit
+#pragma unroll
+    for (int qq = Q - 1; qq >= 0; --qq) {
+        const uint64_t nz = ballot64(sh_pay[64 * qq + lane] != 0);
+        if (top < 0 && nz) {
+            const int hd = 64 * qq + 63 - __clzll((long long)nz);
+            top = 32 * hd + 31 - __clz((int)sh_pay[hd]);
+        }
     }
     // a malformed stream still gets its T tail pixels written (from whatever state there is): the output of a flagged image
     // must not depend on what the workspace held
@@ -576,7 +623,7 @@ __global__ __launch_bounds__(64) void rans_tail_kernel(const float *__restrict__
     struct Row { float sg, mu, wk, bb, dd, y, co; long off; };
     auto fetch = [&](int q) -> Row {
         Row r;
-        const int n = min(64 * (m + (q >> 6) * M) + (q & 63), nc - 1);
+        const int n = min(L * (m + (q / L) * M) + (q % L), nc - 1);
         const int i = div_wc(sg, n), j = n - i * sg.wc;
         const float *src = params + ((long)b * sg.h * sg.w + (long)i * sg.w + j) * LLICTI_PARAM_STRIDE;
         r.off = img + ((long)(2 * i + sg.oi) << sg.lvl) * sg.W + ((long)(2 * j + sg.oj) << sg.lvl);
@@ -709,7 +756,7 @@ __global__ __launch_bounds__(256) void rans_pack_kernel(const uint8_t *__restric
 }
 
 __global__ __launch_bounds__(256) void rans_unpack_kernel(const uint8_t *__restrict__ in, long in_stride, const int32_t *__restrict__ seg_len,
-                                                          int M, uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
+                                                          int M, int min_stream, uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
                                                           int rslot_cap, uint32_t *__restrict__ rpos, int32_t *status)
 {
     const int m = blockIdx.x, b = blockIdx.y;
@@ -733,7 +780,7 @@ __global__ __launch_bounds__(256) void rans_unpack_kernel(const uint8_t *__restr
             long off = 4L * G, tot = 4L * G;
             for (int k = 0; k < G; ++k) {
                 const long len = (long)tab[4 * k] | ((long)tab[4 * k + 1] << 8) | ((long)tab[4 * k + 2] << 16) | ((long)tab[4 * k + 3] << 24);
-                if (len < kRansMinStream || len > seg_n) bad = true;
+                if (len < min_stream || len > seg_n) bad = true;
                 if (k < m % G) off += len;
                 if (k == m % G) n = (int)min(len, (long)seg_n);
                 tot += len;
@@ -743,9 +790,9 @@ __global__ __launch_bounds__(256) void rans_unpack_kernel(const uint8_t *__restr
         }
     }
     uint8_t *o = slots + rslot_off[b * M + m] + 2;               // the bit region (stream offset 2) lands dword aligned
-    if (bad || n < kRansMinStream || n + 2 + 64 > rslot_cap || src + n > in_stride) {
+    if (bad || n < min_stream || n + 2 + 64 > rslot_cap || src + n > in_stride) {
         if (threadIdx.x == 0) flag_image(status, b, LLICTI_EFORMAT);
-        n = kRansMinStream;                                        // a harmless stream: T = 0, no bits, states 2^31
+        n = min_stream;                                            // a harmless stream: T = 0, no bits, states 2^31
         for (int t = threadIdx.x; t < n; t += blockDim.x) o[t] = 0;
     } else {
         const uint8_t *p = in + (long)b * in_stride + src;

@@ -20,7 +20,7 @@ import torch
 from torch import nn
 
 from ...codec import (MODE_AC, MODE_RANS, HipCodec, bytestream_list_to_container, container_to_bytestream_list,
-                      header_dims, mode_of_header)
+                      header_dims, mode_of_header, mode_of_name)
 from ...config import check_supported
 
 
@@ -105,7 +105,7 @@ class LLICTI(nn.Module):
         # container written by compress(): the reference's (torchac-compatible) one unless the config asks
         # for the throughput container, e.g. config.container = "rans8"
         cont = config["container"] if "container" in config else "ac"
-        self.mode = MODE_AC if cont == "ac" else MODE_RANS(int(cont[4:] or 8))
+        self.mode = mode_of_name(cont)
 
     # ------------------------------------------------------------------ plumbing
     def _weights_key(self):

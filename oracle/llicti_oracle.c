@@ -780,9 +780,9 @@ int orc_decode_image(const uint8_t *in, const int32_t seg_len[49], const orc_wei
 /* ------------------------------------------------------------------ rANS container "LLICTI-rANS v3" (see header) */
 typedef struct { long n; uint32_t *clow, *chigh; } stage_syms_t;
 
-#define RANS_LANES      64
+#define RANS_MAX_LANES  128                             /* lanes of a stream: 64, or 128 ("wide" streams: two 64-symbol chunks per step) */
 #define RANS_STATE_BITS 31                              /* a lane state is 2^31 | 31 bits */
-#define RANS_PAY_BITS   (RANS_LANES * RANS_STATE_BITS)  /* 1984: what the 64 initial states carry (the tail stream) */
+#define RANS_MAX_PAY_BITS (RANS_MAX_LANES * RANS_STATE_BITS)   /* what the initial states carry (the tail stream): 1984 / 3968 bits */
 #define RANS_TAIL_MAX   2047
 
 static inline void put_bits(uint8_t *buf, long pos, int n, uint32_t v)      /* LSB first */
@@ -807,20 +807,24 @@ static inline uint32_t rans_push(uint32_t x, uint32_t lo, uint32_t freq) { retur
 static inline int clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
 
 /* symbols of stream m in a stage of nc symbols: chunks m, m + M, ...; only the stage's last chunk can be partial */
-static long rans_stream_count(long nc, int m, int M)
+static long rans_stream_count(long nc, int m, int M, int L)
 {
-    const long nchunks = (nc + 63) / 64;
+    const long nchunks = (nc + L - 1) / L;
     if (nchunks <= m) return 0;
     const long K = (nchunks - m + M - 1) / M;
     const long last = m + (K - 1) * M;
-    return 64 * K - ((last == nchunks - 1 && (nc & 63)) ? 64 - (nc & 63) : 0);
+    return L * K - ((last == nchunks - 1 && (nc % L)) ? L - (nc % L) : 0);
 }
 
 long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *wts, int M,
                            uint8_t *out, long cap, int32_t seg_len[49])
 {
     if (H < 32 || W < 32 || H > 8160 || W > 8160) return -2;
-    if (M < 1 || (M > 32 && M != 64 && M != 128)) return -2;
+    const int wide = (M >> 8) & 1;                      /* M | 0x100: wide streams of 128 lanes (M <= 30) */
+    M &= 0xFF;
+    if (M < 1 || (M > 32 && M != 64 && M != 128) || (wide && M > 30)) return -2;
+    const int L = wide ? 128 : 64;
+    const int PAY_BITS = L * RANS_STATE_BITS;
     const int G = M > 32 ? M / 32 : 1;                  /* streams per segment (the reference's list has 45 stream slots: 32 are used) */
     const long plane_sz = (long)H * W;
     int16_t *planes = (int16_t *)malloc(sizeof(int16_t) * 3 * plane_sz);
@@ -833,7 +837,7 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
     if (cap < 17 + 3L * h4 * w4) { free(planes); return -1; }
     for (int i = 0; i < 49; ++i) seg_len[i] = 0;
     {   /* byte 0: bit 7 rANS, bit 3 format v3, bit 6 latency mode, bits 5,4,2,1,0 = v: M = v + 1 (<= 32), or 64 << v with bit 6 */
-        const int lat = M > 32, v = lat ? (M == 64 ? 0 : 1) : M - 1;
+        const int lat = M > 32 || wide, v = wide ? M + 1 : M > 32 ? (M == 64 ? 0 : 1) : M - 1;     /* extended: 0, 1 = 64 / 128 streams; 2 .. 31 = M + 1 wide streams */
         out[pos++] = (uint8_t)(0x88 | (lat << 6) | (((v >> 3) & 3) << 4) | (v & 7));
     }
     out[pos++] = (uint8_t)h4; out[pos++] = (uint8_t)w4;
@@ -879,19 +883,19 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
     for (int m = 0; m < M && rc >= 0; ++m) {
         /* 1. tail: the stream's last T symbols (decode order), single-state coder, pushed last symbol first; its bits
          *    go UP from bit 0 of the payload, its final state (32 bits, leading one = the payload's highest set bit) on top */
-        uint8_t pay[RANS_PAY_BITS / 8];
+        uint8_t pay[RANS_MAX_PAY_BITS / 8];
         memset(pay, 0, sizeof pay);
-        const long cnt = rans_stream_count(st[S].n, m, M);
+        const long cnt = rans_stream_count(st[S].n, m, M, L);
         uint32_t xt = 1u << 31;
         long tb = 0, T = 0;
         while (T < cnt && T < RANS_TAIL_MAX) {
             const long q = cnt - 1 - T;
-            const long n = 64 * (m + (q / 64) * M) + (q & 63);
+            const long n = (long)L * (m + (q / L) * M) + (q % L);
             const uint32_t lo = st[S].clow[n], freq = st[S].chigh[n] - lo;
             if (freq == 0 || freq > 0x10000u) { rc = -5; break; }
             if (T == 0) xt = freq << 15;          /* absorbing start: the first pushed symbol codes to 2^31 + c_low, no bits */
             const int nb = rans_emit_bits(xt, freq);
-            if (tb + nb + 32 > RANS_PAY_BITS) break;
+            if (tb + nb + 32 > PAY_BITS) break;
             put_bits(pay, tb, nb, xt & ((1u << nb) - 1u));
             tb += nb;
             xt = rans_push(xt >> nb, lo, freq);
@@ -900,21 +904,21 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
         if (rc < 0) break;
         put_bits(pay, tb, 32, xt);
         /* 2. the 64 lanes start from the payload: lane l = 2^31 | payload bits [31 l, 31 l + 31) */
-        uint32_t x[RANS_LANES];
-        for (int l = 0; l < RANS_LANES; ++l) x[l] = (1u << 31) | get_bits(pay, (long)RANS_STATE_BITS * l, RANS_STATE_BITS);
+        uint32_t x[RANS_MAX_LANES];
+        for (int l = 0; l < L; ++l) x[l] = (1u << 31) | get_bits(pay, (long)RANS_STATE_BITS * l, RANS_STATE_BITS);
         /* 3. main coder, last decoded symbol first; bits go UP from bit 0 of the stream's bit region */
         memset(bits, 0, bcap);
         long bp = 0;
         for (int s = ORC_NSTREAM - 1; s >= 0 && rc >= 0; --s) {
-            const long nchunks = (st[s].n + 63) / 64;
+            const long nchunks = (st[s].n + L - 1) / L;
             if (nchunks <= m) continue;
             const long K = (nchunks - m + M - 1) / M;
             for (long k = K - 1; k >= 0 && rc >= 0; --k) {
                 const long c = m + k * M;
-                for (int l = RANS_LANES - 1; l >= 0; --l) {     /* highest lane first: the decoder renormalises lane-ascending, reading DOWN */
-                    const long n = 64 * c + l;
+                for (int l = L - 1; l >= 0; --l) {     /* highest lane first: the decoder renormalises lane-ascending, reading DOWN */
+                    const long n = (long)L * c + l;
                     if (n >= st[s].n) continue;
-                    if (s == S && 64 * k + l >= cnt - T) continue;          /* coded by the tail */
+                    if (s == S && L * k + l >= cnt - T) continue;          /* coded by the tail */
                     const uint32_t lo = st[s].clow[n], freq = st[s].chigh[n] - lo;
                     if (freq == 0 || freq > 0x10000u) { rc = -5; break; }
                     const int nb = rans_emit_bits(x[l], freq);
@@ -927,7 +931,7 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
         if (rc < 0) break;
         const long nbytes = (bp + 7) / 8;
         const long padb = 8 * nbytes - bp;               /* unused (zero) bits on top of the region's last byte */
-        const long bytes = 2 + nbytes + RANS_PAY_BITS / 8;
+        const long bytes = 2 + nbytes + PAY_BITS / 8;
         if (pos + bytes + 4 * G > cap) { rc = -1; break; }
         if (G > 1) {
             /* M = 64 / 128: segment m / G = G little-endian u32 stream lengths, then its G streams */
@@ -939,8 +943,8 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
         out[pos] = (uint8_t)(t16 & 0xFF); out[pos + 1] = (uint8_t)(t16 >> 8);
         memcpy(out + pos + 2, bits, nbytes);
         uint8_t *fs = out + pos + 2 + nbytes;
-        memset(fs, 0, RANS_PAY_BITS / 8);
-        for (int l = 0; l < RANS_LANES; ++l) put_bits(fs, (long)RANS_STATE_BITS * l, RANS_STATE_BITS, x[l] & 0x7FFFFFFFu);
+        memset(fs, 0, PAY_BITS / 8);
+        for (int l = 0; l < L; ++l) put_bits(fs, (long)RANS_STATE_BITS * l, RANS_STATE_BITS, x[l] & 0x7FFFFFFFu);
         pos += bytes;
         seg_len[4 + m / G] += (int32_t)bytes;
     }
@@ -969,8 +973,10 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
     if (seg_len[0] != 3 || seg_len[1] != 12 || seg_len[2] != 2) return -3;
     if ((in[0] & 0x88) != 0x88) return -4;                        /* bit 3 clear: the retired v2 format */
     const int tagv = (((in[0] >> 4) & 3) << 3) | (in[0] & 7);
-    const int M = ((in[0] >> 6) & 1) ? (tagv == 0 ? 64 : tagv == 1 ? 128 : 0) : tagv + 1;
-    if (M == 0) return -4;
+    const int ext = (in[0] >> 6) & 1, wide = ext && tagv >= 2;
+    const int M = ext ? (tagv == 0 ? 64 : tagv == 1 ? 128 : tagv - 1) : tagv + 1;
+    const int L = wide ? 128 : 64;
+    const int PAY_BITS = L * RANS_STATE_BITS;
     const int G = M > 32 ? M / 32 : 1;
     int H, W;
     orc_header_dims(in, seg_len, &H, &W);
@@ -982,7 +988,7 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
     const int h4 = in[1], w4 = in[2];
     if (seg_len[3] != 3 * h4 * w4) return -3;
     /* streams: T | bit region (read DOWN from the sentinel) | 64 x 31-bit states */
-    uint32_t (*x)[RANS_LANES] = (uint32_t (*)[RANS_LANES])malloc(sizeof(uint32_t) * RANS_LANES * M);
+    uint32_t (*x)[RANS_MAX_LANES] = (uint32_t (*)[RANS_MAX_LANES])malloc(sizeof(uint32_t) * RANS_MAX_LANES * M);
     const uint8_t **bitsp = (const uint8_t **)malloc(sizeof(uint8_t *) * M);
     long *cur = (long *)calloc(M, sizeof(long)), *T = (long *)calloc(M, sizeof(long));
     int bad = 0;
@@ -1004,17 +1010,17 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
                 seg_left -= len;
                 if (seg_left < 0 || (m % G == G - 1 && seg_left != 0)) { free(x); free(bitsp); free(cur); free(T); return -3; }
             }
-            if (len < 2 + RANS_PAY_BITS / 8) { free(x); free(bitsp); free(cur); free(T); return -3; }
+            if (len < 2 + PAY_BITS / 8) { free(x); free(bitsp); free(cur); free(T); return -3; }
             const uint8_t *sp = in + pos;
             const int t16 = sp[0] | (sp[1] << 8);
             const int padb = (t16 >> 11) & 7;
-            const long nbytes = len - 2 - RANS_PAY_BITS / 8;
+            const long nbytes = len - 2 - PAY_BITS / 8;
             if ((t16 >> 14) || (nbytes == 0 && padb)) { free(x); free(bitsp); free(cur); free(T); return -3; }
             T[m] = t16 & 0x7FF;
             bitsp[m] = sp + 2;
             cur[m] = 8 * nbytes - padb;                               /* number of data bits */
             const uint8_t *fs = sp + 2 + nbytes;
-            for (int l = 0; l < RANS_LANES; ++l) x[m][l] = (1u << 31) | get_bits(fs, (long)RANS_STATE_BITS * l, RANS_STATE_BITS);
+            for (int l = 0; l < L; ++l) x[m][l] = (1u << 31) | get_bits(fs, (long)RANS_STATE_BITS * l, RANS_STATE_BITS);
             pos += len;
         }
     }
@@ -1040,7 +1046,7 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
             int hc, wc;
             stream_dims(h, w, padH, padW, band, &hc, &wc);
             const long n_sym = (long)hc * wc;
-            const long nchunks = (n_sym + 63) / 64;
+            const long nchunks = (n_sym + L - 1) / L;
             for (int clr = 0; clr < 3; ++clr, ++stage) {
                 const int minv = (clr == 0) ? -127 : minmax[clr];
                 const int maxv = (clr == 0) ? 128 : minmax[3 + clr];
@@ -1050,13 +1056,13 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
                 for (long c = 0; c < nchunks; ++c) {
                     const int m = (int)(c % M);
                     const long k = c / M;
-                    const long cnt = last_stage ? rans_stream_count(n_sym, m, M) : 0;
-                    int nb[RANS_LANES];
-                    for (int l = 0; l < RANS_LANES; ++l) nb[l] = -1;
-                    for (int l = 0; l < RANS_LANES; ++l) {
-                        const long q = 64 * c + l;
+                    const long cnt = last_stage ? rans_stream_count(n_sym, m, M, L) : 0;
+                    int nb[RANS_MAX_LANES];
+                    for (int l = 0; l < L; ++l) nb[l] = -1;
+                    for (int l = 0; l < L; ++l) {
+                        const long q = (long)L * c + l;
                         if (q >= n_sym) break;
-                        if (last_stage && 64 * k + l >= cnt - T[m]) continue;      /* tail symbol: decoded after the stages */
+                        if (last_stage && L * k + l >= cnt - T[m]) continue;      /* tail symbol: decoded after the stages */
                         int i = (int)(q / wc), j = (int)(q % wc);
                         long off = ((long)(2 * i + BAND_OI[src]) << lvl) * W + ((long)(2 * j + BAND_OJ[src]) << lvl);
                         mix_t mx;
@@ -1070,7 +1076,7 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
                         nb[l] = clz32(x[m][l]);
                         if (nb[l] > 16) { bad = 1; nb[l] = 16; }
                     }
-                    for (int l = 0; l < RANS_LANES; ++l) {       /* renormalise lane-ascending, reading DOWN */
+                    for (int l = 0; l < L; ++l) {       /* renormalise lane-ascending, reading DOWN */
                         if (nb[l] < 0) continue;
                         if (cur[m] < nb[l]) { bad = 1; x[m][l] = (x[m][l] << nb[l]) | (1u << 31); continue; }
                         cur[m] -= nb[l];
@@ -1090,20 +1096,20 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
             const int Lp = maxv - minv + 2;
             for (int m = 0; m < M; ++m) {
                 if (cur[m] != 0) bad = 1;                        /* every bit of the main region must have been read */
-                uint8_t pay[RANS_PAY_BITS / 8 + 4];
+                uint8_t pay[RANS_MAX_PAY_BITS / 8 + 4];
                 memset(pay, 0, sizeof pay);
-                for (int l = 0; l < RANS_LANES; ++l) put_bits(pay, (long)RANS_STATE_BITS * l, RANS_STATE_BITS, x[m][l] & 0x7FFFFFFFu);
+                for (int l = 0; l < L; ++l) put_bits(pay, (long)RANS_STATE_BITS * l, RANS_STATE_BITS, x[m][l] & 0x7FFFFFFFu);
                 long top = -1;
-                for (long b = RANS_PAY_BITS - 1; b >= 0; --b)
+                for (long b = PAY_BITS - 1; b >= 0; --b)
                     if ((pay[b >> 3] >> (b & 7)) & 1u) { top = b; break; }
                 if (top < 31) { bad = 1; continue; }
                 uint32_t xt = get_bits(pay, top - 31, 32);
                 long tc = top - 31;
-                const long cnt = rans_stream_count(n_sym, m, M);
+                const long cnt = rans_stream_count(n_sym, m, M, L);
                 if (T[m] > cnt) { bad = 1; continue; }
                 uint32_t f_last = 0;
                 for (long q = cnt - T[m]; q < cnt; ++q) {
-                    const long n = 64 * (m + (q / 64) * M) + (q & 63);
+                    const long n = (long)L * (m + (q / L) * M) + (q % L);
                     int i = (int)(n / wc), j = (int)(n % wc);
                     long off = ((long)(2 * i + BAND_OI[src]) << lvl) * W + ((long)(2 * j + BAND_OJ[src]) << lvl);
                     mix_t mx;

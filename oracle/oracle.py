@@ -233,14 +233,14 @@ def _list_to_segments(bl):
     return np.frombuffer(b"".join(segs), dtype=np.uint8).copy(), seg_len
 
 
-def encode_image_rans(rgb, weights: "Weights", M=8):
-    """uint8 [3,H,W] -> bytestream_list holding the rANS container (M streams in the first M stream slots)."""
+def encode_image_rans(rgb, weights: "Weights", M=8, wide=False):
+    """uint8 [3,H,W] -> bytestream_list holding the rANS v3 container (M streams; wide: 128 lanes per stream instead of 64)."""
     rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
     _, H, W = rgb.shape
-    cap = 8 * H * W + 4096 + 512 * M
+    cap = 8 * H * W + 4096 + 1024 * M
     out = np.empty(cap, np.uint8)
     seg = np.zeros(49, np.int32)
-    n = lib().orc_encode_image_rans(_p(rgb), H, W, C.byref(weights.c), int(M), _p(out), C.c_long(cap), _p(seg))
+    n = lib().orc_encode_image_rans(_p(rgb), H, W, C.byref(weights.c), int(M) | (0x100 if wide else 0), _p(out), C.c_long(cap), _p(seg))
     if n < 0:
         raise RuntimeError(f"orc_encode_image_rans failed: {n}")
     return _segments_to_list(out[:n], seg)

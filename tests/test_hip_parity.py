@@ -294,6 +294,36 @@ def test_rans_container_bitexact(torch_mod, codecs, oracle_weights, kind, H, W, 
     assert np.array_equal(rec.cpu().numpy(), rgb)
 
 
+@pytest.mark.parametrize("kind,H,W,wname,M", [("smooth", 67, 93, "trainedlike", 1), ("noise", 128, 192, "rand1337", 10),
+                                              ("smooth", 150, 131, "trainedlike", 7), ("noise", 33, 250, "trainedlike", 30),
+                                              ("smooth", 256, 384, "trainedlike", 5)])
+def test_rans_wide_container_bitexact(torch_mod, codecs, oracle_weights, kind, H, W, wname, M):
+    """Wide streams (128 lanes per stream, two 64-symbol chunks per coder step): HIP bytes == oracle bytes, both decoders invert
+    it (the HIP one on a poisoned workspace), and the container is only accepted in the mode its header names."""
+    from oracle import oracle as orc
+    from llicti_amd._lib import LlictiError
+    from llicti_amd.codec import MODE_RANS, container_to_bytestream_list, mode_of_header
+    torch = torch_mod
+    c = codecs(wname)
+    W_o = oracle_weights(wname)
+    rgb = make_batch(kind, 2, H, W, seed0=90)
+    mode = MODE_RANS(M, wide=True)
+    cont, seg = c.encode(_dev(torch, rgb), mode=mode)
+    c.check()
+    cont_h, seg_h = cont.cpu().numpy(), seg.cpu().numpy()
+    assert mode_of_header(int(cont_h[0, 0])) == mode
+    for b in range(2):
+        bl = container_to_bytestream_list(cont_h[b], seg_h[b])
+        assert bl == orc.encode_image_rans(rgb[b], W_o, M, wide=True)
+        assert np.array_equal(orc.decode_image_rans(bl, W_o), rgb[b])
+        assert sum(1 for row in bl[1:] for x in row if len(x)) == M
+    rec = _decode_poisoned(c, cont, seg, H, W, mode)
+    assert np.array_equal(rec.cpu().numpy(), rgb)
+    c.decode(cont, seg, H, W, mode=MODE_RANS(M))            # same M, narrow streams: another container
+    with pytest.raises(LlictiError):
+        c.check()
+
+
 def test_rans_v3_known_answer_hip(torch_mod, codecs):
     """The committed known-answer vectors of the rANS v3 container (tests/golden/rans_v3_vectors.npz, frozen by
     test_rans_v3_known_answer on the CPU): the HIP encoder reproduces the stored bytes, the HIP decoder turns the stored bytes
@@ -307,18 +337,18 @@ def test_rans_v3_known_answer_hip(torch_mod, codecs):
         c = codecs(wname)
         rgb = load_case(case)["rgb"]
         H, W = rgb.shape[1:]
-        for M in (1, 4):
-            want, lens = vec[f"{case}_M{M}_bytes"], vec[f"{case}_M{M}_seglen"]
+        for key, mode in (("M1", MODE_RANS(1)), ("M4", MODE_RANS(4)), ("W3", MODE_RANS(3, wide=True))):
+            want, lens = vec[f"{case}_{key}_bytes"], vec[f"{case}_{key}_seglen"]
             seg_want = np.concatenate([lens[:4], lens[9:]]).astype(np.int32)        # bytestream_list rows of 9 -> the 49 segments
-            cont, seg = c.encode(_dev(torch, rgb[None]), mode=MODE_RANS(M))
+            cont, seg = c.encode(_dev(torch, rgb[None]), mode=mode)
             c.check()
             n = int(seg.sum().item())
-            assert np.array_equal(seg[0].cpu().numpy(), seg_want), (case, M)
-            assert n == want.size and np.array_equal(cont[0, :n].cpu().numpy(), want), (case, M)
+            assert np.array_equal(seg[0].cpu().numpy(), seg_want), (case, key)
+            assert n == want.size and np.array_equal(cont[0, :n].cpu().numpy(), want), (case, key)
             cont2 = torch.zeros_like(cont)
             cont2[0, :n] = _dev(torch, want)
-            rec = _decode_poisoned(c, cont2, _dev(torch, seg_want[None]), H, W, MODE_RANS(M))
-            assert np.array_equal(rec[0].cpu().numpy(), rgb), (case, M)
+            rec = _decode_poisoned(c, cont2, _dev(torch, seg_want[None]), H, W, mode)
+            assert np.array_equal(rec[0].cpu().numpy(), rgb), (case, key)
 
 
 def test_rans_kodak_batch_roundtrip(torch_mod, codecs):
@@ -641,15 +671,15 @@ def _decode_poisoned(c, cont, seg, H, W, mode=0):
 
 @pytest.mark.parametrize("mode_name,B,H,W", [("ac", 3, 128, 192), ("ac", 2, 250, 131), ("ac_anchors", 3, 128, 192),
                                              ("ac_anchors", 2, 250, 131), ("rans4", 3, 128, 192),
-                                             ("rans16", 2, 250, 131), ("rans1", 2, 67, 93)])
+                                             ("rans16", 2, 250, 131), ("rans1", 2, 67, 93), ("wrans3", 3, 128, 192)])
 def test_decode_on_poisoned_workspace(torch_mod, codecs, mode_name, B, H, W):
     """Losslessness of the PIPELINED decoders (3-stream AC chunk pipeline with ac_chunks() > 1, rANS next-step
     prefetch, CNN halo / odd-edge clamps), with B > 1: the workspace is overwritten with 0xA5 between encode and
     decode, and a second decode runs on a FRESH context that never saw the encoder at all."""
-    from llicti_amd.codec import HipCodec, MODE_RANS
+    from llicti_amd.codec import HipCodec, mode_of_name
     torch = torch_mod
     c = codecs("trainedlike")
-    mode = 0 if mode_name.startswith("ac") else MODE_RANS(int(mode_name[4:]))
+    mode = 0 if mode_name.startswith("ac") else mode_of_name(mode_name)
     # the AC decoder has two table forms (full rows for few images, anchor rows for many): both are run here
     anchors = mode_name == "ac_anchors"
     rgb = np.concatenate([make_batch("smooth", B - 1, H, W, seed0=300), make_batch("noise", 1, H, W, seed0=301)])
@@ -964,7 +994,8 @@ def test_ac_anchor_decoder_many_images_and_edges(torch_mod, codecs, oracle_weigh
     assert np.array_equal(rec.cpu().numpy(), edge)
 
 
-def test_rans_v3_integrity_check_detects_corruption(torch_mod, codecs, oracle_weights):
+@pytest.mark.parametrize("wide", [False, True])
+def test_rans_v3_integrity_check_detects_corruption(torch_mod, codecs, oracle_weights, wide):
     """rANS v3 ends with three known quantities: the main bit region is read to its last bit, and the tail coder (whose
     stream is what the 64 lane states are left with) returns to its start state 2^31 with no bit left.  A corrupted stream
     bit, final state or tail count ends, with overwhelming probability, in one of them being wrong -- both decoders (HIP,
@@ -977,14 +1008,15 @@ def test_rans_v3_integrity_check_detects_corruption(torch_mod, codecs, oracle_we
     c = codecs("trainedlike")
     W_o = oracle_weights("trainedlike")
     rgb = make_batch("smooth", 2, 96, 128, seed0=700)
-    mode = MODE_RANS(2)
+    mode = MODE_RANS(2, wide=wide)
     cont, seg = c.encode(_dev(torch, rgb), mode=mode)
     c.check()
     seg_h = seg.cpu().numpy()
     hdr = int(seg_h[1, :4].sum())
     s0 = int(seg_h[1, 4])
+    pay = 496 if wide else 248                     # bytes of the final states: 64 / 128 lanes x 31 bits
     # a bit of the bit region | a final state | the tail count | the last byte of the bit region
-    for where, val in ((hdr + 2 + 400, 0x10), (hdr + s0 - 100, 0x04), (hdr, 0x01), (hdr + s0 - 249, 0xFF)):
+    for where, val in ((hdr + 2 + 400, 0x10), (hdr + s0 - 100, 0x04), (hdr, 0x01), (hdr + s0 - pay - 1, 0xFF)):
         bad = cont.clone()
         bad[1, where] ^= val
         rec = c.decode(bad, seg, 96, 128, mode=mode)

@@ -79,6 +79,11 @@ def test_workspace_and_container_bounds():
     assert L.llicti_workspace_bytes(1, 512, 768, 0x100 | 33) == 0    # M in 1 .. 32, 64 or 128
     assert L.llicti_workspace_bytes(1, 512, 768, 0x100 | 96) == 0
     assert L.llicti_workspace_bytes(1, 512, 768, 7) == 0
+    # wide streams (128 lanes): M in 1 .. 30
+    assert L.llicti_workspace_bytes(24, 512, 768, 0x300 | 10) > L.llicti_workspace_bytes(24, 512, 768, 0x100 | 10)
+    assert L.llicti_workspace_bytes(1, 512, 768, 0x300 | 30) > 0
+    assert L.llicti_workspace_bytes(1, 512, 768, 0x300 | 31) == 0 and L.llicti_workspace_bytes(1, 512, 768, 0x300) == 0
+    assert L.llicti_workspace_bytes(1, 512, 768, 0x200 | 4) == 0
 
 
 def test_weight_packing_and_state_dict_names():

@@ -157,7 +157,7 @@ def test_rans_container_oracle_roundtrip(M, oracle_weights):
 
 def test_rans_v3_known_answer(oracle_weights):
     """The rANS v3 container is a format of this build (no reference counterpart to pin it to), so it is frozen by known-answer
-    vectors: tests/golden/rans_v3_vectors.npz holds the container bytes for three fixture images x M in {1, 4}
+    vectors: tests/golden/rans_v3_vectors.npz holds the container bytes for three fixture images x {M = 1, M = 4, 3 wide streams}
     (make_rans_v3_vectors.py).  The oracle must reproduce them byte for byte -- a changed byte is a changed format and needs a new
     version bit -- and decode them back to the fixture's pixels; the GPU suite holds the HIP path to the oracle."""
     import hashlib
@@ -167,21 +167,42 @@ def test_rans_v3_known_answer(oracle_weights):
     for case, wname in [("smooth_67x93_tl", "trainedlike"), ("noise_32x32_rand", "rand1337"), ("noise_33x64_tl", "trainedlike")]:
         rgb = load_case(case)["rgb"]
         W = oracle_weights(wname)
-        for M in (1, 4):
-            want = vec[f"{case}_M{M}_bytes"].tobytes()
-            assert hashlib.sha256(want).digest() == vec[f"{case}_M{M}_sha256"].tobytes()
-            bl = orc.encode_image_rans(rgb, W, M)
+        for key, M, wide, tag in (("M1", 1, False, 0x88), ("M4", 4, False, 0x8B), ("W3", 3, True, 0xCC)):
+            want = vec[f"{case}_{key}_bytes"].tobytes()
+            assert hashlib.sha256(want).digest() == vec[f"{case}_{key}_sha256"].tobytes()
+            bl = orc.encode_image_rans(rgb, W, M, wide)
             got = b"".join(s for row in bl for s in row)
-            assert got == want, (case, M)
-            assert [len(s) for row in bl for s in row] == list(vec[f"{case}_M{M}_seglen"])
-            assert got[0] == {1: 0x88, 4: 0x8B}[M]
+            assert got == want, (case, key)
+            assert [len(s) for row in bl for s in row] == list(vec[f"{case}_{key}_seglen"])
+            assert got[0] == tag
             # rebuild the list from the stored bytes alone and decode it
-            lens, pos, flat = list(vec[f"{case}_M{M}_seglen"]), 0, []
+            lens, pos, flat = list(vec[f"{case}_{key}_seglen"]), 0, []
             for n in lens:
                 flat.append(want[pos:pos + n])
                 pos += n
             bl2 = [flat[9 * r: 9 * r + 9] for r in range(6)]
             assert np.array_equal(orc.decode_image_rans(bl2, W), rgb)
+
+
+@pytest.mark.parametrize("M", [1, 5, 10, 30])
+def test_rans_wide_container_oracle_roundtrip(M, oracle_weights):
+    """Wide streams (128 lanes, header byte 0 = extended tag with v = M + 1): lossless; a stream's 128 x 31-bit states cost 496 bytes
+    when it has no symbols, about 7 bytes over the ideal length when it has; a wide container of M streams is never mistaken for a
+    narrow one (the tags differ) and M = 31, 32 do not exist."""
+    from llicti_amd.codec import MODE_RANS, mode_of_header, rans_tag
+    c = load_case("smooth_67x93_tl")
+    W = oracle_weights("trainedlike")
+    bl = orc.encode_image_rans(c["rgb"], W, M, wide=True)
+    assert bl[0][0][0] == rans_tag(M, wide=True) == {1: 0xCA, 5: 0xCE, 10: 0xDB, 30: 0xFF}[M]
+    assert mode_of_header(bl[0][0][0]) == MODE_RANS(M, wide=True) == (0x300 | M)
+    assert np.array_equal(orc.decode_image_rans(bl, W), c["rgb"])
+    n_ac = sum(len(x) for row in orc.encode_image(c["rgb"], W) for x in row)
+    n_r = sum(len(x) for row in bl for x in row)
+    assert -64 <= n_r - n_ac <= 510 * M + 64
+    if M == 1:
+        assert n_r - n_ac <= 10
+    with pytest.raises(RuntimeError):
+        orc.encode_image_rans(c["rgb"], W, 31, wide=True)
 
 
 @pytest.mark.parametrize("case,wname", [("fwd_smooth_64x96_tl", "trainedlike"), ("fwd_noise_32x64_rand", "rand1337")])
