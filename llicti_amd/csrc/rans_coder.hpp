@@ -67,11 +67,12 @@ __device__ __forceinline__ int rans_emit_bits(uint32_t x, uint32_t freq)
 // is off by at most one and one signed remainder test repairs it (8 operations instead of a 32-bit division)
 __device__ __forceinline__ uint32_t rans_push(uint32_t x, uint32_t lo, uint32_t freq)
 {
-    uint32_t q = (uint32_t)((float)x * __builtin_amdgcn_rcpf((float)freq));
-    int32_t r = (int32_t)(x - q * freq);
-    if (r < 0) { q -= 1; r += (int32_t)freq; }
-    else if (r >= (int32_t)freq) { q += 1; r -= (int32_t)freq; }
-    return (q << 16) + (uint32_t)r + lo;
+    const uint32_t q = (uint32_t)((float)x * __builtin_amdgcn_rcpf((float)freq));
+    const int32_t r = (int32_t)(x - q * freq);
+    const bool neg = r < 0, big = r >= (int32_t)freq;                            // selects, not branches: the push is on the coder's dependency chain
+    const uint32_t q2 = q + (big ? 1u : 0u) - (neg ? 1u : 0u);
+    const int32_t r2 = r + (neg ? (int32_t)freq : 0) - (big ? (int32_t)freq : 0);
+    return (q2 << 16) + (uint32_t)r2 + lo;
 }
 // n bits (0 <= n <= 32) at bit position pos of a little-endian dword array in LDS
 __device__ __forceinline__ uint32_t lds_get_bits(const uint32_t *buf, int pos, int n)
@@ -167,6 +168,9 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restr
         // newest load, i.e. wait for it with s_waitcnt vmcnt(0) in every step).  Loads are unconditional
         // (clamped address); the raw value is masked only where it is consumed.
         auto fetch = [&](int k, int qq) -> uint32_t { return pp[min(L * (m + max(k, 0) * M) + 64 * qq + lane, d.n - 1)]; };
+        // One step of one sub-chunk, without a divergent branch: the two chains of a step -- state (bits to emit, push) and bit
+        // cursor (prefix sum, window) -- are each ~20 dependent operations, and a lone wave pays every exec-mask branch between them
+        // in full.  An inactive lane codes the neutral pair (freq 2^16: no bits, and its push is discarded).
         auto code = [&](int k, int qq, uint32_t raw, uint32_t &x) {
             if (k < 0) return;                                       // wave-uniform
             const int n = L * (m + k * M) + 64 * qq + lane;
@@ -174,17 +178,26 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restr
             const uint32_t v = active ? raw : 0u;                    // (lo, c_high) = (0, 2^16 stored as 0): freq 2^16, no bits
             const uint32_t lo = v & 0xFFFFu;
             uint32_t hi = v >> 16;
-            if (hi == 0) hi = 0x10000u;
+            hi = (hi == 0) ? 0x10000u : hi;
             uint32_t freq = hi - lo;
-            if (freq == 0 || hi < lo) { bad = 1; freq = 1; }
+            const bool wrong = (freq == 0) | (hi < lo);
+            bad = wrong ? 1 : bad;
+            freq = wrong ? 1u : freq;
             const int nb = rans_emit_bits(x, freq);
             // the decoder renormalises stream-lane-ascending reading DOWN: the highest lane's bits lowest (sub-chunk Q - 1 is coded first)
             const int incl = wave_incl_scan(nb);
             const int total = __builtin_amdgcn_readlane(incl, 63);
-            lds_or_bits(sh_win, bp + (total - incl) - 32 * wbase, nb, x & ((1u << nb) - 1u));
+            {
+                const int pos = bp + (total - incl) - 32 * wbase;    // nb = 0: ORs zeros
+                const uint32_t bits = x & ((1u << nb) - 1u);
+                const int sh = pos & 31;
+                atomicOr(&sh_win[pos >> 5], bits << sh);
+                atomicOr(&sh_win[(pos >> 5) + 1], (uint32_t)(((uint64_t)bits << sh) >> 32));
+            }
             bp += total;
-            if (active) x = rans_push(x >> nb, lo, freq);
-            if (bp - 32 * wbase >= 2048) {                           // the window's lower half is complete
+            const uint32_t xn = rans_push(x >> nb, lo, freq);
+            x = active ? xn : x;
+            if (bp - 32 * wbase >= 2048) {                           // the window's lower half is complete (wave-uniform)
                 __syncthreads();
                 if (wbase + 64 <= cap_dw) out32[wbase + lane] = sh_win[lane]; else bad = 2;
                 const uint32_t up = sh_win[64 + lane];
