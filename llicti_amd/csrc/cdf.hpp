@@ -111,7 +111,8 @@ __global__ __launch_bounds__(256) void cdf_pairs_kernel(const int16_t *__restric
         Mix m;
         mix_prepare(par, clr, yv, cov, m);
         const uint32_t lo = cdf_entry(m, gr, sym);
-        const uint32_t hi = (sym == gr.Lp - 2) ? 0u : cdf_entry(m, gr, sym + 1);
+        const uint32_t hi1 = cdf_entry(m, gr, min(sym + 1, gr.Lp - 2));     // unconditional (clamped): no divergent branch around ten erfc chains
+        const uint32_t hi = (sym == gr.Lp - 2) ? 0u : hi1;
         pairs[((long)clr * s.B + b) * nc + n] = (hi << 16) | lo;
     }
 }

@@ -136,7 +136,7 @@ __device__ __forceinline__ float mix_cdf(const Mix &m, float pt)
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
         const float z = (pt - m.mu[k]) * m.rsig[k];
-        const float c = 0.5f * erfc_spec(kNegRsqrt2 * z);
+        const float c = 0.5f * erfc_spec_nobranch(kNegRsqrt2 * z);    // same bits as erfc_spec; the five chains interleave
         const float t = m.wn[k] * c;
         acc = (k == 0) ? t : acc + t;
     }
