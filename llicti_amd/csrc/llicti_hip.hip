@@ -859,8 +859,8 @@ static int decode_sub(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in
                 }
                 if (last) {
                     ProfSpan span(c, PROF_RANS_TAIL, sr);
-                    if (Q == 2) rans_tail_kernel<2><<<B * M, 64, 0, sr>>>(params, sg, M, rstate, rpos, rtail, planes, fplanes, mm, status);
-                    else rans_tail_kernel<1><<<B * M, 64, 0, sr>>>(params, sg, M, rstate, rpos, rtail, planes, fplanes, mm, status);
+                    if (Q == 2) rans_tail_kernel<2><<<B * M, 64 * (1 + kTailAhead), 0, sr>>>(params, sg, M, rstate, rpos, rtail, planes, fplanes, mm, status);
+                    else rans_tail_kernel<1><<<B * M, 64 * (1 + kTailAhead), 0, sr>>>(params, sg, M, rstate, rpos, rtail, planes, fplanes, mm, status);
                 }
                 if (sr != s) { HIPCHK(hipEventRecord(evcr[1], sr)); HIPCHK(hipStreamWaitEvent(s, evcr[1], 0)); }
             }

@@ -578,15 +578,22 @@ __global__ __launch_bounds__(64 * kRansWaves * Q) void rans_decode_stage_kernel(
     }
 }
 
-// After the last stage the 64 states of a stream ARE its tail stream (31 bits each, the tail coder's final state on top,
-// its leading one the highest set bit).  One wavefront per stream decodes the T tail symbols serially -- all of the last
-// stage's Cg channel (level 0, band x10) -- with all 64 lanes on one symbol: the approximate mixture at the 64 anchors 8 l
-// (Lp <= 512) picks a bucket, then 12 x 5 lanes evaluate the 12 exact table entries around it, one mixture component per
-// lane, and a ballot proves the symbol (an exact 13-ary search takes over when the hint is wrong).
-// Checks: the main region was read to its last bit, the tail state ends at its start state (freq << 15 of the symbol the
-// tail encoder began with; 2^31 when T = 0) with no bit left.
+// After the last stage the 64 Q states of a stream ARE its tail stream (31 bits each, the tail coder's final state on top,
+// its leading one the highest set bit).  The T tail symbols -- all of the last stage's Cg channel (level 0, band x10) -- come out
+// of ONE coder state, serially; a lone wavefront spends ~540 instructions on a symbol and is bound by its own issue rate, so the
+// work is split over the four wavefronts of a workgroup (one per SIMD):
+//   * wavefronts 1..3 PREPARE symbols (everything that does not depend on the coder state): the position's CNN outputs, the
+//     component's mean / 1 / sigma / normalised weight exactly as mix_prepare() has them, and the approximate mixture at the 64
+//     anchors 8 l (Lp <= 512).  Round r + 1's three symbols are prepared (into the other half of a ping-pong LDS buffer) while
+//   * wavefront 0 DECODES round r's three: the anchors pick a bucket, 12 x 5 lanes evaluate the 12 exact table entries around it
+//     (lane = 5 e + mc: mixture component mc of window entry e), and a ballot proves the symbol (an exact 13-ary search takes over
+//     when the hint is wrong); state update, bit-granular renormalisation from the payload in LDS.
+// One barrier per round.  Checks: the main region was read to its last bit, the tail state ends at its start state (freq << 15 of
+// the symbol the tail encoder began with; 2^31 when T = 0) with no bit left.
+constexpr int kTailAhead = 3;                    // symbols per round = preparing wavefronts
+
 template <int Q>
-__global__ __launch_bounds__(64) void rans_tail_kernel(const float *__restrict__ params, StageGeom sg, int M,
+__global__ __launch_bounds__(64 * (1 + kTailAhead)) void rans_tail_kernel(const float *__restrict__ params, StageGeom sg, int M,
                                                        const uint32_t *__restrict__ rstate, const uint32_t *__restrict__ rpos,
                                                        const uint32_t *__restrict__ rtail,
                                                        int16_t *__restrict__ planes, float *__restrict__ fplanes,
@@ -594,15 +601,87 @@ __global__ __launch_bounds__(64) void rans_tail_kernel(const float *__restrict__
 {
     constexpr int L = 64 * Q;
     __shared__ uint32_t sh_pay[64 * Q + 2];
-    const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M, lane = threadIdx.x;
+    __shared__ float sh_cmp[2][kTailAhead][16];         // [0..4] mu, [5..9] 1 / sigma, [10..14] normalised weight of the five components
+    __shared__ int sh_e1[2][kTailAhead][64];            // approximate table entry at anchor 8 l
+    __shared__ long sh_off[2][kTailAhead];              // the symbol's pixel
+    const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nc = sg.hc * sg.wc;
     const int cnt = rans_stream_count(nc, m, M, L);
     bool bad = rpos[sidx] != 0 || (int)rtail[sidx] > cnt;
     const int T = min((int)rtail[sidx], cnt);
+    const int R = (T + kTailAhead - 1) / kTailAhead;    // rounds
+    int minv, maxv, shift;
+    clr_range(minmax + 4 * b, 2, minv, maxv, shift);
+    const Grid gr = make_grid(minv, maxv);
+    const int max_symbol = gr.Lp - 2;
+    const long img = (long)b * 3 * sg.plane;
+    const int mc = lane % 5, we = lane / 5;
+
+    if (wave != 0) {
+        // ---- preparing wavefronts: symbol t = kTailAhead r + (wave - 1) of round r (t counts the tail's symbols in decoding order)
+        const int i = wave - 1;
+        struct Row { float sg, mu, wk, bb, dd, y, co; long off; };
+        auto fetch = [&](int t) -> Row {
+            Row r;
+            const int q = min(max(cnt - T + t, 0), max(cnt - 1, 0));      // position in the stream's share of the last stage
+            const int n = min(L * (m + (q / L) * M) + (q % L), nc - 1);
+            const int pi = div_wc(sg, n), pj = n - pi * sg.wc;
+            const float *src = params + ((long)b * sg.h * sg.w + (long)pi * sg.w + pj) * LLICTI_PARAM_STRIDE;
+            r.off = img + ((long)(2 * pi + sg.oi) << sg.lvl) * sg.W + ((long)(2 * pj + sg.oj) << sg.lvl);
+            r.sg = src[10 + mc]; r.mu = src[16 + 10 + mc]; r.wk = src[32 + 10 + mc];      // the Cg channel's sigma, mu, weight ...
+            r.bb = src[48 + 5 + mc]; r.dd = src[48 + 10 + mc];                                // ... and its cross-channel factors
+            r.y = fplanes[r.off]; r.co = fplanes[r.off + sg.plane];
+            return r;
+        };
+        auto prepare = [&](const Row &row, int buf) {
+            // component mc, exactly as mix_prepare() does
+            const float t1 = row.bb * row.y;
+            const float t2 = row.dd * row.co;
+            const float tt = t1 + t2;
+            const float mu = row.mu + tt;
+            const float rsig = 1.0f / ((row.sg > kScaleBound) ? row.sg : kScaleBound);
+            const float w = (row.wk > kWeightBound) ? row.wk : kWeightBound;
+            float wk5[5], mu5[5], rs5[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) wk5[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w), k));
+            const float ssum = (((wk5[0] + wk5[1]) + wk5[2]) + wk5[3]) + wk5[4];
+            const float wn = w / (1e-9f + ssum);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                mu5[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mu), k));
+                rs5[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rsig), k));
+                wk5[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wn), k));
+            }
+            // the approximate mixture (all five components in every lane) at anchor 8 l
+            const int i1 = min(8 * lane, max_symbol);
+            const float pt1 = sample_pt(gr, i1);
+            float sum = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) { Comp ck; ck.mu = mu5[k]; ck.rsig = rs5[k]; ck.wn = wk5[k]; sum += term_fast(comp_fast(ck), pt1); }
+            sh_e1[buf][i][lane] = (int)__builtin_rintf(sum * gr.scale) + i1;
+            if (lane < 5) { sh_cmp[buf][i][lane] = mu; sh_cmp[buf][i][5 + lane] = rsig; sh_cmp[buf][i][10 + lane] = wn; }
+            if (lane == 0) sh_off[buf][i] = row.off;
+        };
+        Row rowA = fetch(i);
+        Row rowB = fetch(kTailAhead + i);
+        prepare(rowA, 0);
+        __syncthreads();                                  // (payload assembled by wavefront 0)
+        __syncthreads();                                  // round 0 is prepared
+        for (int r = 0; r < R; ++r) {
+            const Row rowC = fetch(kTailAhead * (r + 2) + i);            // two rounds ahead: the loads run under a whole round
+            if (kTailAhead * (r + 1) + i < T) prepare(rowB, (r + 1) & 1);
+            rowB = rowC;
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---- wavefront 0: the coder
 #pragma unroll
     for (int qq = 0; qq < Q; ++qq) sh_pay[64 * qq + lane] = 0;
     if (lane < 2) sh_pay[64 * Q + lane] = 0;
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();                      // same wavefront, in-order LDS
 #pragma unroll
     for (int qq = 0; qq < Q; ++qq) {
         const uint32_t xl = rstate[((long)sidx * Q + qq) * 64 + lane] & 0x7FFFFFFFu;
@@ -624,111 +703,70 @@ __global__ __launch_bounds__(64) void rans_tail_kernel(const float *__restrict__
     if (top < 31) bad = true;
     uint32_t xt = (top >= 31) ? lds_get_bits(sh_pay, top - 31, 32) : (1u << 31);
     int tc = (top >= 31) ? top - 31 : 0;
-    int minv, maxv, shift;
-    clr_range(minmax + 4 * b, 2, minv, maxv, shift);
-    const Grid gr = make_grid(minv, maxv);
-    const int max_symbol = gr.Lp - 2;
-    const long img = (long)b * 3 * sg.plane;
-    // lane = 5 e + mc: mixture component mc of window entry e (e = 0 .. 11; lanes 60 .. 63 idle along).  A lane prepares and
-    // evaluates ONE component (one division for 1 / sigma, one for the weight, one erfc per exact entry); the five terms of an
-    // entry meet over ds_bpermute in the spec's order.
-    const int mc = lane % 5, we = lane / 5;
-    struct Row { float sg, mu, wk, bb, dd, y, co; long off; };
-    auto fetch = [&](int q) -> Row {
-        Row r;
-        const int n = min(L * (m + (q / L) * M) + (q % L), nc - 1);
-        const int i = div_wc(sg, n), j = n - i * sg.wc;
-        const float *src = params + ((long)b * sg.h * sg.w + (long)i * sg.w + j) * LLICTI_PARAM_STRIDE;
-        r.off = img + ((long)(2 * i + sg.oi) << sg.lvl) * sg.W + ((long)(2 * j + sg.oj) << sg.lvl);
-        r.sg = src[10 + mc]; r.mu = src[16 + 10 + mc]; r.wk = src[32 + 10 + mc];          // the Cg channel's sigma, mu, weight ...
-        r.bb = src[48 + 5 + mc]; r.dd = src[48 + 10 + mc];                                    // ... and its cross-channel factors
-        r.y = fplanes[r.off]; r.co = fplanes[r.off + sg.plane];
-        return r;
-    };
-    Row cur = fetch(max(cnt - T, 0));
-    for (int q = cnt - T; q < cnt; ++q) {
-        const Row nxt = fetch(min(q + 1, cnt - 1));                           // next symbol's row: one step ahead
-        // component mc, exactly as mix_prepare() does
-        const float t1 = cur.bb * cur.y;
-        const float t2 = cur.dd * cur.co;
-        const float tt = t1 + t2;
-        const float mu = cur.mu + tt;
-        const float rsig = 1.0f / ((cur.sg > kScaleBound) ? cur.sg : kScaleBound);
-        const float w = (cur.wk > kWeightBound) ? cur.wk : kWeightBound;
-        float wk5[5], mu5[5], rs5[5];
-#pragma unroll
-        for (int k = 0; k < 5; ++k) wk5[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w), k));
-        const float ssum = (((wk5[0] + wk5[1]) + wk5[2]) + wk5[3]) + wk5[4];
-        const float wn = w / (1e-9f + ssum);
-        const uint32_t slot = xt & 0xFFFFu;
-        // exact entry idx (uniform in the lane's group of five): valid in every lane of the group
-        auto entry_at = [&](int idx) -> uint32_t {
-            const float pt = sample_pt(gr, min(idx, gr.Lp - 1));
-            const float term = wn * (0.5f * erfc_spec_nobranch(kNegRsqrt2 * ((pt - mu) * rsig)));
-            const int g0 = 4 * 5 * min(we, 11);
-            const float a0 = __int_as_float(__builtin_amdgcn_ds_bpermute(g0, __float_as_int(term)));
-            const float a1 = __int_as_float(__builtin_amdgcn_ds_bpermute(g0 + 4, __float_as_int(term)));
-            const float a2 = __int_as_float(__builtin_amdgcn_ds_bpermute(g0 + 8, __float_as_int(term)));
-            const float a3 = __int_as_float(__builtin_amdgcn_ds_bpermute(g0 + 12, __float_as_int(term)));
-            const float a4 = __int_as_float(__builtin_amdgcn_ds_bpermute(g0 + 16, __float_as_int(term)));
-            const float acc = (((a0 + a1) + a2) + a3) + a4;
-            const float qf = __builtin_rintf(acc * gr.scale);
-            return (idx <= max_symbol) ? ((uint32_t)((int)qf + idx) & 0xFFFFu) : 0x10000u;      // past the top symbol: c_high = 2^16
-        };
-        // 1. hint: the approximate mixture (all five components in every lane) at the 64 anchors 8 l
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            mu5[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mu), k));
-            rs5[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rsig), k));
-            wk5[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wn), k));
-        }
-        int wb;
-        {
-            const int i1 = min(8 * lane, max_symbol);
-            const float pt1 = sample_pt(gr, i1);
-            float sum = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 5; ++k) { Comp ck; ck.mu = mu5[k]; ck.rsig = rs5[k]; ck.wn = wk5[k]; sum += term_fast(comp_fast(ck), pt1); }
-            const int e1 = (int)__builtin_rintf(sum * gr.scale) + i1;
+    __syncthreads();                                      // round 0 is prepared
+    for (int r = 0; r < R; ++r) {
+        const int buf = r & 1;
+        for (int i = 0; i < kTailAhead && kTailAhead * r + i < T; ++i) {
+            const float mu = sh_cmp[buf][i][mc], rsig = sh_cmp[buf][i][5 + mc], wn = sh_cmp[buf][i][10 + mc];
+            const int e1 = sh_e1[buf][i][lane];
+            const long off = sh_off[buf][i];
+            const uint32_t slot = xt & 0xFFFFu;
+            // exact entry idx (uniform in the lane's group of five): valid in every lane of the group
+            auto entry_at = [&](int idx) -> uint32_t {
+                const float pt = sample_pt(gr, min(idx, gr.Lp - 1));
+                const float term = wn * (0.5f * erfc_spec_nobranch(kNegRsqrt2 * ((pt - mu) * rsig)));
+                const int g0 = 4 * 5 * min(we, 11);
+                const float a0 = __int_as_float(__builtin_amdgcn_ds_bpermute(g0, __float_as_int(term)));
+                const float a1 = __int_as_float(__builtin_amdgcn_ds_bpermute(g0 + 4, __float_as_int(term)));
+                const float a2 = __int_as_float(__builtin_amdgcn_ds_bpermute(g0 + 8, __float_as_int(term)));
+                const float a3 = __int_as_float(__builtin_amdgcn_ds_bpermute(g0 + 12, __float_as_int(term)));
+                const float a4 = __int_as_float(__builtin_amdgcn_ds_bpermute(g0 + 16, __float_as_int(term)));
+                const float acc = (((a0 + a1) + a2) + a3) + a4;
+                const float qf = __builtin_rintf(acc * gr.scale);
+                return (idx <= max_symbol) ? ((uint32_t)((int)qf + idx) & 0xFFFFu) : 0x10000u;      // past the top symbol: c_high = 2^16
+            };
+            // 1. hint: the bucket of 8 entries the prepared anchors put the slot in
             const uint64_t p1 = ballot64(lane == 0 || (8 * lane <= max_symbol && e1 <= (int)slot));
-            wb = max(8 * (__builtin_popcountll(p1) - 1) - 2, 0);
-        }
-        // 2. proof: the 12 exact entries wb .. wb + 11; the symbol is the last one <= slot, its successor must be in the window too
-        uint32_t ent = entry_at(wb + we);
-        uint64_t pw = ballot64(mc == 0 && we < 12 && wb + we <= max_symbol && (ent <= slot || wb + we == 0));
-        int np = __builtin_popcountll(pw);
-        if (np == 0 || np == 12) {
-            // the hint was wrong (only absurd mixtures get here): exact 13-ary search from scratch, then the window at the result
-            int lo = 0, hi = max_symbol + 1;
-            while (hi - lo > 1) {
-                const int stp = (hi - lo + 12) / 13;
-                const int pi = min(lo + stp * (min(we, 11) + 1), hi - 1);
-                const uint32_t e = entry_at(pi);
-                const uint64_t pb = ballot64(mc == 0 && we < 12 && e <= slot);
-                const int k = __builtin_popcountll(pb);                        // probes are ordered: the passes form a prefix
-                const int nlo = (k > 0) ? min(lo + stp * k, hi - 1) : lo;
-                const int nhi = (k < 12) ? min(lo + stp * (k + 1), hi - 1) : hi;
-                lo = nlo; hi = nhi;
+            int wb = max(8 * (__builtin_popcountll(p1) - 1) - 2, 0);
+            // 2. proof: the 12 exact entries wb .. wb + 11; the symbol is the last one <= slot, its successor must be in the window too
+            uint32_t ent = entry_at(wb + we);
+            const uint64_t pw = ballot64(mc == 0 && we < 12 && wb + we <= max_symbol && (ent <= slot || wb + we == 0));
+            int np = __builtin_popcountll(pw);
+            if (np == 0 || np == 12) {
+                // the hint was wrong (only absurd mixtures get here): exact 13-ary search from scratch, then the window at the result
+                int lo = 0, hi = max_symbol + 1;
+                while (hi - lo > 1) {
+                    const int stp = (hi - lo + 12) / 13;
+                    const int pi = min(lo + stp * (min(we, 11) + 1), hi - 1);
+                    const uint32_t e = entry_at(pi);
+                    const uint64_t pb = ballot64(mc == 0 && we < 12 && e <= slot);
+                    const int k = __builtin_popcountll(pb);                        // probes are ordered: the passes form a prefix
+                    const int nlo = (k > 0) ? min(lo + stp * k, hi - 1) : lo;
+                    const int nhi = (k < 12) ? min(lo + stp * (k + 1), hi - 1) : hi;
+                    lo = nlo; hi = nhi;
+                }
+                wb = lo;
+                ent = entry_at(wb + we);
+                np = 1;
             }
-            wb = lo;
-            ent = entry_at(wb + we);
-            np = 1;
+            const uint32_t vlo = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * 5 * (np - 1), (int)ent);
+            const uint32_t vhi = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * 5 * np, (int)ent);
+            const int s = wb + np - 1;
+            if (lane == 0) {
+                const int v = s - shift;
+                planes[off + 2 * sg.plane] = (int16_t)v;
+                fplanes[off + 2 * sg.plane] = (float)v / 255.0f;
+            }
+            xt = (vhi - vlo) * (xt >> 16) + slot - vlo;
+            if (kTailAhead * r + i == T - 1) bad = bad || xt != (vhi - vlo) << 15;      // the encoder's first symbol: absorbing start, no bits
+            else {
+                int nb = __clz((int)xt);
+                if (nb > 16 || tc < nb) { bad = true; nb = min(nb, min(tc, 16)); }  // corrupt: keep going on what is there
+                tc -= nb;
+                xt = ((xt << nb) | lds_get_bits(sh_pay, tc, nb)) | (1u << 31);
+            }
         }
-        const uint32_t vlo = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * 5 * (np - 1), (int)ent);
-        const uint32_t vhi = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * 5 * np, (int)ent);
-        const int s = wb + np - 1;
-        if (lane == 0) {
-            const int v = s - shift;
-            planes[cur.off + 2 * sg.plane] = (int16_t)v;
-            fplanes[cur.off + 2 * sg.plane] = (float)v / 255.0f;
-        }
-        xt = (vhi - vlo) * (xt >> 16) + slot - vlo;
-        if (q == cnt - 1) { bad = bad || xt != (vhi - vlo) << 15; break; }    // the encoder's first symbol: absorbing start, no bits
-        int nb = __clz((int)xt);
-        if (nb > 16 || tc < nb) { bad = true; nb = min(nb, min(tc, 16)); }      // corrupt: keep going on what is there
-        tc -= nb;
-        xt = ((xt << nb) | lds_get_bits(sh_pay, tc, nb)) | (1u << 31);
-        cur = nxt;
+        __syncthreads();
     }
     if (T == 0) bad = bad || xt != (1u << 31);
     if ((bad || tc != 0) && lane == 0) flag_image(status, b, LLICTI_EFORMAT);
