@@ -44,19 +44,21 @@ sys.path.insert(0, ROOT)
 MAC_PER_POSITION = 193248            # 84,480 layer-0 + 92,928 mid + 15,840 out
 PEAK_FP32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_HBM_GBS = 8000.0
-DEFAULT_CONTAINER = "auto"           # rANS v3 with default_streams(batch) streams per image, see below
-MAX_STREAMS_IN_BUDGET = 10           # a v3 stream costs ~6 bytes: 10 per 768x512 image are +0.0007 bpp over the reference-format container (m_sweep)
+DEFAULT_CONTAINER = "auto"           # rANS v3, wide streams (128 lanes), default_streams(batch) of them per image, see below
+MAX_STREAMS_IN_BUDGET = 10           # a wide v3 stream costs ~6.5 bytes: 10 per 768x512 image are +0.0008 bpp over the reference-format container (m_sweep)
 
 
 def default_streams(B, n_cu=256):
     """Streams per image of the timed container: as many as keep ONE decoder workgroup per stream on its own compute unit
     (B * M <= CUs: a second workgroup on a CU slows both by 1.4x, so more streams than that buy nothing) and stay inside the north
-    star's 0.001 bpp (<= 10 per 768x512 image).  24 images on a 256-CU MI355X: 10; 32 images (configs[4] per GPU): 8."""
+    star's 0.001 bpp (<= 10 per 768x512 image).  24 images on a 256-CU MI355X: 10; 32 images (configs[4] per GPU): 8.
+    The streams are WIDE (128 lanes, eight decoder wavefronts = two per SIMD): lanes are nearly free in bytes, and the second
+    wavefront per SIMD is what a stream count inside the bpp budget cannot give (wrans10 against rans10: +2.5 %, m_sweep)."""
     return max(1, min(MAX_STREAMS_IN_BUDGET, n_cu // max(1, B)))
 
 
 def default_container(B, n_cu=256):
-    return f"rans{default_streams(B, n_cu)}"
+    return f"wrans{default_streams(B, n_cu)}"
 NORTH_STAR_MPIX_S = 200.0            # BASELINE.json north_star: >= 200 MPix/s encode+decode on 768x512 at 1 MI355X ...
 NORTH_STAR_DBPP = 0.001              # ... with bpp within 0.001 of the reference
 MAC_PER_BAND = (352 * 48 + 30976 + 5280, 352 * 72 + 30976 + 5280, 352 * 120 + 30976 + 5280)   # layer 0 (K = 48 / 72 / 120) + 4 x 88 x 88 + 4 x 15 x 88
@@ -71,7 +73,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default: 24; 32 at --gpus 8 = BASELINE.json configs[4])")
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=768)
-    ap.add_argument("--container", default=DEFAULT_CONTAINER, help="auto (rANS v3, streams per image from the batch size: default_streams()), rans<M> (M streams per image) or ac (torchac-compatible)")
+    ap.add_argument("--container", default=DEFAULT_CONTAINER, help="auto (rANS v3, wide streams, their number per image from the batch size: default_streams()), rans<M> / wrans<M> (M streams / wide streams per image) or ac (torchac-compatible)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed informational legs (profiling runs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")

@@ -150,12 +150,12 @@ int llicti_ac_decode_u16cdf(llicti_ctx *ctx, const uint16_t *d_cdf, int Lp, int 
 /* mode: LLICTI_MODE_AC = the reference's container (45 torchac-algorithm streams per image, bit-exact
  * to the oracle / reference format); LLICTI_MODE_RANS(M) = "LLICTI-rANS v3", a NEW container of this
  * build (BASELINE.json north_star: "torchac replaced by a HIP rANS coder"): header byte 0 = bit 7 (rANS) | bit 3 (format v3; the
- * retired v2 tag has it clear and is rejected with LLICTI_EFORMAT) | bit 6 (latency mode) | v in bits 5,4,2,1,0 with M = v + 1, or
- * M = 64 << v in latency mode; then M independent
- * 64-way interleaved rANS streams per image (segments 4 .. 4+M-1, the other stream segments empty), same CDFs and
- * symbols, decodable 64*M symbols at a time.  States live in [2^31, 2^32) and renormalise bit by bit (the coder loses
- * ~2^-16 of a symbol's length, like the range coder); a stream = u16 (T | pad << 11) | bit region | 64 x 31-bit final
- * states, and the 64 INITIAL states carry the last T symbols of the stream's last stage, coded by a single-state tail
+ * retired v2 tag has it clear and is rejected with LLICTI_EFORMAT) | bit 6 (extended) | v in bits 5,4,2,1,0 with M = v + 1; extended:
+ * v = 0 / 1 = 64 / 128 streams (latency modes), v >= 2 = v - 1 wide streams (LLICTI_MODE_RANS_WIDE); then M independent
+ * L-way interleaved rANS streams per image (L = 64 lanes, 128 for wide streams; segments 4 .. 4+M-1, the other stream segments
+ * empty), same CDFs and symbols, decodable L*M symbols at a time.  States live in [2^31, 2^32) and renormalise bit by bit (the coder loses
+ * ~2^-16 of a symbol's length, like the range coder); a stream = u16 (T | pad << 11) | bit region | L x 31-bit final
+ * states, and the L INITIAL states carry the last T symbols of the stream's last stage, coded by a single-state tail
  * coder.  Cost over the ideal code length: about 6 bytes per stream that has symbols -- M = 8 is within 0.0005 bpp of the AC
  * container on 768x512 images (whose 45 stream terminations cost about 25 bytes).  Format: oracle/llicti_oracle.h,
  * DESIGN.md section 5. */
@@ -163,7 +163,7 @@ int llicti_ac_decode_u16cdf(llicti_ctx *ctx, const uint16_t *d_cdf, int Lp, int 
 #define LLICTI_MODE_RANS(M)  (0x100 | (M))      /* M in 1 .. 32: one stream per segment; {64, 128}: latency modes for single / large
                                                   images, M / 32 streams per segment behind a table of their u32 lengths (+6 bytes per stream) */
 #define LLICTI_MODE_RANS_WIDE(M) (0x300 | (M))  /* M in 1 .. 30 WIDE streams: 128 lanes per stream (two 64-symbol chunks per coder step, 128 x
-                                                  31-bit states, up to 127 tail symbols), header byte 0 = bit 6 set with v = M + 1 */
+                                                  31-bit states, about twice the tail symbols), header byte 0 = bit 6 set with v = M + 1; eight decoder wavefronts per stream */
 
 /* Bytes of device workspace the two calls below need for B images of H x W in `mode`. */
 size_t llicti_workspace_bytes(int B, int H, int W, int mode);

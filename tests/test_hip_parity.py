@@ -876,13 +876,13 @@ def _bench_container_mode(B=24):
     import importlib.util
     import os
     from conftest import ROOT
-    from llicti_amd.codec import MODE_RANS
+    from llicti_amd.codec import mode_of_name
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     import torch
     name = bench.default_container(B, torch.cuda.get_device_properties(0).multi_processor_count)
-    return name, (0 if name == "ac" else MODE_RANS(int(name[4:])))
+    return name, mode_of_name(name)
 
 
 def test_full_size_oracle_parity(torch_mod, codecs, oracle_weights):
@@ -903,7 +903,7 @@ def test_full_size_oracle_parity(torch_mod, codecs, oracle_weights):
     c.check()
     cont_h, seg_h = cont.cpu().numpy(), seg.cpu().numpy()
     for b in (0, 11, 23):
-        ref = orc.encode_image(rgb[b], W_o) if mode == 0 else orc.encode_image_rans(rgb[b], W_o, mode & 0xFF)
+        ref = orc.encode_image(rgb[b], W_o) if mode == 0 else orc.encode_image_rans(rgb[b], W_o, mode & 0xFF, (mode & ~0xFF) == 0x300)
         assert container_to_bytestream_list(cont_h[b], seg_h[b]) == ref, (name, b)
     rec = _decode_poisoned(c, cont, seg, H, W, mode)
     assert np.array_equal(rec.cpu().numpy(), rgb)
@@ -944,7 +944,7 @@ def test_configs4_per_gpu_batch_oracle_parity(torch_mod, codecs, oracle_weights)
     cont, seg = c.encode(_dev(torch, rgb), mode=mode)
     c.check()
     b = 29
-    ref = orc.encode_image(rgb[b], W_o) if mode == 0 else orc.encode_image_rans(rgb[b], W_o, mode & 0xFF)
+    ref = orc.encode_image(rgb[b], W_o) if mode == 0 else orc.encode_image_rans(rgb[b], W_o, mode & 0xFF, (mode & ~0xFF) == 0x300)
     assert container_to_bytestream_list(cont[b].cpu().numpy(), seg[b].cpu().numpy()) == ref, name
     rec = _decode_poisoned(c, cont, seg, H, W, mode)
     assert np.array_equal(rec.cpu().numpy(), rgb)
@@ -1062,7 +1062,7 @@ def test_bench_line_contract(torch_mod):
               "cpu_baseline", "bpp_delta_vs_reference", "meets_north_star", "north_star_check"):
         assert k in d, k
     assert d["meets_north_star"] is False                       # not the north star's 768x512 shape: never claimed on another one
-    assert abs(d["bpp_delta_vs_reference"]["timed_container_minus_reference_format_bpp"]) < 0.2      # 3 tiny images, 8 streams each
+    assert abs(d["bpp_delta_vs_reference"]["timed_container_minus_reference_format_bpp"]) < 0.6      # 3 tiny images, 10 wide streams each: mostly the 496-byte state blocks
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
