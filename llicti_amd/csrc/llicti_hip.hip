@@ -848,13 +848,13 @@ static int decode_sub(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in
                 {
                 ProfSpan span(c, PROF_RANS_STAGE, sr);
                 if (Q == 2) {
-                    rans_decode_stage_kernel<0, 2><<<B * M, 128 * kRansWaves, 0, sr>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, 0, status);
-                    rans_decode_stage_kernel<1, 2><<<B * M, 128 * kRansWaves, 0, sr>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, 0, status);
-                    rans_decode_stage_kernel<2, 2><<<B * M, 128 * kRansWaves, 0, sr>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status);
+                    rans_decode_stage_pair_kernel<0><<<B * M, 64 * kRansWaves, 0, sr>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, 0, status);
+                    rans_decode_stage_pair_kernel<1><<<B * M, 64 * kRansWaves, 0, sr>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, 0, status);
+                    rans_decode_stage_pair_kernel<2><<<B * M, 64 * kRansWaves, 0, sr>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status);
                 } else {
-                    rans_decode_stage_kernel<0, 1><<<B * M, 64 * kRansWaves, 0, sr>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, 0, status);
-                    rans_decode_stage_kernel<1, 1><<<B * M, 64 * kRansWaves, 0, sr>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, 0, status);
-                    rans_decode_stage_kernel<2, 1><<<B * M, 64 * kRansWaves, 0, sr>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status);
+                    rans_decode_stage_kernel<0><<<B * M, 64 * kRansWaves, 0, sr>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, 0, status);
+                    rans_decode_stage_kernel<1><<<B * M, 64 * kRansWaves, 0, sr>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, 0, status);
+                    rans_decode_stage_kernel<2><<<B * M, 64 * kRansWaves, 0, sr>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status);
                 }
                 }
                 if (last) {

@@ -361,30 +361,27 @@ __device__ __forceinline__ int group_cdf_entry_fast(const CompFast &A, const Com
     return (int)__builtin_rintf(dpp_sum5(term_fast(A, pt), term_fast(B, pt)) * scale) + i;
 }
 
-template <int CLR, int Q>
-__global__ __launch_bounds__(64 * kRansWaves * Q) void rans_decode_stage_kernel(const float *__restrict__ params, StageGeom sg, int M,
+template <int CLR>
+__global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(const float *__restrict__ params, StageGeom sg, int M,
                                                                const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
                                                                int rslot_cap, uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos,
                                                                const uint32_t *__restrict__ rtail,
                                                                int16_t *__restrict__ planes, float *__restrict__ fplanes,
                                                                const int32_t *__restrict__ minmax, int last_stage, int32_t *status)
 {
-    constexpr int L = 64 * Q;                    // lanes of a stream = symbols of a chunk; Q = 2: eight wavefronts, two state registers each
-    __shared__ uint32_t sh_res[2][L][2];         // ping-pong by step parity: [0] = c_low, [1] = c_high
+    __shared__ uint32_t sh_res[2][64][2];        // ping-pong by step parity: [0] = c_low, [1] = c_high
     const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nc = sg.hc * sg.wc;
-    const int nchunks = (nc + L - 1) / L;
+    const int nchunks = (nc + 63) >> 6;
     if (nchunks <= m) return;                    // whole workgroup
     const int K = (nchunks - m + M - 1) / M;
-    uint32_t x[Q];                                                      // every wave: its own copy of the stream's 64 Q states
-#pragma unroll
-    for (int qq = 0; qq < Q; ++qq) x[qq] = rstate[((long)sidx * Q + qq) * 64 + lane];
+    uint32_t x = rstate[(long)sidx * 64 + lane];                       // every wave: its own copy
     int bcur = (int)rpos[sidx];                                          // bit cursor in the stream's bit region, moving DOWN
     const uint32_t *bitw = reinterpret_cast<const uint32_t *>(slots + rslot_off[sidx] + 4);
     const int max_dw = (rslot_cap - 4) >> 2;
-    // the stream's tail symbols (last stage only) are not in the main stream: sequence position L k + stream lane >= tail_from
-    const int tail_from = last_stage ? rans_stream_count(nc, m, M, L) - (int)rtail[sidx] : 0x7FFFFFFF;
+    // the stream's tail symbols (last stage only) are not in the main stream: sequence position 64 k + lane >= tail_from
+    const int tail_from = last_stage ? rans_stream_count(nc, m, M, 64) - (int)rtail[sidx] : 0x7FFFFFFF;
     constexpr int clr = CLR;                     // compile-time: no branch (hence no register merge, hence no s_waitcnt vmcnt(0)) next to the prefetch loads
     int minv, maxv, shift;
     clr_range(minmax + 4 * b, clr, minv, maxv, shift);
@@ -393,7 +390,7 @@ __global__ __launch_bounds__(64 * kRansWaves * Q) void rans_decode_stage_kernel(
     const float fbase = (float)minv - 0.5f;
     const long img = (long)b * 3 * sg.plane;
     const int mA = lane & 3;                                            // component A of this lane; component B is 4 (read from lane 3 only)
-    const int gsym = 16 * wave + (lane >> 2);                           // symbol (lane of the stream, 0 .. L - 1) this 4-lane group resolves
+    const int gsym = 16 * wave + (lane >> 2);                           // symbol (lane of the stream) this 4-lane group resolves
     const int gbit = lane & ~3;                                         // ballot bit of the group's first lane
     const bool head = (mA == 0);
     // Raw CNN outputs / prior-channel pixels of this group's symbol in step k: requested one step ahead, so the
@@ -401,7 +398,7 @@ __global__ __launch_bounds__(64 * kRansWaves * Q) void rans_decode_stage_kernel(
     struct Raw { float sgA, muA, wkA, a0A, a1A, sgB, muB, wkB, a0B, a1B, y, co; long off; bool on; };
     auto fetch = [&](int k) -> Raw {
         Raw r;
-        const int n = min(L * (m + k * M) + gsym, nc - 1);           // clamped: the loads are unconditional
+        const int n = min(64 * (m + k * M) + gsym, nc - 1);          // clamped: the loads are unconditional
         const int i = div_wc(sg, n), j = n - i * sg.wc;          // multiply-shift: a runtime division costs ~25 of the step's ~900 instructions
         const float *par = params + ((long)b * sg.h * sg.w + (long)i * sg.w + j) * LLICTI_PARAM_STRIDE;
         r.off = img + ((long)(2 * i + sg.oi) << sg.lvl) * sg.W + ((long)(2 * j + sg.oj) << sg.lvl);
@@ -413,7 +410,7 @@ __global__ __launch_bounds__(64 * kRansWaves * Q) void rans_decode_stage_kernel(
             r.a0A = par[48 + 5 + mA]; r.a1A = par[48 + 10 + mA]; r.a0B = par[48 + 5 + 4]; r.a1B = par[48 + 10 + 4];
             r.y = fplanes[r.off]; r.co = fplanes[r.off + sg.plane];
         }
-        r.on = (k < K) && (L * (m + k * M) + gsym) < nc && (L * k + gsym) < tail_from;
+        r.on = (k < K) && (64 * (m + k * M) + gsym) < nc && (64 * k + gsym) < tail_from;
         return r;
     };
     // component (sigma, mu, w) -> (mu with the cross-channel update, 1 / max(sigma, bound), max(w, bound)), as mix_prepare()
@@ -428,18 +425,17 @@ __global__ __launch_bounds__(64 * kRansWaves * Q) void rans_decode_stage_kernel(
         return cpt;
     };
     // Stream bits: register window of 128 dwords below wtop (a multiple of 64): lane l of winA holds dword wtop - 64 + l,
-    // of winB dword wtop - 128 + l; bcur stays in (32 (wtop - 64), 32 wtop] and a step consumes at most 1024 Q <= 2048 bits (so no
-    // field starts below dword wtop - 128), pulled with ds_bpermute instead of a dependent global load.
+    // of winB dword wtop - 128 + l; bcur stays in (32 (wtop - 64), 32 wtop] and a step consumes at most 1024 bits, pulled
+    // with ds_bpermute instead of a dependent global load.
     int wtop = max(64, (((bcur + 31) >> 5) + 63) & ~63);
     auto load_dw = [&](int d0) -> uint32_t { return bitw[min(max(d0 + lane, 0), max_dw - 1)]; };
     uint32_t winA = load_dw(wtop - 64), winB = load_dw(wtop - 128);
     Raw cur = fetch(0);
     for (int k = 0; k < K; ++k) {
-        const int chunk0 = L * (m + k * M);
+        const int chunk0 = 64 * (m + k * M);
         const Raw nxt = fetch(min(k + 1, K - 1));
-        // slot of this group's symbol = low half of the state in stream lane gsym of this wave's copy (waves 4 .. 7: the second register)
-        const uint32_t xs = (Q == 1 || wave < kRansWaves) ? x[0] : x[Q - 1];
-        const uint32_t slot = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (gsym & 63), (int)xs) & 0xFFFFu;
+        // slot of this group's symbol = low half of the state in lane gsym of this wave's copy
+        const uint32_t slot = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * gsym, (int)x) & 0xFFFFu;
         {
             if (cur.on) {                        // uniform within the group
                 const long off = cur.off;
@@ -539,7 +535,221 @@ __global__ __launch_bounds__(64 * kRansWaves * Q) void rans_decode_stage_kernel(
         }
         __syncthreads();
         {
-            int below = 0;                                                         // bits of the lower sub-chunks of this step
+            const bool active = chunk0 + lane < nc && 64 * k + lane < tail_from;
+            int nb = 0;
+            if (active) {
+                const uint32_t vlo = sh_res[k & 1][lane][0], vhi = sh_res[k & 1][lane][1];
+                x = (vhi - vlo) * (x >> 16) + (x & 0xFFFFu) - vlo;            // in [freq << 15, freq << 16)
+                nb = min(__clz((int)x), 16);                                   // > 16 only on a corrupt stream (caught by the end checks)
+            }
+            const int incl = wave_incl_scan(nb);
+            const int bpos = bcur - incl;                                       // this lane's bits: [bpos, bpos + nb)
+            const int d = bpos >> 5;                                           // wtop - 128 <= d < wtop on a well-formed stream
+            const uint32_t a0 = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (d & 63), (int)winA);
+            const uint32_t b0 = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (d & 63), (int)winB);
+            const uint32_t a1 = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * ((d + 1) & 63), (int)winA);
+            const uint32_t b1 = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * ((d + 1) & 63), (int)winB);
+            const uint32_t w0 = (d >= wtop - 64) ? a0 : b0;
+            const uint32_t w1 = (d + 1 >= wtop - 64) ? a1 : b1;
+            const uint32_t bits = __builtin_amdgcn_alignbit(w1, w0, (uint32_t)(bpos & 31)) & ((1u << nb) - 1u);
+            x = (x << nb) | bits;
+            bcur -= __builtin_amdgcn_readlane(incl, 63);
+            if (bcur <= 32 * (wtop - 64) && wtop > 64) { wtop -= 64; winA = winB; winB = load_dw(wtop - 128); }
+        }
+        cur = nxt;
+    }
+    if (wave == 0) {
+        rstate[(long)sidx * 64 + lane] = x;
+        if (lane == 0) {
+            rpos[sidx] = (uint32_t)max(bcur, 0);
+            if (bcur < 0) flag_image(status, b, LLICTI_EFORMAT);               // the stream ran out of bits
+        }
+    }
+}
+
+// Wide streams (Q = 2, 128 lanes): FOUR wavefronts per stream, TWO lanes per symbol.  The stage is bound by vector instructions per
+// symbol (a CU's issue saturates at two wavefronts per SIMD), and four lanes per symbol spend them on overhead: four 5-ary rounds
+// are 16 mixture evaluations per symbol where a pair's six ternary rounds are 12, and a wave's per-step fixed costs (fetch, the
+// state update of all 128 lanes) are shared by 32 symbols instead of 16.  A pair's lanes each own three mixture components
+// (0,1,2 / 2,3,4), prepare them as mix_prepare() does and swap the results (quad_perm [1,0,3,2]); both then hold all five in
+// canonical order.  Hint: ternary search on the approximate CDF, one probe per lane.  Proof: lane 0 evaluates the exact entry s,
+// lane 1 entry s + 1, each all five terms in the spec's order -- no cross-lane sum.  Bit-identical to the four-lane kernel.
+__device__ __forceinline__ float pair_swap(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ uint32_t pair_swap_u(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+}
+
+template <int CLR>
+__global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_pair_kernel(const float *__restrict__ params, StageGeom sg, int M,
+                                                               const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
+                                                               int rslot_cap, uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos,
+                                                               const uint32_t *__restrict__ rtail,
+                                                               int16_t *__restrict__ planes, float *__restrict__ fplanes,
+                                                               const int32_t *__restrict__ minmax, int last_stage, int32_t *status)
+{
+    constexpr int Q = 2, L = 64 * Q;
+    __shared__ uint32_t sh_res[2][L][2];         // ping-pong by step parity: [0] = c_low, [1] = c_high
+    const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nc = sg.hc * sg.wc;
+    const int nchunks = (nc + L - 1) / L;
+    if (nchunks <= m) return;                    // whole workgroup
+    const int K = (nchunks - m + M - 1) / M;
+    uint32_t x[Q];                                                      // every wave: its own copy of the stream's 128 states
+#pragma unroll
+    for (int qq = 0; qq < Q; ++qq) x[qq] = rstate[((long)sidx * Q + qq) * 64 + lane];
+    int bcur = (int)rpos[sidx];                                          // bit cursor in the stream's bit region, moving DOWN
+    const uint32_t *bitw = reinterpret_cast<const uint32_t *>(slots + rslot_off[sidx] + 4);
+    const int max_dw = (rslot_cap - 4) >> 2;
+    const int tail_from = last_stage ? rans_stream_count(nc, m, M, L) - (int)rtail[sidx] : 0x7FFFFFFF;
+    constexpr int clr = CLR;
+    int minv, maxv, shift;
+    clr_range(minmax + 4 * b, clr, minv, maxv, shift);
+    const Grid gr = make_grid(minv, maxv);
+    const int max_symbol = gr.Lp - 2;
+    const float fbase = (float)minv - 0.5f;
+    const long img = (long)b * 3 * sg.plane;
+    const int pl = lane & 1;                                            // lane of the pair
+    const bool odd = pl != 0;
+    const int gsym = 32 * wave + (lane >> 1);                           // stream lane (0 .. 127) this pair resolves
+    const int gbit = lane & ~1;                                         // ballot bit of the pair's first lane
+    const bool head = !odd;
+    const int c0 = 2 * pl;                                              // the lane's own components: c0, c0 + 1, c0 + 2
+    struct Raw { float sg[3], mu[3], wk[3], a0[3], a1[3], y, co; long off; bool on; };
+    auto fetch = [&](int k) -> Raw {
+        Raw r;
+        const int n = min(L * (m + k * M) + gsym, nc - 1);           // clamped: the loads are unconditional
+        const int i = div_wc(sg, n), j = n - i * sg.wc;
+        const float *par = params + ((long)b * sg.h * sg.w + (long)i * sg.w + j) * LLICTI_PARAM_STRIDE;
+        r.off = img + ((long)(2 * i + sg.oi) << sg.lvl) * sg.W + ((long)(2 * j + sg.oj) << sg.lvl);
+        r.y = r.co = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            r.sg[t] = par[5 * clr + c0 + t]; r.mu[t] = par[16 + 5 * clr + c0 + t]; r.wk[t] = par[32 + 5 * clr + c0 + t];
+            r.a0[t] = r.a1[t] = 0.0f;
+            if constexpr (clr == 1) r.a0[t] = par[48 + c0 + t];
+            else if constexpr (clr == 2) { r.a0[t] = par[48 + 5 + c0 + t]; r.a1[t] = par[48 + 10 + c0 + t]; }
+        }
+        if constexpr (clr == 1) r.y = fplanes[r.off];
+        else if constexpr (clr == 2) { r.y = fplanes[r.off]; r.co = fplanes[r.off + sg.plane]; }
+        r.on = (k < K) && (L * (m + k * M) + gsym) < nc && (L * k + gsym) < tail_from;
+        return r;
+    };
+    // own[0..2] of the two lanes -> the five components in canonical order (component 2 is computed by both)
+    auto canon = [&](const float own[3], float out[5]) {
+        const float r0 = pair_swap(own[0]), r1 = pair_swap(own[1]), r2 = pair_swap(own[2]);
+        out[0] = odd ? r0 : own[0];
+        out[1] = odd ? r1 : own[1];
+        out[2] = odd ? own[0] : own[2];
+        out[3] = odd ? own[1] : r1;
+        out[4] = odd ? own[2] : r2;
+    };
+    int wtop = max(64, (((bcur + 31) >> 5) + 63) & ~63);
+    auto load_dw = [&](int d0) -> uint32_t { return bitw[min(max(d0 + lane, 0), max_dw - 1)]; };
+    uint32_t winA = load_dw(wtop - 64), winB = load_dw(wtop - 128);
+    Raw cur = fetch(0);
+    for (int k = 0; k < K; ++k) {
+        const int chunk0 = L * (m + k * M);
+        const Raw nxt = fetch(min(k + 1, K - 1));
+        const uint32_t xs = (wave < 2) ? x[0] : x[1];
+        const uint32_t slot = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (gsym & 63), (int)xs) & 0xFFFFu;
+        if (cur.on) {                            // uniform within the pair
+            const long off = cur.off;
+            // the lane's three components as mix_prepare() has them
+            float mu3[3], rs3[3], w3[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                float mu = cur.mu[t];
+                if constexpr (clr == 1) { const float tt = cur.a0[t] * cur.y; mu = mu + tt; }
+                else if constexpr (clr == 2) { const float t1 = cur.a0[t] * cur.y; const float t2 = cur.a1[t] * cur.co; const float tt = t1 + t2; mu = mu + tt; }
+                mu3[t] = mu;
+                rs3[t] = 1.0f / ((cur.sg[t] > kScaleBound) ? cur.sg[t] : kScaleBound);
+                w3[t] = (cur.wk[t] > kWeightBound) ? cur.wk[t] : kWeightBound;
+            }
+            float w5[5], mu5[5], rs5[5], wn5[5];
+            canon(w3, w5);
+            const float ssum = (((w5[0] + w5[1]) + w5[2]) + w5[3]) + w5[4];
+            const float den = 1e-9f + ssum;
+            float wn3[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) wn3[t] = w3[t] / den;
+            canon(mu3, mu5); canon(rs3, rs5); canon(wn3, wn5);
+            CompFast F[5];
+#pragma unroll
+            for (int c = 0; c < 5; ++c) { Comp cc; cc.mu = mu5[c]; cc.rsig = rs5[c]; cc.wn = wn5[c]; F[c] = comp_fast(cc); }
+
+            // 1. hint: ternary search on the approximate table, one probe per lane of the pair
+            int glo = 0, ghi = max_symbol + 1;
+            while (ghi - glo > 1) {
+                const int stp = (ghi - glo + 2) / 3;                    // >= 1
+                const int q1 = min(glo + stp, ghi - 1), q2 = min(glo + 2 * stp, ghi - 1);
+                const int pi = odd ? q2 : q1;
+                const float pt = div255_exact(fbase + (float)pi);
+                float sum = term_fast(F[0], pt);
+                sum += term_fast(F[1], pt);
+                sum += term_fast(F[2], pt);
+                sum += term_fast(F[3], pt);
+                sum += term_fast(F[4], pt);
+                const int e = (int)__builtin_rintf(sum * gr.scale) + pi;
+                const uint64_t bal = ballot64(e <= (int)slot);
+                const int np = __builtin_popcount((uint32_t)(bal >> gbit) & 0x3u);      // ordered probes: the passes form a prefix
+                const int nlo = (np == 0) ? glo : (np == 1) ? q1 : q2;
+                const int nhi = (np == 0) ? q1 : (np == 1) ? q2 : ghi;
+                glo = nlo; ghi = nhi;
+            }
+            // exact table entry i, all five terms in this lane, cdf_entry()'s operations in its order
+            auto entry_exact = [&](int i) -> uint32_t {
+                const float pt = sample_pt(gr, i);
+                const float t0 = wn5[0] * (0.5f * erfc_spec_nobranch(kNegRsqrt2 * ((pt - mu5[0]) * rs5[0])));
+                const float t1 = wn5[1] * (0.5f * erfc_spec_nobranch(kNegRsqrt2 * ((pt - mu5[1]) * rs5[1])));
+                const float t2 = wn5[2] * (0.5f * erfc_spec_nobranch(kNegRsqrt2 * ((pt - mu5[2]) * rs5[2])));
+                const float t3 = wn5[3] * (0.5f * erfc_spec_nobranch(kNegRsqrt2 * ((pt - mu5[3]) * rs5[3])));
+                const float t4 = wn5[4] * (0.5f * erfc_spec_nobranch(kNegRsqrt2 * ((pt - mu5[4]) * rs5[4])));
+                const float acc = (((t0 + t1) + t2) + t3) + t4;
+                return (uint32_t)((int)__builtin_rintf(acc * gr.scale) + i) & 0xFFFFu;
+            };
+            // 2. proof: lane 0 evaluates entry glo, lane 1 entry glo + 1; if the hint is off, gallop away from it and bisect
+            int lo = 0, hi = max_symbol + 1;
+            uint32_t vlo = 0, vhi = 0x10000u;
+            bool have_lo = false, have_hi = false;
+            {
+                const int s1 = glo, s2 = min(glo + 1, max_symbol);
+                const uint32_t eM = entry_exact(odd ? s2 : s1);
+                const uint32_t eO = pair_swap_u(eM);
+                const uint32_t eA = odd ? eO : eM, eB = odd ? eM : eO;
+                const bool leA = (s1 == 0) || (eA <= slot);              // entry 0 is the floor of the search (torchac: left = 0)
+                const bool leB = (s1 + 1 <= max_symbol) && (eB <= slot); // past the top symbol: c_high = 0x10000 by definition
+                if (leA) {
+                    lo = s1; vlo = eA; have_lo = true;
+                    if (leB) { lo = s2; vlo = eB; }
+                    else if (s1 + 1 <= max_symbol) { hi = s2; vhi = eB; have_hi = true; }
+                } else { hi = s1; vhi = eA; have_hi = true; }
+            }
+            int step = 2;
+            while (hi - lo > 1) {                                        // the same probe in both lanes (uniform in the pair)
+                int probe;
+                if (have_lo && have_hi) probe = (lo + hi) >> 1;
+                else if (have_lo) { probe = min(lo + step, hi - 1); step <<= 1; }
+                else { probe = max(hi - step, lo + 1); step <<= 1; }
+                const uint32_t e = entry_exact(probe);
+                if (e <= slot) { lo = probe; vlo = e; have_lo = true; } else { hi = probe; vhi = e; have_hi = true; }
+            }
+            if (!have_lo) vlo = entry_exact(0);
+            if (head) {
+                sh_res[k & 1][gsym][0] = vlo;
+                sh_res[k & 1][gsym][1] = vhi;
+                const int v = lo - shift;
+                planes[off + (long)clr * sg.plane] = (int16_t)v;
+                fplanes[off + (long)clr * sg.plane] = (float)v / 255.0f;
+            }
+        }
+        __syncthreads();
+        {
+            int below = 0;                                                         // bits of the lower sub-chunk of this step
 #pragma unroll
             for (int qq = 0; qq < Q; ++qq) {
                 const int sl = 64 * qq + lane;                                     // stream lane
