@@ -69,7 +69,7 @@ struct Plan {                 // workspace carving for (B, H, W)
 constexpr int kAcAnchorBatch = 96;
 static bool ac_use_anchors(int B, int min_batch = kAcAnchorBatch) { return B >= std::min(min_batch, kAcAnchorBatch); }
 
-constexpr int kMaxSub = 4;
+constexpr int kMaxSub = 3;
 constexpr int kRansMaxStreams = 128;   // rANS streams per image: <= 32 one per segment, 64 / 128 grouped (rans_group())
 constexpr int kStatusHead = 16;       // status words in front of the per-image ones (common.hpp: image_status())
 struct PlanDev {                  // owns its device arrays: a plan that fails half-way through get_plan() frees what it took
@@ -99,25 +99,16 @@ struct llicti_ctx {
     float *d_pack[3] = { nullptr, nullptr, nullptr };
     bool have[3] = { false, false, false };
     std::map<std::tuple<int, int, int, int>, struct PlanDev *> plans;   // (B, H, W, M) -> plan + its device arrays
-    hipStream_t sub[kMaxSub] = { nullptr, nullptr, nullptr, nullptr };    // sub-batch pipelining (decode)
-    hipEvent_t ev_fork = nullptr, ev_join[kMaxSub] = { nullptr, nullptr, nullptr, nullptr };
+    hipStream_t sub[kMaxSub] = { nullptr, nullptr, nullptr };    // internal streams of the AC decode pipeline ([0] unused: the caller's)
     hipEvent_t ev_ac[2][16] = {};      // AC decode pipeline: chunk c of Y / Co done
     hipEvent_t ev_ac_band = nullptr, ev_ac_end[2] = { nullptr, nullptr };
-    int pipeline_s = 4;
     int ac_anchor_min_batch = kAcAnchorBatch;
     const int32_t *img_status = nullptr;   // per-image status words of the last llicti_decode_images call (in its workspace)
     int img_status_n = 0;
-    bool pipeline = false;     // sub-batch pipelining of decode: measured neutral (co-resident CNN and rANS waves share VALU issue)
     int32_t *d_status = nullptr;      // small persistent status word (for the kernel-level entry points)
     int32_t *d_lift_part = nullptr;   // min/max partials of llicti_lift_u8 (1 MB; calls on one context are not concurrent)
     int n_cu = 256;                   // compute units of the device (grid sizing of the persistent kernels)
-    int cnn_cus = 256;                // compute units the band CNN may fill (= n_cu, less inside a CU-partitioned decode)
     int cnn_tile_rows = 0;            // llicti_set_tuning("cnn_tile_rows"): 0 = choose per launch, 16 / 4 = force (tests, A/B)
-    // experiment (LLICTI_CUMASK=<R>): decode as sub-batches whose CNN launches run on streams masked to n_cu - R compute units and
-    // whose rANS stages run on streams masked to the other R, so that one sub-batch's stages overlap another's CNN
-    int cumask_rans = 0;
-    hipStream_t cu_cnn[kMaxSub] = {}, cu_rans[kMaxSub] = {};
-    hipEvent_t ev_cr[kMaxSub][2] = {};
     bool profiling = false;
     std::vector<hipEvent_t> ev;       // event pairs of the profiling spans of the current call
     std::vector<int> ev_cat;          // category of pair i
@@ -174,7 +165,7 @@ struct DeviceGuard {
 };
 
 // AC decode: a stage of nc symbols per stream is cut into C chunks (multiples of 64 symbols) so that the Y, Co and Cg
-// streams of a band run as a three-deep pipeline on three HIP streams (see decode_sub)
+// streams of a band run as a three-deep pipeline on three HIP streams (see decode_batch)
 static int ac_chunks(long nc) { return nc >= 32768 ? 16 : nc >= 4096 ? 8 : nc >= 1024 ? 4 : nc >= 256 ? 2 : 1; }
 static long ac_chunk_rows(long nc) { const int C = ac_chunks(nc); return ((nc + C - 1) / C + 63) / 64 * 64; }
 
@@ -306,28 +297,13 @@ static int rans_streams_of_byte0(int b0)      // -> M (| 0x100 for wide streams)
     return v + 1;
 }
 
-static int sub_batches_max(int B, int M)
-{
-    if (M == 0) return 1;
-    if (B % 4 == 0 && B >= 8) return 4;
-    if (B % 2 == 0 && B >= 4) return 2;
-    return 1;
-}
-
 extern "C" size_t llicti_workspace_bytes(int B, int H, int W, int mode)
 {
     const int ME = mode_streams(mode);
     if (check_dims(B, H, W) || ME < 0) return 0;
     Plan p;
     build_plan(p, B, H, W, ME);
-    size_t need = p.total;
-    const int S = sub_batches_max(B, ME & 0xFF);
-    if (S > 1) {
-        Plan q;
-        build_plan(q, B / S, H, W, ME);
-        need = std::max(need, (size_t)S * align_up(q.total, 256));
-    }
-    return need;
+    return p.total;
 }
 extern "C" size_t llicti_max_container_bytes(int H, int W)
 {
@@ -352,38 +328,18 @@ extern "C" int llicti_create(llicti_ctx **out, int device)
     llicti_ctx *c = new llicti_ctx();
     c->device = device;
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    c->cnn_cus = c->n_cu;
     DeviceGuard guard(c);
-    if (const char *e = getenv("LLICTI_PIPELINE")) { c->pipeline = atoi(e) != 0; c->pipeline_s = atoi(e); }     // experiment switch: sub-batch pipelining of decode
     HIPCHK(hipMalloc(&c->d_status, 64));
     HIPCHK(hipMalloc(&c->d_lift_part, (size_t)kLiftMaxParts * 4 * sizeof(int32_t)));
     HIPCHK(hipMemset(c->d_status, 0, 64));
     HIPCHK(hipEventCreate(&c->ev_call[0]));
     HIPCHK(hipEventCreate(&c->ev_call[1]));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     for (int k = 0; k < 2; ++k) {
         for (int i = 0; i < 16; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev_ac[k][i], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->ev_ac_end[k], hipEventDisableTiming));
     }
     HIPCHK(hipEventCreateWithFlags(&c->ev_ac_band, hipEventDisableTiming));
     for (int i = 1; i < kMaxSub; ++i) HIPCHK(hipStreamCreateWithFlags(&c->sub[i], hipStreamNonBlocking));
-    for (int i = 0; i < kMaxSub; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
-    if (const char *e = getenv("LLICTI_CUMASK")) {
-        const int R = atoi(e);
-        if (R >= 8 && R <= c->n_cu - 8 && c->n_cu <= 256) {
-            uint32_t mr[8] = {}, mc[8] = {};
-            for (int i = 0; i < c->n_cu; ++i) (i < R ? mr : mc)[i >> 5] |= 1u << (i & 31);
-            const int nsub = (c->pipeline && c->pipeline_s >= 4) ? 4 : 2;      // only the queues the decode will use
-            for (int k = 0; k < nsub; ++k) {
-                HIPCHK(hipExtStreamCreateWithCUMask(&c->cu_cnn[k], 8, mc));
-                HIPCHK(hipExtStreamCreateWithCUMask(&c->cu_rans[k], 8, mr));
-                HIPCHK(hipEventCreateWithFlags(&c->ev_cr[k][0], hipEventDisableTiming));
-                HIPCHK(hipEventCreateWithFlags(&c->ev_cr[k][1], hipEventDisableTiming));
-            }
-            c->cumask_rans = R;
-            if (!c->pipeline) { c->pipeline = true; c->pipeline_s = 2; }
-        }
-    }
     // the band CNN stages a whole head (up to 86 KB) in LDS
     HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(0)));
     HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(1)));
@@ -405,12 +361,7 @@ extern "C" int llicti_destroy(llicti_ctx *c)
     for (auto &kv : c->plans) delete kv.second;
     for (int i = 0; i < kMaxSub; ++i) {
         if (c->sub[i]) hipStreamDestroy(c->sub[i]);
-        if (c->ev_join[i]) hipEventDestroy(c->ev_join[i]);
-        if (c->cu_cnn[i]) hipStreamDestroy(c->cu_cnn[i]);
-        if (c->cu_rans[i]) hipStreamDestroy(c->cu_rans[i]);
-        for (int j = 0; j < 2; ++j) if (c->ev_cr[i][j]) hipEventDestroy(c->ev_cr[i][j]);
     }
-    if (c->ev_fork) hipEventDestroy(c->ev_fork);
     for (int k = 0; k < 2; ++k) {
         for (int i = 0; i < 16; ++i) if (c->ev_ac[k][i]) hipEventDestroy(c->ev_ac[k][i]);
         if (c->ev_ac_end[k]) hipEventDestroy(c->ev_ac_end[k]);
@@ -489,7 +440,7 @@ static int launch_band_params(llicti_ctx *c, const float *fplanes, const Geom &g
     // position with the same fmaf chains: the results do not depend on it (test_band_params_bitexact_and_golden runs both).
     const int tiles_x = (g.w + kTileW - 1) / kTileW;
     const long tiles16 = (long)g.B * tiles_x * ((g.h + kTileHMax - 1) / kTileHMax);
-    const bool small = c->cnn_tile_rows ? c->cnn_tile_rows == kTileHSmall : 4 * tiles16 < c->cnn_cus;
+    const bool small = c->cnn_tile_rows ? c->cnn_tile_rows == kTileHSmall : 4 * tiles16 < c->n_cu;
     const int TH = small ? kTileHSmall : kTileHMax;
     const int tiles_y = (g.h + TH - 1) / TH;
     const long n_tiles_l = (long)g.B * tiles_x * tiles_y;
@@ -498,7 +449,7 @@ static int launch_band_params(llicti_ctx *c, const float *fplanes, const Geom &g
     const int lds_bytes = cnn_lds_bytes(band, TH);
     const int kCnnThreads = 64 * TH;
     const int wg_per_cu = std::max(1, std::min(4, (160 * 1024) / lds_bytes));
-    int gx = std::min(n_tiles, c->cnn_cus * wg_per_cu / 4);    // 4 heads in grid.y; persistent loop over tiles
+    int gx = std::min(n_tiles, c->n_cu * wg_per_cu / 4);    // 4 heads in grid.y; persistent loop over tiles
     if (gx < 1) gx = 1;
     dim3 grid((unsigned)gx, 4);
     ProfSpan span(c, PROF_CNN, s);
@@ -695,16 +646,6 @@ static int get_plan(llicti_ctx *c, int B, int H, int W, int M, PlanDev **out)
     return 0;
 }
 
-// decode runs as S sub-batches on S streams: the rANS stage kernels are latency bound and occupy a few per
-// cent of the GPU, so one sub-batch's stages overlap another's CNN launches (images are independent)
-static int sub_batches(const llicti_ctx *c, int B, int M)
-{
-    if (!c->pipeline || c->profiling || M == 0) return 1;
-    if (c->pipeline_s >= 4 && B % 4 == 0 && B >= 8) return 4;
-    if (B % 2 == 0 && B >= 4) return 2;
-    return 1;
-}
-
 __global__ void latch_status_kernel(const int32_t *status, int32_t *latched)
 {
     if (*status != 0) *latched = *status;
@@ -800,11 +741,9 @@ extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, 
     return LLICTI_OK;
 }
 
-// sr: the stream the rANS stages run on (== s, or a CU-masked stream chained to s with the two events evcr)
-static int decode_sub(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in_stride, const int32_t *d_seg_len,
-                      int B, int H, int W, int M, uint8_t *ws, uint8_t *d_rgb, hipStream_t s, hipStream_t sr = nullptr, hipEvent_t *evcr = nullptr)
+static int decode_batch(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in_stride, const int32_t *d_seg_len,
+                        int B, int H, int W, int M, uint8_t *ws, uint8_t *d_rgb, hipStream_t s)
 {
-    if (!sr) sr = s;
     const int Q = pd->p.Q;
     const Plan &p = pd->p;
     int16_t *planes = (int16_t *)(ws + p.off_planes);
@@ -844,25 +783,23 @@ static int decode_sub(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in
             const long nc = (long)sg.hc * sg.wc;
             if (M > 0) {
                 const int last = (lvl == 0 && band == 2) ? 1 : 0;      // the last stage's tail symbols are decoded by rans_tail_kernel
-                if (sr != s) { HIPCHK(hipEventRecord(evcr[0], s)); HIPCHK(hipStreamWaitEvent(sr, evcr[0], 0)); }
                 {
-                ProfSpan span(c, PROF_RANS_STAGE, sr);
+                ProfSpan span(c, PROF_RANS_STAGE, s);
                 if (Q == 2) {
-                    rans_decode_stage_pair_kernel<0><<<B * M, 64 * kRansWaves, 0, sr>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, 0, status);
-                    rans_decode_stage_pair_kernel<1><<<B * M, 64 * kRansWaves, 0, sr>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, 0, status);
-                    rans_decode_stage_pair_kernel<2><<<B * M, 64 * kRansWaves, 0, sr>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status);
+                    rans_decode_stage_pair_kernel<0><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, 0, status);
+                    rans_decode_stage_pair_kernel<1><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, 0, status);
+                    rans_decode_stage_pair_kernel<2><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status);
                 } else {
-                    rans_decode_stage_kernel<0><<<B * M, 64 * kRansWaves, 0, sr>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, 0, status);
-                    rans_decode_stage_kernel<1><<<B * M, 64 * kRansWaves, 0, sr>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, 0, status);
-                    rans_decode_stage_kernel<2><<<B * M, 64 * kRansWaves, 0, sr>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status);
+                    rans_decode_stage_kernel<0><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, 0, status);
+                    rans_decode_stage_kernel<1><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, 0, status);
+                    rans_decode_stage_kernel<2><<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status);
                 }
                 }
                 if (last) {
-                    ProfSpan span(c, PROF_RANS_TAIL, sr);
-                    if (Q == 2) rans_tail_kernel<2><<<B * M, 64 * (1 + kTailAhead), 0, sr>>>(params, sg, M, rstate, rpos, rtail, planes, fplanes, mm, status);
-                    else rans_tail_kernel<1><<<B * M, 64 * (1 + kTailAhead), 0, sr>>>(params, sg, M, rstate, rpos, rtail, planes, fplanes, mm, status);
+                    ProfSpan span(c, PROF_RANS_TAIL, s);
+                    if (Q == 2) rans_tail_kernel<2><<<B * M, 64 * (1 + kTailAhead), 0, s>>>(params, sg, M, rstate, rpos, rtail, planes, fplanes, mm, status);
+                    else rans_tail_kernel<1><<<B * M, 64 * (1 + kTailAhead), 0, s>>>(params, sg, M, rstate, rpos, rtail, planes, fplanes, mm, status);
                 }
-                if (sr != s) { HIPCHK(hipEventRecord(evcr[1], sr)); HIPCHK(hipStreamWaitEvent(s, evcr[1], 0)); }
             }
             if (M == 0) {
                 // Y, Co, Cg of this band as a pipeline over chunks of the stage: chunk c of Co needs only chunk c
@@ -937,35 +874,17 @@ extern "C" int llicti_decode_images(llicti_ctx *c, const uint8_t *d_in, size_t i
         if (in_stride < (size_t)(17 + 3 * g4c.h * g4c.w))
             return fail(LLICTI_EINVAL, "decode_images: in_stride %zu is smaller than the %d header bytes of a %dx%d image", in_stride, 17 + 3 * g4c.h * g4c.w, W, H);
     }
-    const int S = sub_batches(c, B, M);
-    const int Bs = B / S;
     PlanDev *pd = nullptr;
-    if (int rc = get_plan(c, Bs, H, W, ME, &pd)) return rc;
-    const size_t sub_total = align_up(pd->p.total, 256);
-    if (workspace_bytes < (size_t)S * sub_total)
-        return fail(LLICTI_ENOSPACE, "decode_images: workspace %zu < %zu", workspace_bytes, (size_t)S * sub_total);
+    if (int rc = get_plan(c, B, H, W, ME, &pd)) return rc;
+    if (workspace_bytes < pd->p.total)
+        return fail(LLICTI_ENOSPACE, "decode_images: workspace %zu < %zu", workspace_bytes, pd->p.total);
     hipStream_t s = (hipStream_t)stream;
     uint8_t *ws = (uint8_t *)d_workspace;
-    const size_t plane3 = (size_t)3 * H * W;
 
     CallScope call(c, s);
-    c->img_status = (S == 1) ? (const int32_t *)(ws + pd->p.off_status) + kStatusHead : nullptr;
-    c->img_status_n = (S == 1) ? B : 0;
-    if (S > 1) HIPCHK(hipEventRecord(c->ev_fork, s));
-    const bool masked = S > 1 && c->cumask_rans > 0;
-    struct CusScope { llicti_ctx *c; ~CusScope() { c->cnn_cus = c->n_cu; } } cus_scope{ c };
-    if (masked) c->cnn_cus = c->n_cu - c->cumask_rans;
-    for (int k = 0; k < S; ++k) {
-        hipStream_t sk = masked ? c->cu_cnn[k] : (k == 0) ? s : c->sub[k];
-        if (sk != s) HIPCHK(hipStreamWaitEvent(sk, c->ev_fork, 0));
-        if (int rc = decode_sub(c, pd, d_in + (size_t)k * Bs * in_stride, in_stride, d_seg_len + (size_t)k * Bs * LLICTI_NSEG,
-                                Bs, H, W, M, ws + (size_t)k * sub_total, d_rgb + (size_t)k * Bs * plane3, sk,
-                                masked ? c->cu_rans[k] : nullptr, masked ? c->ev_cr[k] : nullptr))
-            return rc;
-        if (sk != s) HIPCHK(hipEventRecord(c->ev_join[k], sk));
-    }
-    for (int k = 0; k < S; ++k) if (masked || k > 0) HIPCHK(hipStreamWaitEvent(s, c->ev_join[k], 0));
-    return LLICTI_OK;
+    c->img_status = (const int32_t *)(ws + pd->p.off_status) + kStatusHead;
+    c->img_status_n = B;
+    return decode_batch(c, pd, d_in, in_stride, d_seg_len, B, H, W, M, ws, d_rgb, s);
 }
 
 extern "C" int llicti_check_status(llicti_ctx *c, void *stream)
@@ -1045,7 +964,7 @@ extern "C" int llicti_image_status(llicti_ctx *c, int32_t *h_status, int n, void
 {
     if (!c || !h_status || n < 1) return fail(LLICTI_EINVAL, "image_status: bad argument");
     DeviceGuard guard(c);
-    if (!c->img_status || n > c->img_status_n) return fail(LLICTI_EINVAL, "image_status: the last decode held %d images (per-image status is not kept for pipelined decodes)", c->img_status_n);
+    if (!c->img_status || n > c->img_status_n) return fail(LLICTI_EINVAL, "image_status: the last decode held %d images ", c->img_status_n);
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     HIPCHK(hipMemcpy(h_status, c->img_status, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
     return LLICTI_OK;
