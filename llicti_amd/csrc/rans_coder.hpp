@@ -1,25 +1,25 @@
-// rans_coder.hpp -- LLICTI-rANS v3 container: 64-way interleaved, bit-granular rANS encoder, the table-free stage decoder
+// rans_coder.hpp -- LLICTI-rANS v3 container: 64- or 128-way interleaved, bit-granular rANS encoder, the table-free stage decoders
 // and the tail decoder.  Part of the single translation unit llicti_hip.hip (included in order; not a stand-alone header).
 #pragma once
 
 // ------------------------------------------------------------------------------------------------ rANS container
 // "LLICTI-rANS v3" (format of this build; BASELINE.json north_star: "torchac replaced by a HIP rANS coder"; spec and CPU
 // restatement: oracle/llicti_oracle.h / .c).  Same CDFs and symbols as the AC container; each image has M independent
-// streams, each a 64-way interleaved rANS coder driven by ONE wavefront: lane l of stream m codes symbol n = 64c + l of
-// every chunk c = m (mod M) of every stage, so a whole stage decodes in ceil(nc / 64M) wave steps.
+// streams, each an L-way interleaved rANS coder (L = 64 lanes, or 128 for wide streams) encoded by ONE wavefront: lane l of stream m
+// codes symbol n = Lc + l of every chunk c = m (mod M) of every stage, so a whole stage decodes in ceil(nc / LM) steps.
 // What v3 changes against v2 (16-bit words, states in [2^16, 2^32), ~60 bytes of start / flush overhead per stream):
 //   * states live in [2^31, 2^32) and renormalise BIT by bit (0..16 bits per symbol): x / freq >= 2^15, so the coder loses
 //     ~2^-16 of a symbol's length like the range coder does (v2 lost ~0.005 bpp on smooth content), and a final state is
 //     31 bits flat -- no length field;
 //   * a lane's INITIAL state carries payload instead of nothing: the last T symbols of the stream's last stage are coded by a
-//     single-state "tail" coder whose output (<= 1984 bits) is cut into the 64 x 31 bits the lanes start from.  The decoder
+//     single-state "tail" coder whose output (<= 31 L bits) is cut into the L x 31 bits the lanes start from.  The decoder
 //     is left with those states after the last stage, reassembles the tail stream and decodes its T symbols serially.
-// Cost over the ideal code length: ~8 bytes per stream (v2: ~60) -- M = 8 is within 0.001 bpp of the AC container.
-// Stream bytes:  u16 (T | pad << 11) | bit region, read DOWN from its top minus pad unused bits | 64 x 31-bit final states.
+// Cost over the ideal code length: ~6 bytes per stream (v2: ~60) -- ten streams are within 0.001 bpp of the AC container.
+// Stream bytes:  u16 (T | pad << 11) | bit region, read DOWN from its top minus pad unused bits | L x 31-bit final states.
 constexpr int kRansStateBits = 31;
 constexpr int kRansTailMax = 2047;
-// A stream has 64 Q lanes: Q = 1, or Q = 2 ("wide" streams: two 64-symbol sub-chunks per step, decoded by eight wavefronts -- two per
-// SIMD, which raises a CU's throughput by 1.44x -- at the price of a tail twice as long).  Symbol n of a stage sits in chunk n / 64Q.
+// A stream has 64 Q lanes: Q = 1, or Q = 2 ("wide" streams: two 64-symbol sub-chunks per step, decoded two lanes per symbol by
+// rans_decode_stage_pair_kernel, at the price of a tail twice as long).  Symbol n of a stage sits in chunk n / 64Q.
 template <int Q> struct RansGeo {
     static constexpr int kLanes = 64 * Q;
     static constexpr int kPayBits = kLanes * kRansStateBits;      // 1984 / 3968: what the initial states carry (the tail stream)
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restr
 }
 
 // decode: parse a stream (copied to slot + 2 by rans_unpack_kernel, which also left its validated length in rpos):
-// T and pad (-> bit cursor), the 64 states
+// T and pad (-> bit cursor), the 64 Q states
 template <int Q>
 __global__ __launch_bounds__(64) void rans_init_kernel(const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
                                                        int M, uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos,

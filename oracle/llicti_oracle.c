@@ -903,7 +903,7 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
         }
         if (rc < 0) break;
         put_bits(pay, tb, 32, xt);
-        /* 2. the 64 lanes start from the payload: lane l = 2^31 | payload bits [31 l, 31 l + 31) */
+        /* 2. the L lanes start from the payload: lane l = 2^31 | payload bits [31 l, 31 l + 31) */
         uint32_t x[RANS_MAX_LANES];
         for (int l = 0; l < L; ++l) x[l] = (1u << 31) | get_bits(pay, (long)RANS_STATE_BITS * l, RANS_STATE_BITS);
         /* 3. main coder, last decoded symbol first; bits go UP from bit 0 of the stream's bit region */
@@ -987,7 +987,7 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
     memcpy(minmax, in + 3, 12);
     const int h4 = in[1], w4 = in[2];
     if (seg_len[3] != 3 * h4 * w4) return -3;
-    /* streams: T | bit region (read DOWN from the sentinel) | 64 x 31-bit states */
+    /* streams: T | bit region (read DOWN from the sentinel) | L x 31-bit states */
     uint32_t (*x)[RANS_MAX_LANES] = (uint32_t (*)[RANS_MAX_LANES])malloc(sizeof(uint32_t) * RANS_MAX_LANES * M);
     const uint8_t **bitsp = (const uint8_t **)malloc(sizeof(uint8_t *) * M);
     long *cur = (long *)calloc(M, sizeof(long)), *T = (long *)calloc(M, sizeof(long));
@@ -1087,7 +1087,7 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
             }
         }
         if (lvl == 0) {
-            /* tails: what the 64 states of a stream are left with is the tail stream; its final state sits on top */
+            /* tails: what the L states of a stream are left with is the tail stream; its final state sits on top */
             const int band = 2, clr = 2, src = 3;
             int hc, wc;
             stream_dims(h, w, padH, padW, band, &hc, &wc);
