@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""Debug aid (GPU box): HIP vs oracle rANS container, stream by stream; cross-decodes (HIP decodes the oracle's bytes, the
+"""Debug aid (GPU box; test infrastructure -- it calls the CPU oracle, hence under tests/; not collected by pytest): HIP vs oracle
+rANS container, stream by stream; cross-decodes (HIP decodes the oracle's bytes, the
 oracle decodes HIP's)."""
 import sys, os
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from llicti_amd.codec import HipCodec, MODE_RANS, container_to_bytestream_list, bytestream_list_to_container
 from llicti_amd.weights import pack_state_dict
 from oracle import oracle as orc

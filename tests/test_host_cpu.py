@@ -262,3 +262,28 @@ def test_strict_checkpoint_loading():
     extra["entropymodel.something_else.weight"] = torch.zeros(1)
     with pytest.raises(RuntimeError):
         load_reference_state_dict(dst, extra)
+
+
+def test_oracle_is_test_infrastructure_only():
+    """The CPU oracle is the checker, never the product: no module of the package and no tool imports, loads or runs
+    anything under oracle/ (only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may), and the package
+    has no CPU fallback to fall into -- its library loader raises without the HIP .so."""
+    import os
+    import re
+    from conftest import ROOT
+    pat = re.compile(r"^\s*(from\s+oracle\b|import\s+oracle\b)|^\s*#\s*include\s*[<\"][^>\"]*oracle|liboracle|oracle/_ref/", re.M)
+    bad = []
+    for top in ("llicti_amd", "tools"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".sh", ".hip", ".hpp", ".h")):
+                    p = os.path.join(dirpath, f)
+                    if pat.search(open(p, errors="replace").read()):
+                        bad.append(os.path.relpath(p, ROOT))
+    assert bad == [], bad
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    uses = [m.start() for m in re.finditer(r"from oracle import|import oracle", src)]
+    assert uses, "bench.py's cpu_baseline leg times the oracle"
+    for u in uses:                                     # every import sits inside a function (the baseline / bit-exactness legs), not at module level
+        line_start = src.rfind("\n", 0, u) + 1
+        assert src[line_start:u].strip() == "" and u - line_start >= 4, src[line_start:u + 40]
