@@ -26,7 +26,8 @@ One JSON line is printed by rank 0.
   roofline_cdf_table    configs[3]: the full-table CDF kernel on one 3840x2160 image, SURVEY 8(d)'s bytes (2 Lp + 60 per symbol)
   bpp_delta_vs_reference, m_sweep, ac_container, ac_container_large, single_image, image_4k, natural_like
                         informational legs, N = 1 only, outside the timed region
-  cpu_baseline          the CPU oracle in the reference's structure on the host cores, bounded sample
+  cpu_baseline          the CPU oracle in the reference's structure on the host cores, bounded sample; .torch_cpu: the same path
+                        on plain PyTorch CPU ops (one image)
 """
 from __future__ import annotations
 
@@ -75,6 +76,7 @@ def parse_args(argv=None):
     ap.add_argument("--width", type=int, default=768)
     ap.add_argument("--container", default=DEFAULT_CONTAINER, help="auto (rANS v3, wide streams, their number per image from the batch size: default_streams()), rans<M> / wrans<M> (M streams / wide streams per image) or ac (torchac-compatible)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-torch-cpu", action="store_true", help="skip the PyTorch-CPU run of one image inside cpu_baseline (10-25 s)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed informational legs (profiling runs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--no-ac-leg", action="store_true",
@@ -184,6 +186,36 @@ def cpu_baseline(H, W):
             "sample": f"{n_img} images {W}x{H} uniform-noise RGB (seeds 0..{n_img - 1}), encode {t_enc:.2f}s + decode {t_dec:.2f}s, "
                       "C/OpenMP oracle: materialised Lp-entry tables (OpenMP over positions) + single-thread range coder",
             "enc_s": round(t_enc, 3), "dec_s": round(t_dec, 3)}, bl0
+
+
+def cpu_baseline_torch(H, W):
+    """The north star's wording, literally: a PyTorch-CPU run of the same path (oracle/torch_cpu.py: conv2d interpolator, materialised
+    [positions, 5, Lp] erfc tables, int16 integerisation, single-thread range coder -- the reference's structure on torch CPU ops),
+    ONE image of the workload, encode + decode, lossless checked.  Reported inside cpu_baseline as `torch_cpu`."""
+    import numpy as np
+    import torch
+    from llicti_amd.config import default_config
+    from llicti_amd.graphs.models.LLICTI_nets import LLICTI
+    from oracle import torch_cpu as tc
+    torch.manual_seed(1337)
+    sd = {k: v.detach().cpu() for k, v in LLICTI(default_config()).state_dict().items()}
+    threads = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 64)
+    old = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        rgb = make_batch(1, H, W, 0)[0]
+        t0 = time.time()
+        streams, meta = tc.encode(rgb, sd)
+        t1 = time.time()
+        rec = tc.decode(streams, meta, sd)
+        t2 = time.time()
+    finally:
+        torch.set_num_threads(old)
+    assert np.array_equal(rec, rgb), "PyTorch-CPU baseline: decode(encode(x)) != x"
+    return {"value": round(H * W / 1e6 / (t2 - t0), 5), "unit": "MPix/s", "cores": threads, "kind": "port",
+            "sample": f"1 image {W}x{H} uniform-noise RGB (seed 0), encode {t1 - t0:.2f}s + decode {t2 - t1:.2f}s, plain PyTorch CPU ops "
+                      "(F.conv2d, torch.erfc tables) + single-thread C range coder in place of torchac",
+            "enc_s": round(t1 - t0, 3), "dec_s": round(t2 - t1, 3), "stream_bytes": int(sum(len(x) for x in streams))}
 
 
 class Legs:
@@ -750,6 +782,14 @@ def main(argv=None):
                 if not cb["timed_container_bitexact_vs_hip"]:
                     print("[bench] FAIL: timed (rANS) container of image 0 differs from the CPU oracle's", file=sys.stderr, flush=True)
                     rc = 3
+            if not args.no_torch_cpu:
+                try:
+                    cb["torch_cpu"] = cpu_baseline_torch(H, W)
+                    if bl is not None:                 # its streams are the oracle's to a few bytes (another erfc, another summation order)
+                        n_or = sum(len(x) for row in bl[1:] for x in row)
+                        cb["torch_cpu"]["stream_bytes_minus_oracle"] = cb["torch_cpu"]["stream_bytes"] - n_or
+                except Exception as e:                 # a baseline, not a gate
+                    cb["torch_cpu"] = {"skipped": repr(e)[:200]}
             out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -326,3 +326,32 @@ def test_bpp_delta_vs_reference_tables_report(golden_index, oracle_weights):
                                          "+0.0007 .. +0.002 bpp is small-sample noise (one probability-1/65536 symbol = 1e-3 bpp on 1 kpixel)",
                                  "max_abs_delta_bpp": max(abs(r["delta_bpp"]) for r in full_rows), "images": full_rows}},
                   open(os.path.join(out, "bpp_delta_fixtures.json"), "w"), indent=1)
+
+
+@pytest.mark.parametrize("case,wname", [("smooth_67x93_tl", "trainedlike"), ("noise_33x64_tl", "trainedlike"), ("noise_32x32_rand", "rand1337")])
+def test_torch_cpu_path_roundtrip(case, wname, oracle_weights):
+    """The PyTorch-CPU baseline bench.py times beside the GPU number (oracle/torch_cpu.py: the reference's structure on torch CPU
+    ops -- conv2d interpolator, materialised erfc tables, int16 integerisation -- with the C range coder in place of torchac):
+    its interpolator agrees with the oracle's to 1e-5 (north_star's tolerance), its own round trip is lossless, and its 45 streams
+    are the oracle's size to within 0.1 % (torch's erfc is not the spec's: an entry differs here and there)."""
+    import torch
+    from conftest import load_state_dict
+    from oracle import torch_cpu as tc
+    c = load_case(case)
+    rgb = c["rgb"]
+    sd = load_state_dict(wname)
+    W = oracle_weights(wname)
+    planes, _ = orc.lift(rgb)
+    fp = torch.from_numpy(planes.astype(np.float32) / np.float32(255))
+    H, Wd = rgb.shape[1:]
+    for lvl in range(5):
+        g = orc.level_geom(H, Wd, lvl)
+        for band in range(3):
+            a = tc.band_params(fp, lvl, band, sd, g).permute(1, 2, 0).numpy()
+            assert np.abs(a - orc.band_params(planes, lvl, band, W)).max() < 1e-5
+    streams, meta = tc.encode(rgb, sd)
+    assert len(streams) == 45
+    assert np.array_equal(tc.decode(streams, meta, sd), rgb)
+    n_t = sum(len(s) for s in streams)
+    n_o = sum(len(x) for row in orc.encode_image(rgb, W)[1:] for x in row)
+    assert abs(n_t - n_o) <= max(8, n_o // 1000)
