@@ -1,6 +1,7 @@
 // rans_coder.hpp -- LLICTI-rANS v3 container: 64- or 128-way interleaved, bit-granular rANS encoder, the table-free stage decoders
 // and the tail decoder.  Part of the single translation unit llicti_hip.hip (included in order; not a stand-alone header).
 #pragma once
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------------ rANS container
 // "LLICTI-rANS v3" (format of this build; BASELINE.json north_star: "torchac replaced by a HIP rANS coder"; spec and CPU
@@ -361,7 +362,6 @@ __device__ __forceinline__ int group_cdf_entry_fast(const CompFast &A, const Com
     return (int)__builtin_rintf(dpp_sum5(term_fast(A, pt), term_fast(B, pt)) * scale) + i;
 }
 
-template <int CLR>
 __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(const float *__restrict__ params, StageGeom sg, int M,
                                                                const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
                                                                int rslot_cap, uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos,
@@ -380,9 +380,18 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
     int bcur = (int)rpos[sidx];                                          // bit cursor in the stream's bit region, moving DOWN
     const uint32_t *bitw = reinterpret_cast<const uint32_t *>(slots + rslot_off[sidx] + 4);
     const int max_dw = (rslot_cap - 4) >> 2;
+    // Stream bits: register window of 128 dwords below wtop (a multiple of 64): lane l of winA holds dword wtop - 64 + l,
+    // of winB dword wtop - 128 + l; bcur stays in (32 (wtop - 64), 32 wtop] and a step consumes at most 1024 bits, pulled
+    // with ds_bpermute instead of a dependent global load.
+    int wtop = max(64, (((bcur + 31) >> 5) + 63) & ~63);
+    auto load_dw = [&](int d0) -> uint32_t { return bitw[min(max(d0 + lane, 0), max_dw - 1)]; };
+    uint32_t winA = load_dw(wtop - 64), winB = load_dw(wtop - 128);
+    // One pass per colour channel, Y -> Co -> Cg, in ONE launch per band (see rans_decode_stage_pair_kernel): a stream's chunk of Co
+    // needs only the Y pixels of the same chunk, decoded by this very wavefront a pass earlier.
+    auto pass = [&](auto tag) {
+    constexpr int clr = decltype(tag)::value;    // compile-time: no branch (hence no register merge, hence no s_waitcnt vmcnt(0)) next to the prefetch loads
     // the stream's tail symbols (last stage only) are not in the main stream: sequence position 64 k + lane >= tail_from
-    const int tail_from = last_stage ? rans_stream_count(nc, m, M, 64) - (int)rtail[sidx] : 0x7FFFFFFF;
-    constexpr int clr = CLR;                     // compile-time: no branch (hence no register merge, hence no s_waitcnt vmcnt(0)) next to the prefetch loads
+    const int tail_from = (last_stage && clr == 2) ? rans_stream_count(nc, m, M, 64) - (int)rtail[sidx] : 0x7FFFFFFF;
     int minv, maxv, shift;
     clr_range(minmax + 4 * b, clr, minv, maxv, shift);
     const Grid gr = make_grid(minv, maxv);
@@ -424,12 +433,6 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
         cpt.wn = 0.0f;
         return cpt;
     };
-    // Stream bits: register window of 128 dwords below wtop (a multiple of 64): lane l of winA holds dword wtop - 64 + l,
-    // of winB dword wtop - 128 + l; bcur stays in (32 (wtop - 64), 32 wtop] and a step consumes at most 1024 bits, pulled
-    // with ds_bpermute instead of a dependent global load.
-    int wtop = max(64, (((bcur + 31) >> 5) + 63) & ~63);
-    auto load_dw = [&](int d0) -> uint32_t { return bitw[min(max(d0 + lane, 0), max_dw - 1)]; };
-    uint32_t winA = load_dw(wtop - 64), winB = load_dw(wtop - 128);
     Raw cur = fetch(0);
     for (int k = 0; k < K; ++k) {
         const int chunk0 = 64 * (m + k * M);
@@ -558,6 +561,12 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
         }
         cur = nxt;
     }
+    };
+    pass(std::integral_constant<int, 0>{});
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __syncthreads();
+    pass(std::integral_constant<int, 1>{});
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __syncthreads();
+    pass(std::integral_constant<int, 2>{});
     if (wave == 0) {
         rstate[(long)sidx * 64 + lane] = x;
         if (lane == 0) {
@@ -574,6 +583,7 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
 // (0,1,2 / 2,3,4), prepare them as mix_prepare() does and swap the results (quad_perm [1,0,3,2]); both then hold all five in
 // canonical order.  Hint: ternary search on the approximate CDF, one probe per lane.  Proof: lane 0 evaluates the exact entry s,
 // lane 1 entry s + 1, each all five terms in the spec's order -- no cross-lane sum.  Bit-identical to the four-lane kernel.
+// One launch decodes a band's three stages (Y, Co, Cg passes).
 __device__ __forceinline__ float pair_swap(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
@@ -583,7 +593,6 @@ __device__ __forceinline__ uint32_t pair_swap_u(uint32_t v)
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
 }
 
-template <int CLR>
 __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_pair_kernel(const float *__restrict__ params, StageGeom sg, int M,
                                                                const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
                                                                int rslot_cap, uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos,
@@ -605,8 +614,16 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_pair_kernel
     int bcur = (int)rpos[sidx];                                          // bit cursor in the stream's bit region, moving DOWN
     const uint32_t *bitw = reinterpret_cast<const uint32_t *>(slots + rslot_off[sidx] + 4);
     const int max_dw = (rslot_cap - 4) >> 2;
-    const int tail_from = last_stage ? rans_stream_count(nc, m, M, L) - (int)rtail[sidx] : 0x7FFFFFFF;
-    constexpr int clr = CLR;
+    int wtop = max(64, (((bcur + 31) >> 5) + 63) & ~63);
+    auto load_dw = [&](int d0) -> uint32_t { return bitw[min(max(d0 + lane, 0), max_dw - 1)]; };
+    uint32_t winA = load_dw(wtop - 64), winB = load_dw(wtop - 128);
+    // One pass per colour channel, Y -> Co -> Cg: a stream's chunk of Co needs only the Y pixels of the same chunk (the cross-channel
+    // mean update reads the SAME position, LLICTI_nets.py:474-477), which this very wavefront decoded a pass earlier -- so the band's
+    // three stages are one launch (15 per decode instead of 45: a launch's ramp-up and its wait for the slowest stream are paid once).
+    // The channel is a compile-time constant of the pass: no branch next to the prefetch loads.
+    auto pass = [&](auto tag) {
+    constexpr int clr = decltype(tag)::value;
+    const int tail_from = (last_stage && clr == 2) ? rans_stream_count(nc, m, M, L) - (int)rtail[sidx] : 0x7FFFFFFF;
     int minv, maxv, shift;
     clr_range(minmax + 4 * b, clr, minv, maxv, shift);
     const Grid gr = make_grid(minv, maxv);
@@ -648,9 +665,6 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_pair_kernel
         out[3] = odd ? own[1] : r1;
         out[4] = odd ? own[2] : r2;
     };
-    int wtop = max(64, (((bcur + 31) >> 5) + 63) & ~63);
-    auto load_dw = [&](int d0) -> uint32_t { return bitw[min(max(d0 + lane, 0), max_dw - 1)]; };
-    uint32_t winA = load_dw(wtop - 64), winB = load_dw(wtop - 128);
     Raw cur = fetch(0);
     for (int k = 0; k < K; ++k) {
         const int chunk0 = L * (m + k * M);
@@ -778,6 +792,15 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_pair_kernel
         }
         cur = nxt;
     }
+    };
+    // Between passes: the pixels a wavefront stored are loaded again by the SAME wavefront (same lanes, same positions), through the
+    // same CU's L1 / the same XCD's L2 -- a workgroup-scope fence orders them (an agent-scope __threadfence() writes the L2 back: +0.45 ms
+    // per decode); the barrier frees the ping-pong result buffers.
+    pass(std::integral_constant<int, 0>{});
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __syncthreads();
+    pass(std::integral_constant<int, 1>{});
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __syncthreads();
+    pass(std::integral_constant<int, 2>{});
     if (wave == 0) {
 #pragma unroll
         for (int qq = 0; qq < Q; ++qq) rstate[((long)sidx * Q + qq) * 64 + lane] = x[qq];
