@@ -1067,6 +1067,8 @@ def test_bench_line_contract(torch_mod):
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] == "port" and cb["bitexact_vs_hip"] is True and cb["timed_container_bitexact_vs_hip"] is True
+    tc = cb["torch_cpu"]                                         # the same path on plain PyTorch CPU ops, one image
+    assert tc["value"] > 0 and tc["unit"] == "MPix/s" and tc["cores"] >= 1 and abs(tc["stream_bytes_minus_oracle"]) <= 64
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
     assert d["unit"] == "MPix/s" and d["value"] > 0 and d["dtype"] == "f32" and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"]
