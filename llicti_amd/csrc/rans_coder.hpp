@@ -88,10 +88,11 @@ __device__ __forceinline__ void lds_or_bits(uint32_t *buf, int pos, int n, uint3
     if ((pos & 31) + n > 32) atomicOr(&buf[(pos >> 5) + 1], v >> (32 - (pos & 31)));
 }
 
-// One wavefront per stream.  Slot layout (rslot_off is 64-byte aligned): [0,2) unused | [2,4) T | [4, 4 + nbytes) bit region
+// One wavefront per 64 lanes of a stream (a wide stream: two, one per sub-chunk; their bit fields interleave, so the step's bit
+// totals meet in LDS behind one barrier).  Slot layout (rslot_off is 64-byte aligned): [0,2) unused | [2,4) T | [4, 4 + nbytes) bit region
 // (dword aligned) | 248 Q bytes of final states; rinfo = (2, 2 + nbytes + 248 Q) for rans_pack_kernel.
 template <int Q>
-__global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restrict__ pairs, const StreamDesc *__restrict__ desc,
+__global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__restrict__ pairs, const StreamDesc *__restrict__ desc,
                                                          int B, int M, uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
                                                          int rslot_cap, int32_t *__restrict__ rinfo, int32_t *status)
 {
@@ -99,20 +100,22 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restr
     constexpr int L = GEO::kLanes;
     __shared__ uint32_t sh_pay[64 * Q];             // the tail stream / the final states (62 Q dwords used, the rest slack)
     __shared__ uint32_t sh_pairs[64];
-    __shared__ uint32_t sh_win[128];                // staging window of the bit region: dwords [wbase, wbase + 128)
-    const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M, lane = threadIdx.x;
+    __shared__ uint32_t sh_win[64 * (Q + 1)];       // staging window of the bit region: dwords [wbase, wbase + 64 (Q + 1))
+    __shared__ int sh_tot[2][Q];                    // a step's bit totals per sub-chunk (ping-pong by step parity)
+    const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M;
+    const int tid = threadIdx.x, lane = tid & 63, wq = tid >> 6;      // wavefront wq codes sub-chunk wq (stream lanes 64 wq .. 64 wq + 63)
     uint8_t *slot = slots + rslot_off[sidx];
     uint32_t *out32 = reinterpret_cast<uint32_t *>(slot + 4);
     const int cap_dw = (rslot_cap - 4 - GEO::kPayBytes - 8) >> 2;      // dwords the bit region may take
     int bad = 0;
-#pragma unroll
-    for (int qq = 0; qq < Q; ++qq) sh_pay[64 * qq + lane] = 0;
-    sh_win[lane] = 0; sh_win[64 + lane] = 0;
+    sh_pay[tid] = 0;
+    sh_win[tid] = 0;
+    if (tid < 64) sh_win[64 * Q + tid] = 0;
     __syncthreads();
 
     // 1. tail: the stream's last T symbols of the last stage, last symbol first, single state; bits go UP from bit 0 of
-    //    the payload, the final state (32 bits, leading one = highest set bit of the payload) on top.  Every lane runs the
-    //    (wave-uniform) recursion; lane 0 writes.
+    //    the payload, the final state (32 bits, leading one = highest set bit of the payload) on top.  Every lane of every
+    //    wavefront runs the (uniform) recursion; lane 0 writes (twice over for a wide stream: the same bits, ORed).
     const StreamDesc dl = desc[(long)(LLICTI_NSTREAMS - 1) * B + b];
     const int cnt = rans_stream_count(dl.n, m, M, L);
     int T = 0;
@@ -149,14 +152,13 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restr
         if (lane == 0) { lds_or_bits(sh_pay, tb, 16, xt & 0xFFFFu); lds_or_bits(sh_pay, tb + 16, 16, xt >> 16); }
         __syncthreads();
     }
-    // 2. the lanes start from the payload (lane l of sub-chunk qq = stream lane 64 qq + l)
-    uint32_t x[Q];
-#pragma unroll
-    for (int qq = 0; qq < Q; ++qq) x[qq] = (1u << 31) | lds_get_bits(sh_pay, kRansStateBits * (64 * qq + lane), kRansStateBits);
+    // 2. the lanes start from the payload (lane l of wavefront wq = stream lane 64 wq + l)
+    uint32_t x = (1u << 31) | lds_get_bits(sh_pay, kRansStateBits * tid, kRansStateBits);
     const int tail_from = cnt - T;                  // sequence position (L k + stream lane) of the first tail symbol
 
     // 3. main coder, last decoded symbol first; bits go UP from bit 0 of the bit region
-    int bp = 0, wbase = 0;                          // bit cursor; first dword of the staging window
+    int bp = 0, wbase = 0;                          // bit cursor; first dword of the staging window (workgroup-uniform)
+    int par = 0;                                    // parity of the coded steps (sh_tot)
     for (int st = LLICTI_NSTREAMS - 1; st >= 0; --st) {      // rANS is LIFO: last decoded symbol first
         const StreamDesc d = desc[(long)st * B + b];
         const int nchunks = (d.n + L - 1) / L;
@@ -168,14 +170,14 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restr
         // FIXED roles (the loop is unrolled by four; a rotating ring r0 = r1 ... makes the compiler copy the
         // newest load, i.e. wait for it with s_waitcnt vmcnt(0) in every step).  Loads are unconditional
         // (clamped address); the raw value is masked only where it is consumed.
-        auto fetch = [&](int k, int qq) -> uint32_t { return pp[min(L * (m + max(k, 0) * M) + 64 * qq + lane, d.n - 1)]; };
-        // One step of one sub-chunk, without a divergent branch: the two chains of a step -- state (bits to emit, push) and bit
-        // cursor (prefix sum, window) -- are each ~20 dependent operations, and a lone wave pays every exec-mask branch between them
-        // in full.  An inactive lane codes the neutral pair (freq 2^16: no bits, and its push is discarded).
-        auto code = [&](int k, int qq, uint32_t raw, uint32_t &x) {
-            if (k < 0) return;                                       // wave-uniform
-            const int n = L * (m + k * M) + 64 * qq + lane;
-            const bool active = n < d.n && L * k + 64 * qq + lane < lim;
+        auto fetch = [&](int k) -> uint32_t { return pp[min(L * (m + max(k, 0) * M) + tid, d.n - 1)]; };
+        // One step, without a divergent branch: the two chains of a step -- state (bits to emit, push) and bit cursor (prefix sum,
+        // window) -- are each ~20 dependent operations, and a lone wave pays every exec-mask branch between them in full.  An
+        // inactive lane codes the neutral pair (freq 2^16: no bits, and its push is discarded).
+        auto code = [&](int k, uint32_t raw) {
+            if (k < 0) return;                                       // workgroup-uniform
+            const int n = L * (m + k * M) + tid;
+            const bool active = n < d.n && L * k + tid < lim;
             const uint32_t v = active ? raw : 0u;                    // (lo, c_high) = (0, 2^16 stored as 0): freq 2^16, no bits
             const uint32_t lo = v & 0xFFFFu;
             uint32_t hi = v >> 16;
@@ -185,65 +187,65 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint32_t *__restr
             bad = wrong ? 1 : bad;
             freq = wrong ? 1u : freq;
             const int nb = rans_emit_bits(x, freq);
-            // the decoder renormalises stream-lane-ascending reading DOWN: the highest lane's bits lowest (sub-chunk Q - 1 is coded first)
+            // the decoder renormalises stream-lane-ascending reading DOWN: the highest lane's bits lowest, i.e. sub-chunk Q - 1 first
             const int incl = wave_incl_scan(nb);
             const int total = __builtin_amdgcn_readlane(incl, 63);
+            int below = 0, step_total = total;                       // bits of the sub-chunks above this one; of the whole step
+            if constexpr (Q > 1) {
+                if (lane == 0) sh_tot[par][wq] = total;
+                __syncthreads();
+                step_total = 0;
+#pragma unroll
+                for (int q2 = 0; q2 < Q; ++q2) { const int t2 = sh_tot[par][q2]; step_total += t2; below += (q2 > wq) ? t2 : 0; }
+                par ^= 1;
+            }
             {
-                const int pos = bp + (total - incl) - 32 * wbase;    // nb = 0: ORs zeros
+                const int pos = bp + below + (total - incl) - 32 * wbase;    // nb = 0: ORs zeros
                 const uint32_t bits = x & ((1u << nb) - 1u);
                 const int sh = pos & 31;
                 atomicOr(&sh_win[pos >> 5], bits << sh);
                 atomicOr(&sh_win[(pos >> 5) + 1], (uint32_t)(((uint64_t)bits << sh) >> 32));
             }
-            bp += total;
+            bp += step_total;
             const uint32_t xn = rans_push(x >> nb, lo, freq);
             x = active ? xn : x;
-            if (bp - 32 * wbase >= 2048) {                           // the window's lower half is complete (wave-uniform)
+            if (bp - 32 * wbase >= 2048) {                           // the window's lowest 64 dwords are complete (a step adds <= 1024 Q bits)
                 __syncthreads();
-                if (wbase + 64 <= cap_dw) out32[wbase + lane] = sh_win[lane]; else bad = 2;
-                const uint32_t up = sh_win[64 + lane];
+                if (tid < 64) { if (wbase + 64 <= cap_dw) out32[wbase + tid] = sh_win[tid]; else bad = 2; }
+                const uint32_t up = sh_win[64 + tid];
                 __syncthreads();
-                sh_win[lane] = up; sh_win[64 + lane] = 0;
+                sh_win[tid] = up;
+                if (tid < 64) sh_win[64 * Q + tid] = 0;
                 __syncthreads();
                 wbase += 64;
             }
         };
-        uint32_t r0[Q], r1[Q], r2[Q], r3[Q];
-#pragma unroll
-        for (int qq = 0; qq < Q; ++qq) { r0[qq] = fetch(K - 1, qq); r1[qq] = fetch(K - 2, qq); r2[qq] = fetch(K - 3, qq); r3[qq] = fetch(K - 4, qq); }
+        uint32_t r0 = fetch(K - 1), r1 = fetch(K - 2), r2 = fetch(K - 3), r3 = fetch(K - 4);
         for (int k = K - 1; k >= 0; k -= 4) {                 // steps k, k-1, k-2, k-3 (those below 0 are no-ops)
-#pragma unroll
-            for (int qq = Q - 1; qq >= 0; --qq) { code(k, qq, r0[qq], x[qq]);     r0[qq] = fetch(k - 4, qq); }
-#pragma unroll
-            for (int qq = Q - 1; qq >= 0; --qq) { code(k - 1, qq, r1[qq], x[qq]); r1[qq] = fetch(k - 5, qq); }
-#pragma unroll
-            for (int qq = Q - 1; qq >= 0; --qq) { code(k - 2, qq, r2[qq], x[qq]); r2[qq] = fetch(k - 6, qq); }
-#pragma unroll
-            for (int qq = Q - 1; qq >= 0; --qq) { code(k - 3, qq, r3[qq], x[qq]); r3[qq] = fetch(k - 7, qq); }
+            code(k, r0);     r0 = fetch(k - 4);
+            code(k - 1, r1); r1 = fetch(k - 5);
+            code(k - 2, r2); r2 = fetch(k - 6);
+            code(k - 3, r3); r3 = fetch(k - 7);
         }
     }
     // 4. the rest of the window, the 64 Q final states (31 bits each), T | pad
     __syncthreads();
     const int nbytes = (bp + 7) >> 3;
-#pragma unroll
-    for (int qq = 0; qq < Q; ++qq) sh_pay[64 * qq + lane] = 0;
+    sh_pay[tid] = 0;
     __syncthreads();
-#pragma unroll
-    for (int qq = 0; qq < Q; ++qq) {
-        lds_or_bits(sh_pay, kRansStateBits * (64 * qq + lane), 16, x[qq] & 0xFFFFu);
-        lds_or_bits(sh_pay, kRansStateBits * (64 * qq + lane) + 16, kRansStateBits - 16, (x[qq] >> 16) & 0x7FFFu);
-    }
+    lds_or_bits(sh_pay, kRansStateBits * tid, 16, x & 0xFFFFu);
+    lds_or_bits(sh_pay, kRansStateBits * tid + 16, kRansStateBits - 16, (x >> 16) & 0x7FFFu);
     __syncthreads();
-    const int ndw = (nbytes >> 2) - wbase;                    // whole window dwords still to write (<= 66); then 0..3 bytes
-    if ((nbytes >> 2) + 1 > cap_dw) bad = 2;
+    const int ndw = (nbytes >> 2) - wbase;                    // whole window dwords still to write (<= 64); then 0..3 bytes
+    const bool over = (nbytes >> 2) + 1 > cap_dw;
+    if (over) bad = 2;
     else {
-        if (lane < ndw) out32[wbase + lane] = sh_win[lane];
-        if (64 + lane < ndw) out32[wbase + 64 + lane] = sh_win[64 + lane];
-        if (lane < (nbytes & 3)) slot[4 + (nbytes & ~3) + lane] = (uint8_t)(sh_win[ndw] >> (8 * lane));
+        for (int t = tid; t < ndw; t += 64 * Q) out32[wbase + t] = sh_win[t];
+        if (tid < (nbytes & 3)) slot[4 + (nbytes & ~3) + tid] = (uint8_t)(sh_win[ndw] >> (8 * tid));
         uint8_t *fs = slot + 4 + nbytes;
-        for (int t = lane; t < GEO::kPayBytes; t += 64) fs[t] = (uint8_t)(sh_pay[t >> 2] >> (8 * (t & 3)));
+        for (int t = tid; t < GEO::kPayBytes; t += 64 * Q) fs[t] = (uint8_t)(sh_pay[t >> 2] >> (8 * (t & 3)));
     }
-    if (lane == 0) {
+    if (tid == 0) {
         const int t16 = T | ((8 * nbytes - bp) << 11);               // pad: unused (zero) bits on top of the region's last byte
         slot[2] = (uint8_t)(t16 & 0xFF); slot[3] = (uint8_t)(t16 >> 8);
         rinfo[2 * sidx] = 2; rinfo[2 * sidx + 1] = (bad == 2) ? 0 : 2 + nbytes + GEO::kPayBytes;      // overflowed slot (never with the plan's sizing): nothing to pack, ENOSPACE is latched
