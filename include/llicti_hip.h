@@ -185,7 +185,8 @@ int llicti_decode_images(llicti_ctx *ctx, const uint8_t *d_in, size_t in_stride,
 int llicti_check_status(llicti_ctx *ctx, void *stream);
 
 /* Per-image status of the last llicti_decode_images call: h_status[b] = LLICTI_OK or LLICTI_EFORMAT for image b (a batch with one
- * malformed container decodes the others correctly; the bad image's pixels are deterministic garbage).  Synchronises `stream`. */
+ * malformed container decodes the others correctly; the bad image's pixels are deterministic garbage).  Synchronises `stream`.
+ * The words are latched into the context at the end of the decode: the workspace may be freed or reused before this call. */
 int llicti_image_status(llicti_ctx *ctx, int32_t *h_status, int n, void *stream);
 
 /* Host-side self-test of arithmetic helpers that have no device dependency (the magic division of the stage geometry). */

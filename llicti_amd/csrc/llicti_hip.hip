@@ -103,8 +103,8 @@ struct llicti_ctx {
     hipEvent_t ev_ac[2][16] = {};      // AC decode pipeline: chunk c of Y / Co done
     hipEvent_t ev_ac_band = nullptr, ev_ac_end[2] = { nullptr, nullptr };
     int ac_anchor_min_batch = kAcAnchorBatch;
-    const int32_t *img_status = nullptr;   // per-image status words of the last llicti_decode_images call (in its workspace)
-    int img_status_n = 0;
+    int32_t *d_img_status = nullptr;  // per-image status words of the last llicti_decode_images call, latched from its workspace
+    int img_status_cap = 0, img_status_n = 0;   // (context-owned: the caller may free or reuse the workspace before llicti_image_status)
     int32_t *d_status = nullptr;      // small persistent status word (for the kernel-level entry points)
     int32_t *d_lift_part = nullptr;   // min/max partials of llicti_lift_u8 (1 MB; calls on one context are not concurrent)
     int n_cu = 256;                   // compute units of the device (grid sizing of the persistent kernels)
@@ -369,6 +369,7 @@ extern "C" int llicti_destroy(llicti_ctx *c)
     if (c->ev_ac_band) hipEventDestroy(c->ev_ac_band);
     if (c->d_status) hipFree(c->d_status);
     if (c->d_lift_part) hipFree(c->d_lift_part);
+    if (c->d_img_status) hipFree(c->d_img_status);
     for (auto e : c->ev) hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) if (c->ev_call[i]) hipEventDestroy(c->ev_call[i]);
     }
@@ -618,9 +619,9 @@ extern "C" int llicti_ac_decode_u16cdf(llicti_ctx *c, const uint16_t *d_cdf, int
 }
 
 // ------------------------------------------------------------------------------------------------ whole batch
-static int get_plan(llicti_ctx *c, int B, int H, int W, int M, PlanDev **out)
+static int get_plan(llicti_ctx *c, int B, int H, int W, int ME, PlanDev **out)      // ME: mode_streams() (streams | 0x100 for wide streams)
 {
-    auto key = std::make_tuple(B, H, W, M);
+    auto key = std::make_tuple(B, H, W, ME);
     auto it = c->plans.find(key);
     if (it != c->plans.end()) { *out = it->second; return 0; }
     if (c->plans.size() >= 16) {      // bounded cache: drop everything (plans are cheap to rebuild)
@@ -629,10 +630,13 @@ static int get_plan(llicti_ctx *c, int B, int H, int W, int M, PlanDev **out)
         c->plans.clear();
     }
     std::unique_ptr<PlanDev> pd(new PlanDev());       // an early return below (HIPCHK) frees the plan and what it allocated
-    build_plan(pd->p, B, H, W, M);
-    if (M > 0) {
-        HIPCHK(hipMalloc(&pd->d_rslot_off, (size_t)B * M * sizeof(long)));
-        HIPCHK(hipMemcpy(pd->d_rslot_off, pd->p.rslot_off.data(), (size_t)B * M * sizeof(long), hipMemcpyHostToDevice));
+    build_plan(pd->p, B, H, W, ME);
+    if (!pd->p.rslot_off.empty()) {
+        // the table holds B * p.M entries (p.M = ME & 0xFF), never B * ME
+        const size_t nb = pd->p.rslot_off.size() * sizeof(long);
+        if (pd->p.rslot_off.size() != (size_t)B * pd->p.M) return fail(LLICTI_EINVAL, "plan: stream slot table has %zu entries, expected %d x %d", pd->p.rslot_off.size(), B, pd->p.M);
+        HIPCHK(hipMalloc(&pd->d_rslot_off, nb));
+        HIPCHK(hipMemcpy(pd->d_rslot_off, pd->p.rslot_off.data(), nb, hipMemcpyHostToDevice));
     }
     const size_t n = (size_t)LLICTI_NSTREAMS * B;
     HIPCHK(hipMalloc(&pd->d_desc, n * sizeof(StreamDesc)));
@@ -646,9 +650,11 @@ static int get_plan(llicti_ctx *c, int B, int H, int W, int M, PlanDev **out)
     return 0;
 }
 
-__global__ void latch_status_kernel(const int32_t *status, int32_t *latched)
+// status[0] -> the context's latched word (llicti_check_status); decode: the B per-image words -> the context's copy (llicti_image_status)
+__global__ void latch_status_kernel(const int32_t *status, int32_t *latched, int32_t *img_latched, int B)
 {
-    if (*status != 0) *latched = *status;
+    if (threadIdx.x == 0 && *status != 0) *latched = *status;
+    if (img_latched) for (int b = threadIdx.x; b < B; b += blockDim.x) img_latched[b] = status[kStatusHead + b];
 }
 
 static int pad_int(int H, int W)
@@ -736,7 +742,7 @@ extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, 
         else rans_encode_kernel<1><<<B * M, 64, 0, s>>>(pairs, pd->d_desc, B, M, slots, pd->d_rslot_off, p.rslot_cap, rinfo, status);
         rans_pack_kernel<<<dim3(M, B), 256, 0, s>>>(slots, pd->d_rslot_off, rinfo, M, hdr_bytes, d_out, (long)out_stride, d_seg_len, status);
     }
-    latch_status_kernel<<<1, 1, 0, s>>>(status, c->d_status);
+    latch_status_kernel<<<1, 64, 0, s>>>(status, c->d_status, nullptr, 0);
     HIPCHK(hipGetLastError());
     return LLICTI_OK;
 }
@@ -849,7 +855,7 @@ static int decode_batch(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t 
         ProfSpan span(c, PROF_MISC, s);
         unlift_kernel<<<dim3(gx, B), 256, 0, s>>>(planes, plane, d_rgb);
     }
-    latch_status_kernel<<<1, 1, 0, s>>>(status, c->d_status);
+    latch_status_kernel<<<1, 64, 0, s>>>(status, c->d_status, c->d_img_status, B);      // the workspace is the caller's: it may be gone or reused by the time the words are read
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -877,10 +883,17 @@ extern "C" int llicti_decode_images(llicti_ctx *c, const uint8_t *d_in, size_t i
     hipStream_t s = (hipStream_t)stream;
     uint8_t *ws = (uint8_t *)d_workspace;
 
+    c->img_status_n = 0;
+    if (c->img_status_cap < B) {          // grows rarely (a larger batch than any before): blocking is fine here
+        HIPCHK(hipDeviceSynchronize());
+        if (c->d_img_status) { (void)hipFree(c->d_img_status); c->d_img_status = nullptr; c->img_status_cap = 0; }
+        HIPCHK(hipMalloc(&c->d_img_status, (size_t)B * sizeof(int32_t)));
+        c->img_status_cap = B;
+    }
     CallScope call(c, s);
-    c->img_status = (const int32_t *)(ws + pd->p.off_status) + kStatusHead;
+    if (int rc = decode_batch(c, pd, d_in, in_stride, d_seg_len, B, H, W, M, ws, d_rgb, s)) return rc;
     c->img_status_n = B;
-    return decode_batch(c, pd, d_in, in_stride, d_seg_len, B, H, W, M, ws, d_rgb, s);
+    return LLICTI_OK;
 }
 
 extern "C" int llicti_check_status(llicti_ctx *c, void *stream)
@@ -960,9 +973,9 @@ extern "C" int llicti_image_status(llicti_ctx *c, int32_t *h_status, int n, void
 {
     if (!c || !h_status || n < 1) return fail(LLICTI_EINVAL, "image_status: bad argument");
     DeviceGuard guard(c);
-    if (!c->img_status || n > c->img_status_n) return fail(LLICTI_EINVAL, "image_status: the last decode held %d images ", c->img_status_n);
+    if (!c->d_img_status || n > c->img_status_n) return fail(LLICTI_EINVAL, "image_status: the last decode held %d images ", c->img_status_n);
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-    HIPCHK(hipMemcpy(h_status, c->img_status, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(h_status, c->d_img_status, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
     return LLICTI_OK;
 }
 

@@ -388,6 +388,7 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
     int wtop = max(64, (((bcur + 31) >> 5) + 63) & ~63);
     auto load_dw = [&](int d0) -> uint32_t { return bitw[min(max(d0 + lane, 0), max_dw - 1)]; };
     uint32_t winA = load_dw(wtop - 64), winB = load_dw(wtop - 128);
+    int badx = 0;                                                        // a lane saw a state below 2^15 after its update (clz > 16): malformed stream
     // One pass per colour channel, Y -> Co -> Cg, in ONE launch per band (see rans_decode_stage_pair_kernel): a stream's chunk of Co
     // needs only the Y pixels of the same chunk, decoded by this very wavefront a pass earlier.
     auto pass = [&](auto tag) {
@@ -545,7 +546,9 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
             if (active) {
                 const uint32_t vlo = sh_res[k & 1][lane][0], vhi = sh_res[k & 1][lane][1];
                 x = (vhi - vlo) * (x >> 16) + (x & 0xFFFFu) - vlo;            // in [freq << 15, freq << 16)
-                nb = min(__clz((int)x), 16);                                   // > 16 only on a corrupt stream (caught by the end checks)
+                const int lz = __clz((int)x);
+                badx |= lz > 16;                                               // only a corrupt stream: the oracle rejects it right here, so flag the image (below)
+                nb = min(lz, 16);
             }
             const int incl = wave_incl_scan(nb);
             const int bpos = bcur - incl;                                       // this lane's bits: [bpos, bpos + nb)
@@ -571,9 +574,10 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
     pass(std::integral_constant<int, 2>{});
     if (wave == 0) {
         rstate[(long)sidx * 64 + lane] = x;
+        const bool anybad = ballot64(badx != 0) != 0;
         if (lane == 0) {
             rpos[sidx] = (uint32_t)max(bcur, 0);
-            if (bcur < 0) flag_image(status, b, LLICTI_EFORMAT);               // the stream ran out of bits
+            if (bcur < 0 || anybad) flag_image(status, b, LLICTI_EFORMAT);     // the stream ran out of bits, or a state fell out of [2^31, 2^32)
         }
     }
 }
@@ -619,6 +623,7 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_pair_kernel
     int wtop = max(64, (((bcur + 31) >> 5) + 63) & ~63);
     auto load_dw = [&](int d0) -> uint32_t { return bitw[min(max(d0 + lane, 0), max_dw - 1)]; };
     uint32_t winA = load_dw(wtop - 64), winB = load_dw(wtop - 128);
+    int badx = 0;                                                        // a lane saw a state below 2^15 after its update (clz > 16): malformed stream
     // One pass per colour channel, Y -> Co -> Cg: a stream's chunk of Co needs only the Y pixels of the same chunk (the cross-channel
     // mean update reads the SAME position, LLICTI_nets.py:474-477), which this very wavefront decoded a pass earlier -- so the band's
     // three stages are one launch (15 per decode instead of 45: a launch's ramp-up and its wait for the slowest stream are paid once).
@@ -774,7 +779,9 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_pair_kernel
                 if (active) {
                     const uint32_t vlo = sh_res[k & 1][sl][0], vhi = sh_res[k & 1][sl][1];
                     x[qq] = (vhi - vlo) * (x[qq] >> 16) + (x[qq] & 0xFFFFu) - vlo;  // in [freq << 15, freq << 16)
-                    nb = min(__clz((int)x[qq]), 16);                               // > 16 only on a corrupt stream (caught by the end checks)
+                    const int lz = __clz((int)x[qq]);
+                    badx |= lz > 16;                                               // only a corrupt stream: the oracle rejects it right here, so flag the image (below)
+                    nb = min(lz, 16);
                 }
                 const int incl = wave_incl_scan(nb);
                 const int bpos = bcur - below - incl;                              // this lane's bits: [bpos, bpos + nb)
@@ -806,9 +813,10 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_pair_kernel
     if (wave == 0) {
 #pragma unroll
         for (int qq = 0; qq < Q; ++qq) rstate[((long)sidx * Q + qq) * 64 + lane] = x[qq];
+        const bool anybad = ballot64(badx != 0) != 0;
         if (lane == 0) {
             rpos[sidx] = (uint32_t)max(bcur, 0);
-            if (bcur < 0) flag_image(status, b, LLICTI_EFORMAT);               // the stream ran out of bits
+            if (bcur < 0 || anybad) flag_image(status, b, LLICTI_EFORMAT);     // the stream ran out of bits, or a state fell out of [2^31, 2^32)
         }
     }
 }

@@ -118,3 +118,36 @@ def test_bench_defaults_match_baseline_configs():
     import subprocess
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "started 3 ranks" in (p.stderr + p.stdout)
+
+
+def test_bench_eight_rank_dry_run_configs4():
+    """the 8-rank launch of configs[4] rehearsed without hardware -- rendezvous of 8 gloo ranks on 127.0.0.1, B = 32 per rank,
+    the timed container for that batch (wrans8), MAX / SUM aggregation, the per-rank all_gather and the straggler ratio."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 8 and out["ranks_seen"] == 8 and out["batch_per_gpu"] == 32 and out["container"] == "wrans8"
+    assert "configs[4]" in out["config"]["workload"]
+    assert out["pixels"] == 256 * 512 * 768 and out["elapsed_max_s"] == 8.0 and out["bytes"] == 1000.0 * 36
+    assert [r["rank"] for r in out["per_rank"]] == list(range(8)) and out["distinct_devices"] == 8
+    # rank r reported (1 + r) s for one step of 32 images: its own rate, and slowest / fastest = 8
+    for r in out["per_rank"]:
+        assert abs(r["mpix_s"] - 32 * 512 * 768 / (1.0 + r["rank"]) / 1e6) < 1e-3
+        assert abs(r["pcie_inclusive_mpix_s"] - 32 * 512 * 768 / (2.0 + r["rank"]) / 1e6) < 1e-3
+    assert out["straggler_ratio"] == 8.0
+
+
+def test_distinct_device_accounting():
+    from llicti_amd import shard
+    assert shard.distinct_devices([0x100, 0x200, 0x300]) == 3
+    assert shard.distinct_devices([0x100, 0x100, 0x300]) == 2          # two ranks on one GPU: bench.py refuses without --allow-shared-gpu
+    assert shard.distinct_devices([-1, -1]) == 2                        # unknown identities are not taken for the same device
+    rows, strag = shard.per_rank_report([2.0, 4.0], [1.0, 1.0], 1_000_000, 2, [0x0101, -1], [0, 1])
+    assert rows[0]["mpix_s"] == 1.0 and rows[1]["mpix_s"] == 0.5 and strag == 2.0
+    assert rows[0]["pci"] == "0000:01:01" and rows[1]["pci"] is None
+    assert shard.gather_per_rank([1.5, 2.5]) == [[1.5, 2.5]]           # world = 1: no process group needed

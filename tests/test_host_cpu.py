@@ -287,3 +287,25 @@ def test_oracle_is_test_infrastructure_only():
     for u in uses:                                     # every import sits inside a function (the baseline / bit-exactness legs), not at module level
         line_start = src.rfind("\n", 0, u) + 1
         assert src[line_start:u].strip() == "" and u - line_start >= 4, src[line_start:u + 40]
+
+
+def test_dropin_import_aliases():
+    """the reference's own import lines (main.py:4, :29-33; agents/llicti_agent.py:1-12) resolve to this package after
+    llicti_amd.dropin.install().  Run in a child process: the aliases live in sys.modules."""
+    import subprocess
+    import sys
+    code = (
+        "import llicti_amd.dropin as d; d.install(); d.install()\n"          # idempotent
+        "from agents import *\n"
+        "from graphs.models.LLICTI_nets import LLICTI\n"
+        "from graphs.losses.rate_dist import CompressionRLossList, TrainRLossList\n"
+        "from loggers.rate import RateLogger\n"
+        "import llicti_amd.graphs.models.LLICTI_nets as m, llicti_amd.agents.llicti_agent as a\n"
+        "assert LLICTI is m.LLICTI and globals()['LLICTIAgent'] is a.LLICTIAgent\n"      # main.py:30 looks the class up in globals()
+        "assert CompressionRLossList().forward(3 * 4 * 4, [[b'ab', b''], [b'c']]) == [[1.0, 0.0], [0.5]]\n"
+        "import types, sys\n"
+        "d.uninstall(); sys.modules['graphs'] = types.ModuleType('graphs')\n"   # a foreign 'graphs' already imported: refuse to mix
+        "try:\n    d.install(); raise SystemExit('mixed import accepted')\nexcept ImportError:\n    pass\n"
+        "print('ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
