@@ -307,13 +307,19 @@ def overlap_leg(torch, dev, sd, rgb, mode, steps=6):
             "encdec_mpix_s": round(B * H * W / dt / 1e6, 2), "ms_per_step": round(dt * 1e3, 3)}
 
 
+NATURAL_FIXTURE = ("natural_like_768x512", "smooth", 512, 768, 11)      # tests/golden/ref_ideal_bits.json: the reference's own tables on this image
+
+
 def natural_like_leg(torch, dev, B, H, W, mode):
     """uniform noise + sigma-floor random weights is the worst case for alphabet width and far
     from natural statistics, so the same shapes are also run on a SMOOTH set (low-pass noise + gradient, seed-fixed,
     generated on the GPU) with the "trained-like" weights of tests/golden (sigma of a few grey levels): Lp and bpp
-    in a natural range.  Informational; the headline stays on BASELINE.json's uniform-noise workload."""
+    in a natural range.  Image 0 of the set is the full-size fixture image the reference's own Python was run on in the build
+    container (tests/golden/make_fixture_ideal_bits.py), so the leg carries the north star's WHOLE bpp budget on natural-like content:
+    (timed container - reference-format container), measured here on the GPU, + (build's tables - reference's tables), committed."""
     import numpy as np
-    from llicti_amd.codec import HipCodec
+    from llicti_amd.codec import MODE_AC, HipCodec
+    from llicti_amd.synth import make_image
     wfile = os.path.join(ROOT, "tests", "golden", "weights_trainedlike.npz")
     if not os.path.exists(wfile):
         return None
@@ -329,7 +335,30 @@ def natural_like_leg(torch, dev, B, H, W, mode):
     ramp = torch.linspace(-40, 40, W, device=dev)[None, None, None, :]
     img = 128 + lum + x * 250.0 + ramp + torch.randn((B, 3, H, W), device=dev, generator=g) * 2.0
     rgb = img.round().clamp(0, 255).to(torch.uint8).contiguous()
-    r = Legs(torch, codec, dev).run(rgb, mode, reps=3)
+    fixture = (H, W) == NATURAL_FIXTURE[2:4]
+    if fixture:
+        rgb[0] = torch.from_numpy(make_image(*NATURAL_FIXTURE[1:])).to(dev)
+    legs = Legs(torch, codec, dev)
+    r, cont, seg = legs.run(rgb, mode, reps=3, keep=True)
+    seg_t = seg.cpu().numpy().astype(np.int64)
+    del cont
+    r_ac, cont_ac, seg_ac = legs.run(rgb, MODE_AC, reps=1, keep=True)
+    seg_a = seg_ac.cpu().numpy().astype(np.int64)
+    del cont_ac
+    r["reference_format"] = {k: r_ac[k] for k in ("encdec_mpix_s", "bpp", "bytes")}
+    r["bpp_delta_container_batch"] = round(8.0 * (r["bytes"] - r_ac["bytes"]) / (B * H * W), 6)
+    if fixture:
+        fx, fx_path = _latest_profile_json("bpp_delta_fixtures.json")
+        row = next((im for im in (fx or {}).get("full_size", {}).get("images", []) if im.get("image") == NATURAL_FIXTURE[0]), None)
+        d_cont = 8.0 * float(seg_t[0].sum() - seg_a[0].sum()) / (H * W)
+        r["bpp_delta_container_image0"] = round(d_cont, 6)
+        r["reference_format_bytes_image0"] = int(seg_a[0].sum())
+        if row is not None:
+            # the committed row was computed by the CPU oracle on this very image: its reference-format size must be what the GPU just wrote
+            r["image0_bytes_equal_committed_oracle"] = bool(row.get("reference_format_bytes") == int(seg_a[0].sum()))
+            r["bpp_delta_tables_image0_committed"] = row["delta_bpp"]
+            r["bpp_delta_budget_image0"] = round(abs(d_cont) + abs(row["delta_bpp"]), 6)
+            r["bpp_delta_source"] = fx_path
     mm = None
     try:
         _, _, mmt = codec.lift(rgb[:1])
@@ -337,7 +366,7 @@ def natural_like_leg(torch, dev, B, H, W, mode):
     except Exception:
         pass
     codec.close()
-    r["workload"] = f"{B}x{W}x{H} smooth synthetic RGB, trained-like weights (tests/golden)"
+    r["workload"] = f"{B}x{W}x{H} smooth synthetic RGB, trained-like weights (tests/golden); image 0 = fixture {NATURAL_FIXTURE[0]} (seed {NATURAL_FIXTURE[4]})"
     r["chroma_range_image0"] = mm
     return r
 
@@ -791,6 +820,14 @@ def main(argv=None):
                                        "lossless": True, "what": "timed container vs the reference-format container on the same batch (same tables, same symbols); "
                                                                  "decode(encode(x)) == x asserted on a poisoned workspace; image 0 of both containers == CPU oracle bytes (cpu_baseline)"}
         out.update(legs_out)
+        nl = legs_out.get("natural_like") or {}
+        if "meets_north_star" in out and out["meets_north_star"] is not None and "bpp_delta_budget_image0" in nl:
+            # the budget on natural-like content too (tables + container on the full-size fixture image), and the committed row must be about
+            # the bytes this GPU wrote
+            ok_nl = bool(nl["bpp_delta_budget_image0"] <= NORTH_STAR_DBPP and nl.get("image0_bytes_equal_committed_oracle", False))
+            out["north_star_check"]["natural_like_budget_bpp"] = nl["bpp_delta_budget_image0"]
+            out["north_star_check"]["natural_like_ok"] = ok_nl
+            out["meets_north_star"] = bool(out["meets_north_star"] and ok_nl)
         if not args.no_cpu_baseline and world == 1:
             cb, bl = cpu_baseline(H, W)
             if cont_ac0 is not None:

@@ -7,8 +7,11 @@ sigma-floor seed-1337 weights one probability-1/65536 symbol whose table entry m
 torchac stand-in here only SUMS log2(65536 / (c_high - c_low)) of what the reference hands to the coder and keeps nothing) on
   - image 0 of bench.py's batch (768x512 uniform noise, seed 0) and
   - BASELINE.json configs[0]'s 256x256 image (seed 0),
-with the seed-1337 weights, and writes tests/golden/ref_ideal_bits.json: the 45 per-stream ideal bit counts per image.  Data only.
-tests/test_oracle_golden.py::test_bpp_delta_vs_reference_full_size compares the oracle's tables against them."""
+with the seed-1337 weights, and (round 4) on
+  - one full-size NATURAL-LIKE image: 768x512 "smooth" RGB (make_fixtures.make_image, seed 11) with the "trained-like" weights
+    (make_fixtures.trained_like_: sigma of a few grey levels) -- the content class the sigma-floor noise workload says nothing about,
+and writes tests/golden/ref_ideal_bits.json: the 45 per-stream ideal bit counts per image.  Data only.
+tests/test_oracle_golden.py::test_bpp_delta_vs_reference_tables_report compares the oracle's tables against them."""
 import json
 import os
 import sys
@@ -48,18 +51,23 @@ def main():
     cfg = mf.Cfg(json.load(open(os.path.join(mf.REF, "configs", "llicti_A.json"))))
     torch.use_deterministic_algorithms(True)
     torch.set_num_threads(8)
-    torch.manual_seed(1337)
-    model = LLICTI(cfg).eval()
     out = {}
-    for name, H, W, seed in (("bench_image0_768x512", 512, 768, 0), ("configs0_256x256", 256, 256, 0)):
-        rgb = np.random.default_rng(seed).integers(0, 256, size=(3, H, W), dtype=np.uint8)
+    models = {}
+    for wname in ("rand1337", "trainedlike"):
+        torch.manual_seed(1337)
+        models[wname] = LLICTI(cfg).eval()
+        if wname == "trainedlike":
+            mf.trained_like_(models[wname])
+    for name, kind, H, W, seed, wname in (("bench_image0_768x512", "noise", 512, 768, 0, "rand1337"), ("configs0_256x256", "noise", 256, 256, 0, "rand1337"),
+                                          ("natural_like_768x512", "smooth", 512, 768, 11, "trainedlike")):
+        rgb = mf.make_image(kind, H, W, seed)
         x = torch.from_numpy(rgb.astype(np.float32) / np.float32(255.0)).unsqueeze(0)
         rec.bits = []
         with torch.no_grad():
-            bl, _ = model.compress(x.clone())
+            bl, _ = models[wname].compress(x.clone())
         assert len(rec.bits) == 45
         hdr = sum(len(s) for s in bl[0])
-        out[name] = {"H": H, "W": W, "seed": seed, "weights": "rand1337", "header_bytes": hdr,
+        out[name] = {"H": H, "W": W, "seed": seed, "kind": kind, "weights": wname, "header_bytes": hdr,
                      "ideal_bits_per_stream": rec.bits, "ideal_bits": float(np.sum(rec.bits))}
         print(name, "ideal bpp", (out[name]["ideal_bits"] + 8 * hdr) / (H * W))
     json.dump(out, open(os.path.join(HERE, "ref_ideal_bits.json"), "w"), indent=1)

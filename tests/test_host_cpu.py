@@ -309,3 +309,14 @@ def test_dropin_import_aliases():
         "print('ok')\n")
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
+def test_synth_images_are_the_fixture_generators():
+    """llicti_amd.synth (what bench.py draws) == tests/helpers.make_image == tests/golden/make_fixtures.make_image: a fixture names an
+    image by (kind, H, W, seed)."""
+    from helpers import make_image
+    from llicti_amd import synth
+    for kind, H, W, seed in (("noise", 33, 47, 3), ("smooth", 40, 64, 11)):
+        assert np.array_equal(synth.make_image(kind, H, W, seed), make_image(kind, H, W, seed))
+    with pytest.raises(ValueError):
+        synth.make_image("photo", 32, 32, 0)
