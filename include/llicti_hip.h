@@ -32,8 +32,9 @@
  *                                 strided views of these planes: band (oi,oj) of level l, pixel (i,j)
  *                                 is planes[.., (2i+oi)<<l, (2j+oj)<<l]  (lazyDWT, LLICTI_nets.py:218-225)
  *   fplanes float  [B][3][H][W]   planes / 255 (one IEEE division, LLICTI_nets.py:143-144)
- *   params  float  [B][h*w][64]   raw CNN outputs on the band grid of one (level, band): 4 heads x 16
- *                                 (15 used), reference channel o at (o/15)*16 + o%15
+ *   params  float  [B][64][h*w]   raw CNN outputs on the band grid of one (level, band), CHANNEL-PLANAR: 4 heads x 16 planes
+ *                                 (15 used), reference channel o is plane (o/15)*16 + o%15; position (i, j) at i*w + j -- a
+ *                                 decoder wavefront's consecutive symbols read consecutive floats of the planes it needs
  *   tables  uint16 [B][hc*wc][stride]  integer CDF rows of one stream (stride = Lp rounded up to 8)
  */
 #ifndef LLICTI_HIP_H
@@ -57,7 +58,7 @@ extern "C" {
 #define LLICTI_NSTREAMS 45      /* 5 levels x 3 bands x 3 colour channels per image */
 #define LLICTI_NSEG     49      /* 4 header segments + 45 streams (the reference's bytestream_list) */
 #define LLICTI_NPARAMS  60      /* mixture parameters per position: 15 sigma | 15 mu | 15 weight | 5 a | 5 b | 5 d */
-#define LLICTI_PARAM_STRIDE 64  /* floats per position in HBM: 4 heads x 16 (15 used): reference channel o at (o/15)*16 + o%15 */
+#define LLICTI_PARAM_STRIDE 64  /* channel planes per (image, level, band) in HBM: 4 heads x 16 (15 used): reference channel o is plane (o/15)*16 + o%15 */
 
 typedef struct llicti_ctx llicti_ctx;
 
@@ -93,7 +94,7 @@ int llicti_lift_u8(llicti_ctx *ctx, const uint8_t *d_rgb, int B, int H, int W,
 int llicti_unlift_u8(llicti_ctx *ctx, const int16_t *d_planes, int B, int H, int W, uint8_t *d_rgb, void *stream);
 
 /* K4+K5: interpolator CNN of one (level, band) for every position of the h x w band grid of every
- * image -> d_params [B][h*w][64] (LLICTI_PARAM_STRIDE).  fp32 MFMA, k-ordered accumulation (bit-exact to the numerics spec).
+ * image -> d_params [B][64][h*w] (LLICTI_PARAM_STRIDE channel planes).  fp32 MFMA, k-ordered accumulation (bit-exact to the numerics spec).
  * Replaces LLICTIEntropyModel4.get_params (LLICTI_nets.py:721-753, :822-825). */
 int llicti_band_params_f32(llicti_ctx *ctx, const float *d_fplanes, int B, int H, int W, int lvl, int band,
                            float *d_params, void *stream);
@@ -151,8 +152,9 @@ int llicti_ac_decode_u16cdf(llicti_ctx *ctx, const uint16_t *d_cdf, int Lp, int 
  * to the oracle / reference format); LLICTI_MODE_RANS(M) = "LLICTI-rANS v3", a NEW container of this
  * build (BASELINE.json north_star: "torchac replaced by a HIP rANS coder"): header byte 0 = bit 7 (rANS) | bit 3 (format v3; the
  * retired v2 tag has it clear and is rejected with LLICTI_EFORMAT) | bit 6 (extended) | v in bits 5,4,2,1,0 with M = v + 1; extended:
- * v = 0 / 1 = 64 / 128 streams (latency modes), v >= 2 = v - 1 wide streams (LLICTI_MODE_RANS_WIDE); then M independent
- * L-way interleaved rANS streams per image (L = 64 lanes, 128 for wide streams; segments 4 .. 4+M-1, the other stream segments
+ * v = 0 / 1 = 64 / 128 streams (latency modes), v = 2 .. 15 = v - 1 wide streams (LLICTI_MODE_RANS_WIDE), v = 16 .. 31 = xwide streams
+ * (LLICTI_MODE_RANS_X); then M independent
+ * L-way interleaved rANS streams per image (L = 64 lanes, 128 for wide, 256 for xwide streams; segments 4 .. 4+M-1, the other stream segments
  * empty), same CDFs and symbols, decodable L*M symbols at a time.  States live in [2^31, 2^32) and renormalise bit by bit (the coder loses
  * ~2^-16 of a symbol's length, like the range coder); a stream = u16 (T | pad << 11) | bit region | L x 31-bit final
  * states, and the L INITIAL states carry the last T symbols of the stream's last stage, coded by a single-state tail
@@ -162,8 +164,11 @@ int llicti_ac_decode_u16cdf(llicti_ctx *ctx, const uint16_t *d_cdf, int Lp, int 
 #define LLICTI_MODE_AC        0
 #define LLICTI_MODE_RANS(M)  (0x100 | (M))      /* M in 1 .. 32: one stream per segment; {64, 128}: latency modes for single / large
                                                   images, M / 32 streams per segment behind a table of their u32 lengths (+6 bytes per stream) */
-#define LLICTI_MODE_RANS_WIDE(M) (0x300 | (M))  /* M in 1 .. 30 WIDE streams: 128 lanes per stream (two 64-symbol chunks per coder step, 128 x
-                                                  31-bit states, about twice the tail symbols), header byte 0 = bit 6 set with v = M + 1; eight decoder wavefronts per stream */
+#define LLICTI_MODE_RANS_WIDE(M) (0x300 | (M))  /* M in 1 .. 14 WIDE streams: 128 lanes per stream (two 64-symbol chunks per coder step, 128 x
+                                                  31-bit states, about twice the tail symbols), header byte 0 = bit 6 set with v = M + 1; two decoder lanes per symbol */
+#define LLICTI_MODE_RANS_X(M) (0x500 | (M))     /* M in 1 .. 14, 32, 64 XWIDE streams: 256 lanes per stream, header byte 0 = bit 6 set with v = M + 15 (32 / 64: v = 30 / 31;
+                                                  64: two streams per segment); ONE decoder lane per symbol, four wavefronts per stream: the fewest vector instructions
+                                                  per symbol of the three (about 7.5 bytes per stream: 9 per 768x512 image are +0.0009 bpp over the reference format) */
 
 /* Bytes of device workspace the two calls below need for B images of H x W in `mode`. */
 size_t llicti_workspace_bytes(int B, int H, int W, int mode);

@@ -22,26 +22,40 @@ MODE_AC = 0                      # the reference's container: 45 torchac-algorit
 
 
 def MODE_RANS(M=8, wide=False):
-    """"LLICTI-rANS v3" container: M independent interleaved rANS streams per image.  64 lanes per stream with M in
-    1 .. 32, 64, 128; wide=True: 128 lanes per stream (two 64-symbol chunks per coder step), M in 1 .. 30
-    (include/llicti_hip.h)."""
-    return (0x300 if wide else 0x100) | int(M)
+    """"LLICTI-rANS v3" container: M independent interleaved rANS streams per image.  wide = 0 / False: 64 lanes per stream, M in
+    1 .. 32, 64, 128; wide = 1 / True: 128 lanes (two 64-symbol chunks per coder step), M in 1 .. 14; wide = 2 ("xwide"): 256 lanes,
+    one decoder lane per symbol, M in 1 .. 14, 32, 64 (include/llicti_hip.h)."""
+    return (0x100 + 0x200 * int(wide)) | int(M)
+
+
+def _mode_wide(mode: int) -> int:
+    return ((mode & ~0xFF) - 0x100) // 0x200
 
 
 def rans_tag(M, wide=False):
     """Header byte 0 of a rANS v3 container with M streams per image."""
+    wide = int(wide)
     ext = 1 if (M > 32 or wide) else 0
-    v = M + 1 if wide else ({64: 0, 128: 1}[M] if ext else M - 1)
+    if wide == 2:
+        v = {32: 30, 64: 31}.get(M, M + 15)
+    elif wide == 1:
+        v = M + 1
+    else:
+        v = {64: 0, 128: 1}[M] if ext else M - 1
     return 0x88 | (ext << 6) | (((v >> 3) & 3) << 4) | (v & 7)
 
 
 def mode_of_header(byte0: int) -> int:
     if byte0 == 5:
         return MODE_AC
-    if (byte0 & 0x88) == 0x88:          # rANS v3: bits 5,4,2,1,0 = v; bit 6 clear: M = v + 1; set: v = 0, 1 -> 64, 128 streams, v >= 2 -> v - 1 wide streams
-        v = (((byte0 >> 4) & 3) << 3) | (byte0 & 7)
+    if (byte0 & 0x88) == 0x88:          # rANS v3: bits 5,4,2,1,0 = v; bit 6 clear: M = v + 1; set: v = 0, 1 -> 64, 128 streams, 2 .. 15 -> v - 1 wide streams,
+        v = (((byte0 >> 4) & 3) << 3) | (byte0 & 7)       # 16 .. 29 -> v - 15 xwide streams, 30 / 31 -> 32 / 64 xwide streams
         if (byte0 >> 6) & 1:
-            return MODE_RANS(64 << v) if v <= 1 else MODE_RANS(v - 1, wide=True)
+            if v <= 1:
+                return MODE_RANS(64 << v)
+            if v < 16:
+                return MODE_RANS(v - 1, wide=1)
+            return MODE_RANS({30: 32, 31: 64}.get(v, v - 15), wide=2)
         return MODE_RANS(v + 1)
     if (byte0 & 0x88) == 0x80:
         raise ValueError(f"container tag 0x{byte0:02x} is the retired LLICTI-rANS v2 format; this build reads and writes v3 only")
@@ -49,19 +63,21 @@ def mode_of_header(byte0: int) -> int:
 
 
 def mode_of_name(name: str) -> int:
-    """"ac" | "rans<M>" | "wrans<M>" (wide streams) -> mode."""
+    """"ac" | "rans<M>" | "wrans<M>" (wide streams: 128 lanes) | "xrans<M>" (xwide streams: 256 lanes) -> mode."""
     name = str(name).lower()
     if name == "ac":
         return MODE_AC
+    if name.startswith("xrans"):
+        return MODE_RANS(int(name[5:]), wide=2)
     if name.startswith("wrans"):
-        return MODE_RANS(int(name[5:]), wide=True)
+        return MODE_RANS(int(name[5:]), wide=1)
     if name.startswith("rans"):
         return MODE_RANS(int(name[4:] or 8))
-    raise ValueError(f"unknown container {name!r}: ac, rans<M> or wrans<M>")
+    raise ValueError(f"unknown container {name!r}: ac, rans<M>, wrans<M> or xrans<M>")
 
 
 def name_of_mode(mode: int) -> str:
-    return "ac" if mode == MODE_AC else ("wrans%d" if (mode & ~0xFF) == 0x300 else "rans%d") % (mode & 0xFF)
+    return "ac" if mode == MODE_AC else ("rans%d", "wrans%d", "xrans%d")[_mode_wide(mode)] % (mode & 0xFF)
 
 
 def _ptr(t):
@@ -134,9 +150,9 @@ class HipCodec:
     def band_params(self, fplanes, lvl, band):
         B, _, H, W = fplanes.shape
         _, _, h, w, _, _, _, _ = _lib.level_geom(H, W, lvl, band)
-        out = torch.empty((B, h * w, 64), dtype=torch.float32, device=self.device)
+        out = torch.empty((B, 64, h, w), dtype=torch.float32, device=self.device)
         _lib.check(self.L.llicti_band_params_f32(self.ctx, _ptr(fplanes), B, H, W, lvl, band, _ptr(out), _stream_ptr(self.device)))
-        return out.view(B, h, w, 64)           # 4 heads x 16 (15 used); params60() gives the reference's 60 channels
+        return out                             # channel-planar: 4 heads x 16 planes (15 used; the 16th is never written); params60() gives the reference's 60 channels
 
     def lift_train(self, rgb):
         """uint8 [B,3,H,W] -> float32 [B,3,H,W] planes of the training path's float lift (Y - 127/255, Co, Cg)."""
@@ -159,14 +175,15 @@ class HipCodec:
         fplanes = self.lift_train(rgb)
         res = []
         for lvl in range(5):
-            bands = [self.selfinfo(fplanes, self.band_params(fplanes, lvl, b).reshape(rgb.shape[0], -1, 64), lvl, b) for b in range(3)]
+            bands = [self.selfinfo(fplanes, self.band_params(fplanes, lvl, b), lvl, b) for b in range(3)]
             res.append(torch.cat(bands, dim=1))
         return res
 
     @staticmethod
     def params60(p64):
-        """[.., 64] device layout -> [.., 60] in the reference's channel order (LLICTI_nets.py:381-387)."""
-        return p64.reshape(*p64.shape[:-1], 4, 16)[..., :15].reshape(*p64.shape[:-1], 60)
+        """[B, 64, h, w] device layout (channel planes) -> [B, h, w, 60] in the reference's channel order (LLICTI_nets.py:381-387)."""
+        B, _, h, w = p64.shape
+        return p64.reshape(B, 4, 16, h, w)[:, :, :15].reshape(B, 60, h, w).permute(0, 2, 3, 1)
 
     def cdf_tables(self, planes, params, mm, lvl, band, clr, row_stride=512):
         B, _, H, W = planes.shape

@@ -482,12 +482,21 @@ __global__ __launch_bounds__(CnnGeo<TH>::kThreads) void band_params_kernel(const
             __builtin_amdgcn_sched_barrier(0);
         });
 
-        // D row 4q + r = output 4q + r of this head; params[pos][head][16]
+        // D row 4q + r = output 4q + r of this head -> channel plane head * 16 + 4q + r of params[img][64][h * w] (numerics.hpp: ParRow).
+        // A store instruction writes 16 consecutive positions (64 bytes) of four planes; plane 15 of a head does not exist (15 outputs).
+        {
+            const long npos = (long)g.h * g.w;
 #pragma unroll
-        for (int n = 0; n < kNT; ++n) {
-            const int i = i0 + ((wave * kNT) >> 1) + (n >> 1), j = j0 + 16 * (n & 1) + px;
-            if (i < g.h && j < g.w)
-                *reinterpret_cast<f32x4 *>(params + (((long)img * g.h + i) * g.w + j) * kParamStride + head * 16 + 4 * q) = a2[n];
+            for (int n = 0; n < kNT; ++n) {
+                const int i = i0 + ((wave * kNT) >> 1) + (n >> 1), j = j0 + 16 * (n & 1) + px;
+                if (i < g.h && j < g.w) {
+                    float *dst = params + ((long)img * kParamStride + head * 16 + 4 * q) * npos + (long)i * g.w + j;
+                    dst[0] = a2[n][0];
+                    dst[npos] = a2[n][1];
+                    dst[2 * npos] = a2[n][2];
+                    if (q < 3) dst[3 * npos] = a2[n][3];
+                }
+            }
         }
         cur ^= 1;
     }

@@ -67,31 +67,14 @@ __global__ __launch_bounds__(256) void cdf_pairs_kernel(const int16_t *__restric
                                                         const int32_t *__restrict__ minmax, StageGeom s,
                                                         uint32_t *__restrict__ pairs)
 {
-    // A thread needs its position's whole 256-byte row of CNN outputs: read straight from HBM/L2 that is 60
-    // loads touching 64 different lines each.  Instead every wave moves its 64 consecutive rows (16 KB,
-    // contiguous in the band grid) with 16 fully coalesced float4 loads into LDS (row pitch 68 floats: the
-    // per-lane ds_read_b128 that follow are bank-conflict free) and each lane picks its row up from there.
-    constexpr int kPitch4 = 17;                                   // float4 per staged row
-    __shared__ float4 stage[4][64 * kPitch4];
+    // Channel-planar CNN outputs (numerics.hpp: ParRow): the 64 lanes of a wave walk 64 consecutive positions, so each of a thread's
+    // 60 parameter loads is one fully coalesced 256-byte wave access -- no LDS staging (round 3 moved position-major rows through LDS).
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int np = s.h * s.w;
     const int p0 = (blockIdx.x * 4 + wave) * 64;
     if (p0 >= np) return;                                         // whole wave
-    const float4 *src = reinterpret_cast<const float4 *>(params + ((long)b * np + p0) * LLICTI_PARAM_STRIDE);
-    const int rows = min(64, np - p0);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int f4 = q * 64 + lane, r = f4 >> 4, c4 = f4 & 15;
-        stage[wave][r * kPitch4 + c4] = src[min(r, rows - 1) * 16 + c4];
-    }
-    __builtin_amdgcn_wave_barrier();                              // same wave, in-order LDS: no s_barrier needed
-    float par[LLICTI_PARAM_STRIDE];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {                                // heads of 16 floats, 15 used each: 0-14, 16-30, 32-46, 48-62
-        const float4 v = stage[wave][lane * kPitch4 + c];
-        par[4 * c] = v.x; par[4 * c + 1] = v.y; par[4 * c + 2] = v.z; par[4 * c + 3] = v.w;
-    }
+    const ParRow par = par_row(params, b, np, min(p0 + lane, np - 1));
     const int p = p0 + lane;
     const int i = p / s.w, j = p - i * s.w;
     if (p >= np || i >= s.hc || j >= s.wc) return;                // padded row / column of the band grid: not coded
@@ -149,7 +132,7 @@ __global__ __launch_bounds__(64 * kTabWaves) void cdf_table_kernel(const int16_t
     // rows [n0, n0 + cnt) of every image -> tables[b][cap_rows][row_stride] (row n at index n - n0)
     for (int n = n0 + wave0; n < min(nc, n0 + cnt); n += nwaves) {
         const int i = n / s.wc, j = n - i * s.wc;
-        const float *par = params + ((long)b * s.h * s.w + (long)i * s.w + j) * LLICTI_PARAM_STRIDE;
+        const ParRow par = par_row(params, b, (long)s.h * s.w, (long)i * s.w + j);
         const long off = img + ((long)(2 * i + s.oi) << s.lvl) * s.W + ((long)(2 * j + s.oj) << s.lvl);
         // component mi, prepared exactly as mix_prepare() does
         const float sgm = par[5 * clr + mi];
@@ -247,7 +230,7 @@ __global__ __launch_bounds__(64 * kTabWaves) void cdf_anchor_kernel(const int16_
     const int mi = min(lane, 4);                         // lanes 0..4 prepare one mixture component each
     for (int n = n0 + wave0; n < min(nc, n0 + cnt); n += nwaves) {
         const int i = n / s.wc, j = n - i * s.wc;
-        const float *par = params + ((long)b * s.h * s.w + (long)i * s.w + j) * LLICTI_PARAM_STRIDE;
+        const ParRow par = par_row(params, b, (long)s.h * s.w, (long)i * s.w + j);
         const long off = img + ((long)(2 * i + s.oi) << s.lvl) * s.W + ((long)(2 * j + s.oj) << s.lvl);
         // component mi, prepared exactly as mix_prepare() does
         const float sgm = par[5 * clr + mi];

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void selfinfo_kernel(const float *__restrict__
     const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= (long)s.h * s.w) return;
     const int i = (int)(n / s.w), j = (int)(n - (long)i * s.w);
-    const float *par = params + ((long)b * s.h * s.w + n) * LLICTI_PARAM_STRIDE;
+    const ParRow par = par_row(params, b, (long)s.h * s.w, n);
     int rr = 2 * i + s.oi, cc = 2 * j + s.oj;
     if (rr >= s.Hl) rr -= 2;                       // lazyDWT's replicate pad of the odd edge (pad=True geometry)
     if (cc >= s.Wl) cc -= 2;

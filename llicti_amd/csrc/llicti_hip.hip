@@ -54,7 +54,7 @@ struct Plan {                 // workspace carving for (B, H, W)
     std::vector<long> pair_base;        // per (lvl, band): first pair of [clr][B][nc]
     size_t max_container;
     int M = 0;                          // rANS streams per image (0: AC container only)
-    int Q = 1;                          // 64-lane sub-chunks per stream step (2: wide streams of 128 lanes)
+    int Q = 1;                          // 64-lane sub-chunks per stream step (2: wide streams of 128 lanes; 4: xwide streams of 256 lanes)
     int rslot_cap = 0;
     std::vector<long> rslot_off;        // [B*M] byte offsets into the slots region
     size_t off_rinfo, off_rstate, off_rpos, off_rtail;
@@ -173,10 +173,11 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static int stage_index(int lvl, int band, int clr) { return (LLICTI_NLEVELS - 1 - lvl) * 9 + band * 3 + clr; }   // scale 4..0
 
-// ME: streams per image, | 0x100 for wide (128-lane) streams -- what mode_streams() returns and the plan cache is keyed on
+// ME: streams per image, | 0x100 for wide (128-lane) streams, | 0x200 for xwide (256-lane) streams -- what mode_streams() returns and the
+// plan cache is keyed on
 static void build_plan(Plan &p, int B, int H, int W, int ME)
 {
-    const int M = ME & 0xFF, Q = (ME >> 8) ? 2 : 1;
+    const int M = ME & 0xFF, Q = 1 << (ME >> 8);
     p.B = B; p.H = H; p.W = W; p.M = M; p.Q = Q;
     const size_t plane = (size_t)H * W;
     size_t o = 0;
@@ -233,7 +234,7 @@ static void build_plan(Plan &p, int B, int H, int W, int ME)
             const long nchunks = (p.desc[(size_t)st * B].n + L - 1) / L;
             syms += (nchunks + M - 1) / M * L;
         }
-        const int pay_bytes = Q == 2 ? RansGeo<2>::kPayBytes : RansGeo<1>::kPayBytes;
+        const int pay_bytes = Q * RansGeo<1>::kPayBytes;
         p.rslot_cap = (int)align_up((size_t)(2 * syms + 4 + 8 + pay_bytes + 16 + 64), 64);   // + T, the 31-bit states, slack, zero pad
         p.rslot_off.assign((size_t)B * M, 0);
         for (long i = 0; i < (long)B * M; ++i) p.rslot_off[i] = (long)i * p.rslot_cap;
@@ -270,31 +271,35 @@ static void build_plan(Plan &p, int B, int H, int W, int ME)
 
 // mode: 0 = AC container (torchac-compatible, the reference's format); 0x100 | M = rANS container (v3) with M
 // streams per image, M in 1 .. 32 (one per container segment) or {64, 128} (latency modes: 2 / 4 streams per segment)
-static int mode_streams(int mode)      // -> M, | 0x100 for wide streams (LLICTI_MODE_RANS_WIDE); 0: AC container; -1: unknown
+static int mode_streams(int mode)      // -> M, | 0x100 for wide streams (LLICTI_MODE_RANS_WIDE), | 0x200 for xwide streams (LLICTI_MODE_RANS_X); 0: AC container; -1: unknown
 {
     if (mode == 0) return 0;
     const int M = mode & 0xFF;
-    if ((mode & ~0xFF) == 0x300) return (M >= 1 && M <= 30) ? (M | 0x100) : -1;
+    if ((mode & ~0xFF) == 0x500) return ((M >= 1 && M <= 14) || M == 32 || M == 64) ? (M | 0x200) : -1;
+    if ((mode & ~0xFF) == 0x300) return (M >= 1 && M <= 14) ? (M | 0x100) : -1;
     if ((mode & ~0xFF) != 0x100) return -1;
     if (M < 1 || (M > 32 && M != 64 && M != 128)) return -1;
     return M;
 }
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 // Header byte 0 of the rANS v3 container (the AC container stores the number of scales, 5, there): bit 7 = rANS, bit 3 = format v3 (the
-// retired v2 had it clear), bit 6 = latency mode, bits 5,4,2,1,0 = a 5-bit value v:  M = v + 1 (1 .. 32 streams, one per segment), or
-// with bit 6 set M = 64 << v (v = 0, 1: 64 / 128 streams, M / 32 per segment)
-// ... and v = M + 1 (2 .. 31) with bit 6 set: M wide streams of 128 lanes.
+// retired v2 had it clear), bit 6 = extended, bits 5,4,2,1,0 = a 5-bit value v:  M = v + 1 (1 .. 32 streams of 64 lanes, one per segment);
+// extended: v = 0, 1: 64 / 128 streams of 64 lanes (M / 32 per segment); v = 2 .. 15: v - 1 wide streams (128 lanes); v = 16 .. 29: v - 15
+// xwide streams (256 lanes); v = 30, 31: 32 / 64 xwide streams (64: two per segment).
 static int rans_byte0(int M, int Q)
 {
-    const int ext = (M > 32 || Q == 2) ? 1 : 0, v = Q == 2 ? M + 1 : M > 32 ? (M == 64 ? 0 : 1) : M - 1;
+    const int ext = (M > 32 || Q > 1) ? 1 : 0;
+    const int v = Q == 4 ? (M == 32 ? 30 : M == 64 ? 31 : M + 15) : Q == 2 ? M + 1 : M > 32 ? (M == 64 ? 0 : 1) : M - 1;
     return 0x88 | (ext << 6) | (((v >> 3) & 3) << 4) | (v & 7);
 }
-static int rans_streams_of_byte0(int b0)      // -> M (| 0x100 for wide streams); 0: not a v3 tag
+static int rans_streams_of_byte0(int b0)      // -> M (| 0x100 for wide, | 0x200 for xwide streams); 0: not a v3 tag
 {
     if ((b0 & 0x88) != 0x88) return 0;
     const int v = (((b0 >> 4) & 3) << 3) | (b0 & 7);
-    if ((b0 >> 6) & 1) return v == 0 ? 64 : v == 1 ? 128 : ((v - 1) | 0x100);
-    return v + 1;
+    if (!((b0 >> 6) & 1)) return v + 1;
+    if (v <= 1) return 64 << v;
+    if (v < 16) return (v - 1) | 0x100;
+    return (v == 30 ? 32 : v == 31 ? 64 : v - 15) | 0x200;
 }
 
 extern "C" size_t llicti_workspace_bytes(int B, int H, int W, int mode)
@@ -311,9 +316,10 @@ extern "C" size_t llicti_max_container_bytes(int H, int W)
     Plan p, q;
     build_plan(p, 1, H, W, 32);     // covers the AC container and M <= 32 ...
     build_plan(q, 1, H, W, kRansMaxStreams);     // ... and the many-stream latency modes (more per-stream slack)
-    Plan w;
-    build_plan(w, 1, H, W, 30 | 0x100);          // ... and wide streams (larger state blocks)
-    return std::max(std::max(p.max_container, q.max_container), w.max_container);
+    Plan w, x;
+    build_plan(w, 1, H, W, 14 | 0x100);          // ... and wide ...
+    build_plan(x, 1, H, W, 64 | 0x200);          // ... and xwide streams (larger state blocks)
+    return std::max(std::max(p.max_container, q.max_container), std::max(w.max_container, x.max_container));
 }
 
 extern "C" int llicti_create(llicti_ctx **out, int device)
@@ -692,7 +698,7 @@ extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, 
     if (check_dims(B, H, W)) return LLICTI_EINVAL;
     const int ME = mode_streams(mode);
     if (ME < 0) return fail(LLICTI_EINVAL, "encode_images: unknown mode 0x%x", mode);
-    const int M = ME & 0xFF, Q = (ME >> 8) ? 2 : 1;
+    const int M = ME & 0xFF, Q = 1 << (ME >> 8);
     for (int b = 0; b < 3; ++b) if (!c->have[b]) return fail(LLICTI_ENOWEIGHTS, "band %d weights not set", b);
     DeviceGuard guard(c);
     PlanDev *pd = nullptr;
@@ -738,7 +744,8 @@ extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, 
     } else {
         ProfSpan span(c, PROF_RANS_ENC, s);
         int32_t *rinfo = (int32_t *)(ws + p.off_rinfo);
-        if (Q == 2) rans_encode_kernel<2><<<B * M, 128, 0, s>>>(pairs, pd->d_desc, B, M, slots, pd->d_rslot_off, p.rslot_cap, rinfo, status);
+        if (Q == 4) rans_encode_kernel<4><<<B * M, 256, 0, s>>>(pairs, pd->d_desc, B, M, slots, pd->d_rslot_off, p.rslot_cap, rinfo, status);
+        else if (Q == 2) rans_encode_kernel<2><<<B * M, 128, 0, s>>>(pairs, pd->d_desc, B, M, slots, pd->d_rslot_off, p.rslot_cap, rinfo, status);
         else rans_encode_kernel<1><<<B * M, 64, 0, s>>>(pairs, pd->d_desc, B, M, slots, pd->d_rslot_off, p.rslot_cap, rinfo, status);
         rans_pack_kernel<<<dim3(M, B), 256, 0, s>>>(slots, pd->d_rslot_off, rinfo, M, hdr_bytes, d_out, (long)out_stride, d_seg_len, status);
     }
@@ -774,9 +781,10 @@ static int decode_batch(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t 
         if (M == 0) {
             unpack_kernel<<<dim3(LLICTI_NSTREAMS, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, B, slots, pd->d_slot_off, pd->d_slot_cap, slot_len, status);
         } else {
-            rans_unpack_kernel<<<dim3(M, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, M, Q == 2 ? RansGeo<2>::kMinStream : RansGeo<1>::kMinStream,
+            rans_unpack_kernel<<<dim3(M, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, M, 2 + Q * RansGeo<1>::kPayBytes,
                                                           slots, pd->d_rslot_off, p.rslot_cap, rpos, status);
-            if (Q == 2) rans_init_kernel<2><<<B * M, 64, 0, s>>>(slots, pd->d_rslot_off, M, rstate, rpos, rtail, status);
+            if (Q == 4) rans_init_kernel<4><<<B * M, 64, 0, s>>>(slots, pd->d_rslot_off, M, rstate, rpos, rtail, status);
+            else if (Q == 2) rans_init_kernel<2><<<B * M, 64, 0, s>>>(slots, pd->d_rslot_off, M, rstate, rpos, rtail, status);
             else rans_init_kernel<1><<<B * M, 64, 0, s>>>(slots, pd->d_rslot_off, M, rstate, rpos, rtail, status);
         }
     }
@@ -791,7 +799,9 @@ static int decode_batch(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t 
                 const int last = (lvl == 0 && band == 2) ? 1 : 0;      // the last stage's tail symbols are decoded by rans_tail_kernel
                 {
                 ProfSpan span(c, PROF_RANS_STAGE, s);
-                if (Q == 2) {
+                if (Q == 4) {
+                    rans_decode_stage_lane_kernel<4><<<B * M, 256, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status);
+                } else if (Q == 2) {
                     rans_decode_stage_pair_kernel<<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status);
                 } else {
                     rans_decode_stage_kernel<<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status);
@@ -799,7 +809,8 @@ static int decode_batch(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t 
                 }
                 if (last) {
                     ProfSpan span(c, PROF_RANS_TAIL, s);
-                    if (Q == 2) rans_tail_kernel<2><<<B * M, 64 * (1 + kTailAhead), 0, s>>>(params, sg, M, rstate, rpos, rtail, planes, fplanes, mm, status);
+                    if (Q == 4) rans_tail_kernel<4><<<B * M, 64 * (1 + kTailAhead), 0, s>>>(params, sg, M, rstate, rpos, rtail, planes, fplanes, mm, status);
+                    else if (Q == 2) rans_tail_kernel<2><<<B * M, 64 * (1 + kTailAhead), 0, s>>>(params, sg, M, rstate, rpos, rtail, planes, fplanes, mm, status);
                     else rans_tail_kernel<1><<<B * M, 64 * (1 + kTailAhead), 0, s>>>(params, sg, M, rstate, rpos, rtail, planes, fplanes, mm, status);
                 }
             }

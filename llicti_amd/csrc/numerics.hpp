@@ -100,10 +100,27 @@ constexpr float kNegRsqrt2 = (float)(-0.70710678118654752440);
 
 struct Mix { float rsig[5], mu[5], wn[5]; };     // rsig = 1 / max(sigma, bound): one IEEE division per mixture
 
-// par: the raw CNN outputs of one position, one 16-float row per head (15 used):
+// The raw CNN outputs in HBM are CHANNEL-PLANAR per (level, band): params[b][ch][pos], ch = 0 .. 63 (4 heads x 16, 15 used), pos
+// = i * w + j over the band grid -- so that whatever walks consecutive positions (a decoder wavefront's symbols of a step, a thread
+// per position) reads consecutive floats of one channel plane, fully coalesced, and touches only the channels it needs.  ParRow is
+// one position of that layout; par[ch] is ONE load at plane stride.  (Round 3 kept position-major rows of 64 floats: a decoder lane
+// then gathered single dwords at a 256-byte stride and every colour pass pulled whole rows, 1.6-3.1x the bytes it used.)
 //   head 0 sigma | head 1 mu | head 2 weight (each Y, Co, Cg x 5 mixtures) | head 3 a, b, d x 5
-// i.e. reference channel o (LLICTI_nets.py:381-387) sits at par[(o / 15) * 16 + o % 15].
-__device__ __forceinline__ void mix_prepare(const float *par, int clr, float yv, float cov, Mix &m)
+// i.e. reference channel o (LLICTI_nets.py:381-387) sits at ch = (o / 15) * 16 + o % 15.
+struct ParRow {
+    const float *img;       // &params[b][0][0]: wave-uniform wherever a wave works on one image
+    long stride;            // floats between channel planes: h * w
+    int pos;                // the position (the only per-lane part of an address: img + ch * stride stays on the scalar unit)
+    __device__ __forceinline__ float operator[](int ch) const { return (img + (long)ch * stride)[pos]; }
+};
+__device__ __forceinline__ ParRow par_row(const float *params, int b, long npos, long pos)
+{
+    return ParRow{ params + (long)b * 64 * npos, npos, (int)pos };
+}
+
+// par: a ParRow, or a plain array of the position's 64 values (same indexing)
+template <class PAR>
+__device__ __forceinline__ void mix_prepare(const PAR &par, int clr, float yv, float cov, Mix &m)
 {
     float w[5];
 #pragma unroll

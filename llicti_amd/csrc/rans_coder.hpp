@@ -19,16 +19,17 @@
 // Stream bytes:  u16 (T | pad << 11) | bit region, read DOWN from its top minus pad unused bits | L x 31-bit final states.
 constexpr int kRansStateBits = 31;
 constexpr int kRansTailMax = 2047;
-// A stream has 64 Q lanes: Q = 1, or Q = 2 ("wide" streams: two 64-symbol sub-chunks per step, decoded two lanes per symbol by
-// rans_decode_stage_pair_kernel, at the price of a tail twice as long).  Symbol n of a stage sits in chunk n / 64Q.
+// A stream has 64 Q lanes: Q = 1, Q = 2 ("wide" streams: two 64-symbol sub-chunks per step, decoded two lanes per symbol by
+// rans_decode_stage_pair_kernel, at the price of a tail twice as long) or Q = 4 ("xwide": 256 lanes, decoded ONE lane per symbol by
+// rans_decode_stage_lane_kernel, four wavefronts per stream).  Symbol n of a stage sits in chunk n / 64Q.
 template <int Q> struct RansGeo {
     static constexpr int kLanes = 64 * Q;
-    static constexpr int kPayBits = kLanes * kRansStateBits;      // 1984 / 3968: what the initial states carry (the tail stream)
-    static constexpr int kPayBytes = kPayBits / 8;                // 248 / 496
-    static constexpr int kPayDw = (kPayBits + 31) / 32;           // 62 / 124
+    static constexpr int kPayBits = kLanes * kRansStateBits;      // 1984 / 3968 / 7936: what the initial states carry (the tail stream)
+    static constexpr int kPayBytes = kPayBits / 8;                // 248 / 496 / 992
+    static constexpr int kPayDw = (kPayBits + 31) / 32;           // 62 / 124 / 248
     static constexpr int kMinStream = 2 + kPayBytes;              // T | pad, (empty bit region), states
 };
-constexpr int kRansPayBytesMax = RansGeo<2>::kPayBytes;
+constexpr int kRansPayBytesMax = RansGeo<4>::kPayBytes;
 
 __device__ __forceinline__ int lanes_below(uint64_t mask)
 {
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
             bp += step_total;
             const uint32_t xn = rans_push(x >> nb, lo, freq);
             x = active ? xn : x;
-            if (bp - 32 * wbase >= 2048) {                           // the window's lowest 64 dwords are complete (a step adds <= 1024 Q bits)
+            while (bp - 32 * wbase >= 2048) {                        // the window's lowest 64 dwords are complete (a step adds <= 1024 Q bits: Q = 4 may flush twice)
                 __syncthreads();
                 if (tid < 64) { if (wbase + 64 <= cap_dw) out32[wbase + tid] = sh_win[tid]; else bad = 2; }
                 const uint32_t up = sh_win[64 + tid];
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
         Raw r;
         const int n = min(64 * (m + k * M) + gsym, nc - 1);          // clamped: the loads are unconditional
         const int i = div_wc(sg, n), j = n - i * sg.wc;          // multiply-shift: a runtime division costs ~25 of the step's ~900 instructions
-        const float *par = params + ((long)b * sg.h * sg.w + (long)i * sg.w + j) * LLICTI_PARAM_STRIDE;
+        const ParRow par = par_row(params, b, (long)sg.h * sg.w, (long)i * sg.w + j);
         r.off = img + ((long)(2 * i + sg.oi) << sg.lvl) * sg.W + ((long)(2 * j + sg.oj) << sg.lvl);
         r.sgA = par[5 * clr + mA]; r.muA = par[16 + 5 * clr + mA]; r.wkA = par[32 + 5 * clr + mA];
         r.sgB = par[5 * clr + 4];  r.muB = par[16 + 5 * clr + 4];  r.wkB = par[32 + 5 * clr + 4];
@@ -648,7 +649,7 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_pair_kernel
         Raw r;
         const int n = min(L * (m + k * M) + gsym, nc - 1);           // clamped: the loads are unconditional
         const int i = div_wc(sg, n), j = n - i * sg.wc;
-        const float *par = params + ((long)b * sg.h * sg.w + (long)i * sg.w + j) * LLICTI_PARAM_STRIDE;
+        const ParRow par = par_row(params, b, (long)sg.h * sg.w, (long)i * sg.w + j);
         r.off = img + ((long)(2 * i + sg.oi) << sg.lvl) * sg.W + ((long)(2 * j + sg.oj) << sg.lvl);
         r.y = r.co = 0.0f;
 #pragma unroll
@@ -821,6 +822,203 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_pair_kernel
     }
 }
 
+// XWIDE streams (Q = 4, 256 lanes): ONE lane per symbol, one wavefront per 64 stream lanes -- four per workgroup, one per SIMD.
+// The stage decoders are bound by vector instructions ISSUED per symbol (a lone wavefront per SIMD issues one every ~4 cycles whatever
+// it does), and lanes that share a symbol spend them on each other: the pair kernel runs 12 approximate mixture evaluations (six ternary
+// rounds x two lanes) and two preparations per symbol, this kernel 9 (binary search) and one; the two exact entries c_low, c_high are the
+// same ten erfc either way.  ~26 instead of ~41 issued instructions per symbol.  What makes one lane per symbol possible without halving
+// the wavefronts per workgroup is the lane count of the STREAM (bytes are per stream, 0.06 bit per lane), and what makes it cheap is the
+// channel-planar `params` layout: a wavefront's 64 symbols are 64 consecutive positions, so every parameter load is one coalesced
+// 256-byte access whose address is scalar base + lane position.
+// Each wavefront owns the states of its 64 stream lanes (no copies): a step's symbols never leave their lane -- slot, search, c_low /
+// c_high and the state update all happen in it -- and the only exchange is the four wavefronts' bit totals (LDS, one barrier per step),
+// from which every lane knows where its bits start.  The stream's bits come from an LDS ring of 512 dwords (a step takes at most
+// 128), refilled 128 dwords at a time: requested at the end of a step, stored at the end of the next, used after the barrier that follows.
+template <int Q>
+__global__ __launch_bounds__(64 * Q) void rans_decode_stage_lane_kernel(const float *__restrict__ params, StageGeom sg, int M,
+                                                               const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
+                                                               int rslot_cap, uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos,
+                                                               const uint32_t *__restrict__ rtail,
+                                                               int16_t *__restrict__ planes, float *__restrict__ fplanes,
+                                                               const int32_t *__restrict__ minmax, int last_stage, int32_t *status)
+{
+    constexpr int L = 64 * Q;
+    constexpr int kRing = 512, kRefill = 128;    // dwords; a step consumes at most 16 L bits = L / 2 dwords
+    static_assert(L / 2 <= kRefill && kRing >= 4 * kRefill && 64 * Q >= kRefill, "ring sizing");
+    __shared__ uint32_t sh_ring[kRing];          // stream dword d at sh_ring[d & (kRing - 1)]
+    __shared__ int sh_tot[2][Q];                 // a step's bit totals per wavefront (ping-pong by step parity)
+    const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;      // tid = lane of the stream
+    const int nc = sg.hc * sg.wc;
+    const int nchunks = (nc + L - 1) / L;
+    if (nchunks <= m) return;                    // whole workgroup
+    const int K = (nchunks - m + M - 1) / M;
+    uint32_t x = rstate[(long)sidx * L + tid];
+    int bcur = (int)rpos[sidx];                  // bit cursor in the stream's bit region, moving DOWN
+    const uint32_t *bitw = reinterpret_cast<const uint32_t *>(slots + rslot_off[sidx] + 4);
+    const int max_dw = (rslot_cap - 4) >> 2;
+    auto load_dw = [&](int d) -> uint32_t { return bitw[min(max(d, 0), max_dw - 1)]; };
+    // ring window [wlo, wlo + kRing): everything a step can touch, dwords (bcur >> 5) - L / 2 .. (bcur >> 5) + 1, with two steps of slack below
+    int wlo = ((((bcur >> 5) + 2) + kRefill - 1) & ~(kRefill - 1)) - kRing;
+    for (int t = tid; t < kRing; t += L) sh_ring[(wlo + t) & (kRing - 1)] = load_dw(wlo + t);
+    uint32_t pf = 0;                             // a refill in flight: dwords [wlo, wlo + kRefill) of the NEW wlo, lanes 0 .. kRefill - 1
+    bool pend = false;
+    int badx = 0;                                // a lane saw a state below 2^15 after its update (clz > 16): malformed stream
+    int par = 0;                                 // step parity over the whole launch (sh_tot)
+    __syncthreads();
+
+    auto pass = [&](auto tag) {
+    constexpr int clr = decltype(tag)::value;    // compile-time: no branch next to the prefetch loads
+    const int tail_from = (last_stage && clr == 2) ? rans_stream_count(nc, m, M, L) - (int)rtail[sidx] : 0x7FFFFFFF;
+    int minv, maxv, shift;
+    clr_range(minmax + 4 * b, clr, minv, maxv, shift);
+    const Grid gr = make_grid(minv, maxv);
+    const int max_symbol = gr.Lp - 2;
+    const float fbase = (float)minv - 0.5f;
+    const long img = (long)b * 3 * sg.plane;
+    const long npos = (long)sg.h * sg.w;
+    struct Raw { float sg[5], mu[5], wk[5], a0[5], a1[5], y, co; long off; bool on; };
+    auto fetch = [&](int k) -> Raw {
+        Raw r;
+        const int n = min(L * (m + k * M) + tid, nc - 1);            // clamped: the loads are unconditional
+        const int i = div_wc(sg, n), j = n - i * sg.wc;
+        const ParRow prw = par_row(params, b, npos, (long)i * sg.w + j);
+        r.off = img + ((long)(2 * i + sg.oi) << sg.lvl) * sg.W + ((long)(2 * j + sg.oj) << sg.lvl);
+        r.y = r.co = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            r.sg[t] = prw[5 * clr + t]; r.mu[t] = prw[16 + 5 * clr + t]; r.wk[t] = prw[32 + 5 * clr + t];
+            r.a0[t] = r.a1[t] = 0.0f;
+            if constexpr (clr == 1) r.a0[t] = prw[48 + t];
+            else if constexpr (clr == 2) { r.a0[t] = prw[48 + 5 + t]; r.a1[t] = prw[48 + 10 + t]; }
+        }
+        if constexpr (clr == 1) r.y = fplanes[r.off];
+        else if constexpr (clr == 2) { r.y = fplanes[r.off]; r.co = fplanes[r.off + sg.plane]; }
+        r.on = (k < K) && (L * (m + k * M) + tid) < nc && (L * k + tid) < tail_from;
+        return r;
+    };
+    Raw cur = fetch(0);
+    for (int k = 0; k < K; ++k) {
+        const Raw nxt = fetch(min(k + 1, K - 1));
+        const uint32_t slot = x & 0xFFFFu;
+        uint32_t vlo = 0, vhi = 0x10000u;
+        if (cur.on) {
+            // the five components as mix_prepare() has them
+            float mu5[5], rs5[5], wn5[5], w5[5];
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                float mu = cur.mu[t];
+                if constexpr (clr == 1) { const float tt = cur.a0[t] * cur.y; mu = mu + tt; }
+                else if constexpr (clr == 2) { const float t1 = cur.a0[t] * cur.y; const float t2 = cur.a1[t] * cur.co; const float tt = t1 + t2; mu = mu + tt; }
+                mu5[t] = mu;
+                rs5[t] = 1.0f / ((cur.sg[t] > kScaleBound) ? cur.sg[t] : kScaleBound);
+                w5[t] = (cur.wk[t] > kWeightBound) ? cur.wk[t] : kWeightBound;
+            }
+            const float ssum = (((w5[0] + w5[1]) + w5[2]) + w5[3]) + w5[4];
+            const float den = 1e-9f + ssum;
+            CompFast F[5];
+#pragma unroll
+            for (int t = 0; t < 5; ++t) { wn5[t] = w5[t] / den; Comp cc; cc.mu = mu5[t]; cc.rsig = rs5[t]; cc.wn = wn5[t]; F[t] = comp_fast(cc); }
+
+            // 1. hint: binary search on the approximate table (probes 1 .. max_symbol: regular sample points only)
+            int glo = 0, ghi = max_symbol + 1;
+            while (ghi - glo > 1) {
+                const int pi = (glo + ghi) >> 1;
+                const float pt = div255_exact(fbase + (float)pi);
+                float sum = term_fast(F[0], pt);
+                sum += term_fast(F[1], pt);
+                sum += term_fast(F[2], pt);
+                sum += term_fast(F[3], pt);
+                sum += term_fast(F[4], pt);
+                const int e = (int)__builtin_rintf(sum * gr.scale) + pi;
+                const bool le = e <= (int)slot;
+                glo = le ? pi : glo;
+                ghi = le ? ghi : pi;
+            }
+            // exact table entry i, cdf_entry()'s operations in its order
+            auto entry_exact = [&](int i) -> uint32_t {
+                const float pt = sample_pt(gr, i);
+                const float t0 = wn5[0] * (0.5f * erfc_spec_nobranch(kNegRsqrt2 * ((pt - mu5[0]) * rs5[0])));
+                const float t1 = wn5[1] * (0.5f * erfc_spec_nobranch(kNegRsqrt2 * ((pt - mu5[1]) * rs5[1])));
+                const float t2 = wn5[2] * (0.5f * erfc_spec_nobranch(kNegRsqrt2 * ((pt - mu5[2]) * rs5[2])));
+                const float t3 = wn5[3] * (0.5f * erfc_spec_nobranch(kNegRsqrt2 * ((pt - mu5[3]) * rs5[3])));
+                const float t4 = wn5[4] * (0.5f * erfc_spec_nobranch(kNegRsqrt2 * ((pt - mu5[4]) * rs5[4])));
+                const float acc = (((t0 + t1) + t2) + t3) + t4;
+                return (uint32_t)((int)__builtin_rintf(acc * gr.scale) + i) & 0xFFFFu;
+            };
+            // 2. the two entries the state update needs anyway, entry[s] and entry[s + 1], are also the proof of the hint;
+            //    if it is off, gallop away from it and bisect with exact entries (bit-identical to an exact search whatever the hint was)
+            int lo = 0, hi = max_symbol + 1;
+            bool have_lo = false, have_hi = false;
+            {
+                const int s1 = glo, s2 = min(glo + 1, max_symbol);
+                const uint32_t eA = entry_exact(s1), eB = entry_exact(s2);
+                const bool leA = (s1 == 0) || (eA <= slot);              // entry 0 is the floor of the search (torchac: left = 0)
+                const bool leB = (s1 + 1 <= max_symbol) && (eB <= slot); // past the top symbol: c_high = 0x10000 by definition
+                if (leA) {
+                    lo = s1; vlo = eA; have_lo = true;
+                    if (leB) { lo = s2; vlo = eB; }
+                    else if (s1 + 1 <= max_symbol) { hi = s2; vhi = eB; have_hi = true; }
+                } else { hi = s1; vhi = eA; have_hi = true; }
+            }
+            int step = 2;
+            while (hi - lo > 1) {
+                int probe;
+                if (have_lo && have_hi) probe = (lo + hi) >> 1;
+                else if (have_lo) { probe = min(lo + step, hi - 1); step <<= 1; }
+                else { probe = max(hi - step, lo + 1); step <<= 1; }
+                const uint32_t e = entry_exact(probe);
+                if (e <= slot) { lo = probe; vlo = e; have_lo = true; } else { hi = probe; vhi = e; have_hi = true; }
+            }
+            if (!have_lo) vlo = entry_exact(0);
+            const int v = lo - shift;
+            planes[cur.off + (long)clr * sg.plane] = (int16_t)v;
+            fplanes[cur.off + (long)clr * sg.plane] = (float)v / 255.0f;
+        }
+        // state update of this lane, bit-granular renormalisation: lane l of the stream takes its clz(x) bits below those of lanes < l
+        int nb = 0;
+        if (cur.on) {
+            x = (vhi - vlo) * (x >> 16) + slot - vlo;                          // in [freq << 15, freq << 16)
+            const int lz = __clz((int)x);
+            badx |= lz > 16;                                                   // only a corrupt stream: the oracle rejects it too
+            nb = min(lz, 16);
+        }
+        const int incl = wave_incl_scan(nb);
+        if (lane == 63) sh_tot[par][wave] = incl;
+        __syncthreads();                                                       // (also: last step's ring refill is visible)
+        int below = 0, step_total = 0;
+#pragma unroll
+        for (int q2 = 0; q2 < Q; ++q2) { const int t2 = sh_tot[par][q2]; step_total += t2; below += (q2 < wave) ? t2 : 0; }
+        par ^= 1;
+        {
+            const int bpos = bcur - below - incl;                              // this lane's bits: [bpos, bpos + nb)
+            const int d = bpos >> 5;
+            const uint32_t w0 = sh_ring[d & (kRing - 1)], w1 = sh_ring[(d + 1) & (kRing - 1)];
+            const uint32_t bits = __builtin_amdgcn_alignbit(w1, w0, (uint32_t)(bpos & 31)) & ((1u << nb) - 1u);
+            x = (x << nb) | bits;
+        }
+        bcur -= step_total;
+        // ring: store the refill requested a step ago (its slots held dwords >= wlo + kRing: above anything this step's readers touch),
+        // then request the next one if fewer than two steps of dwords are left below the cursor
+        if (pend) { if (tid < kRefill) sh_ring[(wlo + tid) & (kRing - 1)] = pf; pend = false; }
+        if ((bcur >> 5) - 2 * kRefill < wlo) { wlo -= kRefill; if (tid < kRefill) pf = load_dw(wlo + tid); pend = true; }
+        cur = nxt;
+    }
+    };
+    // Between passes: the pixels a lane stored are loaded again by the SAME lane (same position) -- a workgroup-scope fence orders them
+    pass(std::integral_constant<int, 0>{});
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    pass(std::integral_constant<int, 1>{});
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    pass(std::integral_constant<int, 2>{});
+    rstate[(long)sidx * L + tid] = x;
+    const int anybad = __syncthreads_or(badx);
+    if (tid == 0) {
+        rpos[sidx] = (uint32_t)max(bcur, 0);
+        if (bcur < 0 || anybad) flag_image(status, b, LLICTI_EFORMAT);     // the stream ran out of bits, or a state fell out of [2^31, 2^32)
+    }
+}
+
 // After the last stage the 64 Q states of a stream ARE its tail stream (31 bits each, the tail coder's final state on top,
 // its leading one the highest set bit).  The T tail symbols -- all of the last stage's Cg channel (level 0, band x10) -- come out
 // of ONE coder state, serially; a lone wavefront spends ~540 instructions on a symbol and is bound by its own issue rate, so the
@@ -870,7 +1068,7 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead)) void rans_tail_kernel(const 
             const int q = min(max(cnt - T + t, 0), max(cnt - 1, 0));      // position in the stream's share of the last stage
             const int n = min(L * (m + (q / L) * M) + (q % L), nc - 1);
             const int pi = div_wc(sg, n), pj = n - pi * sg.wc;
-            const float *src = params + ((long)b * sg.h * sg.w + (long)pi * sg.w + pj) * LLICTI_PARAM_STRIDE;
+            const ParRow src = par_row(params, b, (long)sg.h * sg.w, (long)pi * sg.w + pj);
             r.off = img + ((long)(2 * pi + sg.oi) << sg.lvl) * sg.W + ((long)(2 * pj + sg.oj) << sg.lvl);
             r.sg = src[10 + mc]; r.mu = src[16 + 10 + mc]; r.wk = src[32 + 10 + mc];      // the Cg channel's sigma, mu, weight ...
             r.bb = src[48 + 5 + mc]; r.dd = src[48 + 10 + mc];                                // ... and its cross-channel factors

@@ -780,9 +780,9 @@ int orc_decode_image(const uint8_t *in, const int32_t seg_len[49], const orc_wei
 /* ------------------------------------------------------------------ rANS container "LLICTI-rANS v3" (see header) */
 typedef struct { long n; uint32_t *clow, *chigh; } stage_syms_t;
 
-#define RANS_MAX_LANES  128                             /* lanes of a stream: 64, or 128 ("wide" streams: two 64-symbol chunks per step) */
+#define RANS_MAX_LANES  256                             /* lanes of a stream: 64, 128 ("wide": two 64-symbol chunks per step) or 256 ("xwide": four) */
 #define RANS_STATE_BITS 31                              /* a lane state is 2^31 | 31 bits */
-#define RANS_MAX_PAY_BITS (RANS_MAX_LANES * RANS_STATE_BITS)   /* what the initial states carry (the tail stream): 1984 / 3968 bits */
+#define RANS_MAX_PAY_BITS (RANS_MAX_LANES * RANS_STATE_BITS)   /* what the initial states carry (the tail stream): 1984 / 3968 / 7936 bits */
 #define RANS_TAIL_MAX   2047
 
 static inline void put_bits(uint8_t *buf, long pos, int n, uint32_t v)      /* LSB first */
@@ -820,10 +820,13 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
                            uint8_t *out, long cap, int32_t seg_len[49])
 {
     if (H < 32 || W < 32 || H > 8160 || W > 8160) return -2;
-    const int wide = (M >> 8) & 1;                      /* M | 0x100: wide streams of 128 lanes (M <= 30) */
+    const int wide = (M >> 8) & 3;                      /* M | 0x100: wide streams of 128 lanes (M <= 14); M | 0x200: xwide streams of 256 lanes (M <= 14, 32, 64) */
     M &= 0xFF;
-    if (M < 1 || (M > 32 && M != 64 && M != 128) || (wide && M > 30)) return -2;
-    const int L = wide ? 128 : 64;
+    if (wide == 0 && (M < 1 || (M > 32 && M != 64 && M != 128))) return -2;
+    if (wide == 1 && (M < 1 || M > 14)) return -2;
+    if (wide == 2 && (M < 1 || (M > 14 && M != 32 && M != 64))) return -2;
+    if (wide == 3) return -2;
+    const int L = 64 << wide;
     const int PAY_BITS = L * RANS_STATE_BITS;
     const int G = M > 32 ? M / 32 : 1;                  /* streams per segment (the reference's list has 45 stream slots: 32 are used) */
     const long plane_sz = (long)H * W;
@@ -836,8 +839,10 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
     const int h4 = h, w4 = w;
     if (cap < 17 + 3L * h4 * w4) { free(planes); return -1; }
     for (int i = 0; i < 49; ++i) seg_len[i] = 0;
-    {   /* byte 0: bit 7 rANS, bit 3 format v3, bit 6 latency mode, bits 5,4,2,1,0 = v: M = v + 1 (<= 32), or 64 << v with bit 6 */
-        const int lat = M > 32 || wide, v = wide ? M + 1 : M > 32 ? (M == 64 ? 0 : 1) : M - 1;     /* extended: 0, 1 = 64 / 128 streams; 2 .. 31 = M + 1 wide streams */
+    {   /* byte 0: bit 7 rANS, bit 3 format v3, bit 6 extended, bits 5,4,2,1,0 = v: M = v + 1 (<= 32) streams of 64 lanes; extended: v = 0, 1:
+         * 64 / 128 streams of 64 lanes; 2 .. 15: v - 1 wide streams; 16 .. 29: v - 15 xwide streams; 30, 31: 32 / 64 xwide streams */
+        const int lat = M > 32 || wide;
+        const int v = wide == 2 ? (M == 32 ? 30 : M == 64 ? 31 : M + 15) : wide == 1 ? M + 1 : M > 32 ? (M == 64 ? 0 : 1) : M - 1;
         out[pos++] = (uint8_t)(0x88 | (lat << 6) | (((v >> 3) & 3) << 4) | (v & 7));
     }
     out[pos++] = (uint8_t)h4; out[pos++] = (uint8_t)w4;
@@ -973,9 +978,9 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
     if (seg_len[0] != 3 || seg_len[1] != 12 || seg_len[2] != 2) return -3;
     if ((in[0] & 0x88) != 0x88) return -4;                        /* bit 3 clear: the retired v2 format */
     const int tagv = (((in[0] >> 4) & 3) << 3) | (in[0] & 7);
-    const int ext = (in[0] >> 6) & 1, wide = ext && tagv >= 2;
-    const int M = ext ? (tagv == 0 ? 64 : tagv == 1 ? 128 : tagv - 1) : tagv + 1;
-    const int L = wide ? 128 : 64;
+    const int ext = (in[0] >> 6) & 1, wide = !ext || tagv < 2 ? 0 : tagv < 16 ? 1 : 2;
+    const int M = !ext ? tagv + 1 : tagv == 0 ? 64 : tagv == 1 ? 128 : tagv < 16 ? tagv - 1 : tagv == 30 ? 32 : tagv == 31 ? 64 : tagv - 15;
+    const int L = 64 << wide;
     const int PAY_BITS = L * RANS_STATE_BITS;
     const int G = M > 32 ? M / 32 : 1;
     int H, W;

@@ -114,8 +114,10 @@ long orc_stream_pairs(const int16_t *planes, int H, int W, const int16_t minmax[
 /* ---- rANS container ("LLICTI-rANS v3", a NEW format of this build: the reference has only torchac) ----
  * Same header segments except byte 0: bit 7 = rANS, bit 3 = format v3 (v2 had it clear and is rejected), bit 6 = extended, bits
  * 5,4,2,1,0 = v.  Not extended: M = v + 1 streams (1 .. 32) of L = 64 lanes.  Extended, v = 0 / 1: M = 64 / 128 streams of 64 lanes
- * (latency modes: M / 32 streams per segment behind a table of their u32 lengths).  Extended, v = 2 .. 31: M = v - 1 WIDE streams
- * (1 .. 30) of L = 128 lanes.
+ * (latency modes: M / 32 streams per segment behind a table of their u32 lengths).  Extended, v = 2 .. 15: M = v - 1 WIDE streams
+ * (1 .. 14) of L = 128 lanes.  Extended, v = 16 .. 29: M = v - 15 XWIDE streams (1 .. 14) of L = 256 lanes; v = 30 / 31: 32 / 64 xwide
+ * streams (64: two per segment behind the length table).  (Round 3 gave v = 2 .. 31 to 1 .. 30 wide streams; no container with more
+ * than 14 wide streams was ever written outside a test.)
  * Same CDFs, same symbols; the 45 torchac streams are replaced by M independent L-way interleaved rANS streams per image
  * (seg_len[4 .. 4+M-1], the rest 0).  Stage st (decode order) has nc symbols in cropped raster order; symbol n sits in chunk
  * n/L, lane n%L; chunk c belongs to stream c % M and is that stream's step c / M of the stage.
@@ -128,15 +130,15 @@ long orc_stream_pairs(const int16_t *planes, int H, int W, const int16_t minmax[
  *   tail       a lane's initial state carries payload instead of nothing: the stream's last T symbols of the LAST stage
  *              (sequence positions cnt-T .. cnt-1 of its cnt symbols there) are coded by a single-state coder of the same kind,
  *              last symbol first, the first pushed symbol starting from x = f << 15 (it codes to 2^31 + c_low without a bit);
- *              its bits go up from bit 0 of a 31 L-bit payload (1984 / 3968 bits), its final 32-bit state on top (leading one =
+ *              its bits go up from bit 0 of a 31 L-bit payload (1984 / 3968 / 7936 bits), its final 32-bit state on top (leading one =
  *              the payload's highest set bit).  T is maximal with 32 + bits <= 31 L (T <= 2047).  Lane l starts from 2^31 | payload
  *              bits [31 l, 31 l + 31).  After the last stage the decoder is left with exactly those states: it reassembles the payload,
  *              finds the tail state by its leading one, decodes the T symbols reading downwards, and must end with the tail
  *              coder's start state and no bit left (and the main region read to its last bit) -- the format's integrity check.
  *   stream     u16 LE (T | pad << 11, bits 14-15 zero) | bit region, LSB first, ceil(bits / 8) bytes, pad = unused zero bits on
- *              top of its last byte | L x 31-bit final states (low 31 bits of x_l at bit 31 l; 248 / 496 bytes).
- * Cost over the ideal code length: ~6 bytes per stream that has symbols (v2: ~60; wide: ~6.5), an empty stream 250 / 498.
- * M: streams per image, | 0x100 for wide streams.  Returns total bytes or <0. */
+ *              top of its last byte | L x 31-bit final states (low 31 bits of x_l at bit 31 l; 248 / 496 / 992 bytes).
+ * Cost over the ideal code length: ~6 bytes per stream that has symbols (v2: ~60; wide: ~6.5; xwide: ~7.5), an empty stream 250 / 498 / 994.
+ * M: streams per image, | 0x100 for wide streams, | 0x200 for xwide streams.  Returns total bytes or <0. */
 long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *wts, int M,
                            uint8_t *out, long cap, int32_t seg_len[49]);
 int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const orc_weights *wts,

@@ -40,10 +40,11 @@ for case in range(N):
         else:
             imgs.append(np.random.default_rng(seed).choice(np.array([0, 255], np.uint8), size=(3, H, W)))
     rgb = np.stack(imgs)
-    M = int(rng.choice([0, 1, 2, 3, 4, 8, 10, 11, 16, 32, 64, 128, -1, -5, -10, -30]))     # negative: |M| wide streams
-    wide, M = M < 0, abs(M)
+    M = int(rng.choice([0, 1, 2, 3, 4, 8, 10, 11, 16, 32, 64, 128, -1, -5, -10, -14, -1001, -1003, -1009, -1014, -1032, -1064]))     # negative: |M| wide streams, |M| - 1000 xwide streams
+    wide = 0 if M >= 0 else (2 if M <= -1000 else 1)
+    M = abs(M) % 1000
     mode = MODE_AC if M == 0 else MODE_RANS(M, wide)
-    tag = f"case {case}: {wname} x{scale} {kind} B={B} {W}x{H} M={M}{' wide' if wide else ''}"
+    tag = f"case {case}: {wname} x{scale} {kind} B={B} {W}x{H} M={M}{('', ' wide', ' xwide')[wide]}"
     codec = HipCodec("cuda:0")
     codec.load_state_dict(sd)
     W_o = orc.Weights(pack_state_dict(sd))
@@ -60,7 +61,7 @@ for case in range(N):
         ref = orc.encode_image(rgb[b], W_o) if M == 0 else orc.encode_image_rans(rgb[b], W_o, M, wide)
         assert container_to_bytestream_list(ch[b], sh[b]) == ref, "BYTES " + tag + f" image {b}"
     codec.close()
-    counts[f"container:{'ac' if M == 0 else ('wrans%d' if wide else 'rans%d') % M}"] += 1
+    counts[f"container:{'ac' if M == 0 else ('rans%d', 'wrans%d', 'xrans%d')[wide] % M}"] += 1
     counts[f"kind:{kind}"] += 1
     counts[f"weights:{wname}x{scale}"] += 1
     pixels += B * H * W

@@ -151,9 +151,9 @@ def test_cdf_table_kernel_adversarial_params(torch_mod, codecs):
               3: rng.uniform(0, 1, 15), 4: rng.uniform(0, 1, 15), 5: rng.uniform(0, 1, 15)}[k]
         par60[r, 0:15], par60[r, 15:30], par60[r, 30:45] = sig, mu, wt
         par60[r, 45:60] = rng.uniform(-1, 1, 15)
-    par64 = np.zeros((1, n, 4, 16), np.float32)
-    par64[0, :, :, :15] = par60.reshape(n, 4, 15)
-    params = _dev(torch, par64.reshape(1, n, 64))
+    par64 = np.zeros((1, 4, 16, n), np.float32)                    # channel-planar device layout: [B][64 planes][h * w]
+    par64[0, :, :15, :] = par60.reshape(n, 4, 15).transpose(1, 2, 0)
+    params = _dev(torch, par64.reshape(1, 64, h, w))
     for (mnco, mncg, mxco, mxcg) in ((-255, -255, 255, 255), (-3, -40, 5, 61), (0, -1, 0, 0)):
         mm2 = _dev(torch, np.array([[mnco, mncg, mxco, mxcg]], np.int32))
         for clr in range(3):
@@ -295,7 +295,7 @@ def test_rans_container_bitexact(torch_mod, codecs, oracle_weights, kind, H, W, 
 
 
 @pytest.mark.parametrize("kind,H,W,wname,M", [("smooth", 67, 93, "trainedlike", 1), ("noise", 128, 192, "rand1337", 10),
-                                              ("smooth", 150, 131, "trainedlike", 7), ("noise", 33, 250, "trainedlike", 30),
+                                              ("smooth", 150, 131, "trainedlike", 7), ("noise", 33, 250, "trainedlike", 14),
                                               ("smooth", 256, 384, "trainedlike", 5)])
 def test_rans_wide_container_bitexact(torch_mod, codecs, oracle_weights, kind, H, W, wname, M):
     """Wide streams (128 lanes per stream, two 64-symbol chunks per coder step): HIP bytes == oracle bytes, both decoders invert
@@ -324,6 +324,41 @@ def test_rans_wide_container_bitexact(torch_mod, codecs, oracle_weights, kind, H
         c.check()
 
 
+@pytest.mark.parametrize("kind,H,W,wname,M,B", [("smooth", 67, 93, "trainedlike", 1, 2), ("noise", 128, 192, "rand1337", 9, 2),
+                                                ("smooth", 150, 131, "trainedlike", 7, 3), ("noise", 33, 250, "trainedlike", 14, 2),
+                                                ("smooth", 256, 384, "trainedlike", 5, 2), ("noise", 250, 131, "rand1337", 32, 1),
+                                                ("smooth", 512, 768, "trainedlike", 64, 1), ("noise", 512, 768, "rand1337", 9, 2)])
+def test_rans_xwide_container_bitexact(torch_mod, codecs, oracle_weights, kind, H, W, wname, M, B):
+    """XWIDE streams (256 lanes per stream, ONE decoder lane per symbol: rans_decode_stage_lane_kernel): HIP bytes == oracle bytes, both
+    decoders invert it (the HIP one on a poisoned workspace, whose LDS bit ring is refilled from the stream one step ahead), and the
+    container is only accepted in the mode its header names.  Shapes: coded crops narrower than the band grid, stages shorter than one
+    chunk, a stage that ends mid-chunk, 64 streams (two per segment), a full-size image (the ring is refilled ~60 times per stream)."""
+    from oracle import oracle as orc
+    from llicti_amd._lib import LlictiError
+    from llicti_amd.codec import MODE_RANS, container_to_bytestream_list, mode_of_header
+    torch = torch_mod
+    c = codecs(wname)
+    W_o = oracle_weights(wname)
+    rgb = make_batch(kind, B, H, W, seed0=90)
+    mode = MODE_RANS(M, wide=2)
+    cont, seg = c.encode(_dev(torch, rgb), mode=mode)
+    c.check()
+    cont_h, seg_h = cont.cpu().numpy(), seg.cpu().numpy()
+    assert mode_of_header(int(cont_h[0, 0])) == mode
+    for b in range(B):
+        bl = container_to_bytestream_list(cont_h[b], seg_h[b])
+        assert bl == orc.encode_image_rans(rgb[b], W_o, M, wide=2)
+        if b == 0:
+            assert np.array_equal(orc.decode_image_rans(bl, W_o), rgb[b])
+        assert sum(1 for row in bl[1:] for x in row if len(x)) == (32 if M == 64 else M)
+    rec = _decode_poisoned(c, cont, seg, H, W, mode)
+    assert np.array_equal(rec.cpu().numpy(), rgb)
+    if M <= 14:
+        c.decode(cont, seg, H, W, mode=MODE_RANS(M, wide=1))    # same M, wide streams: another container
+        with pytest.raises(LlictiError):
+            c.check()
+
+
 def test_rans_v3_known_answer_hip(torch_mod, codecs):
     """The committed known-answer vectors of the rANS v3 container (tests/golden/rans_v3_vectors.npz, frozen by
     test_rans_v3_known_answer on the CPU): the HIP encoder reproduces the stored bytes, the HIP decoder turns the stored bytes
@@ -337,7 +372,7 @@ def test_rans_v3_known_answer_hip(torch_mod, codecs):
         c = codecs(wname)
         rgb = load_case(case)["rgb"]
         H, W = rgb.shape[1:]
-        for key, mode in (("M1", MODE_RANS(1)), ("M4", MODE_RANS(4)), ("W3", MODE_RANS(3, wide=True))):
+        for key, mode in (("M1", MODE_RANS(1)), ("M4", MODE_RANS(4)), ("W3", MODE_RANS(3, wide=True)), ("X3", MODE_RANS(3, wide=2))):
             want, lens = vec[f"{case}_{key}_bytes"], vec[f"{case}_{key}_seglen"]
             seg_want = np.concatenate([lens[:4], lens[9:]]).astype(np.int32)        # bytestream_list rows of 9 -> the 49 segments
             cont, seg = c.encode(_dev(torch, rgb[None]), mode=mode)
@@ -671,7 +706,8 @@ def _decode_poisoned(c, cont, seg, H, W, mode=0):
 
 @pytest.mark.parametrize("mode_name,B,H,W", [("ac", 3, 128, 192), ("ac", 2, 250, 131), ("ac_anchors", 3, 128, 192),
                                              ("ac_anchors", 2, 250, 131), ("rans4", 3, 128, 192),
-                                             ("rans16", 2, 250, 131), ("rans1", 2, 67, 93), ("wrans3", 3, 128, 192)])
+                                             ("rans16", 2, 250, 131), ("rans1", 2, 67, 93), ("wrans3", 3, 128, 192), ("xrans3", 3, 128, 192),
+                                             ("xrans9", 2, 250, 131)])
 def test_decode_on_poisoned_workspace(torch_mod, codecs, mode_name, B, H, W):
     """Losslessness of the PIPELINED decoders (3-stream AC chunk pipeline with ac_chunks() > 1, rANS next-step
     prefetch, CNN halo / odd-edge clamps), with B > 1: the workspace is overwritten with 0xA5 between encode and
@@ -903,7 +939,7 @@ def test_full_size_oracle_parity(torch_mod, codecs, oracle_weights):
     c.check()
     cont_h, seg_h = cont.cpu().numpy(), seg.cpu().numpy()
     for b in (0, 11, 23):
-        ref = orc.encode_image(rgb[b], W_o) if mode == 0 else orc.encode_image_rans(rgb[b], W_o, mode & 0xFF, (mode & ~0xFF) == 0x300)
+        ref = orc.encode_image(rgb[b], W_o) if mode == 0 else orc.encode_image_rans(rgb[b], W_o, mode & 0xFF, ((mode & ~0xFF) - 0x100) // 0x200)
         assert container_to_bytestream_list(cont_h[b], seg_h[b]) == ref, (name, b)
     rec = _decode_poisoned(c, cont, seg, H, W, mode)
     assert np.array_equal(rec.cpu().numpy(), rgb)
@@ -944,27 +980,37 @@ def test_configs4_per_gpu_batch_oracle_parity(torch_mod, codecs, oracle_weights)
     cont, seg = c.encode(_dev(torch, rgb), mode=mode)
     c.check()
     b = 29
-    ref = orc.encode_image(rgb[b], W_o) if mode == 0 else orc.encode_image_rans(rgb[b], W_o, mode & 0xFF, (mode & ~0xFF) == 0x300)
+    ref = orc.encode_image(rgb[b], W_o) if mode == 0 else orc.encode_image_rans(rgb[b], W_o, mode & 0xFF, ((mode & ~0xFF) - 0x100) // 0x200)
     assert container_to_bytestream_list(cont[b].cpu().numpy(), seg[b].cpu().numpy()) == ref, name
     rec = _decode_poisoned(c, cont, seg, H, W, mode)
     assert np.array_equal(rec.cpu().numpy(), rgb)
 
 
 def test_4k_image_oracle_parity(torch_mod, codecs, oracle_weights):
-    """BASELINE.json configs[3] against the oracle: one 3840x2160 uniform-noise image (bench.py's image_4k leg) in the rANS32
-    container, HIP bytes == oracle bytes (about a minute of CPU: the oracle evaluates 24.9 M symbols), lossless."""
+    """BASELINE.json configs[3] against the oracle: one 3840x2160 uniform-noise image (bench.py's image_4k leg) in the container that
+    leg's HEADLINE uses (bench.IMAGE_4K_HEADLINE: the fastest mode within 0.001 bpp of the reference format -- 64 xwide streams), HIP bytes
+    == oracle bytes (about a minute of CPU: the oracle evaluates 24.9 M symbols), lossless on a poisoned workspace, and inside the budget
+    against the reference-format container of the same image (whose bytes are the oracle's too)."""
+    import bench
     from oracle import oracle as orc
-    from llicti_amd.codec import MODE_RANS, container_to_bytestream_list
+    from llicti_amd.codec import container_to_bytestream_list, mode_of_name
     torch = torch_mod
     c = codecs("rand1337")
     W_o = oracle_weights("rand1337")
     rgb = np.random.default_rng(0).integers(0, 256, size=(1, 3, 2160, 3840), dtype=np.uint8)
-    cont, seg = c.encode(_dev(torch, rgb), mode=MODE_RANS(32))
+    mode = mode_of_name(bench.IMAGE_4K_HEADLINE)
+    cont, seg = c.encode(_dev(torch, rgb), mode=mode)
     c.check()
     got = container_to_bytestream_list(cont[0].cpu().numpy(), seg[0].cpu().numpy())
-    assert got == orc.encode_image_rans(rgb[0], W_o, 32)
-    rec = _decode_poisoned(c, cont, seg, 2160, 3840, MODE_RANS(32))
+    ref = orc.encode_image_rans(rgb[0], W_o, mode & 0xFF, ((mode & ~0xFF) - 0x100) // 0x200)
+    assert got == ref
+    rec = _decode_poisoned(c, cont, seg, 2160, 3840, mode)
     assert np.array_equal(rec.cpu().numpy(), rgb)
+    n_timed = int(seg.sum().item())
+    cont_a, seg_a = c.encode(_dev(torch, rgb))
+    c.check()
+    dbpp = 8.0 * (n_timed - int(seg_a.sum().item())) / (2160 * 3840)
+    assert abs(dbpp) <= 0.001, f"{bench.IMAGE_4K_HEADLINE}: {dbpp:+.6f} bpp against the reference-format container"
 
 
 @pytest.mark.parametrize("wname,kind", [("rand1337", "noise"), ("trainedlike", "smooth")])
@@ -994,7 +1040,7 @@ def test_ac_anchor_decoder_many_images_and_edges(torch_mod, codecs, oracle_weigh
     assert np.array_equal(rec.cpu().numpy(), edge)
 
 
-@pytest.mark.parametrize("wide", [False, True])
+@pytest.mark.parametrize("wide", [0, 1, 2])
 def test_rans_v3_integrity_check_detects_corruption(torch_mod, codecs, oracle_weights, wide):
     """rANS v3 ends with three known quantities: the main bit region is read to its last bit, and the tail coder (whose
     stream is what the 64 lane states are left with) returns to its start state 2^31 with no bit left.  A corrupted stream
@@ -1014,7 +1060,7 @@ def test_rans_v3_integrity_check_detects_corruption(torch_mod, codecs, oracle_we
     seg_h = seg.cpu().numpy()
     hdr = int(seg_h[1, :4].sum())
     s0 = int(seg_h[1, 4])
-    pay = 496 if wide else 248                     # bytes of the final states: 64 / 128 lanes x 31 bits
+    pay = 248 << int(wide)                         # bytes of the final states: 64 / 128 / 256 lanes x 31 bits
     # a bit of the bit region | a final state | the tail count | the last byte of the bit region
     for where, val in ((hdr + 2 + 400, 0x10), (hdr + s0 - 100, 0x04), (hdr, 0x01), (hdr + s0 - pay - 1, 0xFF)):
         bad = cont.clone()

@@ -81,8 +81,12 @@ def test_workspace_and_container_bounds():
     assert L.llicti_workspace_bytes(1, 512, 768, 7) == 0
     # wide streams (128 lanes): M in 1 .. 30
     assert L.llicti_workspace_bytes(24, 512, 768, 0x300 | 10) > L.llicti_workspace_bytes(24, 512, 768, 0x100 | 10)
-    assert L.llicti_workspace_bytes(1, 512, 768, 0x300 | 30) > 0
-    assert L.llicti_workspace_bytes(1, 512, 768, 0x300 | 31) == 0 and L.llicti_workspace_bytes(1, 512, 768, 0x300) == 0
+    assert L.llicti_workspace_bytes(1, 512, 768, 0x300 | 14) > 0
+    assert L.llicti_workspace_bytes(1, 512, 768, 0x300 | 15) == 0 and L.llicti_workspace_bytes(1, 512, 768, 0x300) == 0
+    # xwide streams (256 lanes): 1 .. 14, 32, 64
+    assert L.llicti_workspace_bytes(24, 512, 768, 0x500 | 9) > L.llicti_workspace_bytes(24, 512, 768, 0x300 | 9)
+    assert L.llicti_workspace_bytes(1, 512, 768, 0x500 | 64) > 0 and L.llicti_workspace_bytes(1, 512, 768, 0x500 | 32) > 0
+    assert L.llicti_workspace_bytes(1, 512, 768, 0x500 | 15) == 0 and L.llicti_workspace_bytes(1, 512, 768, 0x500 | 128) == 0 and L.llicti_workspace_bytes(1, 512, 768, 0x700 | 4) == 0
     assert L.llicti_workspace_bytes(1, 512, 768, 0x200 | 4) == 0
 
 

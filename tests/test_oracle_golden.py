@@ -157,7 +157,7 @@ def test_rans_container_oracle_roundtrip(M, oracle_weights):
 
 def test_rans_v3_known_answer(oracle_weights):
     """The rANS v3 container is a format of this build (no reference counterpart to pin it to), so it is frozen by known-answer
-    vectors: tests/golden/rans_v3_vectors.npz holds the container bytes for three fixture images x {M = 1, M = 4, 3 wide streams}
+    vectors: tests/golden/rans_v3_vectors.npz holds the container bytes for three fixture images x {M = 1, M = 4, 3 wide streams, 3 xwide streams}
     (make_rans_v3_vectors.py).  The oracle must reproduce them byte for byte -- a changed byte is a changed format and needs a new
     version bit -- and decode them back to the fixture's pixels; the GPU suite holds the HIP path to the oracle."""
     import hashlib
@@ -167,7 +167,7 @@ def test_rans_v3_known_answer(oracle_weights):
     for case, wname in [("smooth_67x93_tl", "trainedlike"), ("noise_32x32_rand", "rand1337"), ("noise_33x64_tl", "trainedlike")]:
         rgb = load_case(case)["rgb"]
         W = oracle_weights(wname)
-        for key, M, wide, tag in (("M1", 1, False, 0x88), ("M4", 4, False, 0x8B), ("W3", 3, True, 0xCC)):
+        for key, M, wide, tag in (("M1", 1, 0, 0x88), ("M4", 4, 0, 0x8B), ("W3", 3, 1, 0xCC), ("X3", 3, 2, 0xEA)):
             want = vec[f"{case}_{key}_bytes"].tobytes()
             assert hashlib.sha256(want).digest() == vec[f"{case}_{key}_sha256"].tobytes()
             bl = orc.encode_image_rans(rgb, W, M, wide)
@@ -184,16 +184,16 @@ def test_rans_v3_known_answer(oracle_weights):
             assert np.array_equal(orc.decode_image_rans(bl2, W), rgb)
 
 
-@pytest.mark.parametrize("M", [1, 5, 10, 30])
+@pytest.mark.parametrize("M", [1, 5, 10, 14])
 def test_rans_wide_container_oracle_roundtrip(M, oracle_weights):
     """Wide streams (128 lanes, header byte 0 = extended tag with v = M + 1): lossless; a stream's 128 x 31-bit states cost 496 bytes
     when it has no symbols, about 7 bytes over the ideal length when it has; a wide container of M streams is never mistaken for a
-    narrow one (the tags differ) and M = 31, 32 do not exist."""
+    narrow one (the tags differ) and M = 15 .. 32 do not exist (round 4 gave their tags to the xwide streams)."""
     from llicti_amd.codec import MODE_RANS, mode_of_header, rans_tag
     c = load_case("smooth_67x93_tl")
     W = oracle_weights("trainedlike")
     bl = orc.encode_image_rans(c["rgb"], W, M, wide=True)
-    assert bl[0][0][0] == rans_tag(M, wide=True) == {1: 0xCA, 5: 0xCE, 10: 0xDB, 30: 0xFF}[M]
+    assert bl[0][0][0] == rans_tag(M, wide=True) == {1: 0xCA, 5: 0xCE, 10: 0xDB, 14: 0xDF}[M]
     assert mode_of_header(bl[0][0][0]) == MODE_RANS(M, wide=True) == (0x300 | M)
     assert np.array_equal(orc.decode_image_rans(bl, W), c["rgb"])
     n_ac = sum(len(x) for row in orc.encode_image(c["rgb"], W) for x in row)
@@ -201,8 +201,41 @@ def test_rans_wide_container_oracle_roundtrip(M, oracle_weights):
     assert -64 <= n_r - n_ac <= 510 * M + 64
     if M == 1:
         assert n_r - n_ac <= 10
+    for bad in (15, 30, 31):
+        with pytest.raises(RuntimeError):
+            orc.encode_image_rans(c["rgb"], W, bad, wide=True)
+
+
+@pytest.mark.parametrize("M,case,wname", [(1, "smooth_67x93_tl", "trainedlike"), (9, "noise_67x93_rand", "rand1337"), (14, "smooth_64x48_tl", "trainedlike"),
+                                          (32, "noise_33x64_tl", "trainedlike"), (64, "smooth_67x93_tl", "trainedlike")])
+def test_rans_xwide_container_oracle_roundtrip(M, case, wname, oracle_weights):
+    """XWIDE streams (256 lanes; header byte 0 = extended tag with v = M + 15, 30 / 31 for 32 / 64 streams, 64 = two per segment): lossless;
+    a stream's 256 x 31-bit states cost 992 bytes when it has no symbols, about 8 bytes over the ideal length when it has; the tags of
+    narrow, wide and xwide containers are disjoint; M = 15 .. 31 and 128 do not exist."""
+    from llicti_amd.codec import MODE_RANS, mode_of_header, mode_of_name, name_of_mode, rans_tag
+    c = load_case(case)
+    W = oracle_weights(wname)
+    bl = orc.encode_image_rans(c["rgb"], W, M, wide=2)
+    assert bl[0][0][0] == rans_tag(M, wide=2) == {1: 0xE8, 9: 0xF8, 14: 0xFD, 32: 0xFE, 64: 0xFF}[M]
+    assert mode_of_header(bl[0][0][0]) == MODE_RANS(M, wide=2) == (0x500 | M) == mode_of_name(f"xrans{M}")
+    assert name_of_mode(0x500 | M) == f"xrans{M}"
+    assert np.array_equal(orc.decode_image_rans(bl, W), c["rgb"])
+    assert sum(1 for row in bl[1:] for x in row if len(x)) == (32 if M == 64 else M)
+    n_ac = sum(len(x) for row in orc.encode_image(c["rgb"], W) for x in row)
+    n_r = sum(len(x) for row in bl for x in row)
+    assert -64 <= n_r - n_ac <= 1006 * M + 64
+    if M == 1:
+        assert n_r - n_ac <= 12
+    # a flipped payload byte is caught by the tail coder's end condition
+    flat = bytearray(bl[1][0])
+    flat[len(flat) // 2] ^= 0x10
+    bad = [list(r) for r in bl]
+    bad[1][0] = bytes(flat)
     with pytest.raises(RuntimeError):
-        orc.encode_image_rans(c["rgb"], W, 31, wide=True)
+        orc.decode_image_rans(bad, W)
+    for badM in (15, 31, 128):
+        with pytest.raises(RuntimeError):
+            orc.encode_image_rans(c["rgb"], W, badM, wide=2)
 
 
 @pytest.mark.parametrize("case,wname", [("fwd_smooth_64x96_tl", "trainedlike"), ("fwd_noise_32x64_rand", "rand1337")])
