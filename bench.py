@@ -46,20 +46,19 @@ MAC_PER_POSITION = 193248            # 84,480 layer-0 
 PEAK_FP32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_HBM_GBS = 8000.0
 DEFAULT_CONTAINER = "auto"           # rANS v3, xwide streams (256 lanes), default_streams(batch) of them per image, see below
-MAX_STREAMS_IN_BUDGET = 9            # an xwide v3 stream costs ~8 bytes: 9 per 768x512 image are +0.0009 bpp over the reference-format container (m_sweep)
+MAX_STREAMS_IN_BUDGET = 9            # = llicti_amd.codec.MAX_STREAMS_IN_BUDGET: an xwide v3 stream costs ~8 bytes: 9 per 768x512 image are +0.0009 bpp over the reference-format container (m_sweep)
 
 
 def default_streams(B, n_cu=256):
-    """Streams per image of the timed container: as many as keep ONE decoder workgroup per stream on its own compute unit
-    (B * M <= CUs: a second workgroup on a CU slows both by 1.4x, so more streams than that buy nothing) and stay inside the north
-    star's 0.001 bpp (<= 9 per 768x512 image).  24 images on a 256-CU MI355X: 9; 32 images (configs[4] per GPU): 8.
-    The streams are XWIDE (256 lanes, four decoder wavefronts, ONE lane per symbol): lanes are nearly free in bytes (0.06 bit each),
-    streams are not (~8 bytes each), and one lane per symbol is the fewest vector instructions per symbol a stage decoder can run."""
-    return max(1, min(MAX_STREAMS_IN_BUDGET, n_cu // max(1, B)))
+    """Streams per image of the timed container (llicti_amd.codec.auto_streams: what LLICTI(config.container = "auto") and the batched
+    LLICTIAgent.eval_model use too): one decoder workgroup per stream on its own compute unit, at most MAX_STREAMS_IN_BUDGET."""
+    from llicti_amd.codec import auto_streams
+    return auto_streams(B, n_cu)
 
 
 def default_container(B, n_cu=256):
-    return f"xrans{default_streams(B, n_cu)}"
+    from llicti_amd.codec import auto_container
+    return auto_container(B, n_cu)
 NORTH_STAR_MPIX_S = 200.0            # BASELINE.json north_star: >= 200 MPix/s encode+decode on 768x512 at 1 MI355X ...
 NORTH_STAR_DBPP = 0.001              # ... with bpp within 0.001 of the reference
 MAC_PER_BAND = (352 * 48 + 30976 + 5280, 352 * 72 + 30976 + 5280, 352 * 120 + 30976 + 5280)   # layer 0 (K = 48 / 72 / 120) + 4 x 88 x 88 + 4 x 15 x 88
@@ -484,6 +483,49 @@ def natural_like_leg(torch, dev, B, H, W, mode):
     return r
 
 
+def api_path_leg(torch, dev, B, H, W, n_images=240):
+    """the measured throughput THROUGH the drop-in API.  `n_images` synthetic images (in host memory, uint8) go through
+    LLICTIAgent.eval_model with config.eval_batch = B and config.container = "auto": per batch H2D of the uint8 RGB, encode, D2H of the
+    containers, container -> the reference's bytestream_list (6 lists x 9 `bytes` per image), rate bookkeeping, bytestream_list -> container,
+    H2D, decode, the lossless check and the per-image log line -- everything eval_model does (agents/llicti_agent.py:122-164) inside one
+    wall clock, the host half of batch k overlapped with the GPU half of batch k + 1.  Beside it the one-image loop in the default
+    (reference-format) container on a few images: what a caller gets who changes nothing but the import."""
+    import logging
+    import numpy as np
+    from llicti_amd.agents.llicti_agent import LLICTIAgent
+    from llicti_amd.config import default_config
+    logging.getLogger("Agent").setLevel(logging.WARNING)           # 240 log lines are formatted, not printed
+    imgs = [np.random.default_rng(1000 + i).integers(0, 256, size=(3, H, W), dtype=np.uint8) for i in range(n_images)]
+    out = {"workload": f"{n_images} x {W}x{H} uniform-noise RGB through LLICTIAgent.eval_model, eval_batch = {B}, container auto, wall clock incl. transfers, "
+                       "container <-> bytestream_list, rates, lossless check, log lines"}
+    agent = LLICTIAgent(default_config(test_data=imgs[:2 * B], eval_batch=B, container="auto"))
+    agent.run()                                                   # warm-up: plans, workspaces, pinned staging buffers
+    agent.config["test_data"] = imgs
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = agent.run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert len(res) == n_images and all(r["max_abs_err"] == 0.0 for r in res)
+    out["batched"] = {"mpix_s": round(n_images * H * W / dt / 1e6, 2), "wall_s": round(dt, 4), "ms_per_image": round(dt / n_images * 1e3, 3),
+                      "bpsp": round(float(np.mean([r["bpsp"] for r in res])), 5), "container": agent.model.container,
+                      "gpu_enc_ms_per_image": round(float(np.mean([r["enc_s"] for r in res])) * 1e3, 3),
+                      "gpu_dec_ms_per_image": round(float(np.mean([r["dec_s"] for r in res])) * 1e3, 3)}
+    del agent
+    a1 = LLICTIAgent(default_config(test_data=imgs[:1]))
+    a1.run()
+    a1.config["test_data"] = imgs[:3]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r1 = a1.run()
+    torch.cuda.synchronize()
+    dt1 = time.perf_counter() - t0
+    out["one_image_default_container"] = {"mpix_s": round(3 * H * W / dt1 / 1e6, 3), "ms_per_image": round(dt1 / 3 * 1e3, 2), "container": a1.model.container,
+                                          "enc_s": round(float(np.mean([r["enc_s"] for r in r1])), 4), "dec_s": round(float(np.mean([r["dec_s"] for r in r1])), 4)}
+    logging.getLogger("Agent").setLevel(logging.NOTSET)
+    return out
+
+
 def table_kernel_roofline(codec, torch, H=2160, W=3840):
     """BASELINE.json configs[3]: one 3840x2160 image, the full-table CDF kernel (the reference's get_cdfs +
     _convert_to_int_and_normalize, LLICTI_nets.py:938-983) at level 0 -- HBM-write bound by construction.
@@ -793,6 +835,7 @@ def main(argv=None):
                                 "headline_is_tested_mode": bool(best == IMAGE_4K_HEADLINE), "ac": r4k_ac, **modes4k}
         del big
         legs.free()
+        legs_out["api_path"] = api_path_leg(torch, dev, B, H, W)
         legs_out["overlapped_streams"] = overlap_leg(torch, dev, sd, rgb, mode)
         legs_out["natural_like"] = natural_like_leg(torch, dev, B, H, W, mode)
         torch.cuda.empty_cache()

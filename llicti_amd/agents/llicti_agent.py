@@ -20,20 +20,31 @@ from ..loggers.rate import RateLogger
 from ..weights import load_reference_state_dict
 
 
-def _iter_test_images(config, device):
-    """Test loader, batch 1, no crop (dataloaders/image_dl.py:40-45, :106-111): float32 1x3xHxW = uint8/255.
-    `test_data` is a directory of .png/.jpg or "synthetic:HxWxN" (seeded uniform RGB)."""
+def _iter_test_images_u8(config):
+    """The test images as uint8 [3,H,W] host arrays (the batched eval path uploads uint8: a quarter of the float32 bytes)."""
     src = config.test_data
-    if isinstance(src, str) and src.startswith("synthetic:"):
+    if not isinstance(src, str):                       # an in-memory data set: any iterable of uint8 [3,H,W] arrays
+        for rgb in src:
+            rgb = np.asarray(rgb)
+            if rgb.dtype != np.uint8 or rgb.ndim != 3 or rgb.shape[0] != 3:
+                raise ValueError("in-memory test_data must yield uint8 [3, H, W] arrays")
+            yield rgb
+        return
+    if src.startswith("synthetic:"):
         H, W, N = (int(v) for v in src.split(":")[1].split("x"))
         for i in range(N):
-            rgb = np.random.default_rng(i).integers(0, 256, size=(3, H, W), dtype=np.uint8)
-            yield torch.from_numpy(rgb.astype(np.float32) / np.float32(255)).unsqueeze(0).to(device)
+            yield np.random.default_rng(i).integers(0, 256, size=(3, H, W), dtype=np.uint8)
         return
     from ..fileio import read_image
-    names = sorted(f for f in os.listdir(src) if f.lower().endswith((".png", ".jpg", ".ppm")))
-    for f in names:
-        rgb = read_image(os.path.join(src, f))
+    for f in sorted(f for f in os.listdir(src) if f.lower().endswith((".png", ".jpg", ".ppm"))):
+        yield read_image(os.path.join(src, f))
+
+
+def _iter_test_images(config, device):
+    """Test loader, batch 1, no crop (dataloaders/image_dl.py:40-45, :106-111): float32 1x3xHxW = uint8/255.
+    `test_data` is a directory of .png/.jpg/.ppm, "synthetic:HxWxN" (seeded uniform RGB) or an in-memory
+    iterable of uint8 [3,H,W] arrays."""
+    for rgb in _iter_test_images_u8(config):
         yield torch.from_numpy(rgb.astype(np.float32) / np.float32(255)).unsqueeze(0).to(device)
 
 
@@ -113,12 +124,118 @@ class LLICTIAgent:
         rate, rate2 = self.valid_logger.display(lr=0.0, typ="va")
         return float(rate + rate2)
 
+    def _log_image(self, idx, H, W, bpsp, enc_time, dec_time, maxx_abserr):
+        """The reference's per-image line (llicti_agent.py:154-162), unchanged."""
+        print_text = "{:3d} {:3d}x{:3d} ".format(idx, H, W)
+        if maxx_abserr >= 0.5:
+            self.logger.info(print_text + "bpsp= {:.3f} Enc/Dec-Times:{:.3f}/{:.3f} "
+                             "(Error: Decoded img does NOT match original image perfectly! "
+                             "The maximum of absolute error is {:.4f})".format(bpsp, enc_time, dec_time, maxx_abserr))
+        else:
+            self.logger.info(print_text + "bpsp= {:.3f} Enc/Dec-Times:{:.3f}/{:.3f} "
+                             "(Check: Decoded img matches original)".format(bpsp, enc_time, dec_time))
+
+    @torch.no_grad()
+    def eval_model_batched(self, eval_batch):
+        """eval_model for throughput: consecutive test images of one size are coded `eval_batch` at a time through
+        LLICTI.encode_batch_async / decode_batch_async -- the same bytestream_lists, rates, lossless check and per-image log lines as
+        the one-image loop (llicti_agent.py:122-164), in the same order.  The loop is software-pipelined one batch deep: while the GPU
+        encodes batch k + 1 the host cuts batch k's containers into bytestream_lists, books their rates and packs them again for the
+        decoder, so neither side waits for the other.  Enc/Dec-Times of an image are its batch's GPU time (HIP events around the
+        enqueued calls, transfers included) divided by the batch size.  With config.keep_streams the lists stay in self.results."""
+        self.model.eval()
+        self.results = []
+        keep = bool(self.config["keep_streams"]) if "keep_streams" in self.config else False
+        stream = torch.cuda.current_stream(self.device)
+
+        def batches():
+            cur = []
+            for rgb in _iter_test_images_u8(self.config):
+                if cur and (rgb.shape != cur[0].shape or len(cur) == eval_batch):
+                    yield cur
+                    cur = []
+                cur.append(rgb)
+            if cur:
+                yield cur
+
+        def start_encode(imgs, slot):
+            B = len(imgs)
+            host = self.model._pinned(("rgb_in", slot), (B,) + imgs[0].shape, torch.uint8)
+            np.stack(imgs, out=host.numpy())
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            enc = self.model.encode_batch_async(host.to(self.device, non_blocking=True), slot=slot)
+            e1.record(stream)
+            return {"enc": enc, "e_enc": (e0, e1), "B": B, "H": imgs[0].shape[1], "W": imgs[0].shape[2]}
+
+        def finish(job, idx0):
+            """host half of a batch: lists, rates, decode enqueue; then (synchronising) the lossless check and the log lines"""
+            enc = job["enc"]
+            lists = enc.lists(check=False)
+            numel = 3 * job["H"] * job["W"]
+            rates = [self.compr_loss.forward(numel, bl) for bl in lists]
+            d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            d0.record(stream)
+            rec = self.model.decode_batch_async(lists, self.device, slot=job["slot"])
+            err = (rec.to(torch.int16) - enc.rgb.to(torch.int16)).abs().amax(dim=(1, 2, 3))    # per image, = max|x - x_reco| * 255
+            d1.record(stream)
+            err_h = self.model._pinned(("err", job["slot"]), (job["B"],), torch.int16)
+            err_h.copy_(err, non_blocking=True)                # read in report() behind its own event: no wait for later batches
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            return {"job": job, "lists": lists, "rates": rates, "err": err_h, "ev": ev, "e_dec": (d0, d1), "idx0": idx0}
+
+        def report(fin):
+            job = fin["job"]
+            fin["ev"].synchronize()                            # this batch's decode and check are done; what was enqueued behind them keeps running
+            err = fin["err"].numpy().astype(np.float64)
+            enc_ms = job["e_enc"][0].elapsed_time(job["e_enc"][1])
+            dec_ms = fin["e_dec"][0].elapsed_time(fin["e_dec"][1])
+            for b in range(job["B"]):
+                bl, rate1_list = fin["lists"][b], fin["rates"][b]
+                self.test_logger(rate1_list)                   # llicti_agent.py:140
+                bpsp = sum(len(s) * 8 for row in bl for s in row) / (3 * job["H"] * job["W"])
+                enc_t, dec_t = enc_ms / 1e3 / job["B"], dec_ms / 1e3 / job["B"]
+                self._log_image(fin["idx0"] + b, job["H"], job["W"], bpsp, enc_t, dec_t, float(err[b]))
+                r = {"idx": fin["idx0"] + b, "H": job["H"], "W": job["W"], "bpsp": bpsp, "enc_s": enc_t, "dec_s": dec_t,
+                     "max_abs_err": float(err[b]), "rates": rate1_list, "batch": job["B"]}
+                if keep:
+                    r["bytestream_list"] = bl
+                self.results.append(r)
+
+        idx, k, pending, prev_fin = 0, 0, None, None
+        for imgs in batches():
+            job = start_encode(imgs, k & 1)                    # GPU: encode batch k ...
+            job["slot"] = k & 1
+            if pending is not None:                            # ... host: lists / rates / repack of batch k - 1, decode k - 1 enqueued behind encode k
+                if prev_fin is not None:
+                    report(prev_fin)
+                prev_fin = finish(pending, pending["idx0"])
+            job["idx0"] = idx
+            idx += job["B"]
+            pending = job
+            k += 1
+        if pending is not None:
+            if prev_fin is not None:
+                report(prev_fin)
+            prev_fin = finish(pending, pending["idx0"])
+        if prev_fin is not None:
+            report(prev_fin)
+        # device-side failures (malformed container, overflow) are latched in the context: one check at the end -- a check per batch
+        # would synchronise the whole stream and undo the pipelining; a failed image shows up in its own log line (max error) anyway
+        self.model.codec().check()
+        if self.results:
+            self.test_logger.display(lr=0.0, typ="te")
+        return self.results
+
     @torch.no_grad()
     def eval_model(self):
+        eval_batch = int(self.config["eval_batch"]) if "eval_batch" in self.config else 1
+        if eval_batch > 1:
+            return self.eval_model_batched(eval_batch)
         self.model.eval()
         self.results = []
         for batch_idx, x in enumerate(_iter_test_images(self.config, self.device)):
-            print_text = "{:3d} {:3d}x{:3d} ".format(batch_idx, x.shape[2], x.shape[3])
             torch.cuda.synchronize()
             t0 = time.time()
             bytestream_list, xorg = self.model.compress(x)
@@ -133,15 +250,11 @@ class LLICTIAgent:
             dec_time = time.time() - t0
             maxx_abserr = float(((x - x_reco) * 255).abs().max())
             bpsp = total / torch.numel(x)
-            if maxx_abserr >= 0.5:
-                self.logger.info(print_text + "bpsp= {:.3f} Enc/Dec-Times:{:.3f}/{:.3f} "
-                                 "(Error: Decoded img does NOT match original image perfectly! "
-                                 "The maximum of absolute error is {:.4f})".format(bpsp, enc_time, dec_time, maxx_abserr))
-            else:
-                self.logger.info(print_text + "bpsp= {:.3f} Enc/Dec-Times:{:.3f}/{:.3f} "
-                                 "(Check: Decoded img matches original)".format(bpsp, enc_time, dec_time))
+            self._log_image(batch_idx, x.shape[2], x.shape[3], bpsp, enc_time, dec_time, maxx_abserr)
             self.results.append({"idx": batch_idx, "H": int(x.shape[2]), "W": int(x.shape[3]), "bpsp": bpsp,
                                  "enc_s": enc_time, "dec_s": dec_time, "max_abs_err": maxx_abserr, "rates": rate1_list})
+            if "keep_streams" in self.config and self.config["keep_streams"]:
+                self.results[-1]["bytestream_list"] = bytestream_list
         if self.results:
             self.test_logger.display(lr=0.0, typ="te")     # mean scale x band x channel table (llicti_agent.py:164)
         return self.results

@@ -21,6 +21,22 @@ NSEG = 49
 MODE_AC = 0                      # the reference's container: 45 torchac-algorithm streams per image
 
 
+MAX_STREAMS_IN_BUDGET = 9        # an xwide v3 stream costs ~8 bytes: 9 per 768x512 image are +0.0009 bpp over the reference-format container
+
+
+def auto_streams(B, n_cu=256):
+    """Streams per image of the throughput container for a batch of B images: as many as keep ONE decoder workgroup per stream on its
+    own compute unit (B * M <= CUs: a second workgroup on a CU slows both by 1.4x, so more streams than that buy nothing) and stay
+    inside the north star's 0.001 bpp (<= 9 per 768x512 image).  24 images on a 256-CU MI355X: 9; 32 images (configs[4] per GPU): 8."""
+    return max(1, min(MAX_STREAMS_IN_BUDGET, n_cu // max(1, B)))
+
+
+def auto_container(B, n_cu=256):
+    """Name of the throughput container for B images per call: xwide streams (256 lanes, one decoder lane per symbol -- lanes are nearly
+    free in bytes, 0.06 bit each; streams are not, ~8 bytes each), auto_streams(B) of them per image."""
+    return f"xrans{auto_streams(B, n_cu)}"
+
+
 def MODE_RANS(M=8, wide=False):
     """"LLICTI-rANS v3" container: M independent interleaved rANS streams per image.  wide = 0 / False: 64 lanes per stream, M in
     1 .. 32, 64, 128; wide = 1 / True: 128 lanes (two 64-symbol chunks per coder step), M in 1 .. 14; wide = 2 ("xwide"): 256 lanes,
@@ -73,7 +89,7 @@ def mode_of_name(name: str) -> int:
         return MODE_RANS(int(name[5:]), wide=1)
     if name.startswith("rans"):
         return MODE_RANS(int(name[4:] or 8))
-    raise ValueError(f"unknown container {name!r}: ac, rans<M>, wrans<M> or xrans<M>")
+    raise ValueError(f"unknown container {name!r}: ac, rans<M>, wrans<M> or xrans<M> (or \"auto\" where a batch size is known)")
 
 
 def name_of_mode(mode: int) -> str:

@@ -101,7 +101,8 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
     constexpr int L = GEO::kLanes;
     __shared__ uint32_t sh_pay[64 * Q];             // the tail stream / the final states (62 Q dwords used, the rest slack)
     __shared__ uint32_t sh_pairs[64];
-    __shared__ uint32_t sh_win[64 * (Q + 1)];       // staging window of the bit region: dwords [wbase, wbase + 64 (Q + 1))
+    constexpr int kFlush = 64 * Q, kWin = 4 * kFlush;      // dwords: one flush = one dword per thread; a step adds at most kFlush / 2
+    __shared__ uint32_t sh_win[kWin];               // staging RING of the bit region: stream dword d at sh_win[d & (kWin - 1)], d in [wbase, wbase + kWin)
     __shared__ int sh_tot[2][Q];                    // a step's bit totals per sub-chunk (ping-pong by step parity)
     const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M;
     const int tid = threadIdx.x, lane = tid & 63, wq = tid >> 6;      // wavefront wq codes sub-chunk wq (stream lanes 64 wq .. 64 wq + 63)
@@ -110,8 +111,8 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
     const int cap_dw = (rslot_cap - 4 - GEO::kPayBytes - 8) >> 2;      // dwords the bit region may take
     int bad = 0;
     sh_pay[tid] = 0;
-    sh_win[tid] = 0;
-    if (tid < 64) sh_win[64 * Q + tid] = 0;
+#pragma unroll
+    for (int t = 0; t < kWin; t += kFlush) sh_win[t + tid] = 0;
     __syncthreads();
 
     // 1. tail: the stream's last T symbols of the last stage, last symbol first, single state; bits go UP from bit 0 of
@@ -200,26 +201,26 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
                 for (int q2 = 0; q2 < Q; ++q2) { const int t2 = sh_tot[par][q2]; step_total += t2; below += (q2 > wq) ? t2 : 0; }
                 par ^= 1;
             }
+            // The ring's lowest kFlush dwords are complete once the cursor has passed them -- and every wavefront's ORs of the PREVIOUS
+            // step are done once this step's barrier (above; Q = 1: same wavefront, program order) has been passed: they are written out
+            // and zeroed here, one dword per thread, with no barrier of their own (this step's ORs start at bp, beyond them; the zeroed slots
+            // come round again 3 kFlush dwords later).  One barrier per step instead of four.
+            if (bp - 32 * wbase >= 32 * kFlush) {                    // workgroup-uniform
+                const int slot_i = (wbase + tid) & (kWin - 1);
+                if (wbase + kFlush <= cap_dw) out32[wbase + tid] = sh_win[slot_i]; else bad = 2;
+                sh_win[slot_i] = 0;
+                wbase += kFlush;
+            }
             {
-                const int pos = bp + below + (total - incl) - 32 * wbase;    // nb = 0: ORs zeros
+                const int pos = bp + below + (total - incl);                 // nb = 0: ORs zeros
                 const uint32_t bits = x & ((1u << nb) - 1u);
                 const int sh = pos & 31;
-                atomicOr(&sh_win[pos >> 5], bits << sh);
-                atomicOr(&sh_win[(pos >> 5) + 1], (uint32_t)(((uint64_t)bits << sh) >> 32));
+                atomicOr(&sh_win[(pos >> 5) & (kWin - 1)], bits << sh);
+                atomicOr(&sh_win[((pos >> 5) + 1) & (kWin - 1)], (uint32_t)(((uint64_t)bits << sh) >> 32));
             }
             bp += step_total;
             const uint32_t xn = rans_push(x >> nb, lo, freq);
             x = active ? xn : x;
-            while (bp - 32 * wbase >= 2048) {                        // the window's lowest 64 dwords are complete (a step adds <= 1024 Q bits: Q = 4 may flush twice)
-                __syncthreads();
-                if (tid < 64) { if (wbase + 64 <= cap_dw) out32[wbase + tid] = sh_win[tid]; else bad = 2; }
-                const uint32_t up = sh_win[64 + tid];
-                __syncthreads();
-                sh_win[tid] = up;
-                if (tid < 64) sh_win[64 * Q + tid] = 0;
-                __syncthreads();
-                wbase += 64;
-            }
         };
         uint32_t r0 = fetch(K - 1), r1 = fetch(K - 2), r2 = fetch(K - 3), r3 = fetch(K - 4);
         for (int k = K - 1; k >= 0; k -= 4) {                 // steps k, k-1, k-2, k-3 (those below 0 are no-ops)
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
             code(k - 3, r3); r3 = fetch(k - 7);
         }
     }
-    // 4. the rest of the window, the 64 Q final states (31 bits each), T | pad
+    // 4. the rest of the ring, the 64 Q final states (31 bits each), T | pad
     __syncthreads();
     const int nbytes = (bp + 7) >> 3;
     sh_pay[tid] = 0;
@@ -237,12 +238,12 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
     lds_or_bits(sh_pay, kRansStateBits * tid, 16, x & 0xFFFFu);
     lds_or_bits(sh_pay, kRansStateBits * tid + 16, kRansStateBits - 16, (x >> 16) & 0x7FFFu);
     __syncthreads();
-    const int ndw = (nbytes >> 2) - wbase;                    // whole window dwords still to write (<= 64); then 0..3 bytes
+    const int ndw = (nbytes >> 2) - wbase;                    // whole ring dwords still to write (< 2 kFlush); then 0..3 bytes
     const bool over = (nbytes >> 2) + 1 > cap_dw;
     if (over) bad = 2;
     else {
-        for (int t = tid; t < ndw; t += 64 * Q) out32[wbase + t] = sh_win[t];
-        if (tid < (nbytes & 3)) slot[4 + (nbytes & ~3) + tid] = (uint8_t)(sh_win[ndw] >> (8 * tid));
+        for (int t = tid; t < ndw; t += 64 * Q) out32[wbase + t] = sh_win[(wbase + t) & (kWin - 1)];
+        if (tid < (nbytes & 3)) slot[4 + (nbytes & ~3) + tid] = (uint8_t)(sh_win[(wbase + ndw) & (kWin - 1)] >> (8 * tid));
         uint8_t *fs = slot + 4 + nbytes;
         for (int t = tid; t < GEO::kPayBytes; t += 64 * Q) fs[t] = (uint8_t)(sh_pay[t >> 2] >> (8 * (t & 3)));
     }

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from ...codec import (MODE_AC, MODE_RANS, HipCodec, bytestream_list_to_container, container_to_bytestream_list,
+from ...codec import (MODE_AC, MODE_RANS, NSEG, HipCodec, auto_container, bytestream_list_to_container, container_to_bytestream_list,
                       header_dims, mode_of_header, mode_of_name)
 from ...config import check_supported
 
@@ -102,10 +102,12 @@ class LLICTI(nn.Module):
         self.entropymodel = LLICTIEntropyLayer(config)
         self._codec = None
         self._weights_version = None
-        # container written by compress(): the reference's (torchac-compatible) one unless the config asks
-        # for the throughput container, e.g. config.container = "rans8"
-        cont = config["container"] if "container" in config else "ac"
-        self.mode = mode_of_name(cont)
+        # container written by compress(): the reference's (torchac-compatible) one unless the config asks for a throughput container,
+        # e.g. config.container = "xrans9", or "auto": the fastest one inside the north star's 0.001 bpp for the batch size of the call
+        # (llicti_amd.codec.auto_container: xwide rANS streams, one decoder workgroup per stream and compute unit)
+        self.container = str(config["container"]) if "container" in config else "ac"
+        self.mode = None if self.container == "auto" else mode_of_name(self.container)
+        self._stage = {}                # pinned host staging buffers of the batched path, by (tag, shape)
 
     # ------------------------------------------------------------------ plumbing
     def _weights_key(self):
@@ -155,16 +157,48 @@ class LLICTI(nn.Module):
         lists, x_ycocg = self.compress_batch(x)
         return lists[0], x_ycocg
 
+    def mode_for_batch(self, B, device=None):
+        """Container mode of a call with B images: the configured one, or for "auto" the throughput container for that batch size."""
+        if self.mode is not None:
+            return self.mode
+        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        return mode_of_name(auto_container(B, torch.cuda.get_device_properties(dev).multi_processor_count))
+
+    def _pinned(self, tag, shape, dtype):
+        key = (tag, tuple(shape), dtype)
+        t = self._stage.get(key)
+        if t is None:
+            if len(self._stage) >= 16:
+                self._stage.clear()
+            t = torch.empty(shape, dtype=dtype).pin_memory()
+            self._stage[key] = t
+        return t
+
     @torch.no_grad()
     def compress_batch(self, x):
+        """x: [B,3,H,W] float32 in {k/255} or uint8 -> (list of B bytestream_lists, x_ycocg).  Synchronous."""
+        enc = self.encode_batch_async(x, want_ycocg=True)
+        return enc.lists(), enc.x_ycocg
+
+    @torch.no_grad()
+    def encode_batch_async(self, x, want_ycocg=False, slot=0):
+        """Enqueue the encode of a batch and the download of its containers (pinned host buffers, only the bytes in use); returns an
+        EncodedBatch whose lists() waits for the download and cuts the containers into the reference's bytestream_lists.  Nothing here
+        blocks the host: a caller can enqueue the next batch before it converts this one (LLICTIAgent.eval_model with eval_batch > 1).
+        `slot` selects one of the staging buffer sets (two batches in flight need two)."""
         codec = self.codec(x.device if x.is_cuda else None)
-        rgb = self._to_u8(x).to(codec.device).contiguous()
-        cont, seg = codec.encode(rgb, mode=self.mode)
-        _, fplanes, _ = codec.lift(rgb)               # x_ycocg = (YCoCg - [127,0,0]) / 255 (LLICTI_nets.py:143-144)
-        codec.check()
-        cont_h, seg_h = cont.cpu().numpy(), seg.cpu().numpy()
-        lists = [container_to_bytestream_list(cont_h[b], seg_h[b]) for b in range(rgb.shape[0])]
-        return lists, fplanes
+        rgb = self._to_u8(x).to(codec.device, non_blocking=True).contiguous()
+        B, _, H, W = rgb.shape
+        mode = self.mode_for_batch(B, codec.device)
+        cont, seg = codec.encode(rgb, mode=mode)
+        x_ycocg = codec.lift(rgb)[1] if want_ycocg else None     # x_ycocg = (YCoCg - [127,0,0]) / 255 (LLICTI_nets.py:143-144)
+        seg_h = self._pinned(("seg", slot), (B, NSEG), torch.int32)
+        cont_h = self._pinned(("cont_out", slot), tuple(cont.shape), torch.uint8)
+        seg_h.copy_(seg, non_blocking=True)
+        cont_h.copy_(cont, non_blocking=True)                      # one contiguous copy of the container strides, right behind the encode
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(codec.device))
+        return EncodedBatch(codec, rgb, cont_h, seg_h, ev, x_ycocg, mode)
 
     @torch.no_grad()
     def decompres(self, bytestream_list, devc=None, xorg=None):
@@ -174,31 +208,67 @@ class LLICTI(nn.Module):
 
     @torch.no_grad()
     def decompres_batch(self, lists, devc=None):
+        rgb = self.decode_batch_async(lists, devc)
+        self.codec().check()
+        return rgb.to(torch.float32) / 255           # LLICTI_nets.py:87
+
+    @torch.no_grad()
+    def decode_batch_async(self, lists, devc=None, slot=0):
+        """bytestream_lists of B same-size images -> uint8 [B,3,H,W] on the device, enqueued (upload from a pinned buffer + decode);
+        device-side failures are reported by codec().check() / image_status()."""
         codec = self.codec(devc if (devc is not None and torch.device(devc).type == "cuda") else None)
         dims = None
-        bufs, segs = [], []
         for bl in lists:
-            hdr = bytes(bl[0][0]) + bytes(bl[0][1]) + bytes(bl[0][2])
+            if len(bl) != 6 or any(len(r) != 9 for r in bl):
+                raise ValueError("bytestream_list must be 6 lists of 9 byte strings")
             if len(bl[0][0]) != 3 or len(bl[0][1]) != 12 or len(bl[0][2]) != 2:
                 raise ValueError("malformed header streams")
+            hdr = bytes(bl[0][0]) + bytes(bl[0][1]) + bytes(bl[0][2])
             mode = mode_of_header(hdr[0])               # AC container: hdr[0] == num_scales (LLICTI_nets.py:424)
             d = header_dims(hdr) + (mode,)
             if dims is None:
                 dims = d
             elif d != dims:
                 raise ValueError("all images of one decompres_batch call must have the same size and container")
-            b, s = bytestream_list_to_container(bl)
-            bufs.append(b)
-            segs.append(s)
         H, W, mode = dims
+        B = len(lists)
         stride = codec.max_container_bytes(H, W)
-        cont = np.zeros((len(lists), stride), np.uint8)
-        for i, b in enumerate(bufs):
-            if b.size > stride:
-                raise ValueError("container larger than any valid stream set for this image size")
-            cont[i, :b.size] = b
-        cont_d = torch.from_numpy(cont).to(codec.device)
-        seg_d = torch.from_numpy(np.stack(segs)).to(codec.device)
-        rgb = codec.decode(cont_d, seg_d, H, W, mode=mode)
-        codec.check()
-        return rgb.to(torch.float32) / 255           # LLICTI_nets.py:87
+        cont_h = self._pinned(("cont_in", slot), (B, stride), torch.uint8)
+        seg_h = self._pinned(("seg_in", slot), (B, NSEG), torch.int32)
+        cont_np, seg_np = cont_h.numpy(), seg_h.numpy()
+        for i, bl in enumerate(lists):
+            pos, k = 0, 0
+            for r, row in enumerate(bl):
+                for s in (row[:4] if r == 0 else row):
+                    n = len(s)
+                    if pos + n > stride:
+                        raise ValueError("container larger than any valid stream set for this image size")
+                    if n:
+                        cont_np[i, pos:pos + n] = np.frombuffer(s, dtype=np.uint8)
+                    seg_np[i, k] = n
+                    pos += n
+                    k += 1
+        cont_d = cont_h.to(codec.device, non_blocking=True)      # one contiguous copy; bytes past a container's own length are never read (validated lengths)
+        seg_d = seg_h.to(codec.device, non_blocking=True)
+        return codec.decode(cont_d, seg_d, H, W, mode=mode)
+
+
+class EncodedBatch:
+    """Handle of one enqueued batch encode (LLICTI.encode_batch_async): the device input, the pinned host copies of the containers and
+    their segment lengths, and the event recorded behind the download."""
+
+    def __init__(self, codec, rgb, cont_h, seg_h, ev, x_ycocg, mode):
+        self.codec, self.rgb, self.cont_h, self.seg_h, self.ev = codec, rgb, cont_h, seg_h, ev
+        self.x_ycocg, self.mode = x_ycocg, mode
+        self._lists = None
+
+    def lists(self, check=True):
+        """Wait for the download (NOT for anything enqueued after it) and cut the containers into bytestream_lists (6 lists x 9 `bytes`).
+        check=False leaves the device-side status to a later codec.check() (which synchronises the whole stream)."""
+        if self._lists is None:
+            self.ev.synchronize()
+            if check:
+                self.codec.check()
+            seg_np, cont_np = self.seg_h.numpy(), self.cont_h.numpy()
+            self._lists = [container_to_bytestream_list(cont_np[b], seg_np[b]) for b in range(seg_np.shape[0])]
+        return self._lists

@@ -576,6 +576,50 @@ def test_agent_eval_model(torch_mod, caplog):
     assert all(len(r["rates"]) == 6 and all(len(row) == 9 for row in r["rates"]) for r in res)
 
 
+def test_agent_batched_eval_equals_unbatched(torch_mod, tmp_path, caplog, oracle_weights):
+    """LLICTIAgent.eval_model with config.eval_batch groups consecutive same-size test images and codes them through the
+    batched, software-pipelined path (LLICTI.encode_batch_async / decode_batch_async, config.container = "auto").  Its bytestream_lists
+    equal, image by image, what the one-image loop writes in the same container, and the oracle's for one image; per-image log lines,
+    rates and the lossless check are the same; a size change inside the data set closes a batch; an in-memory data set works."""
+    import logging
+    from oracle import oracle as orc
+    from llicti_amd import fileio
+    from llicti_amd.agents.llicti_agent import LLICTIAgent
+    from llicti_amd.codec import auto_container, mode_of_header, mode_of_name
+    from llicti_amd.config import default_config
+    caplog.set_level(logging.INFO)
+    # 7 + 2 + 1 images of three sizes as files (the reference's test loader reads a directory): batches 3, 3, 1 | 2 | 1
+    imgs = [make_image("noise" if i % 2 else "smooth", 96, 128, 400 + i) for i in range(7)] + \
+           [make_image("smooth", 67, 93, 410 + i) for i in range(2)] + [make_image("noise", 128, 96, 420)]
+    for i, im in enumerate(imgs):
+        fileio.write_image(str(tmp_path / f"img_{i:02d}.ppm"), im)
+    cname = auto_container(3)
+    assert cname == auto_container(1) == "xrans9"
+    a_b = LLICTIAgent(default_config(test_data=str(tmp_path), eval_batch=3, container="auto", keep_streams=True))
+    res_b = a_b.run()
+    n_lines = sum("Check: Decoded img matches original" in r.message for r in caplog.records)
+    a_u = LLICTIAgent(default_config(test_data=str(tmp_path), container=cname, keep_streams=True))
+    res_u = a_u.run()
+    assert len(res_b) == len(res_u) == 10 and n_lines == 10
+    assert [r["batch"] for r in res_b] == [3, 3, 3, 3, 3, 3, 1, 2, 2, 1]
+    for rb, ru, im in zip(res_b, res_u, imgs):
+        assert (rb["idx"], rb["H"], rb["W"]) == (ru["idx"], ru["H"], ru["W"]) == (rb["idx"], im.shape[1], im.shape[2])
+        assert rb["bytestream_list"] == ru["bytestream_list"]
+        assert rb["rates"] == ru["rates"] and rb["bpsp"] == ru["bpsp"]
+        assert rb["max_abs_err"] == 0.0 and ru["max_abs_err"] < 1e-3
+        assert mode_of_header(rb["bytestream_list"][0][0][0]) == mode_of_name(cname)
+    W_o = oracle_weights("rand1337")                     # the agent's seed-1337 default init (no checkpoint in the test directory)
+    for i in (4, 8):
+        assert res_b[i]["bytestream_list"] == orc.encode_image_rans(imgs[i], W_o, 9, 2)
+    # the mean rate table of both runs is the same text
+    assert a_b.test_logger.display(lr=0.0, typ="te") == a_u.test_logger.display(lr=0.0, typ="te")
+    # in-memory data set, default (reference-format) container, batch of 4: equals the one-image reference-format path
+    a_m = LLICTIAgent(default_config(test_data=imgs[:4], eval_batch=4, keep_streams=True))
+    res_m = a_m.run()
+    assert len(res_m) == 4 and all(r["max_abs_err"] == 0.0 for r in res_m)
+    assert res_m[1]["bytestream_list"] == orc.encode_image(imgs[1], W_o)
+
+
 def test_cli_file_roundtrip(torch_mod, tmp_path, capsys):
     """image file -> .llic -> image file through the command-line front end, both containers."""
     from llicti_amd import cli, fileio
@@ -1108,7 +1152,7 @@ def test_bench_line_contract(torch_mod):
               "cpu_baseline", "bpp_delta_vs_reference", "meets_north_star", "north_star_check"):
         assert k in d, k
     assert d["meets_north_star"] is False                       # not the north star's 768x512 shape: never claimed on another one
-    assert abs(d["bpp_delta_vs_reference"]["timed_container_minus_reference_format_bpp"]) < 0.6      # 3 tiny images, 10 wide streams each: mostly the 496-byte state blocks
+    assert abs(d["bpp_delta_vs_reference"]["timed_container_minus_reference_format_bpp"]) < 4.0      # 3 tiny images, 9 xwide streams each: mostly the 992-byte state blocks (12 kpixel images)
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k

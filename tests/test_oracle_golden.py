@@ -356,12 +356,13 @@ def test_bpp_delta_vs_reference_tables_report(golden_index, oracle_weights):
         else:
             # the WHOLE budget on natural-like content at full size -- (build's tables - reference's tables) + (timed container -
             # reference-format container), the second term from the oracle's two containers of this very image (HIP == oracle bytes, -m gpu)
-            import bench
-            M = bench.MAX_STREAMS_IN_BUDGET
+            from llicti_amd.codec import auto_container, mode_of_name
+            cname = auto_container(24)                   # the container bench.py times for BASELINE's batch of 24
+            mode = mode_of_name(cname)
             n_ac = sum(len(x) for rw in orc.encode_image(rgb, W) for x in rw)
-            n_rans = sum(len(x) for rw in orc.encode_image_rans(rgb, W, M, True) for x in rw)
+            n_rans = sum(len(x) for rw in orc.encode_image_rans(rgb, W, mode & 0xFF, ((mode & ~0xFF) - 0x100) // 0x200) for x in rw)
             cont = 8.0 * (n_rans - n_ac) / (H * Wd)
-            row.update({"container": f"wrans{M}", "container_minus_reference_format_bpp": round(cont, 6), "reference_format_bytes": n_ac,
+            row.update({"container": cname, "container_minus_reference_format_bpp": round(cont, 6), "reference_format_bytes": n_ac,
                         "budget_bpp": round(abs(d) + abs(cont), 6)})
             budget = abs(d) + abs(cont)
             assert abs(d) < 2e-4, (name, d)
