@@ -419,6 +419,22 @@ class PciePipeline:
         return last
 
 
+def summarize_pcie_spans(spans, skip=2):
+    """bench.PciePipeline.run(trace=True) spans -> where the pipelined step goes: the compute stream's period (encode(k) start to
+    encode(k + 1) start), its idle gaps between consecutive compute calls, every operation's duration inside the pipeline."""
+    import statistics
+    ops = {}
+    for sp in spans:
+        ops.setdefault(sp["op"], []).append(sp)
+    inside = {k: round(statistics.median(s["end_ms"] - s["start_ms"] for s in sorted(v, key=lambda s: s["step"])[skip:]), 4) for k, v in ops.items()}
+    enc = sorted(ops["encode"], key=lambda s: s["step"])
+    calls = sorted(ops["encode"] + ops["decode"], key=lambda s: s["start_ms"])
+    period = [enc[i + 1]["start_ms"] - enc[i]["start_ms"] for i in range(skip, len(enc) - 1)]
+    gaps = [calls[i + 1]["start_ms"] - calls[i]["end_ms"] for i in range(2 * skip, len(calls) - 1)]
+    return {"compute_period_ms": round(statistics.median(period), 4), "compute_idle_gap_ms_per_step": round(2 * statistics.median(gaps), 4),
+            "compute_idle_gap_ms_max": round(max(gaps), 4), "inside_pipeline_ms": inside}
+
+
 NATURAL_FIXTURE = ("natural_like_768x512", "smooth", 512, 768, 11)      # tests/golden/ref_ideal_bits.json: the reference's own tables on this image
 
 
@@ -743,6 +759,16 @@ def main(argv=None):
     pcie_spread = [round(B * H * W / e / 1e6, 1) for e in (est[-1], est[0])]      # slowest, fastest repeat (this rank), MPix/s
     codec.check()
     assert np.array_equal(last.numpy(), rgb_h)
+    # one traced pipelined run (timing events around every transfer and compute call on its own stream): does the compute stream run
+    # back to back (period = resident step, no idle gaps) or do the transfers hold it up?  Says so in every line, whatever the box.
+    pcie_trace = None
+    try:
+        _, spans = pipe.run(3 + 6, trace=True)
+        pcie_trace = summarize_pcie_spans(spans)
+        pcie_trace["resident_step_ms"] = round((t_enc + t_dec) * 1e3, 4)
+        pcie_trace["transfers_overlap_compute"] = bool(pcie_trace["compute_period_ms"] <= 1.03 * (t_enc + t_dec) * 1e3)
+    except Exception as e:                       # diagnostics only
+        pcie_trace = {"skipped": repr(e)[:200]}
     del rgb_pin, cont_pin, seg_pin, rec_pin, last, pipe, pcie_pipeline
 
     # ---- dominant-kernel timing with HIP events on the launch stream, in extra (untimed) profiled steps
@@ -800,8 +826,13 @@ def main(argv=None):
         # (3) configs[1]: ONE 768x512 image
         one = rgb[:1].contiguous()
         legs_out["single_image"] = {"workload": f"1x{W}x{H} (BASELINE.json configs[1])",
-                                    "rans128": legs.run(one, MODE_RANS(128), reps=5), "rans32": legs.run(one, MODE_RANS(32), reps=5), "rans16": legs.run(one, MODE_RANS(16), reps=5),
+                                    "rans128": legs.run(one, MODE_RANS(128), reps=5), "rans64": legs.run(one, MODE_RANS(64), reps=5), "rans32": legs.run(one, MODE_RANS(32), reps=5),
+                                    "rans16": legs.run(one, MODE_RANS(16), reps=5), "xrans64": legs.run(one, MODE_RANS(64, wide=2), reps=5),
+                                    "xrans32": legs.run(one, MODE_RANS(32, wide=2), reps=5), "xrans9": legs.run(one, MODE_RANS(9, wide=2), reps=5),
                                     "ac": legs.run(one, MODE_AC, reps=1)}
+        for nm, r in legs_out["single_image"].items():
+            if isinstance(r, dict) and nm != "ac":
+                r["bpp_delta_vs_ac_container"] = round(r["bpp"] - legs_out["single_image"]["ac"]["bpp"], 5)
         legs.free()
         # (4) the reference-format container where it has enough streams in flight
         try:
@@ -882,7 +913,7 @@ def main(argv=None):
             "per_rank": per_rows, "straggler_ratio": straggler,
             "value_pcie_inclusive": round(agg_pcie["pixels"] / agg_pcie["elapsed_s"] / 1e6, 3),
             "value_pcie_serial": round(agg_pcie_serial["pixels"] / agg_pcie_serial["elapsed_s"] / 1e6, 3),
-            "pcie_inclusive_repeats_mpix_s": pcie_spread,
+            "pcie_inclusive_repeats_mpix_s": pcie_spread, "pcie_pipeline_trace": pcie_trace,
             "pcie_note": "same step with H2D of RGB + D2H of containers (encode) and H2D of containers + D2H of RGB (decode) inside "
                          "the timed region, pinned host buffers, whole container stride copied; value_pcie_inclusive: transfers on their own "
                          "HIP streams, double buffered, overlapped with compute (decode of step k-1 behind encode of step k), steady state = (long run - short run) / extra steps; value_pcie_serial: "

@@ -86,6 +86,7 @@ def main():
         est.append((t[1] - t[0]) / a.steps * 1e3)
     # host-side cost of issuing one pipelined step (no GPU wait inside run() except its final synchronise)
     _, spans = pipe.run(3 + a.steps, trace=True)
+    summary = bench.summarize_pcie_spans(spans)
     ops = {}
     for sp in spans:
         ops.setdefault(sp["op"], []).append(sp)
@@ -103,7 +104,7 @@ def main():
         key = f'{c["op"]} <- ' + (max(cand, key=lambda s: s["end_ms"])["op"] if cand else "previous compute call")
         blame[key] = blame.get(key, 0) + 1
     out = {
-        "workload": f"{B}x{W}x{H} uniform-noise RGB, container {name}", "mpix_per_step": B * H * W / 1e6,
+        "workload": f"{B}x{W}x{H} uniform-noise RGB, container {name}", "mpix_per_step": B * H * W / 1e6, "summary": summary,
         "alone_ms": alone, "inside_pipeline_ms": inside,
         "transfer_GBps_alone": {k: round(nbytes[k] / alone[k] / 1e6, 1) for k in nbytes},
         "transfer_GBps_inside": {k: round(nbytes[k] / inside[k] / 1e6, 1) for k in nbytes},
