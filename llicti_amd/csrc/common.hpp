@@ -86,6 +86,12 @@ __device__ __forceinline__ void flag_image(int32_t *status, int b, int code)
     atomicExch(&status[16 + b], code);
 }
 
+// Workgroup barrier that waits for this wavefront's LDS (and scalar) traffic only.  __syncthreads() is a workgroup-scope fence + s_barrier, and
+// the fence drains vmcnt too: every global load in flight (the coders' prefetches of the NEXT steps' operands) and every global store
+// just issued (decoded pixels, flushed stream words) would have to complete before the barrier -- a memory round trip per coder step.
+// Where only LDS words cross between the wavefronts, this is the barrier to use.  ("memory": the compiler keeps LDS accesses on their side.)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // wave-wide vote as a 64-bit lane mask, straight from the comparison (HIP's __ballot(int) first materialises the
 // predicate as 0/1 in a VGPR and compares it again: two extra vector operations per vote)
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
     __shared__ uint32_t sh_pairs[64];
     constexpr int kFlush = 64 * Q, kWin = 4 * kFlush;      // dwords: one flush = one dword per thread; a step adds at most kFlush / 2
     __shared__ uint32_t sh_win[kWin];               // staging RING of the bit region: stream dword d at sh_win[d & (kWin - 1)], d in [wbase, wbase + kWin)
-    __shared__ int sh_tot[2][Q];                    // a step's bit totals per sub-chunk (ping-pong by step parity)
+    __shared__ __attribute__((aligned(16))) int sh_tot[2][Q][4];       // a round's four bit totals per sub-chunk (ping-pong by round parity)
     const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M;
     const int tid = threadIdx.x, lane = tid & 63, wq = tid >> 6;      // wavefront wq codes sub-chunk wq (stream lanes 64 wq .. 64 wq + 63)
     uint8_t *slot = slots + rslot_off[sidx];
@@ -168,66 +168,86 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
         const int K = (nchunks - m + M - 1) / M;
         const uint32_t *pp = pairs + d.pair_off;
         const int lim = (st == LLICTI_NSTREAMS - 1) ? tail_from : 0x7FFFFFFF;
-        // The pair loads do not depend on the coder state: four steps are kept in flight in four registers with
-        // FIXED roles (the loop is unrolled by four; a rotating ring r0 = r1 ... makes the compiler copy the
-        // newest load, i.e. wait for it with s_waitcnt vmcnt(0) in every step).  Loads are unconditional
-        // (clamped address); the raw value is masked only where it is consumed.
+        // Pair loads are unconditional (clamped address); the raw value is masked only where it is consumed.
         auto fetch = [&](int k) -> uint32_t { return pp[min(L * (m + max(k, 0) * M) + tid, d.n - 1)]; };
-        // One step, without a divergent branch: the two chains of a step -- state (bits to emit, push) and bit cursor (prefix sum,
-        // window) -- are each ~20 dependent operations, and a lone wave pays every exec-mask branch between them in full.  An
-        // inactive lane codes the neutral pair (freq 2^16: no bits, and its push is discarded).
-        auto code = [&](int k, uint32_t raw) {
-            if (k < 0) return;                                       // workgroup-uniform
-            const int n = L * (m + k * M) + tid;
-            const bool active = n < d.n && L * k + tid < lim;
-            const uint32_t v = active ? raw : 0u;                    // (lo, c_high) = (0, 2^16 stored as 0): freq 2^16, no bits
-            const uint32_t lo = v & 0xFFFFu;
-            uint32_t hi = v >> 16;
-            hi = (hi == 0) ? 0x10000u : hi;
-            uint32_t freq = hi - lo;
-            const bool wrong = (freq == 0) | (hi < lo);
-            bad = wrong ? 1 : bad;
-            freq = wrong ? 1u : freq;
-            const int nb = rans_emit_bits(x, freq);
-            // the decoder renormalises stream-lane-ascending reading DOWN: the highest lane's bits lowest, i.e. sub-chunk Q - 1 first
-            const int incl = wave_incl_scan(nb);
-            const int total = __builtin_amdgcn_readlane(incl, 63);
-            int below = 0, step_total = total;                       // bits of the sub-chunks above this one; of the whole step
-            if constexpr (Q > 1) {
-                if (lane == 0) sh_tot[par][wq] = total;
-                __syncthreads();
-                step_total = 0;
+        // FOUR steps per round.  The state recurrence of a lane -- x -> bits to emit -> push -> x -- does not depend on where the bits
+        // go, and it is the only serial chain the coder has (~25 dependent operations a step); WHERE they go needs a prefix sum over
+        // the stream's lanes, i.e. for a multi-wavefront stream an LDS exchange behind a barrier -- a ~350-cycle round trip that the
+        // per-step form put on that chain (a step took ~2,000 cycles for ~90 instructions).  So a round first runs the recurrence
+        // four steps ahead, keeping (bits, count) of each step in registers, then places the four steps' fields with ONE exchange:
+        // four independent prefix sums, one 16-byte LDS write per wavefront, one barrier, four pairs of ORs.  No divergent branch: an
+        // inactive lane (past the stage's end, a tail symbol, a step below 0) codes the neutral pair (freq 2^16: no bits, push discarded).
+        auto round4 = [&](int k, uint32_t raw0, uint32_t raw1, uint32_t raw2, uint32_t raw3) {
+            const uint32_t raws[4] = { raw0, raw1, raw2, raw3 };
+            uint32_t fld[4];
+            int nbs[4];
 #pragma unroll
-                for (int q2 = 0; q2 < Q; ++q2) { const int t2 = sh_tot[par][q2]; step_total += t2; below += (q2 > wq) ? t2 : 0; }
+            for (int j = 0; j < 4; ++j) {                            // steps k, k - 1, k - 2, k - 3: the recurrence
+                const int kk = k - j;
+                const int n = L * (m + kk * M) + tid;
+                const bool active = kk >= 0 && n < d.n && L * kk + tid < lim;
+                const uint32_t v = active ? raws[j] : 0u;            // (lo, c_high) = (0, 2^16 stored as 0): freq 2^16, no bits
+                const uint32_t lo = v & 0xFFFFu;
+                uint32_t hi = v >> 16;
+                hi = (hi == 0) ? 0x10000u : hi;
+                uint32_t freq = hi - lo;
+                const bool wrong = (freq == 0) | (hi < lo);
+                bad = wrong ? 1 : bad;
+                freq = wrong ? 1u : freq;
+                const int nb = rans_emit_bits(x, freq);
+                nbs[j] = nb;
+                fld[j] = x & ((1u << nb) - 1u);
+                const uint32_t xn = rans_push(x >> nb, lo, freq);
+                x = active ? xn : x;
+            }
+            // placement: the decoder renormalises stream-lane-ascending reading DOWN -- the highest lane's bits lowest, i.e. sub-chunk
+            // Q - 1 first -- and step k's bits below step k - 1's
+            int incl[4], total[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { incl[j] = wave_incl_scan(nbs[j]); total[j] = __builtin_amdgcn_readlane(incl[j], 63); }
+            int below[4] = { 0, 0, 0, 0 }, step_total[4] = { total[0], total[1], total[2], total[3] };
+            if constexpr (Q > 1) {
+                if (lane == 0) *reinterpret_cast<int4 *>(&sh_tot[par][wq][0]) = make_int4(total[0], total[1], total[2], total[3]);
+                lds_barrier();                                       // not __syncthreads(): the pair loads of the next rounds stay in flight
+#pragma unroll
+                for (int j = 0; j < 4; ++j) step_total[j] = 0;
+#pragma unroll
+                for (int q2 = 0; q2 < Q; ++q2) {
+                    const int4 t4 = *reinterpret_cast<const int4 *>(&sh_tot[par][q2][0]);
+                    const int t[4] = { t4.x, t4.y, t4.z, t4.w };
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { step_total[j] += t[j]; below[j] += (q2 > wq) ? t[j] : 0; }
+                }
                 par ^= 1;
             }
             // The ring's lowest kFlush dwords are complete once the cursor has passed them -- and every wavefront's ORs of the PREVIOUS
-            // step are done once this step's barrier (above; Q = 1: same wavefront, program order) has been passed: they are written out
-            // and zeroed here, one dword per thread, with no barrier of their own (this step's ORs start at bp, beyond them; the zeroed slots
-            // come round again 3 kFlush dwords later).  One barrier per step instead of four.
-            if (bp - 32 * wbase >= 32 * kFlush) {                    // workgroup-uniform
+            // round are done once this round's barrier (above; Q = 1: same wavefront, program order) has been passed: they are written
+            // out and zeroed here, one dword per thread, with no barrier of their own (this round's ORs start at bp, beyond them; the
+            // zeroed slots come round again 3 kFlush dwords later; a round adds at most 2 kFlush dwords).
+            while (bp - 32 * wbase >= 32 * kFlush) {                 // workgroup-uniform; at most twice
                 const int slot_i = (wbase + tid) & (kWin - 1);
                 if (wbase + kFlush <= cap_dw) out32[wbase + tid] = sh_win[slot_i]; else bad = 2;
                 sh_win[slot_i] = 0;
                 wbase += kFlush;
             }
-            {
-                const int pos = bp + below + (total - incl);                 // nb = 0: ORs zeros
-                const uint32_t bits = x & ((1u << nb) - 1u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int pos = bp + below[j] + (total[j] - incl[j]);        // nb = 0: ORs zeros
                 const int sh = pos & 31;
-                atomicOr(&sh_win[(pos >> 5) & (kWin - 1)], bits << sh);
-                atomicOr(&sh_win[((pos >> 5) + 1) & (kWin - 1)], (uint32_t)(((uint64_t)bits << sh) >> 32));
+                atomicOr(&sh_win[(pos >> 5) & (kWin - 1)], fld[j] << sh);
+                atomicOr(&sh_win[((pos >> 5) + 1) & (kWin - 1)], (uint32_t)(((uint64_t)fld[j] << sh) >> 32));
+                bp += step_total[j];
             }
-            bp += step_total;
-            const uint32_t xn = rans_push(x >> nb, lo, freq);
-            x = active ? xn : x;
         };
-        uint32_t r0 = fetch(K - 1), r1 = fetch(K - 2), r2 = fetch(K - 3), r3 = fetch(K - 4);
-        for (int k = K - 1; k >= 0; k -= 4) {                 // steps k, k-1, k-2, k-3 (those below 0 are no-ops)
-            code(k, r0);     r0 = fetch(k - 4);
-            code(k - 1, r1); r1 = fetch(k - 5);
-            code(k - 2, r2); r2 = fetch(k - 6);
-            code(k - 3, r3); r3 = fetch(k - 7);
+        // The pair loads do not depend on the coder state: two rounds (eight steps) are kept in flight in registers with FIXED roles
+        // (a rotating ring makes the compiler copy the newest load, i.e. wait for it with s_waitcnt vmcnt(0) in every round)
+        uint32_t a0 = fetch(K - 1), a1 = fetch(K - 2), a2 = fetch(K - 3), a3 = fetch(K - 4);
+        uint32_t b0 = fetch(K - 5), b1 = fetch(K - 6), b2 = fetch(K - 7), b3 = fetch(K - 8);
+        for (int k = K - 1; k >= 0; k -= 8) {                 // steps k .. k - 7 (those below 0 are no-ops)
+            round4(k, a0, a1, a2, a3);
+            a0 = fetch(k - 8); a1 = fetch(k - 9); a2 = fetch(k - 10); a3 = fetch(k - 11);
+            if (k - 4 >= 0) round4(k - 4, b0, b1, b2, b3);         // workgroup-uniform
+            b0 = fetch(k - 12); b1 = fetch(k - 13); b2 = fetch(k - 14); b3 = fetch(k - 15);
         }
     }
     // 4. the rest of the ring, the 64 Q final states (31 bits each), T | pad
@@ -541,7 +561,7 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();      // LDS words only cross here: global loads / stores in flight stay in flight (common.hpp)
         {
             const bool active = chunk0 + lane < nc && 64 * k + lane < tail_from;
             int nb = 0;
@@ -770,7 +790,7 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_pair_kernel
                 fplanes[off + (long)clr * sg.plane] = (float)v / 255.0f;
             }
         }
-        __syncthreads();
+        lds_barrier();      // LDS words only cross here: global loads / stores in flight stay in flight (common.hpp)
         {
             int below = 0;                                                         // bits of the lower sub-chunk of this step
 #pragma unroll
@@ -986,7 +1006,7 @@ __global__ __launch_bounds__(64 * Q) void rans_decode_stage_lane_kernel(const fl
         }
         const int incl = wave_incl_scan(nb);
         if (lane == 63) sh_tot[par][wave] = incl;
-        __syncthreads();                                                       // (also: last step's ring refill is visible)
+        lds_barrier();                  // (also: last step's ring refill is visible)  not __syncthreads(): the pixel stores above and the next step's parameter loads stay in flight
         int below = 0, step_total = 0;
 #pragma unroll
         for (int q2 = 0; q2 < Q; ++q2) { const int t2 = sh_tot[par][q2]; step_total += t2; below += (q2 < wave) ? t2 : 0; }
@@ -1114,7 +1134,7 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead)) void rans_tail_kernel(const 
             const Row rowC = fetch(kTailAhead * (r + 2) + i);            // two rounds ahead: the loads run under a whole round
             if (kTailAhead * (r + 1) + i < T) prepare(rowB, (r + 1) & 1);
             rowB = rowC;
-            __syncthreads();
+            lds_barrier();      // LDS words only cross here: global loads / stores in flight stay in flight (common.hpp)
         }
         return;
     }
@@ -1208,7 +1228,7 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead)) void rans_tail_kernel(const 
                 xt = ((xt << nb) | lds_get_bits(sh_pay, tc, nb)) | (1u << 31);
             }
         }
-        __syncthreads();
+        lds_barrier();      // LDS words only cross here: global loads / stores in flight stay in flight (common.hpp)
     }
     if (T == 0) bad = bad || xt != (1u << 31);
     if ((bad || tc != 0) && lane == 0) flag_image(status, b, LLICTI_EFORMAT);
