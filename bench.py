@@ -786,8 +786,8 @@ def main(argv=None):
         call_ms += ms[0]
         kernel_ms[name] = {k: round(v, 3) for k, v in cat.items() if v > 0}
         kernel_ms[name]["call"] = round(ms[0], 3)
-        for i, t in enumerate(per[:15]):             # launch order: scale 4..0 x band 0..2
-            cnn_level_ms[4 - i // 3] += t
+        for l, t in enumerate(codec.last_cnn_level_ms()):
+            cnn_level_ms[l] += t
     codec.set_profiling(False)
     assert abs(sum(MAC_PER_BAND) - MAC_PER_POSITION) == 0
 

@@ -218,12 +218,16 @@ int llicti_last_timing(llicti_ctx *ctx, float ms[4], int *n_launch);
 #define LLICTI_PROF_AC 5
 #define LLICTI_PROF_MISC 6
 int llicti_last_timing_detail(llicti_ctx *ctx, float cat_ms[LLICTI_NPROF], float *cnn_launch_ms, int cnn_cap, int *n_cnn);
+/* ... and the band-CNN time of that call per level (a level's launches may be split into sub-batches: their count is not fixed). */
+int llicti_last_cnn_level_ms(llicti_ctx *ctx, float level_ms[LLICTI_NLEVELS]);
 /* Tuning switches that never change a result.  "cnn_tile_rows" (0 = per launch, 16, 4): force the band CNN's 16-row throughput tiles
  * or its 4-row latency tiles (default: 4 rows whenever the 16-row tiles could not give every compute unit a workgroup).
  * "ac_anchor_min_batch" (default 96): from this many images per call on,
  * llicti_decode_images decodes the AC container over anchor rows (every 8th table entry from cdf_anchor_kernel, the 8
  * entries of the located bucket evaluated by the decoding wavefront) instead of full table rows; values above the
- * default are clamped to it (the workspace is sized for the default). */
+ * default are clamped to it (the workspace is sized for the default).  "enc_chunk_images" (default 0 = never): llicti_encode_images
+ * runs a (level, band) whose CNN outputs exceed 200 MB in sub-batches of this many images, so that the outputs of one CNN launch could
+ * still be in the memory-side cache when the pairs kernel behind it reads them (measured on MI355X: no gain, hence off). */
 int llicti_set_tuning(llicti_ctx *ctx, const char *key, int value);
 /* enable / disable the per-kernel event timing above (off by default: it adds event records). */
 int llicti_set_profiling(llicti_ctx *ctx, int enable);

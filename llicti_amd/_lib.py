@@ -67,6 +67,7 @@ _SIGS = {
     "llicti_selftest": (_i, []),
     "llicti_last_timing": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(_i)]),
     "llicti_last_timing_detail": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, C.POINTER(_i)]),
+    "llicti_last_cnn_level_ms": (_i, [_vp, C.POINTER(C.c_float)]),
     "llicti_set_profiling": (_i, [_vp, _i]),
     "llicti_set_tuning": (_i, [_vp, C.c_char_p, _i]),
 }

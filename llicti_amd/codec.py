@@ -311,6 +311,12 @@ class HipCodec:
         _lib.check(self.L.llicti_last_timing_detail(self.ctx, cat, per, 64, C.byref(n)))
         return dict(zip(self.PROF_CATS, [float(v) for v in cat])), [float(per[i]) for i in range(min(n.value, 64))]
 
+    def last_cnn_level_ms(self):
+        """-> [ms of the band-CNN launches of level 0 .. 4] of the last whole-batch call (profiling on)."""
+        ms = (C.c_float * 5)()
+        _lib.check(self.L.llicti_last_cnn_level_ms(self.ctx, ms))
+        return [float(v) for v in ms]
+
     def last_timing(self):
         ms = (C.c_float * 4)()
         n = C.c_int()

@@ -65,7 +65,7 @@ __device__ __forceinline__ void clr_range(const int32_t *mm, int clr, int &minv,
 // encoder: thread per coded position; the two entries the coder reads, for Y, Co, Cg
 __global__ __launch_bounds__(256) void cdf_pairs_kernel(const int16_t *__restrict__ planes, const float *__restrict__ params,
                                                         const int32_t *__restrict__ minmax, StageGeom s,
-                                                        uint32_t *__restrict__ pairs)
+                                                        uint32_t *__restrict__ pairs, int pair_batch)
 {
     // Channel-planar CNN outputs (numerics.hpp: ParRow): the 64 lanes of a wave walk 64 consecutive positions, so each of a thread's
     // 60 parameter loads is one fully coalesced 256-byte wave access -- no LDS staging (round 3 moved position-major rows through LDS).
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void cdf_pairs_kernel(const int16_t *__restric
         const uint32_t lo = cdf_entry(m, gr, sym);
         const uint32_t hi1 = cdf_entry(m, gr, min(sym + 1, gr.Lp - 2));     // unconditional (clamped): no divergent branch around ten erfc chains
         const uint32_t hi = (sym == gr.Lp - 2) ? 0u : hi1;
-        pairs[((long)clr * s.B + b) * nc + n] = (hi << 16) | lo;
+        pairs[((long)clr * pair_batch + b) * nc + n] = (hi << 16) | lo;      // [clr][image of the whole batch][n]: a sub-batch launch passes the batch size and a shifted base
     }
 }
 

@@ -109,9 +109,12 @@ struct llicti_ctx {
     int32_t *d_lift_part = nullptr;   // min/max partials of llicti_lift_u8 (1 MB; calls on one context are not concurrent)
     int n_cu = 256;                   // compute units of the device (grid sizing of the persistent kernels)
     int cnn_tile_rows = 0;            // llicti_set_tuning("cnn_tile_rows"): 0 = choose per launch, 16 / 4 = force (tests, A/B)
+    int enc_chunk_images = 0;         // llicti_set_tuning("enc_chunk_images"): encoder sub-batch of a (level, band) whose CNN outputs exceed 200 MB (0: never split; measured: no gain, profiles/r4/tried_encoder_subbatch.json)
     bool profiling = false;
     std::vector<hipEvent_t> ev;       // event pairs of the profiling spans of the current call
     std::vector<int> ev_cat;          // category of pair i
+    std::vector<int> ev_tag;          // level of a PROF_CNN pair (-1 otherwise)
+    float last_cnn_level_ms[LLICTI_NLEVELS] = {};
     int ev_used = 0;                  // events used (2 per span)
     hipEvent_t ev_call[2] = { nullptr, nullptr };
     float last_ms[4] = { 0, 0, 0, 0 };
@@ -127,7 +130,7 @@ struct ProfSpan {
     llicti_ctx *c;
     hipStream_t s;
     hipEvent_t e1 = nullptr;
-    ProfSpan(llicti_ctx *c_, int cat, hipStream_t s_) : c(c_), s(s_)
+    ProfSpan(llicti_ctx *c_, int cat, hipStream_t s_, int tag = -1) : c(c_), s(s_)
     {
         if (!c->profiling) return;
         if ((int)c->ev.size() < c->ev_used + 2) {
@@ -137,8 +140,10 @@ struct ProfSpan {
             c->ev.push_back(a);
             c->ev.push_back(b);
             c->ev_cat.push_back(cat);
+            c->ev_tag.push_back(tag);
         }
         c->ev_cat[c->ev_used / 2] = cat;
+        c->ev_tag[c->ev_used / 2] = tag;
         if (hipEventRecord(c->ev[c->ev_used], s) != hipSuccess) return;
         e1 = c->ev[c->ev_used + 1];
         c->ev_used += 2;
@@ -413,6 +418,11 @@ extern "C" int llicti_set_tuning(llicti_ctx *c, const char *key, int value)
         c->cnn_tile_rows = value;
         return LLICTI_OK;
     }
+    if (!strcmp(key, "enc_chunk_images")) {
+        if (value < 0) return fail(LLICTI_EINVAL, "set_tuning: enc_chunk_images must be >= 0");
+        c->enc_chunk_images = value;
+        return LLICTI_OK;
+    }
     return fail(LLICTI_EINVAL, "set_tuning: unknown key '%s'", key);
 }
 
@@ -459,7 +469,7 @@ static int launch_band_params(llicti_ctx *c, const float *fplanes, const Geom &g
     int gx = std::min(n_tiles, c->n_cu * wg_per_cu / 4);    // 4 heads in grid.y; persistent loop over tiles
     if (gx < 1) gx = 1;
     dim3 grid((unsigned)gx, 4);
-    ProfSpan span(c, PROF_CNN, s);
+    ProfSpan span(c, PROF_CNN, s, g.lvl);
     switch (band + (small ? 3 : 0)) {
     case 0: band_params_kernel<0><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[0], params, tiles_x, tiles_y, n_tiles); break;
     case 1: band_params_kernel<1><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[1], params, tiles_x, tiles_y, n_tiles); break;
@@ -533,14 +543,13 @@ extern "C" int llicti_selfinfo_f32(llicti_ctx *c, const float *d_fplanes, const 
     return LLICTI_OK;
 }
 
+// pair_batch: images of the whole batch (the [clr][image][n] layout of `pairs`); g.B may be a sub-batch whose pointers the caller has shifted
 static int launch_cdf_pairs(const int16_t *planes, const float *params, const int32_t *mm, const Geom &g, int band,
-                            uint32_t *pairs, hipStream_t s)
+                            uint32_t *pairs, int pair_batch, hipStream_t s)
 {
     StageGeom sg = make_stage(g, band);
-    const long nc = (long)sg.hc * sg.wc;
     const long np = (long)sg.h * sg.w;                    // the kernel walks the band grid (rows of CNN outputs are contiguous there)
-    (void)nc;
-    cdf_pairs_kernel<<<dim3((unsigned)((np + 255) / 256), g.B), 256, 0, s>>>(planes, params, mm, sg, pairs);
+    cdf_pairs_kernel<<<dim3((unsigned)((np + 255) / 256), g.B), 256, 0, s>>>(planes, params, mm, sg, pairs, pair_batch);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -590,7 +599,7 @@ extern "C" int llicti_cdf_pairs_u32(llicti_ctx *c, const int16_t *d_planes, cons
     if (check_dims(B, H, W)) return LLICTI_EINVAL;
     if (lvl < 0 || lvl >= LLICTI_NLEVELS || band < 0 || band > 2) return fail(LLICTI_EINVAL, "cdf_pairs: bad level/band");
     Geom g = make_geom(B, H, W, lvl);
-    return launch_cdf_pairs(d_planes, d_params, d_minmax, g, band, d_pairs, (hipStream_t)stream);
+    return launch_cdf_pairs(d_planes, d_params, d_minmax, g, band, d_pairs, B, (hipStream_t)stream);
 }
 
 extern "C" int llicti_ac_encode_u16cdf(llicti_ctx *c, const uint16_t *d_cdf, int Lp, int row_stride, const int16_t *d_sym,
@@ -729,10 +738,22 @@ extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, 
     // the encoder has no dependency between stages: every (level, band) reads only original pixels
     for (int lvl = LLICTI_NLEVELS - 1; lvl >= 0; --lvl) {
         Geom g = make_geom(B, H, W, lvl);
+        // A launch's CNN outputs are read once, by the pairs kernel right behind it: at level 0 of a large batch they are 25 MB per image
+        // (604 MB for 24 images), far more than the 256 MB the chip's memory-side cache holds, and the pairs kernel is then bound by
+        // reading them back from HBM.  In sub-batches of `enc_chunk_images` the CNN outputs of one launch stay cache-resident.
+        const long par_bytes_img = (long)g.h * g.w * LLICTI_PARAM_STRIDE * sizeof(float);
+        const int chunk = (c->enc_chunk_images > 0 && (long)B * par_bytes_img > (200L << 20)) ? std::min(B, c->enc_chunk_images) : B;
         for (int band = 0; band < 3; ++band) {
-            if (int rc = launch_band_params(c, fplanes, g, band, params, s)) return rc;
-            ProfSpan span(c, PROF_PAIRS, s);
-            if (int rc = launch_cdf_pairs(planes, params, mm, g, band, pairs + p.pair_base[lvl * 3 + band], s)) return rc;
+            StageGeom sgb = make_stage(g, band);
+            const long nc = (long)sgb.hc * sgb.wc;
+            for (int b0 = 0; b0 < B; b0 += chunk) {
+                Geom gs = g;
+                gs.B = std::min(chunk, B - b0);
+                if (int rc = launch_band_params(c, fplanes + (long)b0 * 3 * g.plane, gs, band, params, s)) return rc;
+                ProfSpan span(c, PROF_PAIRS, s);
+                if (int rc = launch_cdf_pairs(planes + (long)b0 * 3 * g.plane, params, mm + 4 * b0, gs, band,
+                                              pairs + p.pair_base[lvl * 3 + band] + (long)b0 * nc, B, s)) return rc;
+            }
         }
     }
     const int hdr_bytes = 17 + 3 * g4.h * g4.w;
@@ -951,13 +972,14 @@ extern "C" int llicti_last_timing(llicti_ctx *c, float ms[4], int *n_launch)
         c->last_ms[0] = t;
         for (int k = 0; k < PROF_NCAT; ++k) c->last_cat_ms[k] = 0;
         c->last_cnn_ms.clear();
+        for (int l = 0; l < LLICTI_NLEVELS; ++l) c->last_cnn_level_ms[l] = 0;
         for (int i = 0; i + 1 < c->ev_used; i += 2) {
             float k = 0;
             HIPCHK(hipEventSynchronize(c->ev[i + 1]));       // spans of the AC decode pipeline sit on the internal streams
             HIPCHK(hipEventElapsedTime(&k, c->ev[i], c->ev[i + 1]));
             const int cat = c->ev_cat[i / 2];
             c->last_cat_ms[cat] += k;
-            if (cat == PROF_CNN) c->last_cnn_ms.push_back(k);
+            if (cat == PROF_CNN) { c->last_cnn_ms.push_back(k); const int l = c->ev_tag[i / 2]; if (l >= 0 && l < LLICTI_NLEVELS) c->last_cnn_level_ms[l] += k; }
         }
         c->last_ms[1] = c->last_cat_ms[PROF_CNN];
         c->last_launches = (int)c->last_cnn_ms.size();
@@ -977,6 +999,15 @@ extern "C" int llicti_last_timing_detail(llicti_ctx *c, float cat_ms[LLICTI_NPRO
     const int n = (int)c->last_cnn_ms.size();
     if (cnn_launch_ms) for (int i = 0; i < std::min(n, cnn_cap); ++i) cnn_launch_ms[i] = c->last_cnn_ms[i];
     if (n_cnn) *n_cnn = n;
+    return LLICTI_OK;
+}
+
+extern "C" int llicti_last_cnn_level_ms(llicti_ctx *c, float level_ms[LLICTI_NLEVELS])
+{
+    if (!c || !level_ms) return fail(LLICTI_EINVAL, "last_cnn_level_ms: null pointer");
+    float ms[4];
+    if (int rc = llicti_last_timing(c, ms, nullptr)) return rc;
+    for (int l = 0; l < LLICTI_NLEVELS; ++l) level_ms[l] = c->last_cnn_level_ms[l];
     return LLICTI_OK;
 }
 

@@ -100,7 +100,6 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
     using GEO = RansGeo<Q>;
     constexpr int L = GEO::kLanes;
     __shared__ uint32_t sh_pay[64 * Q];             // the tail stream / the final states (62 Q dwords used, the rest slack)
-    __shared__ uint32_t sh_pairs[64];
     constexpr int kFlush = 64 * Q, kWin = 4 * kFlush;      // dwords: one flush = one dword per thread; a step adds at most kFlush / 2
     __shared__ uint32_t sh_win[kWin];               // staging RING of the bit region: stream dword d at sh_win[d & (kWin - 1)], d in [wbase, wbase + kWin)
     __shared__ __attribute__((aligned(16))) int sh_tot[2][Q][4];       // a round's four bit totals per sub-chunk (ping-pong by round parity)
@@ -116,26 +115,32 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
     __syncthreads();
 
     // 1. tail: the stream's last T symbols of the last stage, last symbol first, single state; bits go UP from bit 0 of
-    //    the payload, the final state (32 bits, leading one = highest set bit of the payload) on top.  Every lane of every
-    //    wavefront runs the (uniform) recursion; lane 0 writes (twice over for a wide stream: the same bits, ORed).
+    //    the payload, the final state (32 bits, leading one = highest set bit of the payload) on top.  The recursion is serial and
+    //    wave-uniform (every wavefront runs it, on its scalar unit; thread 0 writes): what a symbol costs is its dependency chain, so
+    //    the chain holds nothing but the state update -- the pairs come out of a register by v_readlane (64 at a time, the next 64 in
+    //    flight), the emitted bits collect in a 64-bit accumulator and reach LDS a dword at a time.  (Round 3 read every pair from LDS
+    //    and ORed every bit field into LDS with an atomic: ~700 cycles a symbol; an xwide stream has ~620 tail symbols.)
     const StreamDesc dl = desc[(long)(LLICTI_NSTREAMS - 1) * B + b];
     const int cnt = rans_stream_count(dl.n, m, M, L);
     int T = 0;
     {
         const uint32_t *pl = pairs + dl.pair_off;
+        auto fetch_blk = [&](int q1) -> uint32_t {      // lane t: the t-th symbol from the end of the q1 symbols that are left
+            const int q = q1 - 1 - lane;
+            return (q >= 0) ? pl[L * (m + (q / L) * M) + (q % L)] : 0u;
+        };
         uint32_t xt = 1u << 31;
         int tb = 0;
+        uint64_t acc = 0;                               // emitted bits not yet in LDS: the low accn (< 32) bits
+        int accn = 0, wdw = 0;
         bool full = false;
+        uint32_t raw = fetch_blk(cnt);
         for (int q1 = cnt; q1 > 0 && !full; q1 -= 64) {
-            const int q = q1 - 1 - lane;              // lane t holds the t-th symbol from the end of what is left
-            uint32_t raw = 0u;
-            if (q >= 0) raw = pl[L * (m + (q / L) * M) + (q % L)];
-            sh_pairs[lane] = raw;
-            __syncthreads();
+            const uint32_t rawn = fetch_blk(q1 - 64);
             const int nblk = min(64, q1);
             for (int t = 0; t < nblk; ++t) {
                 if (T >= kRansTailMax) { full = true; break; }
-                const uint32_t v = sh_pairs[t];
+                const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)raw, t);
                 const uint32_t lo = v & 0xFFFFu;
                 uint32_t hi = v >> 16;
                 if (hi == 0) hi = 0x10000u;
@@ -144,14 +149,20 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
                 if (T == 0) xt = freq << 15;            // absorbing start: the first pushed symbol codes to 2^31 + c_low, no bits
                 const int nb = (T == 0) ? 0 : rans_emit_bits(xt, freq);      // (the closed form needs x >= 2^31)
                 if (tb + nb + 32 > GEO::kPayBits) { full = true; break; }
-                if (lane == 0) lds_or_bits(sh_pay, tb, nb, xt & ((1u << nb) - 1u));
+                acc |= (uint64_t)(xt & ((1u << nb) - 1u)) << accn;
+                accn += nb;
                 tb += nb;
+                if (accn >= 32) {                        // wave-uniform
+                    if (tid == 0) sh_pay[wdw] = (uint32_t)acc;
+                    ++wdw; acc >>= 32; accn -= 32;
+                }
                 xt = rans_push(xt >> nb, lo, freq);
                 ++T;
             }
-            __syncthreads();
+            raw = rawn;
         }
-        if (lane == 0) { lds_or_bits(sh_pay, tb, 16, xt & 0xFFFFu); lds_or_bits(sh_pay, tb + 16, 16, xt >> 16); }
+        acc |= (uint64_t)xt << accn;                     // the final state on top: accn + 32 <= 63 bits
+        if (tid == 0) { sh_pay[wdw] = (uint32_t)acc; if (accn > 0) sh_pay[wdw + 1] = (uint32_t)(acc >> 32); }
         __syncthreads();
     }
     // 2. the lanes start from the payload (lane l of wavefront wq = stream lane 64 wq + l)
