@@ -931,21 +931,25 @@ __global__ __launch_bounds__(64 * Q) void rans_decode_stage_lane_kernel(const fl
     };
     Raw cur = fetch(0);
     for (int k = 0; k < K; ++k) {
-        const Raw nxt = fetch(min(k + 1, K - 1));
         const uint32_t slot = x & 0xFFFFu;
         uint32_t vlo = 0, vhi = 0x10000u;
-        if (cur.on) {
-            // the five components as mix_prepare() has them
-            float mu5[5], rs5[5], wn5[5], w5[5];
+        // the five components as mix_prepare() has them -- computed for every lane (a clamped position's values where the lane is off):
+        // that makes the raw CNN outputs dead right here, so the NEXT step's are loaded into the same registers now and have the whole
+        // search to arrive (no second register set, no copies)
+        float mu5[5], rs5[5], wn5[5], w5[5];
 #pragma unroll
-            for (int t = 0; t < 5; ++t) {
-                float mu = cur.mu[t];
-                if constexpr (clr == 1) { const float tt = cur.a0[t] * cur.y; mu = mu + tt; }
-                else if constexpr (clr == 2) { const float t1 = cur.a0[t] * cur.y; const float t2 = cur.a1[t] * cur.co; const float tt = t1 + t2; mu = mu + tt; }
-                mu5[t] = mu;
-                rs5[t] = 1.0f / ((cur.sg[t] > kScaleBound) ? cur.sg[t] : kScaleBound);
-                w5[t] = (cur.wk[t] > kWeightBound) ? cur.wk[t] : kWeightBound;
-            }
+        for (int t = 0; t < 5; ++t) {
+            float mu = cur.mu[t];
+            if constexpr (clr == 1) { const float tt = cur.a0[t] * cur.y; mu = mu + tt; }
+            else if constexpr (clr == 2) { const float t1 = cur.a0[t] * cur.y; const float t2 = cur.a1[t] * cur.co; const float tt = t1 + t2; mu = mu + tt; }
+            mu5[t] = mu;
+            rs5[t] = 1.0f / ((cur.sg[t] > kScaleBound) ? cur.sg[t] : kScaleBound);
+            w5[t] = (cur.wk[t] > kWeightBound) ? cur.wk[t] : kWeightBound;
+        }
+        const long off_k = cur.off;
+        const bool on_k = cur.on;
+        cur = fetch(min(k + 1, K - 1));
+        if (on_k) {
             const float ssum = (((w5[0] + w5[1]) + w5[2]) + w5[3]) + w5[4];
             const float den = 1e-9f + ssum;
             CompFast F[5];
@@ -1004,12 +1008,12 @@ __global__ __launch_bounds__(64 * Q) void rans_decode_stage_lane_kernel(const fl
             }
             if (!have_lo) vlo = entry_exact(0);
             const int v = lo - shift;
-            planes[cur.off + (long)clr * sg.plane] = (int16_t)v;
-            fplanes[cur.off + (long)clr * sg.plane] = (float)v / 255.0f;
+            planes[off_k + (long)clr * sg.plane] = (int16_t)v;
+            fplanes[off_k + (long)clr * sg.plane] = (float)v / 255.0f;
         }
         // state update of this lane, bit-granular renormalisation: lane l of the stream takes its clz(x) bits below those of lanes < l
         int nb = 0;
-        if (cur.on) {
+        if (on_k) {
             x = (vhi - vlo) * (x >> 16) + slot - vlo;                          // in [freq << 15, freq << 16)
             const int lz = __clz((int)x);
             badx |= lz > 16;                                                   // only a corrupt stream: the oracle rejects it too
@@ -1034,7 +1038,6 @@ __global__ __launch_bounds__(64 * Q) void rans_decode_stage_lane_kernel(const fl
         // then request the next one if fewer than two steps of dwords are left below the cursor
         if (pend) { if (tid < kRefill) sh_ring[(wlo + tid) & (kRing - 1)] = pf; pend = false; }
         if ((bcur >> 5) - 2 * kRefill < wlo) { wlo -= kRefill; if (tid < kRefill) pf = load_dw(wlo + tid); pend = true; }
-        cur = nxt;
     }
     };
     // Between passes: the pixels a lane stored are loaded again by the SAME lane (same position) -- a workgroup-scope fence orders them
