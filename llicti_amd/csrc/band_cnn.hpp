@@ -23,8 +23,9 @@ constexpr int kNT = CNN_NT;                    // pixel tiles (16 positions each
 static_assert(CNN_NT == 2, "one wavefront per tile row (two 16-column pixel tiles)");
 // Workgroup tile = TH rows x 32 columns of band-grid positions, one wavefront per row.  TH = 16 (16 wavefronts, 4 per SIMD) is the
 // throughput form; TH = 4 (4 wavefronts, one per SIMD, a quarter of the work per workgroup) is the LATENCY form for launches whose
-// 16-row tiles would leave most of the chip idle (coarse levels, single images): 4x the workgroups, each done in ~a third of the time.
-constexpr int kTileHMax = 16, kTileHSmall = 4;
+// 16-row tiles would leave most of the chip idle (coarse levels, single images): 4x the workgroups, each done in ~a third of the time;
+// TH = 8 sits between them (round 4): the form for launches of one to three rounds of 16-row tiles, whose last round is mostly empty.
+constexpr int kTileHMax = 16, kTileHMid = 8, kTileHSmall = 4;
 constexpr int kTileW = 32;
 constexpr int kInCols = kTileW + 4;    // taps reach rows i-2 .. i+2 and columns j-2 .. j+2
 constexpr int kInPitch = 48;       // = 16 (mod 32): B-fragment reads that stride by one row stay bank-conflict free

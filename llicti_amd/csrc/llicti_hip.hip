@@ -355,6 +355,9 @@ extern "C" int llicti_create(llicti_ctx **out, int device)
     HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(0)));
     HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(1)));
     HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(2)));
+    HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<0, kTileHMid>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(0, kTileHMid)));
+    HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<1, kTileHMid>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(1, kTileHMid)));
+    HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<2, kTileHMid>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(2, kTileHMid)));
     HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<0, kTileHSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(0, kTileHSmall)));
     HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<1, kTileHSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(1, kTileHSmall)));
     HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<2, kTileHSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(2, kTileHSmall)));
@@ -414,7 +417,8 @@ extern "C" int llicti_set_tuning(llicti_ctx *c, const char *key, int value)
         return LLICTI_OK;
     }
     if (!strcmp(key, "cnn_tile_rows")) {
-        if (value != 0 && value != kTileHMax && value != kTileHSmall) return fail(LLICTI_EINVAL, "set_tuning: cnn_tile_rows must be 0 (automatic), %d or %d", kTileHMax, kTileHSmall);
+        if (value != 0 && value != kTileHMax && value != kTileHMid && value != kTileHSmall && value != -1)
+            return fail(LLICTI_EINVAL, "set_tuning: cnn_tile_rows must be 0 (automatic), %d, %d or %d (-1: round 3's rule, 16 or 4)", kTileHMax, kTileHMid, kTileHSmall);
         c->cnn_tile_rows = value;
         return LLICTI_OK;
     }
@@ -452,31 +456,52 @@ static int launch_lift(const uint8_t *d_rgb, int B, int H, int W, int16_t *plane
 static int launch_band_params(llicti_ctx *c, const float *fplanes, const Geom &g, int band, float *params, hipStream_t s)
 {
     if (!c->have[band]) return fail(LLICTI_ENOWEIGHTS, "band %d weights not set", band);
-    // Tile height: 16 rows while those tiles alone give every compute unit a workgroup (4 heads x tiles >= CUs); otherwise 4 rows
-    // (a quarter of the work per workgroup, 4x the workgroups): coarse levels and single images.  Either form computes each
-    // position with the same fmaf chains: the results do not depend on it (test_band_params_bitexact_and_golden runs both).
+    // Tile height (16, 8 or 4 rows; one wavefront per row, so 16 / 8 / 4 wavefronts per workgroup): the form whose launch is shortest
+    // under a two-parameter model of the persistent grid -- rounds = ceil(tiles / workgroups that fit the chip), a round = a fixed part
+    // (halo rows, staging the head's weights, barrier) + a part per tile row; the constants are the measured 46 / 25 / 15 us of a band-2
+    // tile of 16 / 8 / 4 rows.  Full launches come out at 16 rows; launches of one to three half-empty rounds (levels 3 and 4 of a batch
+    // of 24) at 8; launches that cannot give every compute unit a workgroup (coarse levels of a single image) at 4.  Every form computes
+    // each position with the same fmaf chains: the results do not depend on it (test_band_params_bitexact_and_golden runs all three).
     const int tiles_x = (g.w + kTileW - 1) / kTileW;
-    const long tiles16 = (long)g.B * tiles_x * ((g.h + kTileHMax - 1) / kTileHMax);
-    const bool small = c->cnn_tile_rows ? c->cnn_tile_rows == kTileHSmall : 4 * tiles16 < c->n_cu;
-    const int TH = small ? kTileHSmall : kTileHMax;
+    auto plan_for = [&](int th, int *gx_out, long *tiles_out) -> double {
+        const long tiles = (long)g.B * tiles_x * ((g.h + th - 1) / th);
+        const int per_cu = std::max(1, std::min(4, (160 * 1024) / cnn_lds_bytes(band, th)));
+        const long gx = std::max<long>(1, std::min<long>(tiles, (long)c->n_cu * per_cu / 4));
+        *gx_out = (int)gx; *tiles_out = tiles;
+        return (double)((tiles + gx - 1) / gx) * (4.7 + 2.6 * th);
+    };
+    int TH = kTileHMax, gx = 1;
+    long n_tiles_l = 0;
+    if (c->cnn_tile_rows > 0) { TH = c->cnn_tile_rows; (void)plan_for(TH, &gx, &n_tiles_l); }
+    else if (c->cnn_tile_rows < 0) {                       // round 3's rule (A/B): 4 rows iff the 16-row tiles cannot fill the chip
+        const long tiles16 = (long)g.B * tiles_x * ((g.h + kTileHMax - 1) / kTileHMax);
+        TH = (4 * tiles16 < c->n_cu) ? kTileHSmall : kTileHMax;
+        (void)plan_for(TH, &gx, &n_tiles_l);
+    } else {
+        double best = 0;
+        for (int th : { kTileHMax, kTileHMid, kTileHSmall }) {
+            int gx_t; long nt;
+            const double t = plan_for(th, &gx_t, &nt);
+            if (th == kTileHMax || t < 0.995 * best) { best = t; TH = th; gx = gx_t; n_tiles_l = nt; }    // ties go to the larger form
+        }
+    }
     const int tiles_y = (g.h + TH - 1) / TH;
-    const long n_tiles_l = (long)g.B * tiles_x * tiles_y;
     if (n_tiles_l > 0x7FFFFFFFL) return fail(LLICTI_EINVAL, "band_params: too many tiles");
     const int n_tiles = (int)n_tiles_l;
     const int lds_bytes = cnn_lds_bytes(band, TH);
     const int kCnnThreads = 64 * TH;
-    const int wg_per_cu = std::max(1, std::min(4, (160 * 1024) / lds_bytes));
-    int gx = std::min(n_tiles, c->n_cu * wg_per_cu / 4);    // 4 heads in grid.y; persistent loop over tiles
-    if (gx < 1) gx = 1;
     dim3 grid((unsigned)gx, 4);
     ProfSpan span(c, PROF_CNN, s, g.lvl);
-    switch (band + (small ? 3 : 0)) {
+    switch (band + (TH == kTileHSmall ? 3 : TH == kTileHMid ? 6 : 0)) {
     case 0: band_params_kernel<0><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[0], params, tiles_x, tiles_y, n_tiles); break;
     case 1: band_params_kernel<1><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[1], params, tiles_x, tiles_y, n_tiles); break;
     case 2: band_params_kernel<2><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[2], params, tiles_x, tiles_y, n_tiles); break;
     case 3: band_params_kernel<0, kTileHSmall><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[0], params, tiles_x, tiles_y, n_tiles); break;
     case 4: band_params_kernel<1, kTileHSmall><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[1], params, tiles_x, tiles_y, n_tiles); break;
-    default: band_params_kernel<2, kTileHSmall><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[2], params, tiles_x, tiles_y, n_tiles); break;
+    case 5: band_params_kernel<2, kTileHSmall><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[2], params, tiles_x, tiles_y, n_tiles); break;
+    case 6: band_params_kernel<0, kTileHMid><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[0], params, tiles_x, tiles_y, n_tiles); break;
+    case 7: band_params_kernel<1, kTileHMid><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[1], params, tiles_x, tiles_y, n_tiles); break;
+    default: band_params_kernel<2, kTileHMid><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[2], params, tiles_x, tiles_y, n_tiles); break;
     }
     HIPCHK(hipGetLastError());
     return 0;

@@ -69,7 +69,7 @@ def test_band_params_bitexact_and_golden(torch_mod, codecs, golden_index, oracle
     planes, fplanes, mm = c.lift(_dev(torch, rgb[None]))
     p_host = planes[0].cpu().numpy()
     try:
-        for rows in (16, 4, 0):                    # both tile forms of the kernel (throughput / latency), then the automatic choice
+        for rows in (16, 8, 4, -1, 0):             # the three tile forms of the kernel, round 3's choice rule, then the automatic choice
             c.set_tuning("cnn_tile_rows", rows)
             for lvl in range(5):
                 for band in range(3):
