@@ -54,16 +54,21 @@ __global__ void header_read_kernel(const uint8_t *__restrict__ in, long in_strid
     const int32_t *sl = seg_len + (long)b * LLICTI_NSEG;
     const long plane = (long)H * W;
     __shared__ int ok;
+    __shared__ int sh_bad;
+    __shared__ unsigned long long sh_tot;
+    if (threadIdx.x == 0) { sh_bad = 0; sh_tot = 0ull; }
+    __syncthreads();
+    if (threadIdx.x < LLICTI_NSEG) {               // the 49 lengths in parallel (one thread walking them was most of this kernel's 70 us)
+        const int v = sl[threadIdx.x];
+        if (v < 0 || v > in_stride) atomicOr(&sh_bad, 1);
+        atomicAdd(&sh_tot, (unsigned long long)((v < 0) ? 0 : v));
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
         // every segment length is checked before a single container byte is read: a malformed seg_len must end in
         // LLICTI_EFORMAT, never in an access outside [in, in + in_stride)
-        long tot = 0;
-        bool segs_ok = in_stride >= 17 + 3L * h4 * w4;
-        for (int k = 0; k < LLICTI_NSEG; ++k) {
-            const int v = sl[k];
-            if (v < 0 || v > in_stride) segs_ok = false;
-            tot += (v < 0) ? 0 : v;
-        }
+        const long tot = (long)sh_tot;
+        bool segs_ok = in_stride >= 17 + 3L * h4 * w4 && !sh_bad;
         if (tot > in_stride) segs_ok = false;
         ok = segs_ok && (sl[0] == 3 && sl[1] == 12 && sl[2] == 2 && sl[3] == 3 * h4 * w4);
         if (ok) {

@@ -100,7 +100,13 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
     using GEO = RansGeo<Q>;
     constexpr int L = GEO::kLanes;
     __shared__ uint32_t sh_pay[64 * Q];             // the tail stream / the final states (62 Q dwords used, the rest slack)
-    constexpr int kFlush = 64 * Q, kWin = 4 * kFlush;      // dwords: one flush = one dword per thread; a step adds at most kFlush / 2
+    // dwords: one flush = one dword per thread; a step adds at most kFlush / 2, a round of four steps 2 kFlush.  Ring of 8 flush units: when a
+    // round's barrier opens, up to 3 kFlush dwords are waiting (a leftover below one unit + the previous round's), the round's own ORs reach
+    // 2 kFlush + 1 further -- below wbase + 5 kFlush + 2 -- while slower wavefronts may still be reading / zeroing [wbase, wbase + 2 kFlush):
+    // with 4 units (the size the one-step-per-round form needed) those ORs wrapped onto the units being flushed whenever the wavefronts
+    // of a stream drifted apart -- never in a test that had the chip to itself, at once under a second context's kernels (bench.py's
+    // overlapped_streams leg caught it; tests/test_hip_parity.py::test_two_contexts_concurrently_bitexact now does).
+    constexpr int kFlush = 64 * Q, kWin = 8 * kFlush;
     __shared__ uint32_t sh_win[kWin];               // staging RING of the bit region: stream dword d at sh_win[d & (kWin - 1)], d in [wbase, wbase + kWin)
     __shared__ __attribute__((aligned(16))) int sh_tot[2][Q][4];       // a round's four bit totals per sub-chunk (ping-pong by round parity)
     const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M;
@@ -172,15 +178,31 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
     // 3. main coder, last decoded symbol first; bits go UP from bit 0 of the bit region
     int bp = 0, wbase = 0;                          // bit cursor; first dword of the staging window (workgroup-uniform)
     int par = 0;                                    // parity of the coded steps (sh_tot)
-    for (int st = LLICTI_NSTREAMS - 1; st >= 0; --st) {      // rANS is LIFO: last decoded symbol first
+    // A stage's steps of this stream: K of them (0: the stage has no chunk for stream m), its pairs, the first tail position
+    struct Stg { const uint32_t *pp; int n, K, lim; };
+    auto stage_of = [&](int st) -> Stg {
+        if (st < 0) return Stg{ pairs, 1, 0, 0 };
         const StreamDesc d = desc[(long)st * B + b];
         const int nchunks = (d.n + L - 1) / L;
-        if (nchunks <= m) continue;
-        const int K = (nchunks - m + M - 1) / M;
-        const uint32_t *pp = pairs + d.pair_off;
-        const int lim = (st == LLICTI_NSTREAMS - 1) ? tail_from : 0x7FFFFFFF;
-        // Pair loads are unconditional (clamped address); the raw value is masked only where it is consumed.
-        auto fetch = [&](int k) -> uint32_t { return pp[min(L * (m + max(k, 0) * M) + tid, d.n - 1)]; };
+        return Stg{ pairs + d.pair_off, max(d.n, 1), (nchunks <= m) ? 0 : (nchunks - m + M - 1) / M,
+                    (st == LLICTI_NSTREAMS - 1) ? tail_from : 0x7FFFFFFF };
+    };
+    // Pair loads are unconditional (clamped address); the raw value is masked only where it is consumed.
+    auto fetch_of = [&](const Stg &g, int k) -> uint32_t { return g.pp[min(L * (m + max(k, 0) * M) + tid, g.n - 1)]; };
+    // The pair loads do not depend on the coder state: two rounds (eight steps) are kept in flight in registers with FIXED roles (a
+    // rotating ring makes the compiler copy the newest load, i.e. wait for it with s_waitcnt vmcnt(0) in every round) -- and a stage's
+    // first eight are requested before the PREVIOUS stage's rounds run, so that the 45 stages do not each start with a memory round trip.
+    Stg sg_cur = stage_of(LLICTI_NSTREAMS - 1);
+    uint32_t a0 = fetch_of(sg_cur, sg_cur.K - 1), a1 = fetch_of(sg_cur, sg_cur.K - 2), a2 = fetch_of(sg_cur, sg_cur.K - 3), a3 = fetch_of(sg_cur, sg_cur.K - 4);
+    uint32_t b0 = fetch_of(sg_cur, sg_cur.K - 5), b1 = fetch_of(sg_cur, sg_cur.K - 6), b2 = fetch_of(sg_cur, sg_cur.K - 7), b3 = fetch_of(sg_cur, sg_cur.K - 8);
+    for (int st = LLICTI_NSTREAMS - 1; st >= 0; --st) {      // rANS is LIFO: last decoded symbol first
+        const Stg d = sg_cur;
+        const Stg sg_nxt = stage_of(st - 1);
+        const uint32_t n0 = fetch_of(sg_nxt, sg_nxt.K - 1), n1 = fetch_of(sg_nxt, sg_nxt.K - 2), n2 = fetch_of(sg_nxt, sg_nxt.K - 3), n3 = fetch_of(sg_nxt, sg_nxt.K - 4);
+        const uint32_t n4 = fetch_of(sg_nxt, sg_nxt.K - 5), n5 = fetch_of(sg_nxt, sg_nxt.K - 6), n6 = fetch_of(sg_nxt, sg_nxt.K - 7), n7 = fetch_of(sg_nxt, sg_nxt.K - 8);
+        const int K = d.K;
+        const int lim = d.lim;
+        auto fetch = [&](int k) -> uint32_t { return fetch_of(d, k); };
         // FOUR steps per round.  The state recurrence of a lane -- x -> bits to emit -> push -> x -- does not depend on where the bits
         // go, and it is the only serial chain the coder has (~25 dependent operations a step); WHERE they go needs a prefix sum over
         // the stream's lanes, i.e. for a multi-wavefront stream an LDS exchange behind a barrier -- a ~350-cycle round trip that the
@@ -196,7 +218,7 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
             for (int j = 0; j < 4; ++j) {                            // steps k, k - 1, k - 2, k - 3: the recurrence
                 const int kk = k - j;
                 const int n = L * (m + kk * M) + tid;
-                const bool active = kk >= 0 && n < d.n && L * kk + tid < lim;
+                const bool active = kk >= 0 && n < d.n && L * kk + tid < lim;      // (d.n >= 1: a clamped length of an empty stage, which has K = 0 and never gets here)
                 const uint32_t v = active ? raws[j] : 0u;            // (lo, c_high) = (0, 2^16 stored as 0): freq 2^16, no bits
                 const uint32_t lo = v & 0xFFFFu;
                 uint32_t hi = v >> 16;
@@ -233,8 +255,8 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
             }
             // The ring's lowest kFlush dwords are complete once the cursor has passed them -- and every wavefront's ORs of the PREVIOUS
             // round are done once this round's barrier (above; Q = 1: same wavefront, program order) has been passed: they are written
-            // out and zeroed here, one dword per thread, with no barrier of their own (this round's ORs start at bp, beyond them; the
-            // zeroed slots come round again 3 kFlush dwords later; a round adds at most 2 kFlush dwords).
+            // out and zeroed here, one dword per thread, with no barrier of their own (this round's ORs start at bp, beyond them, and end
+            // below wbase + 5 kFlush + 2: inside the ring of 8 units; a round adds at most 2 kFlush dwords).
             while (bp - 32 * wbase >= 32 * kFlush) {                 // workgroup-uniform; at most twice
                 const int slot_i = (wbase + tid) & (kWin - 1);
                 if (wbase + kFlush <= cap_dw) out32[wbase + tid] = sh_win[slot_i]; else bad = 2;
@@ -250,16 +272,14 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
                 bp += step_total[j];
             }
         };
-        // The pair loads do not depend on the coder state: two rounds (eight steps) are kept in flight in registers with FIXED roles
-        // (a rotating ring makes the compiler copy the newest load, i.e. wait for it with s_waitcnt vmcnt(0) in every round)
-        uint32_t a0 = fetch(K - 1), a1 = fetch(K - 2), a2 = fetch(K - 3), a3 = fetch(K - 4);
-        uint32_t b0 = fetch(K - 5), b1 = fetch(K - 6), b2 = fetch(K - 7), b3 = fetch(K - 8);
         for (int k = K - 1; k >= 0; k -= 8) {                 // steps k .. k - 7 (those below 0 are no-ops)
             round4(k, a0, a1, a2, a3);
             a0 = fetch(k - 8); a1 = fetch(k - 9); a2 = fetch(k - 10); a3 = fetch(k - 11);
             if (k - 4 >= 0) round4(k - 4, b0, b1, b2, b3);         // workgroup-uniform
             b0 = fetch(k - 12); b1 = fetch(k - 13); b2 = fetch(k - 14); b3 = fetch(k - 15);
         }
+        a0 = n0; a1 = n1; a2 = n2; a3 = n3; b0 = n4; b1 = n5; b2 = n6; b3 = n7;
+        sg_cur = sg_nxt;
     }
     // 4. the rest of the ring, the 64 Q final states (31 bits each), T | pad
     __syncthreads();

@@ -1134,6 +1134,64 @@ def test_rans_v3_integrity_check_detects_corruption(torch_mod, codecs, oracle_we
     assert np.array_equal(rec.cpu().numpy(), rgb)
 
 
+def test_two_contexts_concurrently_bitexact(torch_mod):
+    """Two contexts on two HIP streams, encode of batch k next to decode of batch k - 1, with a third stream of unrelated GEMMs: the
+    wavefronts of a coder workgroup drift apart under a neighbour's kernels, which is what exposes hand-offs between them that rely on
+    lockstep (round 4: the encoder's LDS bit ring was one round too small and wrapped onto words still being flushed -- never in a test
+    that had the chip to itself).  Every container must equal the one a quiet single-stream encode wrote, every decode its input, in the
+    timed container and in a narrow and a wide one."""
+    from llicti_amd.codec import HipCodec, mode_of_name
+    torch = torch_mod
+    dev = torch.device("cuda", 0)
+    sd = load_state_dict("rand1337")
+    B, H, W = 24, 512, 768
+    rgb = [_dev(torch, make_batch("noise" if i % 2 == 0 else "smooth", B, H, W, seed0=900 + 40 * i)) for i in range(2)]
+    ce, cd = HipCodec(dev), HipCodec(dev)
+    try:
+        ce.load_state_dict(sd)
+        cd.load_state_dict(sd)
+        s_e, s_d, s_x = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        a = torch.randn((2048, 2048), device=dev)
+        for name in (_bench_container_mode()[0], "rans10", "wrans10"):
+            mode = mode_of_name(name)
+            ref = []
+            for x in rgb:                                       # quiet reference: one stream, nothing else running
+                c0, s0 = ce.encode(x, mode=mode)
+                ce.check()
+                ref.append((c0.clone(), s0.clone()))
+            torch.cuda.synchronize()
+            stride = ref[0][0].shape[1]
+            cont = [torch.empty((B, stride), dtype=torch.uint8, device=dev) for _ in range(2)]
+            seg = [torch.zeros((B, 49), dtype=torch.int32, device=dev) for _ in range(2)]
+            rec = [torch.empty_like(rgb[0]) for _ in range(2)]
+            done = [torch.cuda.Event(), torch.cuda.Event()]
+            for k in range(8):
+                with torch.cuda.stream(s_x):
+                    for _ in range(6):
+                        a = (a @ a).clamp_(-1, 1)               # neighbours on every compute unit
+                with torch.cuda.stream(s_e):
+                    ce.encode(rgb[k & 1], mode=mode, out=cont[k & 1], seg_len=seg[k & 1])
+                    done[k & 1].record(s_e)
+                if k > 0:
+                    with torch.cuda.stream(s_d):
+                        s_d.wait_event(done[(k - 1) & 1])
+                        cd.decode(cont[(k - 1) & 1], seg[(k - 1) & 1], H, W, mode=mode, out=rec[(k - 1) & 1])
+                torch.cuda.synchronize()                        # per iteration: the buffers are checked, then reused
+                j = k & 1
+                assert torch.equal(seg[j], ref[j][1]), (name, k)
+                used = torch.arange(stride, device=dev)[None, :] < ref[j][1].sum(dim=1, keepdim=True)       # an image's own bytes; the rest of its stride is not written
+                assert torch.equal(cont[j] * used, ref[j][0] * used), (name, k)
+                if k > 0:
+                    assert torch.equal(rec[(k - 1) & 1], rgb[(k - 1) & 1]), (name, k)
+            with torch.cuda.stream(s_e):
+                ce.check()
+            with torch.cuda.stream(s_d):
+                cd.check()
+    finally:
+        ce.close()
+        cd.close()
+
+
 def test_bench_line_contract(torch_mod):
     """bench.py's one JSON line carries every field the driver reads (small shape, no informational legs)."""
     import json
