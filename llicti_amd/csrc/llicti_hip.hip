@@ -574,7 +574,7 @@ static int launch_cdf_pairs(const int16_t *planes, const float *params, const in
 {
     StageGeom sg = make_stage(g, band);
     const long np = (long)sg.h * sg.w;                    // the kernel walks the band grid (rows of CNN outputs are contiguous there)
-    cdf_pairs_kernel<<<dim3((unsigned)((np + 255) / 256), g.B), 256, 0, s>>>(planes, params, mm, sg, pairs, pair_batch);
+    cdf_pairs_kernel<<<dim3((unsigned)((np + kPairsThreads - 1) / kPairsThreads), g.B), kPairsThreads, 0, s>>>(planes, params, mm, sg, pairs, pair_batch);
     HIPCHK(hipGetLastError());
     return 0;
 }
