@@ -46,7 +46,7 @@ struct Plan {                 // workspace carving for (B, H, W)
     int B = 0, H = 0, W = 0;
     size_t off_lift_part, off_acstate;
     long ac_cap_rows = 0;             // rows per image of one colour's chunk table buffer
-    size_t off_planes, off_fplanes, off_minmax, off_status, off_params, off_pairs, off_slots, off_slot_len, off_tables;
+    size_t off_planes, off_fplanes, off_minmax, off_status, off_params, off_params2, off_pairs, off_slots, off_slot_len, off_tables;
     size_t total;
     std::vector<StreamDesc> desc;       // stage-major, image-minor: index (stage * B + b)
     std::vector<long> slot_off;
@@ -109,6 +109,8 @@ struct llicti_ctx {
     int32_t *d_lift_part = nullptr;   // min/max partials of llicti_lift_u8 (1 MB; calls on one context are not concurrent)
     int n_cu = 256;                   // compute units of the device (grid sizing of the persistent kernels)
     int cnn_tile_rows = 0;            // llicti_set_tuning("cnn_tile_rows"): 0 = choose per launch, 16 / 4 = force (tests, A/B)
+    int enc_side_levels = 1;          // llicti_set_tuning("enc_side_levels"): 1 = encoder levels 4..1 on a side stream next to level 0 (default), 0 = one queue
+    hipEvent_t ev_enc[2] = { nullptr, nullptr };
     int enc_chunk_images = 0;         // llicti_set_tuning("enc_chunk_images"): encoder sub-batch of a (level, band) whose CNN outputs exceed 200 MB (0: never split; measured: no gain, profiles/r4/tried_encoder_subbatch.json)
     bool profiling = false;
     std::vector<hipEvent_t> ev;       // event pairs of the profiling spans of the current call
@@ -194,6 +196,11 @@ static void build_plan(Plan &p, int B, int H, int W, int ME)
     p.off_fplanes = take((size_t)B * 3 * plane * sizeof(float));
     Geom g0 = make_geom(B, H, W, 0);
     p.off_params = take((size_t)B * g0.h * g0.w * LLICTI_PARAM_STRIDE * sizeof(float));
+    {   // a second, quarter-size buffer for the CNN outputs of levels >= 1: the encoder of a launch-bound call (a single image) runs those
+        // levels on a side stream next to level 0
+        Geom g1 = make_geom(B, H, W, 1);
+        p.off_params2 = take((size_t)B * g1.h * g1.w * LLICTI_PARAM_STRIDE * sizeof(float));
+    }
     // pairs + slots
     p.desc.assign((size_t)LLICTI_NSTREAMS * B, StreamDesc{});
     p.slot_off.assign((size_t)LLICTI_NSTREAMS * B, 0);
@@ -350,6 +357,7 @@ extern "C" int llicti_create(llicti_ctx **out, int device)
         HIPCHK(hipEventCreateWithFlags(&c->ev_ac_end[k], hipEventDisableTiming));
     }
     HIPCHK(hipEventCreateWithFlags(&c->ev_ac_band, hipEventDisableTiming));
+    for (int k = 0; k < 2; ++k) HIPCHK(hipEventCreateWithFlags(&c->ev_enc[k], hipEventDisableTiming));
     for (int i = 1; i < kMaxSub; ++i) HIPCHK(hipStreamCreateWithFlags(&c->sub[i], hipStreamNonBlocking));
     // the band CNN stages a whole head (up to 86 KB) in LDS
     HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(0)));
@@ -381,6 +389,7 @@ extern "C" int llicti_destroy(llicti_ctx *c)
         if (c->ev_ac_end[k]) hipEventDestroy(c->ev_ac_end[k]);
     }
     if (c->ev_ac_band) hipEventDestroy(c->ev_ac_band);
+    for (int k = 0; k < 2; ++k) if (c->ev_enc[k]) hipEventDestroy(c->ev_enc[k]);
     if (c->d_status) hipFree(c->d_status);
     if (c->d_lift_part) hipFree(c->d_lift_part);
     if (c->d_img_status) hipFree(c->d_img_status);
@@ -420,6 +429,11 @@ extern "C" int llicti_set_tuning(llicti_ctx *c, const char *key, int value)
         if (value != 0 && value != kTileHMax && value != kTileHMid && value != kTileHSmall && value != -1)
             return fail(LLICTI_EINVAL, "set_tuning: cnn_tile_rows must be 0 (automatic), %d, %d or %d (-1: round 3's rule, 16 or 4)", kTileHMax, kTileHMid, kTileHSmall);
         c->cnn_tile_rows = value;
+        return LLICTI_OK;
+    }
+    if (!strcmp(key, "enc_side_levels")) {
+        if (value < 0 || value > 1) return fail(LLICTI_EINVAL, "set_tuning: enc_side_levels must be 0 or 1");
+        c->enc_side_levels = value;
         return LLICTI_OK;
     }
     if (!strcmp(key, "enc_chunk_images")) {
@@ -760,9 +774,22 @@ extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, 
         if (int rc = launch_lift(d_rgb, B, H, W, planes, fplanes, mm, (int32_t *)(ws + p.off_lift_part), s)) return rc;
         header_write_kernel<<<B, 256, 0, s>>>(d_rgb, mm, H, W, g4.h, g4.w, pad_int(H, W), byte0, d_out, (long)out_stride, d_seg_len);
     }
-    // the encoder has no dependency between stages: every (level, band) reads only original pixels
+    // The encoder has no dependency between stages: every (level, band) reads only original pixels.  Levels 4..1 (twelve CNN + twelve pairs
+    // launches, a quarter of the work) run on a side stream next to level 0's, with their own quarter-size buffer for the CNN outputs.  Two
+    // CNN launches cannot share a compute unit (a workgroup holds 81-155 KB of its 160 KB LDS), so this is no second queue of matrix work:
+    // what overlaps is the small stuff -- a pairs kernel under the other queue's CNN launch, a launch's ramp-down under the other's ramp-up.
+    // Measured (profiles/r4/ab_encoder_side_stream.json): -0.5 ... -4 % per encode at every batch size tried, 10.75 -> 10.68 ms at B = 24.
+    float *params2 = (float *)(ws + p.off_params2);
+    const bool side = c->enc_side_levels != 0 && !c->profiling;      // (the profiling spans assume one queue)
+    hipStream_t s2 = side ? c->sub[1] : s;
+    if (side) {
+        HIPCHK(hipEventRecord(c->ev_enc[0], s));      // lift and header are done
+        HIPCHK(hipStreamWaitEvent(s2, c->ev_enc[0], 0));
+    }
     for (int lvl = LLICTI_NLEVELS - 1; lvl >= 0; --lvl) {
         Geom g = make_geom(B, H, W, lvl);
+        hipStream_t s = (lvl >= 1) ? s2 : (hipStream_t)stream;          // (shadows the call's stream inside the loop)
+        float *params = (lvl >= 1 && side) ? params2 : (float *)(ws + p.off_params);
         // A launch's CNN outputs are read once, by the pairs kernel right behind it: at level 0 of a large batch they are 25 MB per image
         // (604 MB for 24 images), far more than the 256 MB the chip's memory-side cache holds, and the pairs kernel is then bound by
         // reading them back from HBM.  In sub-batches of `enc_chunk_images` the CNN outputs of one launch stay cache-resident.
@@ -780,6 +807,10 @@ extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, 
                                               pairs + p.pair_base[lvl * 3 + band] + (long)b0 * nc, B, s)) return rc;
             }
         }
+    }
+    if (side) {
+        HIPCHK(hipEventRecord(c->ev_enc[1], s2));
+        HIPCHK(hipStreamWaitEvent(s, c->ev_enc[1], 0));
     }
     const int hdr_bytes = 17 + 3 * g4.h * g4.w;
     if (M == 0) {
