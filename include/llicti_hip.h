@@ -18,7 +18,8 @@
  *     synchronise the stream themselves
  *   - one context per GPU / host thread; a context is not thread-safe and its calls must not overlap on different
  *     streams (llicti_decode_images with the AC container fans out over two internal streams and joins back on `stream`;
- *     llicti_encode_images runs its coarse levels on one internal stream and joins back before the entropy coder)
+ *     llicti_encode_images runs its coarse levels on one internal stream and joins back before the entropy coder, and
+ *     llicti_decode_images its stream copies next to the first CNN launch)
  *   - every call makes the context's device current for its own duration and restores the caller's current device
  *   - calls that BLOCK the host: llicti_create / llicti_destroy / llicti_set_band_weights (device-wide synchronise:
  *     work in flight may still read the old weights), llicti_check_status and llicti_last_timing (they return

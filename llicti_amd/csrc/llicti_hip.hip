@@ -852,24 +852,35 @@ static int decode_batch(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t 
     uint32_t *rstate = (uint32_t *)(ws + p.off_rstate);
     uint32_t *rpos = (uint32_t *)(ws + p.off_rpos);
     uint32_t *rtail = (uint32_t *)(ws + p.off_rtail);
+    // The stream copies and the initial coder states are needed by the first STAGE kernel, not by the first CNN launch (which needs the
+    // header's DC band only): they run on an internal stream next to header_read + the level-4 CNN and are joined in front of the first stage.
+    const bool fork = M > 0 && !c->profiling;        // (the profiling spans assume one queue)
+    hipStream_t su = fork ? c->sub[2] : s;
+    if (fork) {
+        HIPCHK(hipEventRecord(c->ev_enc[0], s));     // the status words are cleared
+        HIPCHK(hipStreamWaitEvent(su, c->ev_enc[0], 0));
+    }
     {
         ProfSpan span(c, PROF_MISC, s);
         header_read_kernel<<<B, 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, H, W, g4.h, g4.w, pad_int(H, W), byte0, planes, fplanes, mm, status);
         if (M == 0) {
             unpack_kernel<<<dim3(LLICTI_NSTREAMS, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, B, slots, pd->d_slot_off, pd->d_slot_cap, slot_len, status);
         } else {
-            rans_unpack_kernel<<<dim3(M, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, M, 2 + Q * RansGeo<1>::kPayBytes,
-                                                          slots, pd->d_rslot_off, p.rslot_cap, rpos, status);
-            if (Q == 4) rans_init_kernel<4><<<B * M, 64, 0, s>>>(slots, pd->d_rslot_off, M, rstate, rpos, rtail, status);
-            else if (Q == 2) rans_init_kernel<2><<<B * M, 64, 0, s>>>(slots, pd->d_rslot_off, M, rstate, rpos, rtail, status);
-            else rans_init_kernel<1><<<B * M, 64, 0, s>>>(slots, pd->d_rslot_off, M, rstate, rpos, rtail, status);
+            rans_unpack_kernel<<<dim3(M, B), 256, 0, su>>>(d_in, (long)in_stride, d_seg_len, M, 2 + Q * RansGeo<1>::kPayBytes,
+                                                           slots, pd->d_rslot_off, p.rslot_cap, rpos, status);
+            if (Q == 4) rans_init_kernel<4><<<B * M, 64, 0, su>>>(slots, pd->d_rslot_off, M, rstate, rpos, rtail, status);
+            else if (Q == 2) rans_init_kernel<2><<<B * M, 64, 0, su>>>(slots, pd->d_rslot_off, M, rstate, rpos, rtail, status);
+            else rans_init_kernel<1><<<B * M, 64, 0, su>>>(slots, pd->d_rslot_off, M, rstate, rpos, rtail, status);
         }
     }
+    if (fork) HIPCHK(hipEventRecord(c->ev_enc[1], su));
+    bool joined = !fork;
     // 45 dependent stages (LLICTI_nets.py:440-498): CNN of band b needs bands < b of this level, Co needs Y, Cg needs Y, Co
     for (int lvl = LLICTI_NLEVELS - 1; lvl >= 0; --lvl) {
         Geom g = make_geom(B, H, W, lvl);
         for (int band = 0; band < 3; ++band) {
             if (int rc = launch_band_params(c, fplanes, g, band, params, s)) return rc;
+            if (!joined) { HIPCHK(hipStreamWaitEvent(s, c->ev_enc[1], 0)); joined = true; }
             StageGeom sg = make_stage(g, band);
             const long nc = (long)sg.hc * sg.wc;
             if (M > 0) {
