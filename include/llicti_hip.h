@@ -18,8 +18,8 @@
  *     synchronise the stream themselves
  *   - one context per GPU / host thread; a context is not thread-safe and its calls must not overlap on different
  *     streams (llicti_decode_images with the AC container fans out over two internal streams and joins back on `stream`;
- *     llicti_encode_images runs its coarse levels on one internal stream and joins back before the entropy coder, and
- *     llicti_decode_images its stream copies next to the first CNN launch)
+ *     llicti_encode_images with the tuning switch "enc_side_levels" runs its coarse levels on one internal stream and joins back before
+ *     the entropy coder)
  *   - every call makes the context's device current for its own duration and restores the caller's current device
  *   - calls that BLOCK the host: llicti_create / llicti_destroy / llicti_set_band_weights (device-wide synchronise:
  *     work in flight may still read the old weights), llicti_check_status and llicti_last_timing (they return
@@ -230,8 +230,8 @@ int llicti_last_cnn_level_ms(llicti_ctx *ctx, float level_ms[LLICTI_NLEVELS]);
  * default are clamped to it (the workspace is sized for the default).  "enc_chunk_images" (default 0 = never): llicti_encode_images
  * runs a (level, band) whose CNN outputs exceed 200 MB in sub-batches of this many images, so that the outputs of one CNN launch could
  * still be in the memory-side cache when the pairs kernel behind it reads them (measured on MI355X: no gain, hence off).
- * "enc_side_levels" (default 1): llicti_encode_images runs levels 4..1 on an internal stream next to level 0's launches and joins it
- * before the entropy coder (0: one queue). */
+ * "enc_side_levels" (default 0; 1: llicti_encode_images runs levels 4..1 on an internal stream next to level 0's launches and joins it
+ * before the entropy coder: -0.3 % of a step on MI355X, at the price of kernel traces whose side-queue durations include waiting). */
 int llicti_set_tuning(llicti_ctx *ctx, const char *key, int value);
 /* enable / disable the per-kernel event timing above (off by default: it adds event records). */
 int llicti_set_profiling(llicti_ctx *ctx, int enable);

@@ -109,15 +109,17 @@ struct llicti_ctx {
     int32_t *d_lift_part = nullptr;   // min/max partials of llicti_lift_u8 (1 MB; calls on one context are not concurrent)
     int n_cu = 256;                   // compute units of the device (grid sizing of the persistent kernels)
     int cnn_tile_rows = 0;            // llicti_set_tuning("cnn_tile_rows"): 0 = choose per launch, 16 / 4 = force (tests, A/B)
-    int enc_side_levels = 1;          // llicti_set_tuning("enc_side_levels"): 1 = encoder levels 4..1 on a side stream next to level 0 (default), 0 = one queue
+    int enc_side_levels = 0;          // llicti_set_tuning("enc_side_levels"): 1 = encoder levels 4..1 on a side stream next to level 0, 0 = one queue (default)
     hipEvent_t ev_enc[2] = { nullptr, nullptr };
     int enc_chunk_images = 0;         // llicti_set_tuning("enc_chunk_images"): encoder sub-batch of a (level, band) whose CNN outputs exceed 200 MB (0: never split; measured: no gain, profiles/r4/tried_encoder_subbatch.json)
     bool profiling = false;
-    std::vector<hipEvent_t> ev;       // event pairs of the profiling spans of the current call
-    std::vector<int> ev_cat;          // category of pair i
-    std::vector<int> ev_tag;          // level of a PROF_CNN pair (-1 otherwise)
+    std::vector<hipEvent_t> ev;       // event pool of the profiling spans
+    struct Span { hipEvent_t e0, e1; int cat, tag; };
+    std::vector<Span> spans;          // spans of the current call: (start, end) events, category, level of a PROF_CNN span (-1 otherwise)
+    hipEvent_t last_ev = nullptr;     // the last event recorded by a span (or the call's opening event) ...
+    hipStream_t last_ev_stream = nullptr;      // ... and the stream it was recorded on: a span that follows on the same stream starts from it
     float last_cnn_level_ms[LLICTI_NLEVELS] = {};
-    int ev_used = 0;                  // events used (2 per span)
+    int ev_used = 0;                  // events of the pool in use
     hipEvent_t ev_call[2] = { nullptr, nullptr };
     float last_ms[4] = { 0, 0, 0, 0 };
     float last_cat_ms[PROF_NCAT] = {};
@@ -129,28 +131,40 @@ struct llicti_ctx {
 // One profiling span: events on `s` before and after the launches it brackets (no-op unless profiling is on).
 // A failed event call only loses the measurement.
 struct ProfSpan {
+    // Spans on one stream are CHAINED: a span starts from the event that closed the previous one (one event per span, not two), so the
+    // spans tile the call's time on that stream and a kernel's span holds its dispatch latency instead of a bubble made by the
+    // measurement (start and end events around every launch read 5-7 % above rocprofv3's kernel durations; chained: ~1 %).
     llicti_ctx *c;
     hipStream_t s;
     hipEvent_t e1 = nullptr;
+    static hipEvent_t pool_get(llicti_ctx *c)
+    {
+        if (c->ev_used == (int)c->ev.size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            c->ev.push_back(e);
+        }
+        return c->ev[c->ev_used++];
+    }
     ProfSpan(llicti_ctx *c_, int cat, hipStream_t s_, int tag = -1) : c(c_), s(s_)
     {
         if (!c->profiling) return;
-        if ((int)c->ev.size() < c->ev_used + 2) {
-            hipEvent_t a = nullptr, b = nullptr;
-            if (hipEventCreate(&a) != hipSuccess) return;
-            if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return; }
-            c->ev.push_back(a);
-            c->ev.push_back(b);
-            c->ev_cat.push_back(cat);
-            c->ev_tag.push_back(tag);
+        hipEvent_t e0 = (c->last_ev && c->last_ev_stream == s) ? c->last_ev : nullptr;
+        if (!e0) {
+            e0 = pool_get(c);
+            if (!e0 || hipEventRecord(e0, s) != hipSuccess) return;
         }
-        c->ev_cat[c->ev_used / 2] = cat;
-        c->ev_tag[c->ev_used / 2] = tag;
-        if (hipEventRecord(c->ev[c->ev_used], s) != hipSuccess) return;
-        e1 = c->ev[c->ev_used + 1];
-        c->ev_used += 2;
+        hipEvent_t e = pool_get(c);
+        if (!e) return;
+        c->spans.push_back(llicti_ctx::Span{ e0, e, cat, tag });
+        e1 = e;
     }
-    ~ProfSpan() { if (e1) (void)hipEventRecord(e1, s); }
+    ~ProfSpan()
+    {
+        if (!e1) return;
+        if (hipEventRecord(e1, s) == hipSuccess) { c->last_ev = e1; c->last_ev_stream = s; }
+        else c->spans.pop_back();
+    }
     ProfSpan(const ProfSpan &) = delete;
     ProfSpan &operator=(const ProfSpan &) = delete;
 };
@@ -730,8 +744,11 @@ struct CallScope {
     CallScope(llicti_ctx *c_, hipStream_t s_) : c(c_), s(s_), on(c_->profiling)
     {
         c->ev_used = 0;
+        c->spans.clear();
+        c->last_ev = nullptr;
         c->timing_pending = false;
         if (on) on = hipEventRecord(c->ev_call[0], s) == hipSuccess;
+        if (on) { c->last_ev = c->ev_call[0]; c->last_ev_stream = s; }
     }
     ~CallScope() { if (on && hipEventRecord(c->ev_call[1], s) == hipSuccess) c->timing_pending = true; }
     CallScope(const CallScope &) = delete;
@@ -774,11 +791,13 @@ extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, 
         if (int rc = launch_lift(d_rgb, B, H, W, planes, fplanes, mm, (int32_t *)(ws + p.off_lift_part), s)) return rc;
         header_write_kernel<<<B, 256, 0, s>>>(d_rgb, mm, H, W, g4.h, g4.w, pad_int(H, W), byte0, d_out, (long)out_stride, d_seg_len);
     }
-    // The encoder has no dependency between stages: every (level, band) reads only original pixels.  Levels 4..1 (twelve CNN + twelve pairs
-    // launches, a quarter of the work) run on a side stream next to level 0's, with their own quarter-size buffer for the CNN outputs.  Two
-    // CNN launches cannot share a compute unit (a workgroup holds 81-155 KB of its 160 KB LDS), so this is no second queue of matrix work:
-    // what overlaps is the small stuff -- a pairs kernel under the other queue's CNN launch, a launch's ramp-down under the other's ramp-up.
-    // Measured (profiles/r4/ab_encoder_side_stream.json): -0.5 ... -4 % per encode at every batch size tried, 10.75 -> 10.68 ms at B = 24.
+    // The encoder has no dependency between stages: every (level, band) reads only original pixels.  With llicti_set_tuning("enc_side_levels", 1)
+    // levels 4..1 (twelve CNN + twelve pairs launches, a quarter of the work) run on a side stream next to level 0's, with their own
+    // quarter-size buffer for the CNN outputs.  Two CNN launches cannot share a compute unit (a workgroup holds 81-155 KB of its 160 KB LDS),
+    // so this is no second queue of matrix work: what overlaps is the small stuff -- a pairs kernel under the other queue's CNN launch, a
+    // launch's ramp-down under the other's ramp-up.  Measured (profiles/r4/ab_encoder_side_stream.json): -0.5 ... -4 % per encode, 10.75 ->
+    // 10.68 ms at B = 24 -- 0.3 % of a step, for which every kernel trace of the run shows the side queue's launches with the time they
+    // spend waiting for a compute unit inside their durations.  Off by default: the per-kernel evidence is worth more than 0.07 ms.
     float *params2 = (float *)(ws + p.off_params2);
     const bool side = c->enc_side_levels != 0 && !c->profiling;      // (the profiling spans assume one queue)
     hipStream_t s2 = side ? c->sub[1] : s;
@@ -852,35 +871,24 @@ static int decode_batch(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t 
     uint32_t *rstate = (uint32_t *)(ws + p.off_rstate);
     uint32_t *rpos = (uint32_t *)(ws + p.off_rpos);
     uint32_t *rtail = (uint32_t *)(ws + p.off_rtail);
-    // The stream copies and the initial coder states are needed by the first STAGE kernel, not by the first CNN launch (which needs the
-    // header's DC band only): they run on an internal stream next to header_read + the level-4 CNN and are joined in front of the first stage.
-    const bool fork = M > 0 && !c->profiling;        // (the profiling spans assume one queue)
-    hipStream_t su = fork ? c->sub[2] : s;
-    if (fork) {
-        HIPCHK(hipEventRecord(c->ev_enc[0], s));     // the status words are cleared
-        HIPCHK(hipStreamWaitEvent(su, c->ev_enc[0], 0));
-    }
     {
         ProfSpan span(c, PROF_MISC, s);
         header_read_kernel<<<B, 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, H, W, g4.h, g4.w, pad_int(H, W), byte0, planes, fplanes, mm, status);
         if (M == 0) {
             unpack_kernel<<<dim3(LLICTI_NSTREAMS, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, B, slots, pd->d_slot_off, pd->d_slot_cap, slot_len, status);
         } else {
-            rans_unpack_kernel<<<dim3(M, B), 256, 0, su>>>(d_in, (long)in_stride, d_seg_len, M, 2 + Q * RansGeo<1>::kPayBytes,
-                                                           slots, pd->d_rslot_off, p.rslot_cap, rpos, status);
-            if (Q == 4) rans_init_kernel<4><<<B * M, 64, 0, su>>>(slots, pd->d_rslot_off, M, rstate, rpos, rtail, status);
-            else if (Q == 2) rans_init_kernel<2><<<B * M, 64, 0, su>>>(slots, pd->d_rslot_off, M, rstate, rpos, rtail, status);
-            else rans_init_kernel<1><<<B * M, 64, 0, su>>>(slots, pd->d_rslot_off, M, rstate, rpos, rtail, status);
+            rans_unpack_kernel<<<dim3(M, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, M, 2 + Q * RansGeo<1>::kPayBytes,
+                                                          slots, pd->d_rslot_off, p.rslot_cap, rpos, status);
+            if (Q == 4) rans_init_kernel<4><<<B * M, 64, 0, s>>>(slots, pd->d_rslot_off, M, rstate, rpos, rtail, status);
+            else if (Q == 2) rans_init_kernel<2><<<B * M, 64, 0, s>>>(slots, pd->d_rslot_off, M, rstate, rpos, rtail, status);
+            else rans_init_kernel<1><<<B * M, 64, 0, s>>>(slots, pd->d_rslot_off, M, rstate, rpos, rtail, status);
         }
     }
-    if (fork) HIPCHK(hipEventRecord(c->ev_enc[1], su));
-    bool joined = !fork;
     // 45 dependent stages (LLICTI_nets.py:440-498): CNN of band b needs bands < b of this level, Co needs Y, Cg needs Y, Co
     for (int lvl = LLICTI_NLEVELS - 1; lvl >= 0; --lvl) {
         Geom g = make_geom(B, H, W, lvl);
         for (int band = 0; band < 3; ++band) {
             if (int rc = launch_band_params(c, fplanes, g, band, params, s)) return rc;
-            if (!joined) { HIPCHK(hipStreamWaitEvent(s, c->ev_enc[1], 0)); joined = true; }
             StageGeom sg = make_stage(g, band);
             const long nc = (long)sg.hc * sg.wc;
             if (M > 0) {
@@ -1040,13 +1048,12 @@ extern "C" int llicti_last_timing(llicti_ctx *c, float ms[4], int *n_launch)
         for (int k = 0; k < PROF_NCAT; ++k) c->last_cat_ms[k] = 0;
         c->last_cnn_ms.clear();
         for (int l = 0; l < LLICTI_NLEVELS; ++l) c->last_cnn_level_ms[l] = 0;
-        for (int i = 0; i + 1 < c->ev_used; i += 2) {
+        for (const llicti_ctx::Span &sp : c->spans) {
             float k = 0;
-            HIPCHK(hipEventSynchronize(c->ev[i + 1]));       // spans of the AC decode pipeline sit on the internal streams
-            HIPCHK(hipEventElapsedTime(&k, c->ev[i], c->ev[i + 1]));
-            const int cat = c->ev_cat[i / 2];
-            c->last_cat_ms[cat] += k;
-            if (cat == PROF_CNN) { c->last_cnn_ms.push_back(k); const int l = c->ev_tag[i / 2]; if (l >= 0 && l < LLICTI_NLEVELS) c->last_cnn_level_ms[l] += k; }
+            HIPCHK(hipEventSynchronize(sp.e1));       // spans of the AC decode pipeline sit on the internal streams
+            HIPCHK(hipEventElapsedTime(&k, sp.e0, sp.e1));
+            c->last_cat_ms[sp.cat] += k;
+            if (sp.cat == PROF_CNN) { c->last_cnn_ms.push_back(k); if (sp.tag >= 0 && sp.tag < LLICTI_NLEVELS) c->last_cnn_level_ms[sp.tag] += k; }
         }
         c->last_ms[1] = c->last_cat_ms[PROF_CNN];
         c->last_launches = (int)c->last_cnn_ms.size();

@@ -38,5 +38,5 @@ for B, H, W, name in ((1, 512, 768, "rans128"), (1, 512, 768, "xrans64"), (2, 51
             res.setdefault(str(v), []).append(round((time.perf_counter() - t0) / 20 * 1e3, 4))
     codec.check()
     out[f"{B}x{W}x{H}_{name}"] = {k: statistics.median(v) for k, v in res.items()}
-codec.set_tuning("enc_side_levels", 1)
+codec.set_tuning("enc_side_levels", 0)
 print(json.dumps(out, indent=1))
