@@ -10,6 +10,10 @@
 //   cdf_table_kernel                  decoder: full Lp-entry uint16 rows                    (HBM / VALU bound)
 //   ac_encode_*_kernel                torchac-algorithm range encoder, one lane per stream  (latency bound)
 //   ac_decode_kernel                  matching decoder, one wavefront per stream            (latency bound)
+//   rans_encode_kernel<Q>             rANS v3 encoder: 64 Q lanes per stream, one wavefront per 64 (latency bound)
+//   rans_decode_stage_*_kernel        rANS v3 stage decoders, table-free: four / two / ONE lane per symbol for streams of 64 / 128 / 256
+//                                     lanes (the timed mode: rans_decode_stage_lane_kernel<4>)    (VALU issue bound)
+//   rans_tail_kernel<Q>               the serial tail coder behind the lanes' initial states      (latency bound)
 //   header / pack / unpack kernels    container assembly in HBM
 //
 // No CPU path exists in this library: every entry point needs a gfx950 device.
