@@ -462,14 +462,16 @@ def test_wild_weights_bitexact_both_containers(torch_mod, scale, kind):
         rec = c.decode(cont, seg, 48, 80)
         c.check()
         assert np.array_equal(rec.cpu().numpy(), rgb)
-        cont, seg = c.encode(_dev(torch, rgb), mode=MODE_RANS(4))
-        c.check()
-        seg_h, cont_h = seg.cpu().numpy(), cont.cpu().numpy()
-        for b in range(2):
-            assert container_to_bytestream_list(cont_h[b], seg_h[b]) == orc.encode_image_rans(rgb[b], W_o, 4), b
-        rec = c.decode(cont, seg, 48, 80, mode=MODE_RANS(4))
-        c.check()
-        assert np.array_equal(rec.cpu().numpy(), rgb)
+        for M, wide in ((4, 0), (3, 1), (3, 2)):               # four, two and ONE decoder lane per symbol: each kernel's own gallop-and-bisect path
+            mode = MODE_RANS(M, wide=wide)
+            cont, seg = c.encode(_dev(torch, rgb), mode=mode)
+            c.check()
+            seg_h, cont_h = seg.cpu().numpy(), cont.cpu().numpy()
+            for b in range(2):
+                assert container_to_bytestream_list(cont_h[b], seg_h[b]) == orc.encode_image_rans(rgb[b], W_o, M, wide), (b, M, wide)
+            rec = c.decode(cont, seg, 48, 80, mode=mode)
+            c.check()
+            assert np.array_equal(rec.cpu().numpy(), rgb), (M, wide)
     finally:
         c.close()
 
@@ -504,7 +506,7 @@ def test_extreme_shapes_roundtrip(torch_mod, codecs, H, W):
     rgb = make_batch("smooth", 1, min(H, 1055), min(W, 2049), seed0=71)
     if rgb.shape[2] != H or rgb.shape[3] != W:
         rgb = np.ascontiguousarray(np.resize(rgb, (1, 3, H, W)))
-    for mode in ((0, MODE_RANS(2)) if H * W < 3_000_000 else (MODE_RANS(2),)):
+    for mode in ((0, MODE_RANS(2), MODE_RANS(2, wide=2)) if H * W < 3_000_000 else (MODE_RANS(2), MODE_RANS(3, wide=2))):
         cont, seg = c.encode(_dev(torch, rgb), mode=mode)
         c.check()
         rec = c.decode(cont, seg, H, W, mode=mode)
