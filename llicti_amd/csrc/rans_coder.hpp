@@ -919,16 +919,18 @@ __global__ __launch_bounds__(64 * Q) void rans_decode_stage_lane_kernel(const fl
     int par = 0;                                 // step parity over the whole launch (sh_tot)
     __syncthreads();
 
-    // Raw CNN outputs (and, for Co / Cg, the position's already decoded pixels) of one step of one colour pass.  fetch_c<clr>(k, pixels):
-    // pixels = false leaves y / co to the caller -- that is how a pass's FIRST step is requested during the previous pass's last one (its
-    // Y / Co were decoded by this very lane at step 0 of the earlier passes and are still in a register), so that a pass does not begin
-    // with a memory round trip (45 passes per decode).
-    struct Raw { float sg[5], mu[5], wk[5], a0[5], a1[5], y, co; long off; bool on; };
+    auto pass = [&](auto tag) {
+    constexpr int clr = decltype(tag)::value;    // compile-time: no branch next to the prefetch loads
+    const int tail_from = (last_stage && clr == 2) ? rans_stream_count(nc, m, M, L) - (int)rtail[sidx] : 0x7FFFFFFF;
+    int minv, maxv, shift;
+    clr_range(minmax + 4 * b, clr, minv, maxv, shift);
+    const Grid gr = make_grid(minv, maxv);
+    const int max_symbol = gr.Lp - 2;
+    const float fbase = (float)minv - 0.5f;
     const long img = (long)b * 3 * sg.plane;
     const long npos = (long)sg.h * sg.w;
-    const int tail_from2 = last_stage ? rans_stream_count(nc, m, M, L) - (int)rtail[sidx] : 0x7FFFFFFF;      // colour pass 2 of the last stage only
-    auto fetch_c = [&](auto tag, int k, bool pixels) -> Raw {
-        constexpr int clr = decltype(tag)::value;
+    struct Raw { float sg[5], mu[5], wk[5], a0[5], a1[5], y, co; long off; bool on; };
+    auto fetch = [&](int k) -> Raw {
         Raw r;
         const int n = min(L * (m + k * M) + tid, nc - 1);            // clamped: the loads are unconditional
         const int i = div_wc(sg, n), j = n - i * sg.wc;
@@ -942,23 +944,12 @@ __global__ __launch_bounds__(64 * Q) void rans_decode_stage_lane_kernel(const fl
             if constexpr (clr == 1) r.a0[t] = prw[48 + t];
             else if constexpr (clr == 2) { r.a0[t] = prw[48 + 5 + t]; r.a1[t] = prw[48 + 10 + t]; }
         }
-        if (pixels) {
-            if constexpr (clr == 1) r.y = fplanes[r.off];
-            else if constexpr (clr == 2) { r.y = fplanes[r.off]; r.co = fplanes[r.off + sg.plane]; }
-        }
-        r.on = (k < K) && (L * (m + k * M) + tid) < nc && (L * k + tid) < ((clr == 2) ? tail_from2 : 0x7FFFFFFF);
+        if constexpr (clr == 1) r.y = fplanes[r.off];
+        else if constexpr (clr == 2) { r.y = fplanes[r.off]; r.co = fplanes[r.off + sg.plane]; }
+        r.on = (k < K) && (L * (m + k * M) + tid) < nc && (L * k + tid) < tail_from;
         return r;
     };
-    float y_first = 0.0f, co_first = 0.0f;      // this lane's Y / Co of step 0 (as the float planes hold them): the next passes' first operands
-
-    auto pass = [&](auto tag, Raw cur) -> Raw {  // cur: the pass's step 0, requested ahead; returns the NEXT pass's step 0 (clr < 2)
-    constexpr int clr = decltype(tag)::value;    // compile-time: no branch next to the prefetch loads
-    int minv, maxv, shift;
-    clr_range(minmax + 4 * b, clr, minv, maxv, shift);
-    const Grid gr = make_grid(minv, maxv);
-    const int max_symbol = gr.Lp - 2;
-    const float fbase = (float)minv - 0.5f;
-    Raw ahead = cur;
+    Raw cur = fetch(0);
     for (int k = 0; k < K; ++k) {
         const uint32_t slot = x & 0xFFFFu;
         uint32_t vlo = 0, vhi = 0x10000u;
@@ -977,8 +968,7 @@ __global__ __launch_bounds__(64 * Q) void rans_decode_stage_lane_kernel(const fl
         }
         const long off_k = cur.off;
         const bool on_k = cur.on;
-        if (k + 1 < K) cur = fetch_c(tag, k + 1, true);
-        else if constexpr (clr < 2) ahead = fetch_c(std::integral_constant<int, clr + 1>{}, 0, false);
+        cur = fetch(min(k + 1, K - 1));
         if (on_k) {
             const float ssum = (((w5[0] + w5[1]) + w5[2]) + w5[3]) + w5[4];
             const float den = 1e-9f + ssum;
@@ -1038,10 +1028,8 @@ __global__ __launch_bounds__(64 * Q) void rans_decode_stage_lane_kernel(const fl
             }
             if (!have_lo) vlo = entry_exact(0);
             const int v = lo - shift;
-            const float fv = (float)v / 255.0f;
             planes[off_k + (long)clr * sg.plane] = (int16_t)v;
-            fplanes[off_k + (long)clr * sg.plane] = fv;
-            if (k == 0) { if constexpr (clr == 0) y_first = fv; else if constexpr (clr == 1) co_first = fv; }
+            fplanes[off_k + (long)clr * sg.plane] = (float)v / 255.0f;
         }
         // state update of this lane, bit-granular renormalisation: lane l of the stream takes its clz(x) bits below those of lanes < l
         int nb = 0;
@@ -1071,17 +1059,13 @@ __global__ __launch_bounds__(64 * Q) void rans_decode_stage_lane_kernel(const fl
         if (pend) { if (tid < kRefill) sh_ring[(wlo + tid) & (kRing - 1)] = pf; pend = false; }
         if ((bcur >> 5) - 2 * kRefill < wlo) { wlo -= kRefill; if (tid < kRefill) pf = load_dw(wlo + tid); pend = true; }
     }
-    ahead.y = y_first;                               // (an off lane's are never used)
-    ahead.co = co_first;
-    return ahead;
     };
     // Between passes: the pixels a lane stored are loaded again by the SAME lane (same position) -- a workgroup-scope fence orders them
-    const Raw r0 = fetch_c(std::integral_constant<int, 0>{}, 0, true);
-    const Raw r1 = pass(std::integral_constant<int, 0>{}, r0);
+    pass(std::integral_constant<int, 0>{});
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    const Raw r2 = pass(std::integral_constant<int, 1>{}, r1);
+    pass(std::integral_constant<int, 1>{});
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    (void)pass(std::integral_constant<int, 2>{}, r2);
+    pass(std::integral_constant<int, 2>{});
     rstate[(long)sidx * L + tid] = x;
     const int anybad = __syncthreads_or(badx);
     if (tid == 0) {
