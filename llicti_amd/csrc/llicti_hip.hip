@@ -214,11 +214,6 @@ static void build_plan(Plan &p, int B, int H, int W, int ME)
     p.off_fplanes = take((size_t)B * 3 * plane * sizeof(float));
     Geom g0 = make_geom(B, H, W, 0);
     p.off_params = take((size_t)B * g0.h * g0.w * LLICTI_PARAM_STRIDE * sizeof(float));
-    {   // a second, quarter-size buffer for the CNN outputs of levels >= 1: the encoder of a launch-bound call (a single image) runs those
-        // levels on a side stream next to level 0
-        Geom g1 = make_geom(B, H, W, 1);
-        p.off_params2 = take((size_t)B * g1.h * g1.w * LLICTI_PARAM_STRIDE * sizeof(float));
-    }
     // pairs + slots
     p.desc.assign((size_t)LLICTI_NSTREAMS * B, StreamDesc{});
     p.slot_off.assign((size_t)LLICTI_NSTREAMS * B, 0);
@@ -293,7 +288,14 @@ static void build_plan(Plan &p, int B, int H, int W, int ME)
         }
     }
     // one chunk buffer per colour channel: full rows (512 x uint16) or anchor rows (kAnchorRow bytes), see ac_use_anchors()
-    p.off_tables = take((size_t)3 * B * p.ac_cap_rows * (ac_use_anchors(B) ? (size_t)kAnchorRow : (size_t)512 * sizeof(uint16_t)));
+    const size_t tables_bytes = (size_t)3 * B * p.ac_cap_rows * (ac_use_anchors(B) ? (size_t)kAnchorRow : (size_t)512 * sizeof(uint16_t));
+    p.off_tables = take(tables_bytes);
+    {   // a second, quarter-size buffer for the CNN outputs of levels >= 1 (llicti_set_tuning("enc_side_levels"): the encoder's coarse levels
+        // on a side stream).  Only the encoder uses it and only the AC DECODER uses the chunk tables, so it shares their bytes where they suffice.
+        Geom g1 = make_geom(B, H, W, 1);
+        const size_t need = (size_t)B * g1.h * g1.w * LLICTI_PARAM_STRIDE * sizeof(float);
+        p.off_params2 = (tables_bytes >= need) ? p.off_tables : (size_t)-1;      // no room (anchor-row tables of a very large batch): the switch is ignored there
+    }
     static_assert(kAnchorRow <= 1024, "anchor rows must fit the full-row buffer");
     p.off_acstate = take((size_t)3 * B * 8 * sizeof(uint32_t));
     p.total = o;
@@ -802,8 +804,8 @@ extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, 
     // launch's ramp-down under the other's ramp-up.  Measured (profiles/r4/ab_encoder_side_stream.json): -0.5 ... -4 % per encode, 10.75 ->
     // 10.68 ms at B = 24 -- 0.3 % of a step, for which every kernel trace of the run shows the side queue's launches with the time they
     // spend waiting for a compute unit inside their durations.  Off by default: the per-kernel evidence is worth more than 0.07 ms.
-    float *params2 = (float *)(ws + p.off_params2);
-    const bool side = c->enc_side_levels != 0 && !c->profiling;      // (the profiling spans assume one queue)
+    const bool side = c->enc_side_levels != 0 && !c->profiling && p.off_params2 != (size_t)-1;      // (the profiling spans assume one queue)
+    float *params2 = side ? (float *)(ws + p.off_params2) : nullptr;
     hipStream_t s2 = side ? c->sub[1] : s;
     if (side) {
         HIPCHK(hipEventRecord(c->ev_enc[0], s));      // lift and header are done
