@@ -1031,6 +1031,13 @@ __global__ __launch_bounds__(64 * Q) void rans_decode_stage_lane_kernel(const fl
             planes[off_k + (long)clr * sg.plane] = (int16_t)v;
             fplanes[off_k + (long)clr * sg.plane] = (float)v / 255.0f;
         }
+        // The next step's CNN outputs were requested ~8,000 cycles ago and are pinned in their registers HERE, in front of the ring's refill
+        // load: left alone, the compiler moves them into the loop-carried registers at the bottom of the loop, behind that load and the
+        // pixel stores, and waits for them with s_waitcnt vmcnt(0) -- in-order counting makes that a wait for the refill load just issued
+        // and for the stores (a memory round trip per step: most of the 22 % of wave cycles this kernel spent parked).
+#pragma unroll
+        for (int t = 0; t < 5; ++t) asm volatile("" : "+v"(cur.sg[t]), "+v"(cur.mu[t]), "+v"(cur.wk[t]), "+v"(cur.a0[t]), "+v"(cur.a1[t]));
+        asm volatile("" : "+v"(cur.y), "+v"(cur.co));
         // state update of this lane, bit-granular renormalisation: lane l of the stream takes its clz(x) bits below those of lanes < l
         int nb = 0;
         if (on_k) {
