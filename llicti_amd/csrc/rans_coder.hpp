@@ -492,7 +492,7 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
     Raw cur = fetch(0);
     for (int k = 0; k < K; ++k) {
         const int chunk0 = 64 * (m + k * M);
-        const Raw nxt = fetch(min(k + 1, K - 1));
+        Raw nxt = fetch(min(k + 1, K - 1));
         // slot of this group's symbol = low half of the state in lane gsym of this wave's copy
         const uint32_t slot = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * gsym, (int)x) & 0xFFFFu;
         {
@@ -592,6 +592,8 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
                 }
             }
         }
+        // (the next step's operands are pinned in their registers here, in front of this step's window reload: see rans_decode_stage_lane_kernel)
+        asm volatile("" : "+v"(nxt.sgA), "+v"(nxt.muA), "+v"(nxt.wkA), "+v"(nxt.a0A), "+v"(nxt.a1A), "+v"(nxt.sgB), "+v"(nxt.muB), "+v"(nxt.wkB), "+v"(nxt.a0B), "+v"(nxt.a1B), "+v"(nxt.y), "+v"(nxt.co));
         lds_barrier();      // LDS words only cross here: global loads / stores in flight stay in flight (common.hpp)
         {
             const bool active = chunk0 + lane < nc && 64 * k + lane < tail_from;
@@ -728,7 +730,7 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_pair_kernel
     Raw cur = fetch(0);
     for (int k = 0; k < K; ++k) {
         const int chunk0 = L * (m + k * M);
-        const Raw nxt = fetch(min(k + 1, K - 1));
+        Raw nxt = fetch(min(k + 1, K - 1));
         const uint32_t xs = (wave < 2) ? x[0] : x[1];
         const uint32_t slot = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (gsym & 63), (int)xs) & 0xFFFFu;
         if (cur.on) {                            // uniform within the pair
@@ -821,6 +823,10 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_pair_kernel
                 fplanes[off + (long)clr * sg.plane] = (float)v / 255.0f;
             }
         }
+        // (the next step's operands are pinned in their registers here, in front of this step's window reload: see rans_decode_stage_lane_kernel)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) asm volatile("" : "+v"(nxt.sg[t]), "+v"(nxt.mu[t]), "+v"(nxt.wk[t]), "+v"(nxt.a0[t]), "+v"(nxt.a1[t]));
+        asm volatile("" : "+v"(nxt.y), "+v"(nxt.co));
         lds_barrier();      // LDS words only cross here: global loads / stores in flight stay in flight (common.hpp)
         {
             int below = 0;                                                         // bits of the lower sub-chunk of this step
