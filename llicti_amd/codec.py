@@ -21,7 +21,7 @@ NSEG = 49
 MODE_AC = 0                      # the reference's container: 45 torchac-algorithm streams per image
 
 
-MAX_STREAMS_IN_BUDGET = 9        # an xwide v3 stream costs ~8 bytes: 9 per 768x512 image are +0.0009 bpp over the reference-format container
+MAX_STREAMS_IN_BUDGET = 10       # a seeded xwide v3 stream costs ~3-5 bytes: 10 per 768x512 image are +0.0007 bpp over the reference-format container (12: +0.0010)
 
 
 def auto_streams(B, n_cu=256):

@@ -846,9 +846,10 @@ extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, 
     } else {
         ProfSpan span(c, PROF_RANS_ENC, s);
         int32_t *rinfo = (int32_t *)(ws + p.off_rinfo);
-        if (Q == 4) rans_encode_kernel<4><<<B * M, 256, 0, s>>>(pairs, pd->d_desc, B, M, slots, pd->d_rslot_off, p.rslot_cap, rinfo, status);
-        else if (Q == 2) rans_encode_kernel<2><<<B * M, 128, 0, s>>>(pairs, pd->d_desc, B, M, slots, pd->d_rslot_off, p.rslot_cap, rinfo, status);
-        else rans_encode_kernel<1><<<B * M, 64, 0, s>>>(pairs, pd->d_desc, B, M, slots, pd->d_rslot_off, p.rslot_cap, rinfo, status);
+        const StageGeom sgl = make_stage(make_geom(B, H, W, 0), 2);      // the last stage: an xwide stream's seed symbols are read from its pixels
+        if (Q == 4) rans_encode_kernel<4><<<B * M, 256, 0, s>>>(pairs, pd->d_desc, B, M, slots, pd->d_rslot_off, p.rslot_cap, rinfo, status, sgl, planes, mm);
+        else if (Q == 2) rans_encode_kernel<2><<<B * M, 128, 0, s>>>(pairs, pd->d_desc, B, M, slots, pd->d_rslot_off, p.rslot_cap, rinfo, status, sgl, planes, mm);
+        else rans_encode_kernel<1><<<B * M, 64, 0, s>>>(pairs, pd->d_desc, B, M, slots, pd->d_rslot_off, p.rslot_cap, rinfo, status, sgl, planes, mm);
         rans_pack_kernel<<<dim3(M, B), 256, 0, s>>>(slots, pd->d_rslot_off, rinfo, M, hdr_bytes, d_out, (long)out_stride, d_seg_len, status);
     }
     latch_status_kernel<<<1, 64, 0, s>>>(status, c->d_status, nullptr, 0);

@@ -30,6 +30,12 @@ template <int Q> struct RansGeo {
     static constexpr int kMinStream = 2 + kPayBytes;              // T | pad, (empty bit region), states
 };
 constexpr int kRansPayBytesMax = RansGeo<4>::kPayBytes;
+// xwide streams (Q = 4) only -- the older stream kinds keep their bytes: the tail coder's START state is 2^31 | the last kSeedSyms symbol indices
+// of the stream (kSeedBits each; the bits above them zero), not an empty state.  A rANS chain ends with a 32-bit state of which only what the
+// symbols put in is information; seeding it with raw symbols turns the ~31 wasted bits into three symbols that are never coded (~3 bytes a
+// stream: ten 256-lane streams an image cost what six cost before).
+template <int Q> constexpr bool kSeeded = (Q == 4);
+constexpr int kSeedSyms = 3, kSeedBits = 9;
 
 __device__ __forceinline__ int lanes_below(uint64_t mask)
 {
@@ -95,7 +101,8 @@ __device__ __forceinline__ void lds_or_bits(uint32_t *buf, int pos, int n, uint3
 template <int Q>
 __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__restrict__ pairs, const StreamDesc *__restrict__ desc,
                                                          int B, int M, uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
-                                                         int rslot_cap, int32_t *__restrict__ rinfo, int32_t *status)
+                                                         int rslot_cap, int32_t *__restrict__ rinfo, int32_t *status,
+                                                         StageGeom sgl, const int16_t *__restrict__ planes, const int32_t *__restrict__ minmax)
 {
     using GEO = RansGeo<Q>;
     constexpr int L = GEO::kLanes;
@@ -136,12 +143,31 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
             return (q >= 0) ? pl[L * (m + (q / L) * M) + (q % L)] : 0u;
         };
         uint32_t xt = 1u << 31;
+        if constexpr (kSeeded<Q>) {
+            // xwide: the coder does not start from an empty state but from 2^31 | the stream's last three SYMBOLS, 9 bits each (sgl = the last
+            // stage's geometry: the symbol is the Cg pixel plus the image's shift) -- 31 bits that carried nothing carry three symbols
+            T = min(kSeedSyms, cnt);
+            int sv = 0;
+            if (lane < T) {
+                const int q = cnt - 1 - lane;
+                const int n = L * (m + (q / L) * M) + (q % L);
+                const int pi = div_wc(sgl, n), pj = n - pi * sgl.wc;
+                int minv, maxv, shift;
+                clr_range(minmax + 4 * b, 2, minv, maxv, shift);
+                sv = (int)planes[((long)b * 3 + 2) * sgl.plane + ((long)(2 * pi + sgl.oi) << sgl.lvl) * sgl.W + ((long)(2 * pj + sgl.oj) << sgl.lvl)] + shift;
+                if (sv < 0 || sv > maxv - minv) { bad = 1; sv = 0; }
+            }
+            bad = __builtin_amdgcn_readlane(bad, 0) | __builtin_amdgcn_readlane(bad, 1) | __builtin_amdgcn_readlane(bad, 2);
+#pragma unroll
+            for (int t = 0; t < kSeedSyms; ++t) xt |= (uint32_t)__builtin_amdgcn_readlane(sv, t) << (kSeedBits * t);
+        }
+        const int cnt_ac = cnt - T;                     // what is left for the coder proper
         int tb = 0;
         uint64_t acc = 0;                               // emitted bits not yet in LDS: the low accn (< 32) bits
         int accn = 0, wdw = 0;
         bool full = false;
-        uint32_t raw = fetch_blk(cnt);
-        for (int q1 = cnt; q1 > 0 && !full; q1 -= 64) {
+        uint32_t raw = fetch_blk(cnt_ac);
+        for (int q1 = cnt_ac; q1 > 0 && !full; q1 -= 64) {
             const uint32_t rawn = fetch_blk(q1 - 64);
             const int nblk = min(64, q1);
             for (int t = 0; t < nblk; ++t) {
@@ -152,8 +178,9 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
                 if (hi == 0) hi = 0x10000u;
                 uint32_t freq = hi - lo;
                 if (freq == 0 || hi < lo) { bad = 1; freq = 1; }
-                if (T == 0) xt = freq << 15;            // absorbing start: the first pushed symbol codes to 2^31 + c_low, no bits
-                const int nb = (T == 0) ? 0 : rans_emit_bits(xt, freq);      // (the closed form needs x >= 2^31)
+                const bool first = !kSeeded<Q> && T == 0;
+                if (first) xt = freq << 15;             // absorbing start (64 / 128 lanes): the first pushed symbol codes to 2^31 + c_low, no bits
+                const int nb = first ? 0 : rans_emit_bits(xt, freq);         // (the closed form needs x >= 2^31)
                 if (tb + nb + 32 > GEO::kPayBits) { full = true; break; }
                 acc |= (uint64_t)(xt & ((1u << nb) - 1u)) << accn;
                 accn += nb;
@@ -1098,7 +1125,8 @@ __global__ __launch_bounds__(64 * Q) void rans_decode_stage_lane_kernel(const fl
 //     (lane = 5 e + mc: mixture component mc of window entry e), and a ballot proves the symbol (an exact 13-ary search takes over
 //     when the hint is wrong); state update, bit-granular renormalisation from the payload in LDS.
 // One barrier per round.  Checks: the main region was read to its last bit, the tail state ends at its start state (freq << 15 of
-// the symbol the tail encoder began with; 2^31 when T = 0) with no bit left.
+// the symbol the tail encoder began with; 2^31 when T = 0) with no bit left.  Xwide streams: the start state is the seed -- the stream's last
+// three symbols, raw -- and the check is that they are symbols of the image's range with zero bits above them.
 constexpr int kTailAhead = 3;                    // symbols per round = preparing wavefronts
 
 template <int Q>
@@ -1118,7 +1146,10 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead)) void rans_tail_kernel(const 
     const int nc = sg.hc * sg.wc;
     const int cnt = rans_stream_count(nc, m, M, L);
     bool bad = rpos[sidx] != 0 || (int)rtail[sidx] > cnt;
-    const int T = min((int)rtail[sidx], cnt);
+    const int Tall = min((int)rtail[sidx], cnt);        // the stream's tail symbols: T coded ones, then (xwide) the seed's
+    const int NS = kSeeded<Q> ? min(kSeedSyms, cnt) : 0;
+    bad = bad || Tall < NS;
+    const int T = max(Tall - NS, 0);
     const int R = (T + kTailAhead - 1) / kTailAhead;    // rounds
     int minv, maxv, shift;
     clr_range(minmax + 4 * b, 2, minv, maxv, shift);
@@ -1133,7 +1164,7 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead)) void rans_tail_kernel(const 
         struct Row { float sg, mu, wk, bb, dd, y, co; long off; };
         auto fetch = [&](int t) -> Row {
             Row r;
-            const int q = min(max(cnt - T + t, 0), max(cnt - 1, 0));      // position in the stream's share of the last stage
+            const int q = min(max(cnt - Tall + t, 0), max(cnt - 1, 0));   // position in the stream's share of the last stage
             const int n = min(L * (m + (q / L) * M) + (q % L), nc - 1);
             const int pi = div_wc(sg, n), pj = n - pi * sg.wc;
             const ParRow src = par_row(params, b, (long)sg.h * sg.w, (long)pi * sg.w + pj);
@@ -1267,7 +1298,7 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead)) void rans_tail_kernel(const 
                 fplanes[off + 2 * sg.plane] = (float)v / 255.0f;
             }
             xt = (vhi - vlo) * (xt >> 16) + slot - vlo;
-            if (kTailAhead * r + i == T - 1) bad = bad || xt != (vhi - vlo) << 15;      // the encoder's first symbol: absorbing start, no bits
+            if (!kSeeded<Q> && kTailAhead * r + i == T - 1) bad = bad || xt != (vhi - vlo) << 15;      // the encoder's first symbol: absorbing start, no bits
             else {
                 int nb = __clz((int)xt);
                 if (nb > 16 || tc < nb) { bad = true; nb = min(nb, min(tc, 16)); }  // corrupt: keep going on what is there
@@ -1277,7 +1308,21 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead)) void rans_tail_kernel(const 
         }
         lds_barrier();      // LDS words only cross here: global loads / stores in flight stay in flight (common.hpp)
     }
-    if (T == 0) bad = bad || xt != (1u << 31);
+    if constexpr (kSeeded<Q>) {
+        // the coder is back at its start state: 2^31 | the stream's last NS symbols, raw (lane t: the t-th from the end)
+        const int sv = (int)(((xt & 0x7FFFFFFFu) >> (kSeedBits * min(lane, kSeedSyms))) & ((1u << kSeedBits) - 1u));
+        bool wrong = (lane < NS) ? sv > max_symbol : (lane <= kSeedSyms && sv != 0);      // (lane kSeedSyms: the bits between the seed and the leading one)
+        if (lane < NS) {
+            const int q = cnt - 1 - lane;
+            const int n = min(L * (m + (q / L) * M) + (q % L), nc - 1);
+            const int pi = div_wc(sg, n), pj = n - pi * sg.wc;
+            const long off = img + ((long)(2 * pi + sg.oi) << sg.lvl) * sg.W + ((long)(2 * pj + sg.oj) << sg.lvl);
+            const int v = min(sv, max_symbol) - shift;
+            planes[off + 2 * sg.plane] = (int16_t)v;
+            fplanes[off + 2 * sg.plane] = (float)v / 255.0f;
+        }
+        bad = bad || ballot64(wrong) != 0;
+    } else if (T == 0) bad = bad || xt != (1u << 31);
     if ((bad || tc != 0) && lane == 0) flag_image(status, b, LLICTI_EFORMAT);
 }
 

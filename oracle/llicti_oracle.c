@@ -778,12 +778,15 @@ int orc_decode_image(const uint8_t *in, const int32_t seg_len[49], const orc_wei
 }
 
 /* ------------------------------------------------------------------ rANS container "LLICTI-rANS v3" (see header) */
-typedef struct { long n; uint32_t *clow, *chigh; } stage_syms_t;
+typedef struct { long n; uint32_t *clow, *chigh; int16_t *sym; } stage_syms_t;
 
 #define RANS_MAX_LANES  256                             /* lanes of a stream: 64, 128 ("wide": two 64-symbol chunks per step) or 256 ("xwide": four) */
 #define RANS_STATE_BITS 31                              /* a lane state is 2^31 | 31 bits */
 #define RANS_MAX_PAY_BITS (RANS_MAX_LANES * RANS_STATE_BITS)   /* what the initial states carry (the tail stream): 1984 / 3968 / 7936 bits */
 #define RANS_TAIL_MAX   2047
+#define RANS_SEED_LANES 256                             /* xwide streams only: the tail coder starts from 2^31 | the stream's last */
+#define RANS_SEED_SYMS  3                               /* three symbol indices, 9 bits each (bits 27..30 zero), instead of from an */
+#define RANS_SEED_BITS  9                               /* empty state: 31 bits that carried nothing now carry three symbols */
 
 static inline void put_bits(uint8_t *buf, long pos, int n, uint32_t v)      /* LSB first */
 {
@@ -874,6 +877,11 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
                 st[si].clow = (uint32_t *)malloc(sizeof(uint32_t) * (long)h * w);
                 st[si].chigh = (uint32_t *)malloc(sizeof(uint32_t) * (long)h * w);
                 st[si].n = orc_stream_pairs(planes, H, W, minmax, lvl, band, clr, params, st[si].clow, st[si].chigh, sym);
+                st[si].sym = NULL;
+                if (si == ORC_NSTREAM - 1) {                 /* the raw seed of an xwide stream's tail coder needs symbol indices */
+                    st[si].sym = (int16_t *)malloc(sizeof(int16_t) * (long)h * w);
+                    memcpy(st[si].sym, sym, sizeof(int16_t) * st[si].n);
+                }
                 total += st[si].n;
                 ++si;
             }
@@ -893,12 +901,17 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
         const long cnt = rans_stream_count(st[S].n, m, M, L);
         uint32_t xt = 1u << 31;
         long tb = 0, T = 0;
+        if (L == RANS_SEED_LANES)                            /* xwide: the coder's start state holds the stream's last symbols raw */
+            for (; T < cnt && T < RANS_SEED_SYMS; ++T) {
+                const long q = cnt - 1 - T;
+                xt |= (uint32_t)st[S].sym[(long)L * (m + (q / L) * M) + (q % L)] << (RANS_SEED_BITS * T);
+            }
         while (T < cnt && T < RANS_TAIL_MAX) {
             const long q = cnt - 1 - T;
             const long n = (long)L * (m + (q / L) * M) + (q % L);
             const uint32_t lo = st[S].clow[n], freq = st[S].chigh[n] - lo;
             if (freq == 0 || freq > 0x10000u) { rc = -5; break; }
-            if (T == 0) xt = freq << 15;          /* absorbing start: the first pushed symbol codes to 2^31 + c_low, no bits */
+            if (T == 0) xt = freq << 15;          /* absorbing start (64 / 128 lanes): the first pushed symbol codes to 2^31 + c_low, no bits */
             const int nb = rans_emit_bits(xt, freq);
             if (tb + nb + 32 > PAY_BITS) break;
             put_bits(pay, tb, nb, xt & ((1u << nb) - 1u));
@@ -954,7 +967,7 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
         seg_len[4 + m / G] += (int32_t)bytes;
     }
     free(bits);
-    for (int s = 0; s < ORC_NSTREAM; ++s) { free(st[s].clow); free(st[s].chigh); }
+    for (int s = 0; s < ORC_NSTREAM; ++s) { free(st[s].clow); free(st[s].chigh); free(st[s].sym); }
     return rc < 0 ? rc : pos;
 }
 
@@ -1113,7 +1126,9 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
                 const long cnt = rans_stream_count(n_sym, m, M, L);
                 if (T[m] > cnt) { bad = 1; continue; }
                 uint32_t f_last = 0;
-                for (long q = cnt - T[m]; q < cnt; ++q) {
+                const long R = (L != RANS_SEED_LANES) ? 0 : cnt < RANS_SEED_SYMS ? cnt : RANS_SEED_SYMS;
+                if (T[m] < R) { bad = 1; continue; }
+                for (long q = cnt - T[m]; q < cnt - R; ++q) {
                     const long n = (long)L * (m + (q / L) * M) + (q % L);
                     int i = (int)(n / wc), j = (int)(n % wc);
                     long off = ((long)(2 * i + BAND_OI[src]) << lvl) * W + ((long)(2 * j + BAND_OJ[src]) << lvl);
@@ -1126,13 +1141,24 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
                     xt = (c_high - c_low) * (xt >> 16) + slot - c_low;
                     planes[clr * plane_sz + off] = (int16_t)(s - shift);
                     f_last = c_high - c_low;
-                    if (q == cnt - 1) break;                     /* the encoder's first symbol: absorbing start, no bits */
+                    if (!R && q == cnt - 1) break;                   /* the encoder's first symbol: absorbing start, no bits */
                     int nb = clz32(xt);
                     if (nb > 16 || tc < nb) { bad = 1; break; }
                     tc -= nb;
                     xt = (xt << nb) | get_bits(pay, tc, nb);
                 }
-                if (xt != (T[m] ? f_last << 15 : 1u << 31) || tc != 0) bad = 1;   /* the tail coder's start state, and no bit left */
+                if (tc != 0) bad = 1;                                            /* no bit left */
+                if (!R) { if (xt != (T[m] ? f_last << 15 : 1u << 31)) bad = 1; continue; }     /* the tail coder's start state */
+                if (!(xt >> 31) || ((xt >> (RANS_SEED_BITS * RANS_SEED_SYMS)) & 0xFu)) bad = 1;
+                for (long t = 0; t < RANS_SEED_SYMS; ++t) {                      /* xwide: the start state is the last symbols, raw */
+                    const int s = (int)((xt >> (RANS_SEED_BITS * t)) & ((1u << RANS_SEED_BITS) - 1u));
+                    if (t >= R) { if (s) bad = 1; continue; }
+                    if (s > Lp - 2) { bad = 1; continue; }
+                    const long q = cnt - 1 - t;
+                    const long n = (long)L * (m + (q / L) * M) + (q % L);
+                    int i = (int)(n / wc), j = (int)(n % wc);
+                    planes[clr * plane_sz + ((long)(2 * i + BAND_OI[src]) << lvl) * W + ((long)(2 * j + BAND_OJ[src]) << lvl)] = (int16_t)(s - shift);
+                }
             }
         }
         free(params);

@@ -111,7 +111,7 @@ def test_bench_defaults_match_baseline_configs():
     a = bench.parse_args([])
     assert a.gpus == 1 and a.batch == 0 and a.container == "auto"
     # streams per image of the timed container: one decoder workgroup per stream on its own compute unit, at most 10 (the bpp budget)
-    assert bench.default_container(24) == "xrans9" and bench.default_container(32) == "xrans8" and bench.default_container(3) == "xrans9"
+    assert bench.default_container(24) == "xrans10" and bench.default_container(32) == "xrans8" and bench.default_container(3) == "xrans10"
     assert bench.default_container(512) == "xrans1" and bench.default_container(24, n_cu=128) == "xrans5"
     # a launcher that started the wrong number of ranks is an error, not a silent single-rank run
     env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")

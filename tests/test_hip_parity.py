@@ -596,7 +596,7 @@ def test_agent_batched_eval_equals_unbatched(torch_mod, tmp_path, caplog, oracle
     for i, im in enumerate(imgs):
         fileio.write_image(str(tmp_path / f"img_{i:02d}.ppm"), im)
     cname = auto_container(3)
-    assert cname == auto_container(1) == "xrans9"
+    assert cname == auto_container(1) == "xrans10"
     a_b = LLICTIAgent(default_config(test_data=str(tmp_path), eval_batch=3, container="auto", keep_streams=True))
     res_b = a_b.run()
     n_lines = sum("Check: Decoded img matches original" in r.message for r in caplog.records)
