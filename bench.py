@@ -46,7 +46,7 @@ MAC_PER_POSITION = 193248            # 84,480 layer-0 
 PEAK_FP32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_HBM_GBS = 8000.0
 DEFAULT_CONTAINER = "auto"           # rANS v3, xwide streams (256 lanes), default_streams(batch) of them per image, see below
-MAX_STREAMS_IN_BUDGET = 10           # = llicti_amd.codec.MAX_STREAMS_IN_BUDGET: a seeded xwide v3 stream costs ~3-5 bytes: 10 per 768x512 image are +0.0007 bpp over the reference-format container (m_sweep)
+MAX_STREAMS_IN_BUDGET = 10           # = llicti_amd.codec.MAX_STREAMS_IN_BUDGET: an xwide v3 stream (two seeded tail chains) costs ~2-3.5 bytes: 10 per 768x512 image are +0.0003 (noise) ... +0.0007 (natural-like) bpp over the reference-format container (m_sweep)
 
 
 def default_streams(B, n_cu=256):
@@ -941,7 +941,7 @@ def main(argv=None):
                 "oracle_tables_vs_reference_tables": fx,
                 "source": fx_path,
                 "note": "reference-format (AC) container: same format, Delta = the table differences of the fixed-arithmetic spec vs the "
-                        "reference's PyTorch floats (fixtures). rANS v3 container: same tables and symbols, about 6 bytes per stream over the ideal "
+                        "reference's PyTorch floats (fixtures). rANS v3 container: same tables and symbols, about 6 bytes per 64-lane stream, 2 - 3.5 per 256-lane stream over the ideal "
                         "code length (0.001 bpp = 49 bytes per 768x512 image; the AC container's 45 terminations cost about 25) -- see m_sweep"}
             dbpp = out["bpp_delta_vs_reference"]["timed_container_minus_reference_format_bpp"]
             # + what the build's tables cost against the reference's own PyTorch tables on full-size images of this workload (committed

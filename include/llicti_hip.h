@@ -160,7 +160,8 @@ int llicti_ac_decode_u16cdf(llicti_ctx *ctx, const uint16_t *d_cdf, int Lp, int 
  * empty), same CDFs and symbols, decodable L*M symbols at a time.  States live in [2^31, 2^32) and renormalise bit by bit (the coder loses
  * ~2^-16 of a symbol's length, like the range coder); a stream = u16 (T | pad << 11) | bit region | L x 31-bit final
  * states, and the L INITIAL states carry the last T symbols of the stream's last stage, coded by a single-state tail
- * coder.  Cost over the ideal code length: about 6 bytes per stream that has symbols -- M = 8 is within 0.0005 bpp of the AC
+ * coder (xwide streams: by two such coders sharing the payload, each started from a seed of raw symbols instead of an empty state).
+ * Cost over the ideal code length: about 6 bytes per stream that has symbols (xwide: 2 - 3.5) -- M = 8 is within 0.0005 bpp of the AC
  * container on 768x512 images (whose 45 stream terminations cost about 25 bytes).  Format: oracle/llicti_oracle.h,
  * DESIGN.md section 5. */
 #define LLICTI_MODE_AC        0
@@ -170,7 +171,7 @@ int llicti_ac_decode_u16cdf(llicti_ctx *ctx, const uint16_t *d_cdf, int Lp, int 
                                                   31-bit states, about twice the tail symbols), header byte 0 = bit 6 set with v = M + 1; two decoder lanes per symbol */
 #define LLICTI_MODE_RANS_X(M) (0x500 | (M))     /* M in 1 .. 14, 32, 64 XWIDE streams: 256 lanes per stream, header byte 0 = bit 6 set with v = M + 15 (32 / 64: v = 30 / 31;
                                                   64: two streams per segment); ONE decoder lane per symbol, four wavefronts per stream: the fewest vector instructions
-                                                  per symbol of the three (about 7.5 bytes per stream: 9 per 768x512 image are +0.0009 bpp over the reference format) */
+                                                  per symbol of the three (2 - 3.5 bytes per stream: 10 per 768x512 image are +0.0003 ... +0.0007 bpp over the reference format) */
 
 /* Bytes of device workspace the two calls below need for B images of H x W in `mode`. */
 size_t llicti_workspace_bytes(int B, int H, int W, int mode);

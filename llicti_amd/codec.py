@@ -21,19 +21,19 @@ NSEG = 49
 MODE_AC = 0                      # the reference's container: 45 torchac-algorithm streams per image
 
 
-MAX_STREAMS_IN_BUDGET = 10       # a seeded xwide v3 stream costs ~3-5 bytes: 10 per 768x512 image are +0.0007 bpp over the reference-format container (12: +0.0010)
+MAX_STREAMS_IN_BUDGET = 10       # an xwide v3 stream (two seeded tail chains) costs ~2-3.5 bytes: 10 per 768x512 image are +0.0003 (noise) ... +0.0007 (natural-like) bpp over the reference-format container (12: +0.00085)
 
 
 def auto_streams(B, n_cu=256):
     """Streams per image of the throughput container for a batch of B images: as many as keep ONE decoder workgroup per stream on its
     own compute unit (B * M <= CUs: a second workgroup on a CU slows both by 1.4x, so more streams than that buy nothing) and stay
-    inside the north star's 0.001 bpp (<= 9 per 768x512 image).  24 images on a 256-CU MI355X: 9; 32 images (configs[4] per GPU): 8."""
+    inside the north star's 0.001 bpp (<= 10 per 768x512 image).  24 images on a 256-CU MI355X: 10; 32 images (configs[4] per GPU): 8."""
     return max(1, min(MAX_STREAMS_IN_BUDGET, n_cu // max(1, B)))
 
 
 def auto_container(B, n_cu=256):
     """Name of the throughput container for B images per call: xwide streams (256 lanes, one decoder lane per symbol -- lanes are nearly
-    free in bytes, 0.06 bit each; streams are not, ~8 bytes each), auto_streams(B) of them per image."""
+    free in bytes, 0.06 bit each; streams are not, ~2-3.5 bytes each), auto_streams(B) of them per image."""
     return f"xrans{auto_streams(B, n_cu)}"
 
 

@@ -912,7 +912,7 @@ static int decode_batch(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t 
                 }
                 if (last) {
                     ProfSpan span(c, PROF_RANS_TAIL, s);
-                    if (Q == 4) rans_tail_kernel<4><<<B * M, 64 * (1 + kTailAhead), 0, s>>>(params, sg, M, rstate, rpos, rtail, planes, fplanes, mm, status);
+                    if (Q == 4) rans_tail_kernel<4><<<B * M, 64 * (1 + kTailAhead) * kTailChains<4>, 0, s>>>(params, sg, M, rstate, rpos, rtail, planes, fplanes, mm, status);
                     else if (Q == 2) rans_tail_kernel<2><<<B * M, 64 * (1 + kTailAhead), 0, s>>>(params, sg, M, rstate, rpos, rtail, planes, fplanes, mm, status);
                     else rans_tail_kernel<1><<<B * M, 64 * (1 + kTailAhead), 0, s>>>(params, sg, M, rstate, rpos, rtail, planes, fplanes, mm, status);
                 }

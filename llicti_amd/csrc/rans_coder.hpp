@@ -30,12 +30,26 @@ template <int Q> struct RansGeo {
     static constexpr int kMinStream = 2 + kPayBytes;              // T | pad, (empty bit region), states
 };
 constexpr int kRansPayBytesMax = RansGeo<4>::kPayBytes;
-// xwide streams (Q = 4) only -- the older stream kinds keep their bytes: the tail coder's START state is 2^31 | the last kSeedSyms symbol indices
-// of the stream (kSeedBits each; the bits above them zero), not an empty state.  A rANS chain ends with a 32-bit state of which only what the
-// symbols put in is information; seeding it with raw symbols turns the ~31 wasted bits into three symbols that are never coded (~3 bytes a
-// stream: ten 256-lane streams an image cost what six cost before).
+// xwide streams (Q = 4) only -- the older stream kinds keep their bytes.  A rANS chain ends in a 32-bit state of which only what the symbols put
+// in is information: a coder that starts from an empty state wastes ~31 bits.  And the tail is serial.  So an xwide stream's tail is coded by TWO
+// single-state coders ("chains") sharing the payload, neither starting empty (spec: oracle/llicti_oracle.c, RANS_SEED_LANES):
+//   seeds    A = number of symbol values of the image's Cg channel, n = rans_seed_count(A) = the largest count with A^n <= 2^31 (<= 31); counting
+//            the stream's symbols from its end (j = 0 the last), chain A starts from 2^31 | sum sym(i) A^i (i < n), chain B from that of sym(n + i):
+//            2 n symbols that are never coded (three each for the full range of 511: ~3 bytes a stream; ten 256-lane streams an image cost what
+//            five cost before);
+//   chains   symbol j >= 2 n goes to chain A if j is even, B if odd, j ascending, while used_A + used_B + bits(j) + 64 <= payload bits;
+//   payload  [0, 32) A's final state, A's fields from bit 32 up in the decoder's reading order; the top 32 bits B's final state, B's fields below
+//            it read downwards; zeros between.  The states sit at fixed places: no search for the payload's highest set bit.
 template <int Q> constexpr bool kSeeded = (Q == 4);
-constexpr int kSeedSyms = 3, kSeedBits = 9;
+constexpr int kSeedMax = 31;
+__host__ __device__ __forceinline__ int rans_seed_count(int A, uint32_t &pw)      // n and A^n
+{
+    int n = 0;
+    uint64_t p = 1;
+    while (n < kSeedMax && p * (uint64_t)A <= (1ull << 31)) { p *= (uint64_t)A; ++n; }
+    pw = (uint32_t)p;
+    return n;
+}
 
 __device__ __forceinline__ int lanes_below(uint64_t mask)
 {
@@ -136,38 +150,142 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
     const StreamDesc dl = desc[(long)(LLICTI_NSTREAMS - 1) * B + b];
     const int cnt = rans_stream_count(dl.n, m, M, L);
     int T = 0;
-    {
+    if constexpr (kSeeded<Q>) {
+        // xwide: two seeded chains (above), chain c on wavefront c.  The chains are independent but for the stop rule, which looks at both:
+        // they run in blocks of 32 steps, record (field, bits) of every step in symbol order and their states of the last block, and meet at a
+        // barrier after each block; the first block that overshoots the payload ends the recursion, and where exactly the sequential rule stops
+        // -- T -- and where each field goes are prefix sums over the records, done by all 256 threads.
+        uint32_t *sh_fld = sh_win;                      // (the ring is not in use yet; zeroed again below)
+        __shared__ uint32_t sh_xs[2][34];
+        __shared__ int sh_used[2][2], sh_scan[2][4], sh_cut[3];
+        const uint32_t *pl = pairs + dl.pair_off;
+        int minv, maxv, shift;
+        clr_range(minmax + 4 * b, 2, minv, maxv, shift);
+        const int A = maxv - minv + 1;
+        uint32_t pw;
+        const int ns = rans_seed_count(A, pw);
+        const int NS = min(2 * ns, cnt);
+        const int ncod = max(min(cnt, kRansTailMax) - 2 * ns, 0);          // candidates j = 2 ns + idx, idx < ncod; chain c takes idx = 2 i + c
+        const int n_own = (wq < 2) ? (ncod + 1 - wq) >> 1 : 0;
+        const int nblk = (((ncod + 1) >> 1) + 31) >> 5;                    // chain A's steps, in blocks
+        uint32_t xc = 1u << 31;
+        if (wq < 2) {
+            const int j = wq * ns + lane;
+            int term = 0;
+            if (lane < ns && j < cnt) {
+                const int q = cnt - 1 - j;
+                const int n = L * (m + (q / L) * M) + (q % L);
+                const int pi = div_wc(sgl, n), pj = n - pi * sgl.wc;
+                int sv = (int)planes[((long)b * 3 + 2) * sgl.plane + ((long)(2 * pi + sgl.oi) << sgl.lvl) * sgl.W + ((long)(2 * pj + sgl.oj) << sgl.lvl)] + shift;
+                if (sv < 0 || sv >= A) { bad = 1; sv = 0; }
+                uint32_t mul = 1;
+                for (int e = 0; e < lane; ++e) mul *= (uint32_t)A;
+                term = (int)((uint32_t)sv * mul);                         // the sum is below A^n <= 2^31
+            }
+            xc += (uint32_t)__builtin_amdgcn_readlane(wave_incl_scan(term), 63);
+        }
+        auto fetch_blk = [&](int blk) -> uint32_t {     // lane t < 32: step 32 blk + t of the wavefront's chain
+            const int i = 32 * blk + (lane & 31);
+            const int q = cnt - 1 - (2 * ns + 2 * i + wq);
+            return (i < n_own) ? pl[L * (m + (q / L) * M) + (q % L)] : 0u;
+        };
+        int used = 0, blk = 0;
+        uint32_t raw = fetch_blk(0);
+        for (;; ++blk) {                                // workgroup-uniform
+            const uint32_t rawn = fetch_blk(blk + 1);
+            if (wq < 2) {
+                const int nst = min(32, n_own - 32 * blk);
+                if (lane == 0) sh_xs[wq][0] = xc;
+                for (int t = 0; t < nst; ++t) {
+                    const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)raw, t);
+                    const uint32_t lo = v & 0xFFFFu;
+                    uint32_t hi = v >> 16;
+                    if (hi == 0) hi = 0x10000u;
+                    uint32_t freq = hi - lo;
+                    if (freq == 0 || hi < lo) { bad = 1; freq = 1; }
+                    const int nb = rans_emit_bits(xc, freq);
+                    if (lane == 0) sh_fld[2 * (32 * blk + t) + wq] = (xc & ((1u << nb) - 1u)) | ((uint32_t)nb << 16);
+                    used += nb;
+                    xc = rans_push(xc >> nb, lo, freq);
+                    if (lane == 0) sh_xs[wq][t + 1] = xc;
+                }
+                if (lane == 0) sh_used[blk & 1][wq] = used;
+            }
+            __syncthreads();
+            raw = rawn;
+            if (sh_used[blk & 1][0] + sh_used[blk & 1][1] + 64 > GEO::kPayBits || blk + 1 >= nblk) break;
+        }
+        const int nrun = min(64 * (blk + 1), ncod);     // records there are
+        // thread tid: records 8 tid .. 8 tid + 7 (2048 >= the tail's maximum): bits of chain A / chain B before each of them
+        int nbv[8], sa = 0, sb = 0;
+        uint32_t fv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int idx = 8 * tid + e;
+            const uint32_t r = (idx < nrun) ? sh_fld[idx] : 0u;
+            nbv[e] = (int)(r >> 16); fv[e] = r & 0xFFFFu;
+            if (e & 1) sb += nbv[e]; else sa += nbv[e];
+        }
+        const int ia = wave_incl_scan(sa), ib = wave_incl_scan(sb);
+        if (lane == 63) { sh_scan[0][wq] = ia; sh_scan[1][wq] = ib; }
+        if (tid == 0) sh_cut[0] = nrun;
+        __syncthreads();
+        int ea = ia - sa, eb = ib - sb;                 // exclusive
+        for (int w2 = 0; w2 < wq; ++w2) { ea += sh_scan[0][w2]; eb += sh_scan[1][w2]; }
+        {
+            int ca = ea, cb = eb, first = 0x7FFFFFFF;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (ca + cb + nbv[e] + 64 > GEO::kPayBits && first == 0x7FFFFFFF) first = 8 * tid + e;
+                if (e & 1) cb += nbv[e]; else ca += nbv[e];
+            }
+            if (first != 0x7FFFFFFF) atomicMin(&sh_cut[0], first);
+        }
+        __syncthreads();
+        const int tcod = sh_cut[0];                     // coded symbols: the sequential rule's stop
+        {
+            int ca = ea, cb = eb;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (8 * tid + e == tcod) { sh_cut[1] = ca; sh_cut[2] = cb; }
+                if (e & 1) cb += nbv[e]; else ca += nbv[e];
+            }
+        }
+        __syncthreads();
+        const int used_a = sh_cut[1], used_b = sh_cut[2];
+        {
+            int ca = ea, cb = eb;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (8 * tid + e < tcod) {
+                    const int pos = (e & 1) ? GEO::kPayBits - 32 - used_b + cb : 32 + used_a - ca - nbv[e];
+                    lds_or_bits(sh_pay, pos, nbv[e], fv[e]);
+                }
+                if (e & 1) cb += nbv[e]; else ca += nbv[e];
+            }
+        }
+        if (tid == 0) {
+            sh_pay[0] = sh_xs[0][((tcod + 1) >> 1) - 32 * blk];
+            sh_pay[GEO::kPayDw - 1] = sh_xs[1][(tcod >> 1) - 32 * blk];
+        }
+        T = NS + tcod;
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < kWin; t += kFlush) sh_win[t + tid] = 0;
+        __syncthreads();
+    } else {
         const uint32_t *pl = pairs + dl.pair_off;
         auto fetch_blk = [&](int q1) -> uint32_t {      // lane t: the t-th symbol from the end of the q1 symbols that are left
             const int q = q1 - 1 - lane;
             return (q >= 0) ? pl[L * (m + (q / L) * M) + (q % L)] : 0u;
         };
         uint32_t xt = 1u << 31;
-        if constexpr (kSeeded<Q>) {
-            // xwide: the coder does not start from an empty state but from 2^31 | the stream's last three SYMBOLS, 9 bits each (sgl = the last
-            // stage's geometry: the symbol is the Cg pixel plus the image's shift) -- 31 bits that carried nothing carry three symbols
-            T = min(kSeedSyms, cnt);
-            int sv = 0;
-            if (lane < T) {
-                const int q = cnt - 1 - lane;
-                const int n = L * (m + (q / L) * M) + (q % L);
-                const int pi = div_wc(sgl, n), pj = n - pi * sgl.wc;
-                int minv, maxv, shift;
-                clr_range(minmax + 4 * b, 2, minv, maxv, shift);
-                sv = (int)planes[((long)b * 3 + 2) * sgl.plane + ((long)(2 * pi + sgl.oi) << sgl.lvl) * sgl.W + ((long)(2 * pj + sgl.oj) << sgl.lvl)] + shift;
-                if (sv < 0 || sv > maxv - minv) { bad = 1; sv = 0; }
-            }
-            bad = __builtin_amdgcn_readlane(bad, 0) | __builtin_amdgcn_readlane(bad, 1) | __builtin_amdgcn_readlane(bad, 2);
-#pragma unroll
-            for (int t = 0; t < kSeedSyms; ++t) xt |= (uint32_t)__builtin_amdgcn_readlane(sv, t) << (kSeedBits * t);
-        }
-        const int cnt_ac = cnt - T;                     // what is left for the coder proper
         int tb = 0;
         uint64_t acc = 0;                               // emitted bits not yet in LDS: the low accn (< 32) bits
         int accn = 0, wdw = 0;
         bool full = false;
-        uint32_t raw = fetch_blk(cnt_ac);
-        for (int q1 = cnt_ac; q1 > 0 && !full; q1 -= 64) {
+        uint32_t raw = fetch_blk(cnt);
+        for (int q1 = cnt; q1 > 0 && !full; q1 -= 64) {
             const uint32_t rawn = fetch_blk(q1 - 64);
             const int nblk = min(64, q1);
             for (int t = 0; t < nblk; ++t) {
@@ -178,9 +296,8 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
                 if (hi == 0) hi = 0x10000u;
                 uint32_t freq = hi - lo;
                 if (freq == 0 || hi < lo) { bad = 1; freq = 1; }
-                const bool first = !kSeeded<Q> && T == 0;
-                if (first) xt = freq << 15;             // absorbing start (64 / 128 lanes): the first pushed symbol codes to 2^31 + c_low, no bits
-                const int nb = first ? 0 : rans_emit_bits(xt, freq);         // (the closed form needs x >= 2^31)
+                if (T == 0) xt = freq << 15;            // absorbing start: the first pushed symbol codes to 2^31 + c_low, no bits
+                const int nb = (T == 0) ? 0 : rans_emit_bits(xt, freq);      // (the closed form needs x >= 2^31)
                 if (tb + nb + 32 > GEO::kPayBits) { full = true; break; }
                 acc |= (uint64_t)(xt & ((1u << nb) - 1u)) << accn;
                 accn += nb;
@@ -1125,48 +1242,62 @@ __global__ __launch_bounds__(64 * Q) void rans_decode_stage_lane_kernel(const fl
 //     (lane = 5 e + mc: mixture component mc of window entry e), and a ballot proves the symbol (an exact 13-ary search takes over
 //     when the hint is wrong); state update, bit-granular renormalisation from the payload in LDS.
 // One barrier per round.  Checks: the main region was read to its last bit, the tail state ends at its start state (freq << 15 of
-// the symbol the tail encoder began with; 2^31 when T = 0) with no bit left.  Xwide streams: the start state is the seed -- the stream's last
-// three symbols, raw -- and the check is that they are symbols of the image's range with zero bits above them.
+// the symbol the tail encoder began with; 2^31 when T = 0) with no bit left.  Xwide streams (two seeded chains, above): a second set of four
+// wavefronts runs chain B; the start states are seeds -- checked to be below A^n, with zero digits where the stream has no symbol -- the
+// chains' cursors must not have crossed and the payload between them must be zero.
 constexpr int kTailAhead = 3;                    // symbols per round = preparing wavefronts
 
+template <int Q> constexpr int kTailChains = kSeeded<Q> ? 2 : 1;      // xwide: two chains, each with its own coder + preparing wavefronts
+
 template <int Q>
-__global__ __launch_bounds__(64 * (1 + kTailAhead)) void rans_tail_kernel(const float *__restrict__ params, StageGeom sg, int M,
+__global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_tail_kernel(const float *__restrict__ params, StageGeom sg, int M,
                                                        const uint32_t *__restrict__ rstate, const uint32_t *__restrict__ rpos,
                                                        const uint32_t *__restrict__ rtail,
                                                        int16_t *__restrict__ planes, float *__restrict__ fplanes,
                                                        const int32_t *__restrict__ minmax, int32_t *status)
 {
-    constexpr int L = 64 * Q;
+    using GEO = RansGeo<Q>;
+    constexpr int L = 64 * Q, NCH = kTailChains<Q>;
     __shared__ uint32_t sh_pay[64 * Q + 2];
-    __shared__ float sh_cmp[2][kTailAhead][16];         // [0..4] mu, [5..9] 1 / sigma, [10..14] normalised weight of the five components
-    __shared__ int sh_e1[2][kTailAhead][64];            // approximate table entry at anchor 8 l
-    __shared__ long sh_off[2][kTailAhead];              // the symbol's pixel
+    __shared__ float sh_cmp[NCH][2][kTailAhead][16];    // [0..4] mu, [5..9] 1 / sigma, [10..14] normalised weight of the five components
+    __shared__ int sh_e1[NCH][2][kTailAhead][64];       // approximate table entry at anchor 8 l
+    __shared__ long sh_off[NCH][2][kTailAhead];         // the symbol's pixel
+    __shared__ int sh_cur[2];                           // xwide: where the two chains stopped reading
     const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chain = wave / (1 + kTailAhead), role = wave - chain * (1 + kTailAhead);      // role 0: the chain's coder
     const int nc = sg.hc * sg.wc;
     const int cnt = rans_stream_count(nc, m, M, L);
     bool bad = rpos[sidx] != 0 || (int)rtail[sidx] > cnt;
-    const int Tall = min((int)rtail[sidx], cnt);        // the stream's tail symbols: T coded ones, then (xwide) the seed's
-    const int NS = kSeeded<Q> ? min(kSeedSyms, cnt) : 0;
-    bad = bad || Tall < NS;
-    const int T = max(Tall - NS, 0);
-    const int R = (T + kTailAhead - 1) / kTailAhead;    // rounds
+    const int Tall = min((int)rtail[sidx], cnt);        // the stream's tail symbols: the coded ones, then (xwide) the seeds'
     int minv, maxv, shift;
     clr_range(minmax + 4 * b, 2, minv, maxv, shift);
     const Grid gr = make_grid(minv, maxv);
     const int max_symbol = gr.Lp - 2;
+    uint32_t pw = 1;
+    const int ns = kSeeded<Q> ? rans_seed_count(max_symbol + 1, pw) : 0;
+    const int NS = min(NCH * ns, cnt);                  // seed symbols (0 for the older stream kinds)
+    bad = bad || Tall < NS;
+    const int Tc = max(Tall - NS, 0);                   // coded symbols; the one with index idx (j = NCH ns + idx from the stream's end) is on chain idx % NCH
+    const int T = (Tc + NCH - 1 - chain) / NCH;         // this chain's
+    const int R = ((Tc + NCH - 1) / NCH + kTailAhead - 1) / kTailAhead;      // rounds (chain 0 has the most symbols)
     const long img = (long)b * 3 * sg.plane;
     const int mc = lane % 5, we = lane / 5;
+    auto pixel_of = [&](int j) -> long {                 // the stream's j-th symbol from its end
+        const int q = min(max(cnt - 1 - j, 0), max(cnt - 1, 0));
+        const int n = min(L * (m + (q / L) * M) + (q % L), nc - 1);
+        const int pi = div_wc(sg, n), pj = n - pi * sg.wc;
+        return ((long)pi << 32) | (uint32_t)pj;
+    };
 
-    if (wave != 0) {
-        // ---- preparing wavefronts: symbol t = kTailAhead r + (wave - 1) of round r (t counts the tail's symbols in decoding order)
-        const int i = wave - 1;
+    if (role != 0) {
+        // ---- preparing wavefronts: symbol t = kTailAhead r + (role - 1) of round r (t counts the chain's symbols in decoding order)
+        const int i = role - 1;
         struct Row { float sg, mu, wk, bb, dd, y, co; long off; };
         auto fetch = [&](int t) -> Row {
             Row r;
-            const int q = min(max(cnt - Tall + t, 0), max(cnt - 1, 0));   // position in the stream's share of the last stage
-            const int n = min(L * (m + (q / L) * M) + (q % L), nc - 1);
-            const int pi = div_wc(sg, n), pj = n - pi * sg.wc;
+            const long pp = pixel_of(NCH * ns + chain + NCH * (T - 1 - t));
+            const int pi = (int)(pp >> 32), pj = (int)(uint32_t)pp;
             const ParRow src = par_row(params, b, (long)sg.h * sg.w, (long)pi * sg.w + pj);
             r.off = img + ((long)(2 * pi + sg.oi) << sg.lvl) * sg.W + ((long)(2 * pj + sg.oj) << sg.lvl);
             r.sg = src[10 + mc]; r.mu = src[16 + 10 + mc]; r.wk = src[32 + 10 + mc];      // the Cg channel's sigma, mu, weight ...
@@ -1199,9 +1330,9 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead)) void rans_tail_kernel(const 
             float sum = 0.0f;
 #pragma unroll
             for (int k = 0; k < 5; ++k) { Comp ck; ck.mu = mu5[k]; ck.rsig = rs5[k]; ck.wn = wk5[k]; sum += term_fast(comp_fast(ck), pt1); }
-            sh_e1[buf][i][lane] = (int)__builtin_rintf(sum * gr.scale) + i1;
-            if (lane < 5) { sh_cmp[buf][i][lane] = mu; sh_cmp[buf][i][5 + lane] = rsig; sh_cmp[buf][i][10 + lane] = wn; }
-            if (lane == 0) sh_off[buf][i] = row.off;
+            sh_e1[chain][buf][i][lane] = (int)__builtin_rintf(sum * gr.scale) + i1;
+            if (lane < 5) { sh_cmp[chain][buf][i][lane] = mu; sh_cmp[chain][buf][i][5 + lane] = rsig; sh_cmp[chain][buf][i][10 + lane] = wn; }
+            if (lane == 0) sh_off[chain][buf][i] = row.off;
         };
         Row rowA = fetch(i);
         Row rowB = fetch(kTailAhead + i);
@@ -1214,42 +1345,53 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead)) void rans_tail_kernel(const 
             rowB = rowC;
             lds_barrier();      // LDS words only cross here: global loads / stores in flight stay in flight (common.hpp)
         }
+        if constexpr (kSeeded<Q>) lds_barrier();          // (the coders exchange their cursors)
         return;
     }
 
-    // ---- wavefront 0: the coder
+    // ---- role 0: the chain's coder (wavefront 0 assembles the payload for both)
+    if (wave == 0) {
 #pragma unroll
-    for (int qq = 0; qq < Q; ++qq) sh_pay[64 * qq + lane] = 0;
-    if (lane < 2) sh_pay[64 * Q + lane] = 0;
-    __builtin_amdgcn_wave_barrier();                      // same wavefront, in-order LDS
+        for (int qq = 0; qq < Q; ++qq) sh_pay[64 * qq + lane] = 0;
+        if (lane < 2) sh_pay[64 * Q + lane] = 0;
+        __builtin_amdgcn_wave_barrier();                  // same wavefront, in-order LDS
 #pragma unroll
-    for (int qq = 0; qq < Q; ++qq) {
-        const uint32_t xl = rstate[((long)sidx * Q + qq) * 64 + lane] & 0x7FFFFFFFu;
-        lds_or_bits(sh_pay, kRansStateBits * (64 * qq + lane), 16, xl & 0xFFFFu);
-        lds_or_bits(sh_pay, kRansStateBits * (64 * qq + lane) + 16, kRansStateBits - 16, xl >> 16);
-    }
-    __syncthreads();
-    int top = -1;                                                              // the payload's highest set bit
-#pragma unroll
-    for (int qq = Q - 1; qq >= 0; --qq) {
-        const uint64_t nz = ballot64(sh_pay[64 * qq + lane] != 0);
-        if (top < 0 && nz) {
-            const int hd = 64 * qq + 63 - __clzll((long long)nz);
-            top = 32 * hd + 31 - __clz((int)sh_pay[hd]);
+        for (int qq = 0; qq < Q; ++qq) {
+            const uint32_t xl = rstate[((long)sidx * Q + qq) * 64 + lane] & 0x7FFFFFFFu;
+            lds_or_bits(sh_pay, kRansStateBits * (64 * qq + lane), 16, xl & 0xFFFFu);
+            lds_or_bits(sh_pay, kRansStateBits * (64 * qq + lane) + 16, kRansStateBits - 16, xl >> 16);
         }
     }
-    // a malformed stream still gets its T tail pixels written (from whatever state there is): the output of a flagged image
-    // must not depend on what the workspace held
-    if (top < 31) bad = true;
-    uint32_t xt = (top >= 31) ? lds_get_bits(sh_pay, top - 31, 32) : (1u << 31);
-    int tc = (top >= 31) ? top - 31 : 0;
+    __syncthreads();
+    uint32_t xt;
+    int tc;                                               // bit cursor: legacy chains and xwide chain B read DOWN to it, xwide chain A reads UP from it
+    if constexpr (kSeeded<Q>) {
+        xt = sh_pay[chain ? GEO::kPayDw - 1 : 0];        // final states at fixed places
+        tc = chain ? GEO::kPayBits - 32 : 32;
+        if (!(xt >> 31)) { bad = true; xt |= 1u << 31; }
+    } else {
+        int top = -1;                                                          // the payload's highest set bit
+#pragma unroll
+        for (int qq = Q - 1; qq >= 0; --qq) {
+            const uint64_t nz = ballot64(sh_pay[64 * qq + lane] != 0);
+            if (top < 0 && nz) {
+                const int hd = 64 * qq + 63 - __clzll((long long)nz);
+                top = 32 * hd + 31 - __clz((int)sh_pay[hd]);
+            }
+        }
+        // a malformed stream still gets its T tail pixels written (from whatever state there is): the output of a flagged image
+        // must not depend on what the workspace held
+        if (top < 31) bad = true;
+        xt = (top >= 31) ? lds_get_bits(sh_pay, top - 31, 32) : (1u << 31);
+        tc = (top >= 31) ? top - 31 : 0;
+    }
     __syncthreads();                                      // round 0 is prepared
     for (int r = 0; r < R; ++r) {
         const int buf = r & 1;
         for (int i = 0; i < kTailAhead && kTailAhead * r + i < T; ++i) {
-            const float mu = sh_cmp[buf][i][mc], rsig = sh_cmp[buf][i][5 + mc], wn = sh_cmp[buf][i][10 + mc];
-            const int e1 = sh_e1[buf][i][lane];
-            const long off = sh_off[buf][i];
+            const float mu = sh_cmp[chain][buf][i][mc], rsig = sh_cmp[chain][buf][i][5 + mc], wn = sh_cmp[chain][buf][i][10 + mc];
+            const int e1 = sh_e1[chain][buf][i][lane];
+            const long off = sh_off[chain][buf][i];
             const uint32_t slot = xt & 0xFFFFu;
             // exact entry idx (uniform in the lane's group of five): valid in every lane of the group
             auto entry_at = [&](int idx) -> uint32_t {
@@ -1270,8 +1412,8 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead)) void rans_tail_kernel(const 
             int wb = max(8 * (__builtin_popcountll(p1) - 1) - 2, 0);
             // 2. proof: the 12 exact entries wb .. wb + 11; the symbol is the last one <= slot, its successor must be in the window too
             uint32_t ent = entry_at(wb + we);
-            const uint64_t pw = ballot64(mc == 0 && we < 12 && wb + we <= max_symbol && (ent <= slot || wb + we == 0));
-            int np = __builtin_popcountll(pw);
+            const uint64_t pw12 = ballot64(mc == 0 && we < 12 && wb + we <= max_symbol && (ent <= slot || wb + we == 0));
+            int np = __builtin_popcountll(pw12);
             if (np == 0 || np == 12) {
                 // the hint was wrong (only absurd mixtures get here): exact 13-ary search from scratch, then the window at the result
                 int lo = 0, hi = max_symbol + 1;
@@ -1298,7 +1440,14 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead)) void rans_tail_kernel(const 
                 fplanes[off + 2 * sg.plane] = (float)v / 255.0f;
             }
             xt = (vhi - vlo) * (xt >> 16) + slot - vlo;
-            if (!kSeeded<Q> && kTailAhead * r + i == T - 1) bad = bad || xt != (vhi - vlo) << 15;      // the encoder's first symbol: absorbing start, no bits
+            if constexpr (kSeeded<Q>) {
+                int nb = __clz((int)xt);
+                const int avail = chain ? tc - 32 : GEO::kPayBits - 32 - tc;      // (never into the other chain's state; whether the chains crossed is checked at the end)
+                if (nb > 16 || avail < nb) { bad = true; nb = min(nb, min(avail, 16)); }   // corrupt: keep going on what is there
+                if (chain) tc -= nb;
+                xt = ((xt << nb) | lds_get_bits(sh_pay, tc, nb)) | (1u << 31);
+                if (!chain) tc += nb;
+            } else if (kTailAhead * r + i == T - 1) bad = bad || xt != (vhi - vlo) << 15;      // the encoder's first symbol: absorbing start, no bits
             else {
                 int nb = __clz((int)xt);
                 if (nb > 16 || tc < nb) { bad = true; nb = min(nb, min(tc, 16)); }  // corrupt: keep going on what is there
@@ -1309,21 +1458,39 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead)) void rans_tail_kernel(const 
         lds_barrier();      // LDS words only cross here: global loads / stores in flight stay in flight (common.hpp)
     }
     if constexpr (kSeeded<Q>) {
-        // the coder is back at its start state: 2^31 | the stream's last NS symbols, raw (lane t: the t-th from the end)
-        const int sv = (int)(((xt & 0x7FFFFFFFu) >> (kSeedBits * min(lane, kSeedSyms))) & ((1u << kSeedBits) - 1u));
-        bool wrong = (lane < NS) ? sv > max_symbol : (lane <= kSeedSyms && sv != 0);      // (lane kSeedSyms: the bits between the seed and the leading one)
-        if (lane < NS) {
-            const int q = cnt - 1 - lane;
-            const int n = min(L * (m + (q / L) * M) + (q % L), nc - 1);
-            const int pi = div_wc(sg, n), pj = n - pi * sg.wc;
+        // the chain is back at its start state: 2^31 | its ns seed symbols in radix A (lane i: digit i = the stream's (chain ns + i)-th symbol from the end)
+        const uint32_t A = (uint32_t)(max_symbol + 1), v = xt & 0x7FFFFFFFu;
+        bad = bad || v >= pw;
+        uint32_t div = 1;
+        for (int e = 0; e < min(lane, ns); ++e) div *= A;
+        const int dg = (lane < ns) ? (int)((v / div) % A) : 0;
+        const int j = chain * ns + lane;
+        if (lane < ns && j < NS) {
+            const long pp = pixel_of(j);
+            const int pi = (int)(pp >> 32), pj = (int)(uint32_t)pp;
             const long off = img + ((long)(2 * pi + sg.oi) << sg.lvl) * sg.W + ((long)(2 * pj + sg.oj) << sg.lvl);
-            const int v = min(sv, max_symbol) - shift;
-            planes[off + 2 * sg.plane] = (int16_t)v;
-            fplanes[off + 2 * sg.plane] = (float)v / 255.0f;
+            const int pv = dg - shift;
+            planes[off + 2 * sg.plane] = (int16_t)pv;
+            fplanes[off + 2 * sg.plane] = (float)pv / 255.0f;
         }
-        bad = bad || ballot64(wrong) != 0;
-    } else if (T == 0) bad = bad || xt != (1u << 31);
-    if ((bad || tc != 0) && lane == 0) flag_image(status, b, LLICTI_EFORMAT);
+        bad = bad || ballot64(lane < ns && j >= NS && dg != 0) != 0;      // digits of symbols the stream does not have
+        if (lane == 0) sh_cur[chain] = tc;
+        lds_barrier();
+        if (chain == 0) {
+            // the chains must not have crossed, and what lies between them is zero
+            const int ca = sh_cur[0], cb = sh_cur[1];
+            uint32_t nz = 0;
+            for (int d = lane; d < GEO::kPayDw; d += 64) {
+                const int lo = max(ca, 32 * d), hi = min(cb, 32 * d + 32);
+                if (lo < hi) nz |= sh_pay[d] & ((hi - lo == 32) ? 0xFFFFFFFFu : (((1u << (hi - lo)) - 1u) << (lo - 32 * d)));
+            }
+            bad = bad || ca > cb || ballot64(nz != 0) != 0;
+        }
+        if (bad && lane == 0) flag_image(status, b, LLICTI_EFORMAT);
+    } else {
+        if (T == 0) bad = bad || xt != (1u << 31);
+        if ((bad || tc != 0) && lane == 0) flag_image(status, b, LLICTI_EFORMAT);
+    }
 }
 
 // M <= 32: stream m is segment 4 + m of the container.  M = 64 / 128 (latency modes for single / large images; the reference's list

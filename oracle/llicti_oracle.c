@@ -784,9 +784,27 @@ typedef struct { long n; uint32_t *clow, *chigh; int16_t *sym; } stage_syms_t;
 #define RANS_STATE_BITS 31                              /* a lane state is 2^31 | 31 bits */
 #define RANS_MAX_PAY_BITS (RANS_MAX_LANES * RANS_STATE_BITS)   /* what the initial states carry (the tail stream): 1984 / 3968 / 7936 bits */
 #define RANS_TAIL_MAX   2047
-#define RANS_SEED_LANES 256                             /* xwide streams only: the tail coder starts from 2^31 | the stream's last */
-#define RANS_SEED_SYMS  3                               /* three symbol indices, 9 bits each (bits 27..30 zero), instead of from an */
-#define RANS_SEED_BITS  9                               /* empty state: 31 bits that carried nothing now carry three symbols */
+/* xwide streams (256 lanes) only -- the older kinds keep their bytes.  Their tail is coded by TWO single-state coders ("chains") that share the
+ * payload, and neither starts from an empty state:
+ *   seeds    with A = the number of symbol values of the image's Cg channel (max - min + 1) and n = the largest count with A^n <= 2^31 (at most
+ *            31; three for the full range of 511, five for 53), and counting the stream's symbols from its end (j = 0: the last one), chain A
+ *            starts from 2^31 | sum sym(i) A^i over i < n and chain B from the same of sym(n + i) (symbol INDICES, raw, radix A; a stream shorter
+ *            than 2 n symbols leaves the missing digits zero): the 31 bits an empty start state wastes carry n symbols that are never coded;
+ *   chains   symbol j >= 2 n is pushed on chain A if j is even, on chain B if it is odd, j ascending (the decoder pops j descending), while
+ *            used_A + used_B + bits(j) + 64 <= payload bits; T = the first j that does not fit (or the stream's length, or 2047);
+ *   payload  bits [0, 32) = A's final state; A's bit fields from bit 32 UPWARDS in the order the decoder reads them (last pushed first); B's
+ *            final state in the top 32 bits, B's fields below it, read DOWNWARDS (last pushed on top); what lies between is zero.
+ * Two chains because the tail is serial: the decoder runs them on two wavefronts, the encoder too. */
+#define RANS_SEED_LANES 256
+#define RANS_SEED_MAX   31
+static inline int rans_seed_count(int A, uint32_t *pw)          /* n and A^n */
+{
+    int n = 0;
+    uint64_t p = 1;
+    while (n < RANS_SEED_MAX && p * (uint64_t)A <= (1ull << 31)) { p *= (uint64_t)A; ++n; }
+    *pw = (uint32_t)p;
+    return n;
+}
 
 static inline void put_bits(uint8_t *buf, long pos, int n, uint32_t v)      /* LSB first */
 {
@@ -817,6 +835,50 @@ static long rans_stream_count(long nc, int m, int M, int L)
     const long K = (nchunks - m + M - 1) / M;
     const long last = m + (K - 1) * M;
     return L * K - ((last == nchunks - 1 && (nc % L)) ? L - (nc % L) : 0);
+}
+
+/* the xwide tail (see RANS_SEED_LANES above): fills pay (zeroed, 7936 bits), returns T or -1 on an impossible pair */
+static long rans_tail_encode_x(const stage_syms_t *sl, int m, int M, long cnt, int A, uint8_t *pay)
+{
+    const int L = RANS_SEED_LANES;
+    const long P = (long)L * RANS_STATE_BITS;
+    uint32_t x[2] = { 1u << 31, 1u << 31 }, pw;
+    const int ns = rans_seed_count(A, &pw);
+    long j = 0;
+    for (int c = 0; c < 2; ++c) {
+        uint32_t mul = 1;
+        for (int i = 0; i < ns && j < cnt; ++i, ++j, mul *= (uint32_t)A) {
+            const long q = cnt - 1 - j;
+            const int sy = sl->sym[(long)L * (m + (q / L) * M) + (q % L)];
+            if (sy < 0 || sy >= A) return -1;
+            x[c] += (uint32_t)sy * mul;
+        }
+    }
+    uint32_t fld[RANS_TAIL_MAX];
+    uint8_t fnb[RANS_TAIL_MAX];
+    long used[2] = { 0, 0 };
+    for (; j < cnt && j < RANS_TAIL_MAX; ++j) {
+        const long q = cnt - 1 - j;
+        const long n = (long)L * (m + (q / L) * M) + (q % L);
+        const uint32_t lo = sl->clow[n], freq = sl->chigh[n] - lo;
+        if (freq == 0 || freq > 0x10000u) return -1;
+        const int c = (int)(j & 1);
+        const int nb = rans_emit_bits(x[c], freq);
+        if (used[0] + used[1] + nb + 64 > P) break;
+        fld[j] = x[c] & ((1u << nb) - 1u);
+        fnb[j] = (uint8_t)nb;
+        used[c] += nb;
+        x[c] = rans_push(x[c] >> nb, lo, freq);
+    }
+    const long T = j;
+    put_bits(pay, 0, 32, x[0]);
+    put_bits(pay, P - 32, 32, x[1]);
+    long pa = 32, pb = P - 32;
+    for (long t = T - 1; t >= 2 * ns; --t) {                   /* the decoder's order */
+        if (t & 1) { pb -= fnb[t]; put_bits(pay, pb, fnb[t], fld[t]); }
+        else { put_bits(pay, pa, fnb[t], fld[t]); pa += fnb[t]; }
+    }
+    return T;
 }
 
 long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *wts, int M,
@@ -901,17 +963,16 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
         const long cnt = rans_stream_count(st[S].n, m, M, L);
         uint32_t xt = 1u << 31;
         long tb = 0, T = 0;
-        if (L == RANS_SEED_LANES)                            /* xwide: the coder's start state holds the stream's last symbols raw */
-            for (; T < cnt && T < RANS_SEED_SYMS; ++T) {
-                const long q = cnt - 1 - T;
-                xt |= (uint32_t)st[S].sym[(long)L * (m + (q / L) * M) + (q % L)] << (RANS_SEED_BITS * T);
-            }
-        while (T < cnt && T < RANS_TAIL_MAX) {
+        if (L == RANS_SEED_LANES) {                          /* xwide: two seeded chains in one payload */
+            T = rans_tail_encode_x(&st[S], m, M, cnt, minmax[5] - minmax[2] + 1, pay);
+            if (T < 0) { rc = -5; break; }
+        }
+        while (L != RANS_SEED_LANES && T < cnt && T < RANS_TAIL_MAX) {
             const long q = cnt - 1 - T;
             const long n = (long)L * (m + (q / L) * M) + (q % L);
             const uint32_t lo = st[S].clow[n], freq = st[S].chigh[n] - lo;
             if (freq == 0 || freq > 0x10000u) { rc = -5; break; }
-            if (T == 0) xt = freq << 15;          /* absorbing start (64 / 128 lanes): the first pushed symbol codes to 2^31 + c_low, no bits */
+            if (T == 0) xt = freq << 15;          /* absorbing start: the first pushed symbol codes to 2^31 + c_low, no bits */
             const int nb = rans_emit_bits(xt, freq);
             if (tb + nb + 32 > PAY_BITS) break;
             put_bits(pay, tb, nb, xt & ((1u << nb) - 1u));
@@ -920,7 +981,7 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
             ++T;
         }
         if (rc < 0) break;
-        put_bits(pay, tb, 32, xt);
+        if (L != RANS_SEED_LANES) put_bits(pay, tb, 32, xt);
         /* 2. the L lanes start from the payload: lane l = 2^31 | payload bits [31 l, 31 l + 31) */
         uint32_t x[RANS_MAX_LANES];
         for (int l = 0; l < L; ++l) x[l] = (1u << 31) | get_bits(pay, (long)RANS_STATE_BITS * l, RANS_STATE_BITS);
@@ -1117,18 +1178,63 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
                 uint8_t pay[RANS_MAX_PAY_BITS / 8 + 4];
                 memset(pay, 0, sizeof pay);
                 for (int l = 0; l < L; ++l) put_bits(pay, (long)RANS_STATE_BITS * l, RANS_STATE_BITS, x[m][l] & 0x7FFFFFFFu);
+                const long cnt = rans_stream_count(n_sym, m, M, L);
+                if (T[m] > cnt) { bad = 1; continue; }
+                if (L == RANS_SEED_LANES) {
+                    /* xwide: two seeded chains (see RANS_SEED_LANES): A reads UP from bit 32, B DOWN from the top state */
+                    uint32_t pw;
+                    const int ns = rans_seed_count(Lp - 1, &pw);
+                    const long NS = cnt < 2 * ns ? cnt : 2 * ns;
+                    if (T[m] < NS) { bad = 1; continue; }
+                    uint32_t xc[2] = { get_bits(pay, 0, 32), get_bits(pay, PAY_BITS - 32, 32) };
+                    if (!(xc[0] >> 31) || !(xc[1] >> 31)) { bad = 1; continue; }
+                    long pa = 32, pb = PAY_BITS - 32;
+                    int stop = 0;
+                    for (long t = T[m] - 1; t >= NS && !stop; --t) {
+                        const long q = cnt - 1 - t;
+                        const long n = (long)L * (m + (q / L) * M) + (q % L);
+                        int i = (int)(n / wc), j = (int)(n % wc);
+                        long off = ((long)(2 * i + BAND_OI[src]) << lvl) * W + ((long)(2 * j + BAND_OJ[src]) << lvl);
+                        mix_t mx;
+                        mix_prepare(params + ((long)i * w + j) * ORC_NPAR, clr, (float)planes[off] / 255.0f,
+                                    (float)planes[plane_sz + off] / 255.0f, &mx);
+                        const int c = (int)(t & 1);
+                        const uint32_t slot = xc[c] & 0xFFFF;
+                        uint32_t c_low, c_high;
+                        const int s = rans_find(&mx, slot, Lp, minv, maxv, &c_low, &c_high);
+                        xc[c] = (c_high - c_low) * (xc[c] >> 16) + slot - c_low;
+                        planes[clr * plane_sz + off] = (int16_t)(s - shift);
+                        const int nb = clz32(xc[c]);
+                        if (nb > 16 || pa + nb > pb) { bad = 1; stop = 1; break; }
+                        if (c) { pb -= nb; xc[c] = (xc[c] << nb) | get_bits(pay, pb, nb); }
+                        else { xc[c] = (xc[c] << nb) | get_bits(pay, pa, nb); pa += nb; }
+                    }
+                    if (stop) continue;
+                    for (long bq = pa; bq < pb; ++bq)
+                        if ((pay[bq >> 3] >> (bq & 7)) & 1u) bad = 1;             /* nothing between the two chains */
+                    for (int c = 0; c < 2; ++c) {                                 /* the start states: the last 2 n symbols, raw */
+                        uint32_t v = xc[c] & 0x7FFFFFFFu;
+                        if (!(xc[c] >> 31) || v >= pw) bad = 1;
+                        for (int i = 0; i < ns; ++i, v /= (uint32_t)(Lp - 1)) {
+                            const int s = (int)(v % (uint32_t)(Lp - 1));
+                            const long t = (long)c * ns + i;
+                            if (t >= NS) { if (s) bad = 1; continue; }
+                            const long q = cnt - 1 - t;
+                            const long n = (long)L * (m + (q / L) * M) + (q % L);
+                            int i2 = (int)(n / wc), j2 = (int)(n % wc);
+                            planes[clr * plane_sz + ((long)(2 * i2 + BAND_OI[src]) << lvl) * W + ((long)(2 * j2 + BAND_OJ[src]) << lvl)] = (int16_t)(s - shift);
+                        }
+                    }
+                    continue;
+                }
                 long top = -1;
                 for (long b = PAY_BITS - 1; b >= 0; --b)
                     if ((pay[b >> 3] >> (b & 7)) & 1u) { top = b; break; }
                 if (top < 31) { bad = 1; continue; }
                 uint32_t xt = get_bits(pay, top - 31, 32);
                 long tc = top - 31;
-                const long cnt = rans_stream_count(n_sym, m, M, L);
-                if (T[m] > cnt) { bad = 1; continue; }
                 uint32_t f_last = 0;
-                const long R = (L != RANS_SEED_LANES) ? 0 : cnt < RANS_SEED_SYMS ? cnt : RANS_SEED_SYMS;
-                if (T[m] < R) { bad = 1; continue; }
-                for (long q = cnt - T[m]; q < cnt - R; ++q) {
+                for (long q = cnt - T[m]; q < cnt; ++q) {
                     const long n = (long)L * (m + (q / L) * M) + (q % L);
                     int i = (int)(n / wc), j = (int)(n % wc);
                     long off = ((long)(2 * i + BAND_OI[src]) << lvl) * W + ((long)(2 * j + BAND_OJ[src]) << lvl);
@@ -1141,24 +1247,13 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
                     xt = (c_high - c_low) * (xt >> 16) + slot - c_low;
                     planes[clr * plane_sz + off] = (int16_t)(s - shift);
                     f_last = c_high - c_low;
-                    if (!R && q == cnt - 1) break;                   /* the encoder's first symbol: absorbing start, no bits */
+                    if (q == cnt - 1) break;                     /* the encoder's first symbol: absorbing start, no bits */
                     int nb = clz32(xt);
                     if (nb > 16 || tc < nb) { bad = 1; break; }
                     tc -= nb;
                     xt = (xt << nb) | get_bits(pay, tc, nb);
                 }
-                if (tc != 0) bad = 1;                                            /* no bit left */
-                if (!R) { if (xt != (T[m] ? f_last << 15 : 1u << 31)) bad = 1; continue; }     /* the tail coder's start state */
-                if (!(xt >> 31) || ((xt >> (RANS_SEED_BITS * RANS_SEED_SYMS)) & 0xFu)) bad = 1;
-                for (long t = 0; t < RANS_SEED_SYMS; ++t) {                      /* xwide: the start state is the last symbols, raw */
-                    const int s = (int)((xt >> (RANS_SEED_BITS * t)) & ((1u << RANS_SEED_BITS) - 1u));
-                    if (t >= R) { if (s) bad = 1; continue; }
-                    if (s > Lp - 2) { bad = 1; continue; }
-                    const long q = cnt - 1 - t;
-                    const long n = (long)L * (m + (q / L) * M) + (q % L);
-                    int i = (int)(n / wc), j = (int)(n % wc);
-                    planes[clr * plane_sz + ((long)(2 * i + BAND_OI[src]) << lvl) * W + ((long)(2 * j + BAND_OJ[src]) << lvl)] = (int16_t)(s - shift);
-                }
+                if (xt != (T[m] ? f_last << 15 : 1u << 31) || tc != 0) bad = 1;   /* the tail coder's start state, and no bit left */
             }
         }
         free(params);

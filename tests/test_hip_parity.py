@@ -612,7 +612,7 @@ def test_agent_batched_eval_equals_unbatched(torch_mod, tmp_path, caplog, oracle
         assert mode_of_header(rb["bytestream_list"][0][0][0]) == mode_of_name(cname)
     W_o = oracle_weights("rand1337")                     # the agent's seed-1337 default init (no checkpoint in the test directory)
     for i in (4, 8):
-        assert res_b[i]["bytestream_list"] == orc.encode_image_rans(imgs[i], W_o, 9, 2)
+        assert res_b[i]["bytestream_list"] == orc.encode_image_rans(imgs[i], W_o, mode_of_name(cname) & 0xFF, 2)
     # ... and both runs logged the same mean rate table ("te" rows, loggers/rate.py) -- once each
     tables = [r.message for r in caplog.records if "scl4->" in r.message]
     assert len(tables) == 2 and tables[0].split("(")[0:-1] == tables[1].split("(")[0:-1]      # identical but for the trailing time stamp
