@@ -111,6 +111,7 @@ struct llicti_ctx {
     int img_status_cap = 0, img_status_n = 0;   // (context-owned: the caller may free or reuse the workspace before llicti_image_status)
     int32_t *d_status = nullptr;      // small persistent status word (for the kernel-level entry points)
     int32_t *d_lift_part = nullptr;   // min/max partials of llicti_lift_u8 (1 MB; calls on one context are not concurrent)
+    float2 *d_phi_lut = nullptr;      // normal CDF on [-6, 6] as (value, difference to the next) pairs: the lane decoder's hint table (rans_coder.hpp)
     int n_cu = 256;                   // compute units of the device (grid sizing of the persistent kernels)
     int cnn_tile_rows = 0;            // llicti_set_tuning("cnn_tile_rows"): 0 = choose per launch, 16 / 4 = force (tests, A/B)
     int enc_side_levels = 0;          // llicti_set_tuning("enc_side_levels"): 1 = encoder levels 4..1 on a side stream next to level 0, 0 = one queue (default)
@@ -370,6 +371,16 @@ extern "C" int llicti_create(llicti_ctx **out, int device)
     HIPCHK(hipMalloc(&c->d_status, 64));
     HIPCHK(hipMalloc(&c->d_lift_part, (size_t)kLiftMaxParts * 4 * sizeof(int32_t)));
     HIPCHK(hipMemset(c->d_status, 0, 64));
+    {
+        std::vector<float2> lut(kPhiLutN);
+        for (int j = 0; j < kPhiLutN; ++j) {
+            const double z0 = -kPhiLutZ + j * (2.0 * kPhiLutZ / kPhiLutN), z1 = -kPhiLutZ + (j + 1) * (2.0 * kPhiLutZ / kPhiLutN);
+            const double v0 = 0.5 * std::erfc(-z0 * 0.70710678118654752440), v1 = 0.5 * std::erfc(-z1 * 0.70710678118654752440);
+            lut[j] = make_float2((float)v0, (float)(v1 - v0));
+        }
+        HIPCHK(hipMalloc(&c->d_phi_lut, sizeof(float2) * kPhiLutN));
+        HIPCHK(hipMemcpy(c->d_phi_lut, lut.data(), sizeof(float2) * kPhiLutN, hipMemcpyHostToDevice));
+    }
     HIPCHK(hipEventCreate(&c->ev_call[0]));
     HIPCHK(hipEventCreate(&c->ev_call[1]));
     for (int k = 0; k < 2; ++k) {
@@ -412,6 +423,7 @@ extern "C" int llicti_destroy(llicti_ctx *c)
     for (int k = 0; k < 2; ++k) if (c->ev_enc[k]) hipEventDestroy(c->ev_enc[k]);
     if (c->d_status) hipFree(c->d_status);
     if (c->d_lift_part) hipFree(c->d_lift_part);
+    if (c->d_phi_lut) hipFree(c->d_phi_lut);
     if (c->d_img_status) hipFree(c->d_img_status);
     for (auto e : c->ev) hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) if (c->ev_call[i]) hipEventDestroy(c->ev_call[i]);
@@ -903,7 +915,7 @@ static int decode_batch(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t 
                 {
                 ProfSpan span(c, PROF_RANS_STAGE, s);
                 if (Q == 4) {
-                    rans_decode_stage_lane_kernel<4><<<B * M, 256, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status);
+                    rans_decode_stage_lane_kernel<4><<<B * M, 256, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status, c->d_phi_lut);
                 } else if (Q == 2) {
                     rans_decode_stage_pair_kernel<<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status);
                 } else {

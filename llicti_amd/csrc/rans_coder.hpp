@@ -30,6 +30,8 @@ template <int Q> struct RansGeo {
     static constexpr int kMinStream = 2 + kPayBytes;              // T | pad, (empty bit region), states
 };
 constexpr int kRansPayBytesMax = RansGeo<4>::kPayBytes;
+constexpr int kPhiLutN = 2048;                   // the lane decoder's hint table (llicti_ctx::d_phi_lut)
+constexpr double kPhiLutZ = 6.0;
 // xwide streams (Q = 4) only -- the older stream kinds keep their bytes.  A rANS chain ends in a 32-bit state of which only what the symbols put
 // in is information: a coder that starts from an empty state wastes ~31 bits.  And the tail is serial.  So an xwide stream's tail is coded by TWO
 // single-state coders ("chains") sharing the payload, neither starting empty (spec: oracle/llicti_oracle.c, RANS_SEED_LANES):
@@ -1042,18 +1044,29 @@ __global__ __launch_bounds__(64 * Q) void rans_decode_stage_lane_kernel(const fl
                                                                int rslot_cap, uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos,
                                                                const uint32_t *__restrict__ rtail,
                                                                int16_t *__restrict__ planes, float *__restrict__ fplanes,
-                                                               const int32_t *__restrict__ minmax, int last_stage, int32_t *status)
+                                                               const int32_t *__restrict__ minmax, int last_stage, int32_t *status,
+                                                               const float2 *__restrict__ phi_lut)
 {
     constexpr int L = 64 * Q;
     constexpr int kRing = 512, kRefill = 128;    // dwords; a step consumes at most 16 L bits = L / 2 dwords
     static_assert(L / 2 <= kRefill && kRing >= 4 * kRefill && 64 * Q >= kRefill, "ring sizing");
     __shared__ uint32_t sh_ring[kRing];          // stream dword d at sh_ring[d & (kRing - 1)]
     __shared__ int sh_tot[2][Q];                 // a step's bit totals per wavefront (ping-pong by step parity)
+    // The hint's mixture evaluations are 45 of the ~55 a symbol costs (nine probes x five components), and on the vector unit each is 15
+    // operations, two of them quarter-rate (rcp, exp2).  The normal CDF of ONE variable is a table: Phi(z) on [-6, 6] in kPhiLutN steps as
+    // (value, difference to the next) pairs (the context's, computed once on the host in double), 16 KB of LDS, read with linear
+    // interpolation -- error <= h^2 / 8 max|Phi''| = 1e-6, a fifteenth of a count of the 16-bit table (the vector form's Abramowitz-Stegun
+    // fit: 1.5e-7; either way the hint is proved or corrected by exact entries).  A term is then fma (table coordinate), clamp, floor,
+    // convert, min, fract, one 8-byte LDS read, two fma: ~1,220 instead of ~1,510 vector instructions per symbol, stage launches -6 %.
+    constexpr int kLutN = kPhiLutN;
+    constexpr float kLutZ = (float)kPhiLutZ, kLutS = kLutN / (2.0f * kLutZ);
+    __shared__ float2 sh_lut[kLutN];
     const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;      // tid = lane of the stream
     const int nc = sg.hc * sg.wc;
     const int nchunks = (nc + L - 1) / L;
     if (nchunks <= m) return;                    // whole workgroup
+    for (int j = tid; j < kLutN; j += L) sh_lut[j] = phi_lut[j];
     const int K = (nchunks - m + M - 1) / M;
     uint32_t x = rstate[(long)sidx * L + tid];
     int bcur = (int)rpos[sidx];                  // bit cursor in the stream's bit region, moving DOWN
@@ -1122,20 +1135,24 @@ __global__ __launch_bounds__(64 * Q) void rans_decode_stage_lane_kernel(const fl
         if (on_k) {
             const float ssum = (((w5[0] + w5[1]) + w5[2]) + w5[3]) + w5[4];
             const float den = 1e-9f + ssum;
-            CompFast F[5];
+            float c1[5], c0[5];                  // table coordinate of component t at sample point pt: u = pt c1 + c0
 #pragma unroll
-            for (int t = 0; t < 5; ++t) { wn5[t] = w5[t] / den; Comp cc; cc.mu = mu5[t]; cc.rsig = rs5[t]; cc.wn = wn5[t]; F[t] = comp_fast(cc); }
+            for (int t = 0; t < 5; ++t) { wn5[t] = w5[t] / den; c1[t] = rs5[t] * kLutS; c0[t] = __builtin_fmaf(-mu5[t], c1[t], kLutZ * kLutS); }
 
             // 1. hint: binary search on the approximate table (probes 1 .. max_symbol: regular sample points only)
             int glo = 0, ghi = max_symbol + 1;
             while (ghi - glo > 1) {
                 const int pi = (glo + ghi) >> 1;
                 const float pt = div255_exact(fbase + (float)pi);
-                float sum = term_fast(F[0], pt);
-                sum += term_fast(F[1], pt);
-                sum += term_fast(F[2], pt);
-                sum += term_fast(F[3], pt);
-                sum += term_fast(F[4], pt);
+                float sum = 0.0f;
+#pragma unroll
+                for (int t = 0; t < 5; ++t) {
+                    // u in [0, kLutN) -- v_med3_f32 returns one of its operands, so a NaN coordinate comes out as NaN, 0 or the bound, and v_cvt_u32_f32
+                    // (which truncates) turns a NaN into 0: the index stays inside the table whatever the CNN produced; v_fract_f32 is what is left
+                    const float u = __builtin_amdgcn_fmed3f(__builtin_fmaf(pt, c1[t], c0[t]), 0.0f, (float)kLutN - 0.0009765625f);
+                    const float2 e2 = sh_lut[(uint32_t)u];
+                    sum = __builtin_fmaf(wn5[t], __builtin_fmaf(e2.y, __builtin_amdgcn_fractf(u), e2.x), sum);
+                }
                 const int e = (int)__builtin_rintf(sum * gr.scale) + pi;
                 const bool le = e <= (int)slot;
                 glo = le ? pi : glo;
@@ -1167,7 +1184,7 @@ __global__ __launch_bounds__(64 * Q) void rans_decode_stage_lane_kernel(const fl
                     else if (s1 + 1 <= max_symbol) { hi = s2; vhi = eB; have_hi = true; }
                 } else { hi = s1; vhi = eA; have_hi = true; }
             }
-            int step = 2;
+            int step = 1;                        // (a hint that is off is off by one: the first gallop probe is the neighbour)
             while (hi - lo > 1) {
                 int probe;
                 if (have_lo && have_hi) probe = (lo + hi) >> 1;
