@@ -1282,7 +1282,9 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_t
     __shared__ int sh_cur[2];                           // xwide: where the two chains stopped reading
     const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int chain = wave / (1 + kTailAhead), role = wave - chain * (1 + kTailAhead);      // role 0: the chain's coder
+    // role 0: the chain's coder.  A workgroup's wavefronts go to the four SIMDs round robin: with two chains the coders are wavefronts 0 and 1 (their
+    // own SIMD each, shared with one preparing wavefront), not 0 and 4 (the same SIMD, taking turns at its issue port)
+    const int chain = wave % NCH, role = wave / NCH;
     const int nc = sg.hc * sg.wc;
     const int cnt = rans_stream_count(nc, m, M, L);
     bool bad = rpos[sidx] != 0 || (int)rtail[sidx] > cnt;
