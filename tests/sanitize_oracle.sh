@@ -1,6 +1,7 @@
 #!/bin/bash
 # The CPU oracle under AddressSanitizer + UBSan (CPU only; GPU sanitizers are not available on the pool): both containers, every
-# stream-count family incl. wide streams, and decodes of corrupted streams (which may fail, but must not read or write out of bounds).
+# stream-count family incl. wide and xwide streams (two seeded tail chains; narrow-range and flat images for the radix-A seeds), and decodes of
+# corrupted streams (which may fail, but must not read or write out of bounds).
 # Not collected by pytest (a minute of CPU); run from the repo root:  bash tests/sanitize_oracle.sh
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
@@ -20,16 +21,23 @@ from helpers import make_image
 rng = np.random.default_rng(1)
 for wname in ("trainedlike", "rand1337"):
     W = orc.Weights(pack_state_dict(dict(np.load(f"$ROOT/tests/golden/weights_{wname}.npz"))))
-    for kind, H, Wd in (("smooth", 67, 93), ("noise", 33, 64), ("noise", 96, 130), ("smooth", 32, 32)):
-        rgb = make_image(kind, H, Wd, 3)
+    for kind, H, Wd in (("smooth", 67, 93), ("noise", 33, 64), ("noise", 96, 130), ("smooth", 32, 32), ("narrow", 96, 130), ("flat", 64, 80)):
+        if kind == "narrow":                                 # three pixel values: a Cg alphabet of a handful of symbols, many seed symbols per chain
+            rgb = (np.random.default_rng(5).integers(0, 3, (3, H, Wd)) + 100).astype(np.uint8)
+        elif kind == "flat":
+            rgb = np.full((3, H, Wd), 77, np.uint8)
+        else:
+            rgb = make_image(kind, H, Wd, 3)
         assert np.array_equal(orc.decode_image(orc.encode_image(rgb, W), W), rgb)
-        for M, wide in ((1, False), (4, False), (10, False), (32, False), (64, False), (128, False), (1, True), (3, True), (10, True), (30, True)):
+        for M, wide in ((1, 0), (4, 0), (10, 0), (32, 0), (64, 0), (128, 0), (1, 1), (3, 1), (10, 1), (14, 1), (1, 2), (3, 2), (10, 2), (14, 2), (32, 2), (64, 2)):
             bl = orc.encode_image_rans(rgb, W, M, wide)
             assert np.array_equal(orc.decode_image_rans(bl, W), rgb), (kind, M, wide)
-            rows = [list(r) for r in bl]                     # one flipped bit in the first non-trivial stream
-            hit = next(((r, c) for r in range(1, 6) for c in range(9) if len(rows[r][c]) > 8), None)
-            if hit:
-                b = bytearray(rows[hit[0]][hit[1]]); b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8)); rows[hit[0]][hit[1]] = bytes(b)
+            hit = next(((r, c) for r in range(1, 6) for c in range(9) if len(bl[r][c]) > 8), None)
+            for trial in range(4 if hit else 0):             # flipped bits in the first non-trivial stream: anywhere, its T | pad, its states (the tail payload)
+                rows = [list(r) for r in bl]
+                b = bytearray(rows[hit[0]][hit[1]])
+                pos = (int(rng.integers(0, len(b))), int(rng.integers(0, 2)), len(b) - 1 - int(rng.integers(0, min(len(b), 248 << wide))), int(rng.integers(0, len(b))))[trial]
+                b[pos] ^= 1 << int(rng.integers(0, 8)); rows[hit[0]][hit[1]] = bytes(b)
                 try:
                     orc.decode_image_rans(rows, W)
                 except RuntimeError:

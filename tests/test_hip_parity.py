@@ -359,6 +359,30 @@ def test_rans_xwide_container_bitexact(torch_mod, codecs, oracle_weights, kind, 
             c.check()
 
 
+@pytest.mark.parametrize("M", [1, 3, 14])
+def test_rans_xwide_tail_seeds_and_chains_bitexact(torch_mod, codecs, oracle_weights, M):
+    """The xwide tail's corner cases on the GPU (two chains from both ends of the payload, seeds of n raw symbols in radix A): one batch of
+    images with 3, 2, 1 and 256 pixel values -- A from a handful to 511, n from 31 to 3, streams shorter than their seeds at M = 14, a flat
+    image whose coded tail symbols are all free (T at the format's cap) -- HIP bytes == oracle bytes for each, decode on a poisoned workspace."""
+    from oracle import oracle as orc
+    from llicti_amd.codec import MODE_RANS, container_to_bytestream_list
+    torch = torch_mod
+    H, W = 64, 96
+    r = np.random.default_rng(21)
+    rgb = np.stack([(r.integers(0, 3, (3, H, W)) + 90).astype(np.uint8), (r.integers(0, 2, (3, H, W)) * 7).astype(np.uint8),
+                    np.full((3, H, W), 201, np.uint8), r.integers(0, 256, (3, H, W), dtype=np.uint8)])
+    c = codecs("trainedlike")
+    W_o = oracle_weights("trainedlike")
+    mode = MODE_RANS(M, wide=2)
+    cont, seg = c.encode(_dev(torch, rgb), mode=mode)
+    c.check()
+    cont_h, seg_h = cont.cpu().numpy(), seg.cpu().numpy()
+    for b in range(len(rgb)):
+        assert container_to_bytestream_list(cont_h[b], seg_h[b]) == orc.encode_image_rans(rgb[b], W_o, M, wide=2), b
+    rec = _decode_poisoned(c, cont, seg, H, W, mode)
+    assert np.array_equal(rec.cpu().numpy(), rgb)
+
+
 def test_rans_v3_known_answer_hip(torch_mod, codecs):
     """The committed known-answer vectors of the rANS v3 container (tests/golden/rans_v3_vectors.npz, frozen by
     test_rans_v3_known_answer on the CPU): the HIP encoder reproduces the stored bytes, the HIP decoder turns the stored bytes

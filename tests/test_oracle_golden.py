@@ -206,11 +206,41 @@ def test_rans_wide_container_oracle_roundtrip(M, oracle_weights):
             orc.encode_image_rans(c["rgb"], W, bad, wide=True)
 
 
+@pytest.mark.parametrize("kind", ["narrow3", "narrow2", "flat", "noise"])
+@pytest.mark.parametrize("M", [1, 3, 14])
+def test_rans_xwide_tail_seeds_and_chains(kind, M, oracle_weights):
+    """The xwide tail (oracle/llicti_oracle.h, "tail, xwide"): two chains sharing the payload from both ends, each started from a seed of n raw
+    symbols in radix A = the image's Cg alphabet, n maximal with A^n <= 2^31.  Few pixel values make A small and n large (up to 31 per chain:
+    streams SHORTER than their seeds on small images), a flat image makes A = 1 (all digits zero, every coded symbol free: T runs to the
+    format's cap or the stream's end), noise gives A = 511, n = 3.  Lossless in all of them, the seeds are worth their bytes (where the content
+    can fill 256 states, a one-stream xwide container is no larger than the one-stream 64-lane one, whose tail starts empty), and a flipped
+    payload byte is caught."""
+    H, Wd = 64, 96
+    r = np.random.default_rng(21)
+    rgb = {"narrow3": lambda: (r.integers(0, 3, (3, H, Wd)) + 90).astype(np.uint8), "narrow2": lambda: (r.integers(0, 2, (3, H, Wd)) * 7).astype(np.uint8),
+           "flat": lambda: np.full((3, H, Wd), 201, np.uint8), "noise": lambda: r.integers(0, 256, (3, H, Wd), dtype=np.uint8)}[kind]()
+    W = oracle_weights("trainedlike")
+    bl = orc.encode_image_rans(rgb, W, M, wide=2)
+    assert np.array_equal(orc.decode_image_rans(bl, W), rgb)
+    n_x = sum(len(x) for row in bl for x in row)
+    if M == 1:
+        n_n = sum(len(x) for row in orc.encode_image_rans(rgb, W, 1, wide=0) for x in row)
+        assert n_x <= n_n + (992 - 248) + 2, (n_x, n_n)      # (at most the three extra sets of 64 states, where the content cannot fill them: flat)
+        if kind in ("noise", "narrow3"):
+            assert n_x <= n_n + 2, (n_x, n_n)
+    s0 = bytearray(bl[1][0])                                   # stream 0: T | pad, bit region, 992 bytes of states = the tail payload
+    for pos in (len(s0) - 992 + 1, len(s0) - 2):              # inside chain A's final state, inside chain B's
+        bad = [list(rw) for rw in bl]
+        b = bytearray(s0); b[pos] ^= 0x40; bad[1][0] = bytes(b)
+        with pytest.raises(RuntimeError):
+            orc.decode_image_rans(bad, W)
+
+
 @pytest.mark.parametrize("M,case,wname", [(1, "smooth_67x93_tl", "trainedlike"), (9, "noise_67x93_rand", "rand1337"), (14, "smooth_64x48_tl", "trainedlike"),
                                           (32, "noise_33x64_tl", "trainedlike"), (64, "smooth_67x93_tl", "trainedlike")])
 def test_rans_xwide_container_oracle_roundtrip(M, case, wname, oracle_weights):
     """XWIDE streams (256 lanes; header byte 0 = extended tag with v = M + 15, 30 / 31 for 32 / 64 streams, 64 = two per segment): lossless;
-    a stream's 256 x 31-bit states cost 992 bytes when it has no symbols, about 8 bytes over the ideal length when it has; the tags of
+    a stream's 256 x 31-bit states cost 992 bytes when it has no symbols, 2 - 3.5 bytes over the ideal length when it has; the tags of
     narrow, wide and xwide containers are disjoint; M = 15 .. 31 and 128 do not exist."""
     from llicti_amd.codec import MODE_RANS, mode_of_header, mode_of_name, name_of_mode, rans_tag
     c = load_case(case)
