@@ -152,6 +152,7 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
     const StreamDesc dl = desc[(long)(LLICTI_NSTREAMS - 1) * B + b];
     const int cnt = rans_stream_count(dl.n, m, M, L);
     int T = 0;
+    int tail_single = 0;                            // xwide: the tail has one chain, not two (bit 14 of the stream's first u16)
     if constexpr (kSeeded<Q>) {
         // xwide: two seeded chains (above), chain c on wavefront c.  The chains are independent but for the stop rule, which looks at both:
         // they run in blocks of 32 steps, record (field, bits) of every step in symbol order and their states of the last block, and meet at a
@@ -166,12 +167,28 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
         const int A = maxv - minv + 1;
         uint32_t pw;
         const int ns = rans_seed_count(A, pw);
-        const int NS = min(2 * ns, cnt);
-        const int ncod = max(min(cnt, kRansTailMax) - 2 * ns, 0);          // candidates j = 2 ns + idx, idx < ncod; chain c takes idx = 2 i + c
-        const int n_own = (wq < 2) ? (ncod + 1 - wq) >> 1 : 0;
-        const int nblk = (((ncod + 1) >> 1) + 31) >> 5;                    // chain A's steps, in blocks
+        // one chain or two (the rule of oracle/llicti_oracle.c, rans_tail_encode_x: a second chain pays when symbols are expensive): on the
+        // stream's last up to 64 symbols, two iff ns * mean(16 - floor(log2 freq)) >= 32 + ns / 2 -- every wavefront computes it for itself
+        int nch = 1;
+        if (cnt >= 2 * ns) {
+            const int k64 = min(cnt, 64);
+            int wgt = 0;
+            if (lane < k64) {
+                const int q = cnt - 1 - lane;
+                const uint32_t v = pl[L * (m + (q / L) * M) + (q % L)];
+                const uint32_t lo = v & 0xFFFFu, hi = (v >> 16) ? (v >> 16) : 0x10000u;
+                wgt = __clz((int)max(hi - lo, 1u)) - 15;
+            }
+            const int wsum = __builtin_amdgcn_readlane(wave_incl_scan(wgt), 63);
+            if (2 * wsum * ns >= k64 * (64 + ns)) nch = 2;
+        }
+        tail_single = (nch == 1);
+        const int NS = min(nch * ns, cnt);
+        const int ncod = max(min(cnt, kRansTailMax) - nch * ns, 0);        // candidates j = nch ns + idx, idx < ncod; chain c takes idx = nch i + c
+        const int n_own = (wq < nch) ? (ncod + nch - 1 - wq) / nch : 0;
+        const int nblk = ((ncod + nch - 1) / nch + 31) >> 5;               // chain A's steps, in blocks
         uint32_t xc = 1u << 31;
-        if (wq < 2) {
+        if (wq < nch) {
             const int j = wq * ns + lane;
             int term = 0;
             if (lane < ns && j < cnt) {
@@ -188,14 +205,14 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
         }
         auto fetch_blk = [&](int blk) -> uint32_t {     // lane t < 32: step 32 blk + t of the wavefront's chain
             const int i = 32 * blk + (lane & 31);
-            const int q = cnt - 1 - (2 * ns + 2 * i + wq);
+            const int q = cnt - 1 - (nch * ns + nch * i + wq);
             return (i < n_own) ? pl[L * (m + (q / L) * M) + (q % L)] : 0u;
         };
         int used = 0, blk = 0;
         uint32_t raw = fetch_blk(0);
         for (;; ++blk) {                                // workgroup-uniform
             const uint32_t rawn = fetch_blk(blk + 1);
-            if (wq < 2) {
+            if (wq < 2) {                               // (an idle chain B records no steps and reports 0 bits)
                 const int nst = min(32, n_own - 32 * blk);
                 if (lane == 0) sh_xs[wq][0] = xc;
                 for (int t = 0; t < nst; ++t) {
@@ -206,7 +223,7 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
                     uint32_t freq = hi - lo;
                     if (freq == 0 || hi < lo) { bad = 1; freq = 1; }
                     const int nb = rans_emit_bits(xc, freq);
-                    if (lane == 0) sh_fld[2 * (32 * blk + t) + wq] = (xc & ((1u << nb) - 1u)) | ((uint32_t)nb << 16);
+                    if (lane == 0) sh_fld[nch * (32 * blk + t) + wq] = (xc & ((1u << nb) - 1u)) | ((uint32_t)nb << 16);
                     used += nb;
                     xc = rans_push(xc >> nb, lo, freq);
                     if (lane == 0) sh_xs[wq][t + 1] = xc;
@@ -215,10 +232,11 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
             }
             __syncthreads();
             raw = rawn;
-            if (sh_used[blk & 1][0] + sh_used[blk & 1][1] + 64 > GEO::kPayBits || blk + 1 >= nblk) break;
+            if (sh_used[blk & 1][0] + sh_used[blk & 1][1] + 32 * nch > GEO::kPayBits || blk + 1 >= nblk) break;
         }
-        const int nrun = min(64 * (blk + 1), ncod);     // records there are
+        const int nrun = min(32 * nch * (blk + 1), ncod);     // records there are
         // thread tid: records 8 tid .. 8 tid + 7 (2048 >= the tail's maximum): bits of chain A / chain B before each of them
+        auto onb = [&](int e) -> bool { return nch == 2 && (e & 1); };      // record 8 tid + e belongs to chain B
         int nbv[8], sa = 0, sb = 0;
         uint32_t fv[8];
 #pragma unroll
@@ -226,7 +244,7 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
             const int idx = 8 * tid + e;
             const uint32_t r = (idx < nrun) ? sh_fld[idx] : 0u;
             nbv[e] = (int)(r >> 16); fv[e] = r & 0xFFFFu;
-            if (e & 1) sb += nbv[e]; else sa += nbv[e];
+            if (onb(e)) sb += nbv[e]; else sa += nbv[e];
         }
         const int ia = wave_incl_scan(sa), ib = wave_incl_scan(sb);
         if (lane == 63) { sh_scan[0][wq] = ia; sh_scan[1][wq] = ib; }
@@ -238,8 +256,8 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
             int ca = ea, cb = eb, first = 0x7FFFFFFF;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                if (ca + cb + nbv[e] + 64 > GEO::kPayBits && first == 0x7FFFFFFF) first = 8 * tid + e;
-                if (e & 1) cb += nbv[e]; else ca += nbv[e];
+                if (ca + cb + nbv[e] + 32 * nch > GEO::kPayBits && first == 0x7FFFFFFF) first = 8 * tid + e;
+                if (onb(e)) cb += nbv[e]; else ca += nbv[e];
             }
             if (first != 0x7FFFFFFF) atomicMin(&sh_cut[0], first);
         }
@@ -250,7 +268,7 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 if (8 * tid + e == tcod) { sh_cut[1] = ca; sh_cut[2] = cb; }
-                if (e & 1) cb += nbv[e]; else ca += nbv[e];
+                if (onb(e)) cb += nbv[e]; else ca += nbv[e];
             }
         }
         __syncthreads();
@@ -260,15 +278,15 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 if (8 * tid + e < tcod) {
-                    const int pos = (e & 1) ? GEO::kPayBits - 32 - used_b + cb : 32 + used_a - ca - nbv[e];
+                    const int pos = onb(e) ? GEO::kPayBits - 32 - used_b + cb : 32 + used_a - ca - nbv[e];
                     lds_or_bits(sh_pay, pos, nbv[e], fv[e]);
                 }
-                if (e & 1) cb += nbv[e]; else ca += nbv[e];
+                if (onb(e)) cb += nbv[e]; else ca += nbv[e];
             }
         }
         if (tid == 0) {
-            sh_pay[0] = sh_xs[0][((tcod + 1) >> 1) - 32 * blk];
-            sh_pay[GEO::kPayDw - 1] = sh_xs[1][(tcod >> 1) - 32 * blk];
+            sh_pay[0] = sh_xs[0][(tcod + nch - 1) / nch - 32 * blk];
+            if (nch == 2) sh_pay[GEO::kPayDw - 1] = sh_xs[1][(tcod >> 1) - 32 * blk];
         }
         T = NS + tcod;
         __syncthreads();
@@ -445,7 +463,7 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
         for (int t = tid; t < GEO::kPayBytes; t += 64 * Q) fs[t] = (uint8_t)(sh_pay[t >> 2] >> (8 * (t & 3)));
     }
     if (tid == 0) {
-        const int t16 = T | ((8 * nbytes - bp) << 11);               // pad: unused (zero) bits on top of the region's last byte
+        const int t16 = T | ((8 * nbytes - bp) << 11) | (tail_single << 14);      // pad: unused (zero) bits on top of the region's last byte
         slot[2] = (uint8_t)(t16 & 0xFF); slot[3] = (uint8_t)(t16 >> 8);
         rinfo[2 * sidx] = 2; rinfo[2 * sidx + 1] = (bad == 2) ? 0 : 2 + nbytes + GEO::kPayBytes;      // overflowed slot (never with the plan's sizing): nothing to pack, ENOSPACE is latched
     }
@@ -468,7 +486,8 @@ __global__ __launch_bounds__(64) void rans_init_kernel(const uint8_t *__restrict
     int T = t16 & 0x7FF;
     const int pad = (t16 >> 11) & 7;
     bool bad = false;
-    if ((t16 >> 14) || (nbytes == 0 && pad)) { bad = true; T = 0; }
+    const int single = kSeeded<Q> ? (t16 >> 14) & 1 : 0;           // xwide: one tail chain instead of two
+    if ((t16 >> (kSeeded<Q> ? 15 : 14)) || (nbytes == 0 && pad)) { bad = true; T = 0; }
     const int cur = bad ? 0 : 8 * nbytes - pad;
     const uint8_t *fs = slot + 4 + nbytes;
 #pragma unroll
@@ -479,7 +498,7 @@ __global__ __launch_bounds__(64) void rans_init_kernel(const uint8_t *__restrict
         for (int k = 0; k < 5; ++k) w |= (uint64_t)fs[min((bpos >> 3) + k, GEO::kPayBytes - 1)] << (8 * k);
         rstate[((long)sidx * Q + qq) * 64 + lane] = (1u << 31) | ((uint32_t)(w >> (bpos & 7)) & 0x7FFFFFFFu);
     }
-    if (lane == 0) { rpos[sidx] = (uint32_t)cur; rtail[sidx] = (uint32_t)T; }
+    if (lane == 0) { rpos[sidx] = (uint32_t)cur; rtail[sidx] = (uint32_t)T | ((uint32_t)single << 16); }
     if (bad && lane == 0) flag_image(status, sidx / M, LLICTI_EFORMAT);
 }
 
@@ -593,7 +612,7 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
     auto pass = [&](auto tag) {
     constexpr int clr = decltype(tag)::value;    // compile-time: no branch (hence no register merge, hence no s_waitcnt vmcnt(0)) next to the prefetch loads
     // the stream's tail symbols (last stage only) are not in the main stream: sequence position 64 k + lane >= tail_from
-    const int tail_from = (last_stage && clr == 2) ? rans_stream_count(nc, m, M, 64) - (int)rtail[sidx] : 0x7FFFFFFF;
+    const int tail_from = (last_stage && clr == 2) ? rans_stream_count(nc, m, M, 64) - (int)(rtail[sidx] & 0xFFFFu) : 0x7FFFFFFF;
     int minv, maxv, shift;
     clr_range(minmax + 4 * b, clr, minv, maxv, shift);
     const Grid gr = make_grid(minv, maxv);
@@ -831,7 +850,7 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_pair_kernel
     // The channel is a compile-time constant of the pass: no branch next to the prefetch loads.
     auto pass = [&](auto tag) {
     constexpr int clr = decltype(tag)::value;
-    const int tail_from = (last_stage && clr == 2) ? rans_stream_count(nc, m, M, L) - (int)rtail[sidx] : 0x7FFFFFFF;
+    const int tail_from = (last_stage && clr == 2) ? rans_stream_count(nc, m, M, L) - (int)(rtail[sidx] & 0xFFFFu) : 0x7FFFFFFF;
     int minv, maxv, shift;
     clr_range(minmax + 4 * b, clr, minv, maxv, shift);
     const Grid gr = make_grid(minv, maxv);
@@ -1084,7 +1103,7 @@ __global__ __launch_bounds__(64 * Q) void rans_decode_stage_lane_kernel(const fl
 
     auto pass = [&](auto tag) {
     constexpr int clr = decltype(tag)::value;    // compile-time: no branch next to the prefetch loads
-    const int tail_from = (last_stage && clr == 2) ? rans_stream_count(nc, m, M, L) - (int)rtail[sidx] : 0x7FFFFFFF;
+    const int tail_from = (last_stage && clr == 2) ? rans_stream_count(nc, m, M, L) - (int)(rtail[sidx] & 0xFFFFu) : 0x7FFFFFFF;
     int minv, maxv, shift;
     clr_range(minmax + 4 * b, clr, minv, maxv, shift);
     const Grid gr = make_grid(minv, maxv);
@@ -1287,19 +1306,22 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_t
     const int chain = wave % NCH, role = wave / NCH;
     const int nc = sg.hc * sg.wc;
     const int cnt = rans_stream_count(nc, m, M, L);
-    bool bad = rpos[sidx] != 0 || (int)rtail[sidx] > cnt;
-    const int Tall = min((int)rtail[sidx], cnt);        // the stream's tail symbols: the coded ones, then (xwide) the seeds'
+    const int rt = (int)(rtail[sidx] & 0xFFFFu);
+    const int nch = (kSeeded<Q> && !(rtail[sidx] >> 16)) ? 2 : 1;      // chains this stream's tail was coded with (xwide: its flag says one or two)
+    bool bad = rpos[sidx] != 0 || rt > cnt;
+    const int Tall = min(rt, cnt);                      // the stream's tail symbols: the coded ones, then (xwide) the seeds'
     int minv, maxv, shift;
     clr_range(minmax + 4 * b, 2, minv, maxv, shift);
     const Grid gr = make_grid(minv, maxv);
     const int max_symbol = gr.Lp - 2;
     uint32_t pw = 1;
     const int ns = kSeeded<Q> ? rans_seed_count(max_symbol + 1, pw) : 0;
-    const int NS = min(NCH * ns, cnt);                  // seed symbols (0 for the older stream kinds)
+    const int NS = min(nch * ns, cnt);                  // seed symbols (0 for the older stream kinds)
     bad = bad || Tall < NS;
-    const int Tc = max(Tall - NS, 0);                   // coded symbols; the one with index idx (j = NCH ns + idx from the stream's end) is on chain idx % NCH
-    const int T = (Tc + NCH - 1 - chain) / NCH;         // this chain's
-    const int R = ((Tc + NCH - 1) / NCH + kTailAhead - 1) / kTailAhead;      // rounds (chain 0 has the most symbols)
+    const bool live = chain < nch;                      // (the second set of wavefronts idles through a one-chain stream's rounds)
+    const int Tc = max(Tall - NS, 0);                   // coded symbols; the one with index idx (j = nch ns + idx from the stream's end) is on chain idx % nch
+    const int T = live ? (Tc + nch - 1 - chain) / nch : 0;      // this chain's
+    const int R = ((Tc + nch - 1) / nch + kTailAhead - 1) / kTailAhead;      // rounds (chain 0 has the most symbols)
     const long img = (long)b * 3 * sg.plane;
     const int mc = lane % 5, we = lane / 5;
     auto pixel_of = [&](int j) -> long {                 // the stream's j-th symbol from its end
@@ -1315,7 +1337,7 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_t
         struct Row { float sg, mu, wk, bb, dd, y, co; long off; };
         auto fetch = [&](int t) -> Row {
             Row r;
-            const long pp = pixel_of(NCH * ns + chain + NCH * (T - 1 - t));
+            const long pp = pixel_of(nch * ns + chain + nch * (T - 1 - t));
             const int pi = (int)(pp >> 32), pj = (int)(uint32_t)pp;
             const ParRow src = par_row(params, b, (long)sg.h * sg.w, (long)pi * sg.w + pj);
             r.off = img + ((long)(2 * pi + sg.oi) << sg.lvl) * sg.W + ((long)(2 * pj + sg.oj) << sg.lvl);
@@ -1385,8 +1407,8 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_t
     uint32_t xt;
     int tc;                                               // bit cursor: legacy chains and xwide chain B read DOWN to it, xwide chain A reads UP from it
     if constexpr (kSeeded<Q>) {
-        xt = sh_pay[chain ? GEO::kPayDw - 1 : 0];        // final states at fixed places
-        tc = chain ? GEO::kPayBits - 32 : 32;
+        xt = live ? sh_pay[chain ? GEO::kPayDw - 1 : 0] : (1u << 31);        // final states at fixed places
+        tc = chain ? GEO::kPayBits - (live ? 32 : 0) : 32;
         if (!(xt >> 31)) { bad = true; xt |= 1u << 31; }
     } else {
         int top = -1;                                                          // the payload's highest set bit
@@ -1461,7 +1483,7 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_t
             xt = (vhi - vlo) * (xt >> 16) + slot - vlo;
             if constexpr (kSeeded<Q>) {
                 int nb = __clz((int)xt);
-                const int avail = chain ? tc - 32 : GEO::kPayBits - 32 - tc;      // (never into the other chain's state; whether the chains crossed is checked at the end)
+                const int avail = chain ? tc - 32 : GEO::kPayBits - (nch == 2 ? 32 : 0) - tc;      // (never into the other chain's state; whether the chains crossed is checked at the end)
                 if (nb > 16 || avail < nb) { bad = true; nb = min(nb, min(avail, 16)); }   // corrupt: keep going on what is there
                 if (chain) tc -= nb;
                 xt = ((xt << nb) | lds_get_bits(sh_pay, tc, nb)) | (1u << 31);
@@ -1479,12 +1501,12 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_t
     if constexpr (kSeeded<Q>) {
         // the chain is back at its start state: 2^31 | its ns seed symbols in radix A (lane i: digit i = the stream's (chain ns + i)-th symbol from the end)
         const uint32_t A = (uint32_t)(max_symbol + 1), v = xt & 0x7FFFFFFFu;
-        bad = bad || v >= pw;
+        bad = bad || (live && v >= pw);
         uint32_t div = 1;
         for (int e = 0; e < min(lane, ns); ++e) div *= A;
         const int dg = (lane < ns) ? (int)((v / div) % A) : 0;
         const int j = chain * ns + lane;
-        if (lane < ns && j < NS) {
+        if (live && lane < ns && j < NS) {
             const long pp = pixel_of(j);
             const int pi = (int)(pp >> 32), pj = (int)(uint32_t)pp;
             const long off = img + ((long)(2 * pi + sg.oi) << sg.lvl) * sg.W + ((long)(2 * pj + sg.oj) << sg.lvl);
@@ -1492,7 +1514,7 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_t
             planes[off + 2 * sg.plane] = (int16_t)pv;
             fplanes[off + 2 * sg.plane] = (float)pv / 255.0f;
         }
-        bad = bad || ballot64(lane < ns && j >= NS && dg != 0) != 0;      // digits of symbols the stream does not have
+        bad = bad || ballot64(live && lane < ns && j >= NS && dg != 0) != 0;      // digits of symbols the stream does not have
         if (lane == 0) sh_cur[chain] = tc;
         lds_barrier();
         if (chain == 0) {

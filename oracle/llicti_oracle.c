@@ -838,14 +838,33 @@ static long rans_stream_count(long nc, int m, int M, int L)
 }
 
 /* the xwide tail (see RANS_SEED_LANES above): fills pay (zeroed, 7936 bits), returns T or -1 on an impossible pair */
-static long rans_tail_encode_x(const stage_syms_t *sl, int m, int M, long cnt, int A, uint8_t *pay)
+static long rans_tail_encode_x(const stage_syms_t *sl, int m, int M, long cnt, int A, uint8_t *pay, int *single)
 {
     const int L = RANS_SEED_LANES;
     const long P = (long)L * RANS_STATE_BITS;
     uint32_t x[2] = { 1u << 31, 1u << 31 }, pw;
     const int ns = rans_seed_count(A, &pw);
+    /* one chain or two: a second chain costs its 32-bit final state and saves what its ns seed symbols would have cost coded -- worth it (and
+     * the faster decode) when symbols are expensive, not when the model predicts them well.  Integer rule, the same in every implementation,
+     * on the stream's last up to 64 symbols (a mean, so that every stream of a statistically uniform batch decides alike: one single-chain
+     * stream makes the whole tail launch wait for its serial decode): two chains iff the stream has 2 ns symbols and
+     * ns * mean(16 - floor(log2 freq)) >= 32 + ns / 2. */
+    int nch = 1;
+    if (cnt >= 2 * ns) {
+        const long k64 = cnt < 64 ? cnt : 64;
+        long wsum = 0;
+        for (long jj = 0; jj < k64; ++jj) {
+            const long q = cnt - 1 - jj;
+            const long n = (long)L * (m + (q / L) * M) + (q % L);
+            const uint32_t freq = sl->chigh[n] - sl->clow[n];
+            if (freq == 0 || freq > 0x10000u) return -1;
+            wsum += clz32(freq) - 15;
+        }
+        if (2 * wsum * ns >= k64 * (64 + ns)) nch = 2;
+    }
+    *single = (nch == 1);
     long j = 0;
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < nch; ++c) {
         uint32_t mul = 1;
         for (int i = 0; i < ns && j < cnt; ++i, ++j, mul *= (uint32_t)A) {
             const long q = cnt - 1 - j;
@@ -854,6 +873,7 @@ static long rans_tail_encode_x(const stage_syms_t *sl, int m, int M, long cnt, i
             x[c] += (uint32_t)sy * mul;
         }
     }
+    const long j0 = j;                                         /* first coded symbol: nch ns (or the stream's end) */
     uint32_t fld[RANS_TAIL_MAX];
     uint8_t fnb[RANS_TAIL_MAX];
     long used[2] = { 0, 0 };
@@ -862,9 +882,9 @@ static long rans_tail_encode_x(const stage_syms_t *sl, int m, int M, long cnt, i
         const long n = (long)L * (m + (q / L) * M) + (q % L);
         const uint32_t lo = sl->clow[n], freq = sl->chigh[n] - lo;
         if (freq == 0 || freq > 0x10000u) return -1;
-        const int c = (int)(j & 1);
+        const int c = (int)((j - j0) % nch);
         const int nb = rans_emit_bits(x[c], freq);
-        if (used[0] + used[1] + nb + 64 > P) break;
+        if (used[0] + used[1] + nb + 32 * nch > P) break;
         fld[j] = x[c] & ((1u << nb) - 1u);
         fnb[j] = (uint8_t)nb;
         used[c] += nb;
@@ -872,10 +892,10 @@ static long rans_tail_encode_x(const stage_syms_t *sl, int m, int M, long cnt, i
     }
     const long T = j;
     put_bits(pay, 0, 32, x[0]);
-    put_bits(pay, P - 32, 32, x[1]);
+    if (nch == 2) put_bits(pay, P - 32, 32, x[1]);
     long pa = 32, pb = P - 32;
-    for (long t = T - 1; t >= 2 * ns; --t) {                   /* the decoder's order */
-        if (t & 1) { pb -= fnb[t]; put_bits(pay, pb, fnb[t], fld[t]); }
+    for (long t = T - 1; t >= j0; --t) {                       /* the decoder's order */
+        if ((t - j0) % nch) { pb -= fnb[t]; put_bits(pay, pb, fnb[t], fld[t]); }
         else { put_bits(pay, pa, fnb[t], fld[t]); pa += fnb[t]; }
     }
     return T;
@@ -963,8 +983,9 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
         const long cnt = rans_stream_count(st[S].n, m, M, L);
         uint32_t xt = 1u << 31;
         long tb = 0, T = 0;
+        int single = 0;                                      /* xwide: one tail chain instead of two (bit 14 of the stream's first u16) */
         if (L == RANS_SEED_LANES) {                          /* xwide: two seeded chains in one payload */
-            T = rans_tail_encode_x(&st[S], m, M, cnt, minmax[5] - minmax[2] + 1, pay);
+            T = rans_tail_encode_x(&st[S], m, M, cnt, minmax[5] - minmax[2] + 1, pay, &single);
             if (T < 0) { rc = -5; break; }
         }
         while (L != RANS_SEED_LANES && T < cnt && T < RANS_TAIL_MAX) {
@@ -1018,7 +1039,7 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
             uint8_t *tab = out + pos - seg_len[4 + m / G] + 4 * (m % G);
             tab[0] = (uint8_t)(bytes & 0xFF); tab[1] = (uint8_t)((bytes >> 8) & 0xFF); tab[2] = (uint8_t)((bytes >> 16) & 0xFF); tab[3] = (uint8_t)(bytes >> 24);
         }
-        const long t16 = T | (padb << 11);
+        const long t16 = T | (padb << 11) | ((long)single << 14);
         out[pos] = (uint8_t)(t16 & 0xFF); out[pos + 1] = (uint8_t)(t16 >> 8);
         memcpy(out + pos + 2, bits, nbytes);
         uint8_t *fs = out + pos + 2 + nbytes;
@@ -1094,8 +1115,8 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
             const int t16 = sp[0] | (sp[1] << 8);
             const int padb = (t16 >> 11) & 7;
             const long nbytes = len - 2 - PAY_BITS / 8;
-            if ((t16 >> 14) || (nbytes == 0 && padb)) { free(x); free(bitsp); free(cur); free(T); return -3; }
-            T[m] = t16 & 0x7FF;
+            if ((t16 >> 15) || (((t16 >> 14) & 1) && L != RANS_SEED_LANES) || (nbytes == 0 && padb)) { free(x); free(bitsp); free(cur); free(T); return -3; }
+            T[m] = (t16 & 0x7FF) | (((t16 >> 14) & 1) << 16);         /* bit 16: the xwide stream's tail has one chain, not two */
             bitsp[m] = sp + 2;
             cur[m] = 8 * nbytes - padb;                               /* number of data bits */
             const uint8_t *fs = sp + 2 + nbytes;
@@ -1141,7 +1162,7 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
                     for (int l = 0; l < L; ++l) {
                         const long q = (long)L * c + l;
                         if (q >= n_sym) break;
-                        if (last_stage && L * k + l >= cnt - T[m]) continue;      /* tail symbol: decoded after the stages */
+                        if (last_stage && L * k + l >= cnt - (T[m] & 0xFFFF)) continue;      /* tail symbol: decoded after the stages */
                         int i = (int)(q / wc), j = (int)(q % wc);
                         long off = ((long)(2 * i + BAND_OI[src]) << lvl) * W + ((long)(2 * j + BAND_OJ[src]) << lvl);
                         mix_t mx;
@@ -1179,18 +1200,20 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
                 memset(pay, 0, sizeof pay);
                 for (int l = 0; l < L; ++l) put_bits(pay, (long)RANS_STATE_BITS * l, RANS_STATE_BITS, x[m][l] & 0x7FFFFFFFu);
                 const long cnt = rans_stream_count(n_sym, m, M, L);
-                if (T[m] > cnt) { bad = 1; continue; }
+                const int nch = (T[m] >> 16) ? 1 : 2;            /* (xwide) */
+                const long Tm = T[m] & 0xFFFF;
+                if (Tm > cnt) { bad = 1; continue; }
                 if (L == RANS_SEED_LANES) {
-                    /* xwide: two seeded chains (see RANS_SEED_LANES): A reads UP from bit 32, B DOWN from the top state */
+                    /* xwide: one or two seeded chains (see RANS_SEED_LANES): A reads UP from bit 32, B DOWN from the top state */
                     uint32_t pw;
                     const int ns = rans_seed_count(Lp - 1, &pw);
-                    const long NS = cnt < 2 * ns ? cnt : 2 * ns;
-                    if (T[m] < NS) { bad = 1; continue; }
-                    uint32_t xc[2] = { get_bits(pay, 0, 32), get_bits(pay, PAY_BITS - 32, 32) };
+                    const long NS = cnt < nch * ns ? cnt : nch * ns;
+                    if (Tm < NS) { bad = 1; continue; }
+                    uint32_t xc[2] = { get_bits(pay, 0, 32), nch == 2 ? get_bits(pay, PAY_BITS - 32, 32) : (1u << 31) };
                     if (!(xc[0] >> 31) || !(xc[1] >> 31)) { bad = 1; continue; }
-                    long pa = 32, pb = PAY_BITS - 32;
+                    long pa = 32, pb = nch == 2 ? PAY_BITS - 32 : PAY_BITS;
                     int stop = 0;
-                    for (long t = T[m] - 1; t >= NS && !stop; --t) {
+                    for (long t = Tm - 1; t >= NS && !stop; --t) {
                         const long q = cnt - 1 - t;
                         const long n = (long)L * (m + (q / L) * M) + (q % L);
                         int i = (int)(n / wc), j = (int)(n % wc);
@@ -1198,7 +1221,7 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
                         mix_t mx;
                         mix_prepare(params + ((long)i * w + j) * ORC_NPAR, clr, (float)planes[off] / 255.0f,
                                     (float)planes[plane_sz + off] / 255.0f, &mx);
-                        const int c = (int)(t & 1);
+                        const int c = (int)((t - NS) % nch);
                         const uint32_t slot = xc[c] & 0xFFFF;
                         uint32_t c_low, c_high;
                         const int s = rans_find(&mx, slot, Lp, minv, maxv, &c_low, &c_high);
@@ -1211,8 +1234,8 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
                     }
                     if (stop) continue;
                     for (long bq = pa; bq < pb; ++bq)
-                        if ((pay[bq >> 3] >> (bq & 7)) & 1u) bad = 1;             /* nothing between the two chains */
-                    for (int c = 0; c < 2; ++c) {                                 /* the start states: the last 2 n symbols, raw */
+                        if ((pay[bq >> 3] >> (bq & 7)) & 1u) bad = 1;             /* nothing between the two chains (behind the one) */
+                    for (int c = 0; c < nch; ++c) {                               /* the start states: the last nch n symbols, raw */
                         uint32_t v = xc[c] & 0x7FFFFFFFu;
                         if (!(xc[c] >> 31) || v >= pw) bad = 1;
                         for (int i = 0; i < ns; ++i, v /= (uint32_t)(Lp - 1)) {
@@ -1234,7 +1257,7 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
                 uint32_t xt = get_bits(pay, top - 31, 32);
                 long tc = top - 31;
                 uint32_t f_last = 0;
-                for (long q = cnt - T[m]; q < cnt; ++q) {
+                for (long q = cnt - Tm; q < cnt; ++q) {
                     const long n = (long)L * (m + (q / L) * M) + (q % L);
                     int i = (int)(n / wc), j = (int)(n % wc);
                     long off = ((long)(2 * i + BAND_OI[src]) << lvl) * W + ((long)(2 * j + BAND_OJ[src]) << lvl);
@@ -1253,7 +1276,7 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
                     tc -= nb;
                     xt = (xt << nb) | get_bits(pay, tc, nb);
                 }
-                if (xt != (T[m] ? f_last << 15 : 1u << 31) || tc != 0) bad = 1;   /* the tail coder's start state, and no bit left */
+                if (xt != (Tm ? f_last << 15 : 1u << 31) || tc != 0) bad = 1;   /* the tail coder's start state, and no bit left */
             }
         }
         free(params);

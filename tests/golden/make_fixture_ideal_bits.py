@@ -10,6 +10,8 @@ torchac stand-in here only SUMS log2(65536 / (c_high - c_low)) of what the refer
 with the seed-1337 weights, and (round 4) on
   - one full-size NATURAL-LIKE image: 768x512 "smooth" RGB (make_fixtures.make_image, seed 11) with the "trained-like" weights
     (make_fixtures.trained_like_: sigma of a few grey levels) -- the content class the sigma-floor noise workload says nothing about,
+  - one full-size image DRAWN FROM THE MODEL (tests/helpers.make_sampled_image: the reference-format decoder fed random bytes, trained-like
+    weights): cheap symbols over the full value range, the class a well-trained model sees,
 and writes tests/golden/ref_ideal_bits.json: the 45 per-stream ideal bit counts per image.  Data only.
 tests/test_oracle_golden.py::test_bpp_delta_vs_reference_tables_report compares the oracle's tables against them."""
 import json
@@ -59,8 +61,15 @@ def main():
         if wname == "trainedlike":
             mf.trained_like_(models[wname])
     for name, kind, H, W, seed, wname in (("bench_image0_768x512", "noise", 512, 768, 0, "rand1337"), ("configs0_256x256", "noise", 256, 256, 0, "rand1337"),
-                                          ("natural_like_768x512", "smooth", 512, 768, 11, "trainedlike")):
-        rgb = mf.make_image(kind, H, W, seed)
+                                          ("natural_like_768x512", "smooth", 512, 768, 11, "trainedlike"),
+                                          ("model_sampled_768x512", "sampled", 512, 768, 5, "trainedlike")):
+        if kind == "sampled":
+            sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+            sys.path.insert(0, os.path.dirname(HERE))
+            from helpers import make_sampled_image  # noqa: E402
+            rgb = make_sampled_image(H, W, seed)
+        else:
+            rgb = mf.make_image(kind, H, W, seed)
         x = torch.from_numpy(rgb.astype(np.float32) / np.float32(255.0)).unsqueeze(0)
         rec.bits = []
         with torch.no_grad():

@@ -21,3 +21,19 @@ def make_image(kind, H, W, seed):
 
 def make_batch(kind, B, H, W, seed0=0):
     return np.stack([make_image(kind, H, W, seed0 + i) for i in range(B)])
+
+
+def make_sampled_image(H, W, seed):
+    """An image DRAWN FROM THE MODEL (trained-like weights): the reference-format decoder run on streams of random bytes (an arithmetic decoder
+    fed random bits emits symbols with the model's own probabilities), behind the header -- size, value ranges, coarsest pixels -- of the smooth
+    image of the same size.  The content class of a model that predicts its data well: cheap symbols (about 4.8 bits each) over the full value
+    range -- what the sigma-floor noise batch and the 21-bpp smooth image are not.  Test infrastructure (uses the CPU oracle); deterministic."""
+    import os
+    from oracle import oracle as orc
+    from llicti_amd.weights import pack_state_dict
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    W_o = orc.Weights(pack_state_dict(dict(np.load(os.path.join(gold, "weights_trainedlike.npz")))))
+    bl = orc.encode_image(make_image("smooth", H, W, 11), W_o)
+    rng = np.random.default_rng(seed)
+    bl = [list(bl[0])] + [[rng.integers(0, 256, len(s), dtype=np.uint8).tobytes() for s in row] for row in bl[1:]]
+    return orc.decode_image(bl, W_o)
