@@ -160,7 +160,8 @@ int llicti_ac_decode_u16cdf(llicti_ctx *ctx, const uint16_t *d_cdf, int Lp, int 
  * empty), same CDFs and symbols, decodable L*M symbols at a time.  States live in [2^31, 2^32) and renormalise bit by bit (the coder loses
  * ~2^-16 of a symbol's length, like the range coder); a stream = u16 (T | pad << 11) | bit region | L x 31-bit final
  * states, and the L INITIAL states carry the last T symbols of the stream's last stage, coded by a single-state tail
- * coder (xwide streams: by two such coders sharing the payload, each started from a seed of raw symbols instead of an empty state).
+ * coder (xwide streams: by one or two such coders sharing the payload -- two where symbols are expensive, the stream says which -- each started
+ * from a seed of raw symbols instead of an empty state).
  * Cost over the ideal code length: about 6 bytes per stream that has symbols (xwide: 2 - 3.5) -- M = 8 is within 0.0005 bpp of the AC
  * container on 768x512 images (whose 45 stream terminations cost about 25 bytes).  Format: oracle/llicti_oracle.h,
  * DESIGN.md section 5. */

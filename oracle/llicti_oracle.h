@@ -135,8 +135,8 @@ long orc_stream_pairs(const int16_t *planes, int H, int W, const int16_t minmax[
  *              bits [31 l, 31 l + 31).  After the last stage the decoder is left with exactly those states: it reassembles the payload,
  *              finds the tail state by its leading one, decodes the T symbols reading downwards, and must end with the tail
  *              coder's start state and no bit left (and the main region read to its last bit) -- the format's integrity check.
- *   tail, xwide (round 4; the 64- and 128-lane kinds above keep their bytes): TWO single-state coders ("chains") share the payload and neither
- *              starts from an empty state.  With A = the number of symbol values of the image's Cg channel (max - min + 1), n = the largest
+ *   tail, xwide (round 4; the 64- and 128-lane kinds above keep their bytes): ONE OR TWO single-state coders ("chains") share the payload and
+ *              none starts from an empty state (described for two; the choice and the one-chain form at the end).  With A = the number of symbol values of the image's Cg channel (max - min + 1), n = the largest
  *              count with A^n <= 2^31 (at most 31) and j counting the stream's symbols from its end (j = 0 the last): chain A starts from
  *              2^31 | sum sym(i) A^i (i < n), chain B from the same of sym(n + i) -- symbol INDICES, raw; missing symbols = zero digits -- so the
  *              ~31 bits an empty start state wastes carry n symbols that are never coded.  Symbol j >= 2 n is pushed on chain A if j is even,
@@ -145,7 +145,12 @@ long orc_stream_pairs(const int16_t *planes, int H, int W, const int16_t minmax[
  *              top 32 bits B's final state, B's fields below it, read DOWN; zeros between.  Checks: both states have their leading one, the
  *              cursors do not cross, the bits between them are zero, each chain ends at a seed below A^n whose digits beyond the stream's
  *              length are zero.  (Two chains: the tail is serial, and both sides run them on two wavefronts.)
- *   stream     u16 LE (T | pad << 11, bits 14-15 zero) | bit region, LSB first, ceil(bits / 8) bytes, pad = unused zero bits on
+ *              One chain or two: the second chain costs its 32-bit final state and saves what its n seed symbols would have cost coded, so it
+ *              pays when symbols are expensive and not when the model predicts them well.  The encoder decides per stream, on its last up to
+ *              64 symbols (k of them): two chains iff the stream has 2 n symbols and n * sum(16 - floor(log2 freq)) / k >= 32 + n / 2 (integer
+ *              form: 2 n sum >= k (64 + n)), and says so in bit 14 of the stream's first u16 (1 = ONE chain).  One chain: n seed symbols, every
+ *              coded symbol on chain A, stop rule with 32 instead of 64, no state on top; the payload above A's fields is zero.
+ *   stream     u16 LE (T | pad << 11 | single << 14: bit 14 only in xwide streams, bit 15 zero) | bit region, LSB first, ceil(bits / 8) bytes, pad = unused zero bits on
  *              top of its last byte | L x 31-bit final states (low 31 bits of x_l at bit 31 l; 248 / 496 / 992 bytes).
  * Cost over the ideal code length: ~6 bytes per stream that has symbols (v2: ~60; wide: ~6.5; xwide: ~2-3.5), an empty stream 250 / 498 / 994.
  * M: streams per image, | 0x100 for wide streams, | 0x200 for xwide streams.  Returns total bytes or <0. */
