@@ -33,8 +33,10 @@ constexpr int kRansPayBytesMax = RansGeo<4>::kPayBytes;
 constexpr int kPhiLutN = 2048;                   // the lane decoder's hint table (llicti_ctx::d_phi_lut)
 constexpr double kPhiLutZ = 6.0;
 // xwide streams (Q = 4) only -- the older stream kinds keep their bytes.  A rANS chain ends in a 32-bit state of which only what the symbols put
-// in is information: a coder that starts from an empty state wastes ~31 bits.  And the tail is serial.  So an xwide stream's tail is coded by TWO
-// single-state coders ("chains") sharing the payload, neither starting empty (spec: oracle/llicti_oracle.c, RANS_SEED_LANES):
+// in is information: a coder that starts from an empty state wastes ~31 bits.  And the tail is serial.  So an xwide stream's tail is coded by up to
+// TWO single-state coders ("chains") sharing the payload, none starting empty (spec: oracle/llicti_oracle.c, RANS_SEED_LANES; two chains where
+// symbols are expensive, one where the model predicts them well and a second final state would cost more than its seed saves: the encoder's
+// integer rule on the stream's last 64 symbols, bit 14 of the stream's first u16 = one chain):
 //   seeds    A = number of symbol values of the image's Cg channel, n = rans_seed_count(A) = the largest count with A^n <= 2^31 (<= 31); counting
 //            the stream's symbols from its end (j = 0 the last), chain A starts from 2^31 | sum sym(i) A^i (i < n), chain B from that of sym(n + i):
 //            2 n symbols that are never coded (three each for the full range of 511: ~3 bytes a stream; ten 256-lane streams an image cost what
