@@ -46,7 +46,7 @@ MAC_PER_POSITION = 193248            # 84,480 layer-0 
 PEAK_FP32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_HBM_GBS = 8000.0
 DEFAULT_CONTAINER = "auto"           # rANS v3, xwide streams (256 lanes), default_streams(batch) of them per image, see below
-MAX_STREAMS_IN_BUDGET = 10           # = llicti_amd.codec.MAX_STREAMS_IN_BUDGET: an xwide v3 stream (two seeded tail chains) costs ~2-3.5 bytes: 10 per 768x512 image are +0.0003 (noise) ... +0.0007 (natural-like) bpp over the reference-format container (m_sweep)
+MAX_STREAMS_IN_BUDGET = 10           # = llicti_amd.codec.MAX_STREAMS_IN_BUDGET: an xwide v3 stream (seeded tail chains, two where they pay) costs ~2-4 bytes: 10 per 768x512 image are +0.0003 (noise) ... +0.0008 (an image drawn from the model) bpp over the reference-format container (m_sweep)
 
 
 def default_streams(B, n_cu=256):

@@ -21,7 +21,7 @@ NSEG = 49
 MODE_AC = 0                      # the reference's container: 45 torchac-algorithm streams per image
 
 
-MAX_STREAMS_IN_BUDGET = 10       # an xwide v3 stream (two seeded tail chains) costs ~2-3.5 bytes: 10 per 768x512 image are +0.0003 (noise) ... +0.0007 (natural-like) bpp over the reference-format container (12: +0.00085)
+MAX_STREAMS_IN_BUDGET = 10       # an xwide v3 stream (seeded tail chains, two where they pay) costs ~2-4 bytes: 10 per 768x512 image are +0.0003 (noise) ... +0.0008 (an image drawn from the model) bpp over the reference-format container
 
 
 def auto_streams(B, n_cu=256):
