@@ -21,7 +21,7 @@ static int fail(int code, const char *fmt, ...)
     } while (0)
 
 extern "C" const char *llicti_last_error(void) { return g_err.c_str(); }
-extern "C" const char *llicti_version(void) { return "llicti_hip 0.4 (gfx950, numerics spec v1, rANS container v3; params channel-planar, xwide streams)"; }
+extern "C" const char *llicti_version(void) { return "llicti_hip 0.5 (gfx950, numerics spec v1, rANS container v3; params channel-planar, xwide streams with seeded tail chains)"; }
 
 // ------------------------------------------------------------------------------------------------ geometry
 struct Geom {
