@@ -34,19 +34,22 @@ def run(B, H, W, mode, name):
     del rgb, cont, seg, rec
     codec._ws = None; codec._ws_key = None
     torch.cuda.empty_cache()
-run(256, 512, 768, MODE_RANS(8), "configs[4] batch on one GPU (rans8)")
-run(256, 512, 768, MODE_RANS(8), "same, warm")
-run(256, 512, 768, MODE_RANS(1), "256 images, ONE rANS stream per image")
+run(256, 512, 768, MODE_RANS(8, wide=2), "configs[4] batch on one GPU (xrans8: the per-GPU container of configs[4])")
+run(256, 512, 768, MODE_RANS(8, wide=2), "same, warm")
+run(32, 512, 768, MODE_RANS(8, wide=2), "configs[4] per-GPU batch (32 images, xrans8)")
+run(256, 512, 768, MODE_RANS(1, wide=2), "256 images, ONE xwide stream per image")
+run(256, 512, 768, MODE_RANS(8), "256 images, narrow streams (rans8)")
 run(64, 512, 768, MODE_AC, "AC container")
-run(1, 8160, 8160, MODE_RANS(32), "largest image (rans32)")
+run(1, 8160, 8160, MODE_RANS(64, wide=2), "largest image, 64 xwide streams")
+run(1, 8160, 8160, MODE_RANS(14, wide=2), "largest image, 14 xwide streams")
 run(1, 8160, 8160, MODE_RANS(128), "largest image, 128-stream latency mode")
-run(3, 2160, 3840, MODE_RANS(64), "three 4K images, 64 streams each")
-run(24, 512, 768, MODE_RANS(10, wide=True), "bench batch in the timed container (wrans10)")
+run(1, 8160, 8160, MODE_RANS(14, wide=1), "largest image, 14 wide streams")
+run(3, 2160, 3840, MODE_RANS(64, wide=2), "three 4K images, 64 xwide streams each")
+run(24, 512, 768, MODE_RANS(10, wide=2), "bench batch in the timed container (xrans10)")
+run(24, 512, 768, MODE_RANS(10, wide=1), "bench batch, wide streams (wrans10)")
 run(24, 512, 768, MODE_RANS(10), "bench batch, narrow streams (rans10)")
-run(256, 512, 768, MODE_RANS(1, wide=True), "256 images, ONE wide stream per image")
-run(1, 8160, 8160, MODE_RANS(30, wide=True), "largest image, 30 wide streams")
-run(7, 1055, 2049, MODE_RANS(11), "odd-size images, 11 streams")
-run(5, 1055, 2049, MODE_RANS(7, wide=True), "odd-size images, 7 wide streams")
+run(7, 1055, 2049, MODE_RANS(11, wide=2), "odd-size images, 11 xwide streams")
+run(5, 1055, 2049, MODE_RANS(7, wide=1), "odd-size images, 7 wide streams")
 run(2, 2160, 3840, MODE_AC, "two 4K images, AC container")
 if len(sys.argv) > 1:
     json.dump({"tool": "tools/stress.py", "note": "single runs incl. first-call plan set-up unless marked warm; decode on a poisoned workspace", "runs": results},
