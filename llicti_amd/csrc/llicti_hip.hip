@@ -924,9 +924,9 @@ static int decode_batch(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t 
                 if (Q == 4) {
                     rans_decode_stage_lane_kernel<4><<<B * M, 256, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status, c->d_phi_lut);
                 } else if (Q == 2) {
-                    rans_decode_stage_pair_kernel<<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status);
+                    rans_decode_stage_pair_kernel<<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, c->d_phi_lut, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status);
                 } else {
-                    rans_decode_stage_kernel<<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status);
+                    rans_decode_stage_kernel<<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, c->d_phi_lut, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status);
                 }
                 }
                 if (last) {

@@ -578,6 +578,27 @@ __device__ __forceinline__ float term_fast(const CompFast &c, float pt)
     const float E = ((p * u) * __builtin_amdgcn_exp2f(-(a * a))) * c.wh;
     return (x < 0.0f) ? c.wn - E : E;
 }
+// The same term read from a table of the normal CDF (llicti_ctx::d_phi_lut copied into LDS: Phi(z) on [-kPhiLutZ, kPhiLutZ] as (value,
+// difference to the next) pairs, linear interpolation, error <= 1e-6): table coordinate by one fma with per-component constants, clamp,
+// truncate, fract, one 8-byte LDS read, two fma -- 7 vector operations instead of 15 (two of them quarter-rate).  All three stage decoders'
+// hints use it (rans_decode_stage_lane_kernel has the details and the measurements).
+struct CompLut { float c1, c0, wn; };
+__device__ __forceinline__ CompLut comp_lut(const Comp &c)
+{
+    constexpr float kS = kPhiLutN / (2.0f * (float)kPhiLutZ);
+    CompLut f;
+    f.c1 = c.rsig * kS;
+    f.c0 = __builtin_fmaf(-c.mu, f.c1, (float)kPhiLutZ * kS);
+    f.wn = c.wn;
+    return f;
+}
+__device__ __forceinline__ float term_lut(const CompLut &c, float pt, const float2 *lut)
+{
+    // u in [0, kPhiLutN): v_med3_f32 returns one of its operands and v_cvt_u32_f32 turns a NaN into 0 -- the index stays inside the table
+    const float u = __builtin_amdgcn_fmed3f(__builtin_fmaf(pt, c.c1, c.c0), 0.0f, (float)kPhiLutN - 0.0009765625f);
+    const float2 e2 = lut[(uint32_t)u];
+    return c.wn * __builtin_fmaf(e2.y, __builtin_amdgcn_fractf(u), e2.x);
+}
 __device__ __forceinline__ int group_cdf_entry_fast(const CompFast &A, const CompFast &B, float fbase, float scale, int i)
 {
     const float pt = div255_exact(fbase + (float)i);     // the exact sample point: near a narrow component the CDF moves by counts per ulp of pt
@@ -585,6 +606,7 @@ __device__ __forceinline__ int group_cdf_entry_fast(const CompFast &A, const Com
 }
 
 __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(const float *__restrict__ params, StageGeom sg, int M,
+                                                               const float2 *__restrict__ phi_lut,
                                                                const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
                                                                int rslot_cap, uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos,
                                                                const uint32_t *__restrict__ rtail,
@@ -592,11 +614,14 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
                                                                const int32_t *__restrict__ minmax, int last_stage, int32_t *status)
 {
     __shared__ uint32_t sh_res[2][64][2];        // ping-pong by step parity: [0] = c_low, [1] = c_high
+    __shared__ float2 sh_lut[kPhiLutN];          // the hint's normal CDF (term_lut)
     const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nc = sg.hc * sg.wc;
     const int nchunks = (nc + 63) >> 6;
     if (nchunks <= m) return;                    // whole workgroup
+    for (int j = threadIdx.x; j < kPhiLutN; j += 64 * kRansWaves) sh_lut[j] = phi_lut[j];
+    __syncthreads();
     const int K = (nchunks - m + M - 1) / M;
     uint32_t x = rstate[(long)sidx * 64 + lane];                       // every wave: its own copy
     int bcur = (int)rpos[sidx];                                          // bit cursor in the stream's bit region, moving DOWN
@@ -678,23 +703,23 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
                 //    round costs one 5-term evaluation (no cross-lane sum) and cuts the bracket to a fifth: 4 rounds for
                 //    Lp = 512 instead of 9 bisection rounds.  The phase is instruction-issue bound (in-kernel stamps), and
                 //    4 x ~85 instructions are fewer than 9 x 56.
-                const CompFast Af = comp_fast(A), Bf = comp_fast(B);
-                CompFast F0, F1, F2, F3;
-                F0.c1 = quad_bcast<0>(Af.c1); F0.c0 = quad_bcast<0>(Af.c0); F0.wh = quad_bcast<0>(Af.wh); F0.wn = quad_bcast<0>(Af.wn);
-                F1.c1 = quad_bcast<1>(Af.c1); F1.c0 = quad_bcast<1>(Af.c0); F1.wh = quad_bcast<1>(Af.wh); F1.wn = quad_bcast<1>(Af.wn);
-                F2.c1 = quad_bcast<2>(Af.c1); F2.c0 = quad_bcast<2>(Af.c0); F2.wh = quad_bcast<2>(Af.wh); F2.wn = quad_bcast<2>(Af.wn);
-                F3.c1 = quad_bcast<3>(Af.c1); F3.c0 = quad_bcast<3>(Af.c0); F3.wh = quad_bcast<3>(Af.wh); F3.wn = quad_bcast<3>(Af.wn);
+                const CompLut Af = comp_lut(A), Bf = comp_lut(B);
+                CompLut F0, F1, F2, F3;
+                F0.c1 = quad_bcast<0>(Af.c1); F0.c0 = quad_bcast<0>(Af.c0); F0.wn = quad_bcast<0>(Af.wn);
+                F1.c1 = quad_bcast<1>(Af.c1); F1.c0 = quad_bcast<1>(Af.c0); F1.wn = quad_bcast<1>(Af.wn);
+                F2.c1 = quad_bcast<2>(Af.c1); F2.c0 = quad_bcast<2>(Af.c0); F2.wn = quad_bcast<2>(Af.wn);
+                F3.c1 = quad_bcast<3>(Af.c1); F3.c0 = quad_bcast<3>(Af.c0); F3.wn = quad_bcast<3>(Af.wn);
                 int glo = 0, ghi = max_symbol + 1;
                 while (ghi - glo > 1) {
                     const int stp = (ghi - glo + 4) / 5;                   // >= 1; the last part is the (smaller) remainder
                     auto probe_at = [&](int j) { return min(glo + stp * (j + 1), ghi - 1); };
                     const int pi = probe_at(mA);
                     const float pt = div255_exact(fbase + (float)pi);     // the exact sample point: near a narrow component the CDF moves by counts per ulp of pt
-                    float sum = term_fast(F0, pt);
-                    sum += term_fast(F1, pt);
-                    sum += term_fast(F2, pt);
-                    sum += term_fast(F3, pt);
-                    sum += term_fast(Bf, pt);
+                    float sum = term_lut(F0, pt, sh_lut);
+                    sum += term_lut(F1, pt, sh_lut);
+                    sum += term_lut(F2, pt, sh_lut);
+                    sum += term_lut(F3, pt, sh_lut);
+                    sum += term_lut(Bf, pt, sh_lut);
                     const int e = (int)__builtin_rintf(sum * gr.scale) + pi;
                     const uint64_t bal = ballot64(e <= (int)slot);
                     // the four probes are ordered, so the passes form a prefix of the quad's lanes (if the approximation
@@ -822,6 +847,7 @@ __device__ __forceinline__ uint32_t pair_swap_u(uint32_t v)
 }
 
 __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_pair_kernel(const float *__restrict__ params, StageGeom sg, int M,
+                                                               const float2 *__restrict__ phi_lut,
                                                                const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
                                                                int rslot_cap, uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos,
                                                                const uint32_t *__restrict__ rtail,
@@ -830,11 +856,14 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_pair_kernel
 {
     constexpr int Q = 2, L = 64 * Q;
     __shared__ uint32_t sh_res[2][L][2];         // ping-pong by step parity: [0] = c_low, [1] = c_high
+    __shared__ float2 sh_lut[kPhiLutN];          // the hint's normal CDF (term_lut)
     const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nc = sg.hc * sg.wc;
     const int nchunks = (nc + L - 1) / L;
     if (nchunks <= m) return;                    // whole workgroup
+    for (int j = threadIdx.x; j < kPhiLutN; j += 64 * kRansWaves) sh_lut[j] = phi_lut[j];
+    __syncthreads();
     const int K = (nchunks - m + M - 1) / M;
     uint32_t x[Q];                                                      // every wave: its own copy of the stream's 128 states
 #pragma unroll
@@ -921,9 +950,9 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_pair_kernel
 #pragma unroll
             for (int t = 0; t < 3; ++t) wn3[t] = w3[t] / den;
             canon(mu3, mu5); canon(rs3, rs5); canon(wn3, wn5);
-            CompFast F[5];
+            CompLut F[5];
 #pragma unroll
-            for (int c = 0; c < 5; ++c) { Comp cc; cc.mu = mu5[c]; cc.rsig = rs5[c]; cc.wn = wn5[c]; F[c] = comp_fast(cc); }
+            for (int c = 0; c < 5; ++c) { Comp cc; cc.mu = mu5[c]; cc.rsig = rs5[c]; cc.wn = wn5[c]; F[c] = comp_lut(cc); }
 
             // 1. hint: ternary search on the approximate table, one probe per lane of the pair
             int glo = 0, ghi = max_symbol + 1;
@@ -932,11 +961,11 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_pair_kernel
                 const int q1 = min(glo + stp, ghi - 1), q2 = min(glo + 2 * stp, ghi - 1);
                 const int pi = odd ? q2 : q1;
                 const float pt = div255_exact(fbase + (float)pi);
-                float sum = term_fast(F[0], pt);
-                sum += term_fast(F[1], pt);
-                sum += term_fast(F[2], pt);
-                sum += term_fast(F[3], pt);
-                sum += term_fast(F[4], pt);
+                float sum = term_lut(F[0], pt, sh_lut);
+                sum += term_lut(F[1], pt, sh_lut);
+                sum += term_lut(F[2], pt, sh_lut);
+                sum += term_lut(F[3], pt, sh_lut);
+                sum += term_lut(F[4], pt, sh_lut);
                 const int e = (int)__builtin_rintf(sum * gr.scale) + pi;
                 const uint64_t bal = ballot64(e <= (int)slot);
                 const int np = __builtin_popcount((uint32_t)(bal >> gbit) & 0x3u);      // ordered probes: the passes form a prefix
