@@ -159,13 +159,23 @@ __global__ __launch_bounds__(CnnGeo<TH>::kThreads) void band_params_kernel(const
     float *lds_in = lds + PO::total;
 
     const int head = blockIdx.y;
-    {   // stage this head's pack (lane-linear image: a straight copy)
-        const float4 *src = reinterpret_cast<const float4 *>(wpack + (long)head * PO::total);
-        float4 *dst = reinterpret_cast<float4 *>(lds);
-        for (int i = threadIdx.x; i < PO::total / 4; i += kCnnThreads) dst[i] = src[i];
-    }
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    if ((int)blockIdx.x >= n_tiles) return;      // (the host never launches such a workgroup; one must not end with LDS-DMA in flight)
+    {   // Stage this head's pack (lane-linear image: a straight copy) by LDS-DMA, 16 bytes per lane: a wavefront requests its 1 KB pieces
+        // back to back and nobody waits before the first tile's barrier (whose fence drains vmcnt).  A copy through registers is one memory
+        // round trip per piece and thread: 20 of them for band 2's 82 KB in a 4-row workgroup -- a quarter of the time of a launch that has
+        // one tile per workgroup (coarse levels, single images), and what made 4-row tiles of band 2 no faster than 8-row ones.
+        const char *src = reinterpret_cast<const char *>(wpack + (long)head * PO::total);
+        constexpr int kFull = PO::total / 256;                                   // whole 1 KB pieces
+        for (int p = __builtin_amdgcn_readfirstlane(wave); p < kFull; p += kCnnThreads / 64)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (long)p * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void *)(lds + p * 256), 16, 0, 0);
+        constexpr int kRem4 = (PO::total - kFull * 256) / 4;                     // the rest: fewer than 64 float4
+        static_assert(PO::total % 4 == 0 && kRem4 < 64, "pack size");
+        if ((int)threadIdx.x < kRem4)
+            reinterpret_cast<float4 *>(lds)[kFull * 64 + threadIdx.x] = reinterpret_cast<const float4 *>(src)[kFull * 64 + threadIdx.x];
+    }
     const int q = lane >> 4;
     const int px = lane & 15;
     const int q_row = q * kInPitch;

@@ -25,10 +25,14 @@ __global__ __launch_bounds__(64) void minmax_reduce_kernel(const int32_t *__rest
 
 // 4 pixels per thread when the plane size allows 4-byte aligned uchar4 / short4 / float4 accesses
 template <int VEC>
+// zero != nullptr (the whole-batch encode, whose first kernel this is): the call's n_zero status words are cleared here, before any kernel that
+// can set them is launched, instead of by a launch of its own.
 __global__ __launch_bounds__(256) void lift_kernel(const uint8_t *__restrict__ rgb, long plane, int16_t *__restrict__ planes,
-                                                   float *__restrict__ fplanes, int32_t *__restrict__ part)
+                                                   float *__restrict__ fplanes, int32_t *__restrict__ part, int32_t *__restrict__ zero, int n_zero)
 {
     const int b = blockIdx.y;
+    if (zero && blockIdx.x == 0 && b == 0)
+        for (int i = threadIdx.x; i < n_zero; i += blockDim.x) zero[i] = 0;
     const uint8_t *src = rgb + (long)b * 3 * plane;
     int16_t *dst = planes + (long)b * 3 * plane;
     float *fdst = fplanes + (long)b * 3 * plane;
@@ -88,9 +92,17 @@ __global__ __launch_bounds__(256) void lift_kernel(const uint8_t *__restrict__ r
     }
 }
 
-__global__ __launch_bounds__(256) void unlift_kernel(const int16_t *__restrict__ planes, long plane, uint8_t *__restrict__ rgb)
+// status != nullptr (the whole-batch decode, whose last kernel this is): the call's status words are latched into the context's here -- every
+// kernel that can set them has finished -- instead of by a launch of its own: word 0 if set, and image b's word by the image's first block.
+__global__ __launch_bounds__(256) void unlift_kernel(const int16_t *__restrict__ planes, long plane, uint8_t *__restrict__ rgb,
+                                                     const int32_t *__restrict__ status, int status_head, int32_t *__restrict__ latched,
+                                                     int32_t *__restrict__ img_latched)
 {
     const int b = blockIdx.y;
+    if (status && blockIdx.x == 0 && threadIdx.x == 0) {
+        if (b == 0 && status[0] != 0) *latched = status[0];
+        if (img_latched) img_latched[b] = status[status_head + b];
+    }
     const int16_t *src = planes + (long)b * 3 * plane;
     uint8_t *dst = rgb + (long)b * 3 * plane;
     for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < plane; p += (long)gridDim.x * blockDim.x) {

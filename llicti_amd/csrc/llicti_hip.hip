@@ -485,15 +485,16 @@ extern "C" int llicti_set_profiling(llicti_ctx *c, int enable)
 
 // ------------------------------------------------------------------------------------------------ launches
 // part: scratch of kLiftMaxParts x 4 int32 (the workspace's for the whole-batch calls, the context's for llicti_lift_u8)
-static int launch_lift(const uint8_t *d_rgb, int B, int H, int W, int16_t *planes, float *fplanes, int32_t *mm, int32_t *part, hipStream_t s)
+static int launch_lift(const uint8_t *d_rgb, int B, int H, int W, int16_t *planes, float *fplanes, int32_t *mm, int32_t *part, hipStream_t s,
+                       int32_t *zero = nullptr, int n_zero = 0)
 {
     const long plane = (long)H * W;
     const bool vec = (plane % 4 == 0) && (((uintptr_t)d_rgb | (uintptr_t)planes | (uintptr_t)fplanes) % 16 == 0);
     const long want = vec ? (plane / 4 + 255) / 256 : (plane + 255) / 256;
     const int gx = (int)std::max<long>(1, std::min<long>(std::min<long>(want, std::max(8, 4096 / B)), kLiftMaxParts / B));
     if ((long)B * gx > kLiftMaxParts) return fail(LLICTI_EINVAL, "lift: batch of %d images exceeds the partials scratch", B);
-    if (vec) lift_kernel<4><<<dim3(gx, B), 256, 0, s>>>(d_rgb, plane, planes, fplanes, part);
-    else lift_kernel<1><<<dim3(gx, B), 256, 0, s>>>(d_rgb, plane, planes, fplanes, part);
+    if (vec) lift_kernel<4><<<dim3(gx, B), 256, 0, s>>>(d_rgb, plane, planes, fplanes, part, zero, n_zero);
+    else lift_kernel<1><<<dim3(gx, B), 256, 0, s>>>(d_rgb, plane, planes, fplanes, part, zero, n_zero);
     minmax_reduce_kernel<<<B, 64, 0, s>>>(part, gx, mm);
     HIPCHK(hipGetLastError());
     return 0;
@@ -524,11 +525,29 @@ static int launch_band_params(llicti_ctx *c, const float *fplanes, const Geom &g
         TH = (4 * tiles16 < c->n_cu) ? kTileHSmall : kTileHMax;
         (void)plan_for(TH, &gx, &n_tiles_l);
     } else {
+        // Launches of one or two rounds of 16-row tiles (coarse levels, single images) are priced from a table instead: a launch's first
+        // round and its later ones per (band, form), measured on single-image launches (rocprofv3, tools/single_image_trace.py) -- the linear
+        // model is off exactly there: a 4-row tile of band 2 takes 21-25 us, not 15 (one wavefront per SIMD cannot keep the matrix pipe busy and
+        // 120 input channels are the longest layer 0), so three rounds of them lost to ONE round of 16-row tiles at level 1 of a lone image
+        // (75 against 47 us).  Band 0 fits two workgroups per compute unit: its rounds are priced as shared.
+        static const double kFirstUs[3][3] = { { 31.5, 18.1, 12.5 }, { 36.4, 20.8, 14.5 }, { 46.3, 26.2, 21.4 } };      // [band][16, 8, 4 rows]
+        static const double kLaterUs[3][3] = { { 31.0, 17.0, 11.0 }, { 36.4, 19.0, 11.2 }, { 46.0, 23.9, 25.2 } };
+        static const double kSharedUs[3] = { 61.3, 31.2, 16.7 };                                                            // band 0, two workgroups per CU
+        int gx16; long nt16;
+        (void)plan_for(kTileHMax, &gx16, &nt16);
+        const bool small_launch = (nt16 + gx16 - 1) / gx16 <= 2;
         double best = 0;
+        int fi = 0;
         for (int th : { kTileHMax, kTileHMid, kTileHSmall }) {
             int gx_t; long nt;
-            const double t = plan_for(th, &gx_t, &nt);
+            double t = plan_for(th, &gx_t, &nt);
+            if (small_launch) {
+                const long rounds = (nt + gx_t - 1) / gx_t;
+                const bool shared = 4L * gx_t > c->n_cu;                   // more workgroups (4 heads) than compute units
+                t = shared ? 2.0 + rounds * kSharedUs[fi] : kFirstUs[band][fi] + (rounds - 1) * kLaterUs[band][fi];
+            }
             if (th == kTileHMax || t < 0.995 * best) { best = t; TH = th; gx = gx_t; n_tiles_l = nt; }    // ties go to the larger form
+            ++fi;
         }
     }
     const int tiles_y = (g.h + TH - 1) / TH;
@@ -569,7 +588,7 @@ extern "C" int llicti_unlift_u8(llicti_ctx *c, const int16_t *d_planes, int B, i
     if (check_dims(B, H, W)) return LLICTI_EINVAL;
     const long plane = (long)H * W;
     const int gx = (int)std::min<long>((plane + 255) / 256, 1024);
-    unlift_kernel<<<dim3(gx, B), 256, 0, (hipStream_t)stream>>>(d_planes, plane, d_rgb);
+    unlift_kernel<<<dim3(gx, B), 256, 0, (hipStream_t)stream>>>(d_planes, plane, d_rgb, nullptr, 0, nullptr, nullptr);
     HIPCHK(hipGetLastError());
     return LLICTI_OK;
 }
@@ -808,12 +827,12 @@ extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, 
     int32_t *slot_len = (int32_t *)(ws + p.off_slot_len);
 
     CallScope call(c, s);
-    zero_words_kernel<<<(kStatusHead + B + 255) / 256, 256, 0, s>>>(status, kStatusHead + B);
     Geom g4 = make_geom(B, H, W, 4);
     const int byte0 = M ? rans_byte0(M, Q) : LLICTI_NLEVELS;
     {
         ProfSpan span(c, PROF_MISC, s);
-        if (int rc = launch_lift(d_rgb, B, H, W, planes, fplanes, mm, (int32_t *)(ws + p.off_lift_part), s)) return rc;
+        // (the lift is the call's first kernel and sets no status: it clears the call's status words on the way)
+        if (int rc = launch_lift(d_rgb, B, H, W, planes, fplanes, mm, (int32_t *)(ws + p.off_lift_part), s, status, kStatusHead + B)) return rc;
         header_write_kernel<<<B, 256, 0, s>>>(d_rgb, mm, H, W, g4.h, g4.w, pad_int(H, W), byte0, d_out, (long)out_stride, d_seg_len);
     }
     // The encoder has no dependency between stages: every (level, band) reads only original pixels.  With llicti_set_tuning("enc_side_levels", 1)
@@ -986,9 +1005,10 @@ static int decode_batch(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t 
     const int gx = (int)std::min<long>((plane + 255) / 256, 1024);
     {
         ProfSpan span(c, PROF_MISC, s);
-        unlift_kernel<<<dim3(gx, B), 256, 0, s>>>(planes, plane, d_rgb);
+        // (the call's status words are latched into the context's by this kernel: the workspace is the caller's, it may be gone or reused by the
+        // time the words are read)
+        unlift_kernel<<<dim3(gx, B), 256, 0, s>>>(planes, plane, d_rgb, status, kStatusHead, c->d_status, c->d_img_status);
     }
-    latch_status_kernel<<<1, 64, 0, s>>>(status, c->d_status, c->d_img_status, B);      // the workspace is the caller's: it may be gone or reused by the time the words are read
     HIPCHK(hipGetLastError());
     return 0;
 }
