@@ -64,9 +64,9 @@ __device__ __forceinline__ void clr_range(const int32_t *mm, int clr, int &minv,
 
 // encoder: thread per coded position; the two entries the coder reads, for Y, Co, Cg
 constexpr int kPairsThreads = 256;       // a workgroup walks 256 consecutive positions (1 KB of every channel plane); 64 ... 1024 measured: 0.61 / 0.62 / 0.60 / 0.64 / 0.69 ms per encode
-__global__ __launch_bounds__(kPairsThreads) void cdf_pairs_kernel(const int16_t *__restrict__ planes, const float *__restrict__ params,
-                                                        const int32_t *__restrict__ minmax, StageGeom s,
-                                                        uint32_t *__restrict__ pairs, int pair_batch)
+__device__ __forceinline__ void cdf_pairs_body(const int16_t *__restrict__ planes, const float *__restrict__ params,
+                                               const int32_t *__restrict__ minmax, const StageGeom &s,
+                                               uint32_t *__restrict__ pairs, int pair_batch)
 {
     // Channel-planar CNN outputs (numerics.hpp: ParRow): the 64 lanes of a wave walk 64 consecutive positions, so each of a thread's
     // 60 parameter loads is one fully coalesced 256-byte wave access -- no LDS staging (round 3 moved position-major rows through LDS).
@@ -99,6 +99,21 @@ __global__ __launch_bounds__(kPairsThreads) void cdf_pairs_kernel(const int16_t 
         const uint32_t hi = (sym == gr.Lp - 2) ? 0u : hi1;
         pairs[((long)clr * pair_batch + b) * nc + n] = (hi << 16) | lo;      // [clr][image of the whole batch][n]: a sub-batch launch passes the batch size and a shifted base
     }
+}
+__global__ __launch_bounds__(kPairsThreads) void cdf_pairs_kernel(const int16_t *__restrict__ planes, const float *__restrict__ params,
+                                                        const int32_t *__restrict__ minmax, StageGeom s,
+                                                        uint32_t *__restrict__ pairs, int pair_batch)
+{
+    cdf_pairs_body(planes, params, minmax, s, pairs, pair_batch);
+}
+// The three bands of one level in ONE launch (blockIdx.z = band; the band grids of a level have the same size, the coded crops differ):
+// the encoder's levels 4..1, whose three CNN outputs fit side by side into the buffer level 0 needs anyway -- two launches fewer per level.
+struct PairsBands { StageGeom sg[3]; const float *params[3]; uint32_t *pairs[3]; };
+__global__ __launch_bounds__(kPairsThreads) void cdf_pairs_bands_kernel(const int16_t *__restrict__ planes, PairsBands a,
+                                                              const int32_t *__restrict__ minmax, int pair_batch)
+{
+    const int band = blockIdx.z;
+    cdf_pairs_body(planes, a.params[band], minmax, a.sg[band], a.pairs[band], pair_batch);
 }
 
 // decoder / seam export: full Lp-entry rows (entries >= Lp padded with 0xFFFF).  Persistent wavefronts, one

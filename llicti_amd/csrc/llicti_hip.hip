@@ -858,6 +858,25 @@ extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, 
         // reading them back from HBM.  In sub-batches of `enc_chunk_images` the CNN outputs of one launch stay cache-resident.
         const long par_bytes_img = (long)g.h * g.w * LLICTI_PARAM_STRIDE * sizeof(float);
         const int chunk = (c->enc_chunk_images > 0 && (long)B * par_bytes_img > (200L << 20)) ? std::min(B, c->enc_chunk_images) : B;
+        const size_t band_floats = (size_t)B * g.h * g.w * LLICTI_PARAM_STRIDE;
+        const Geom g0 = make_geom(B, H, W, 0);
+        if (lvl >= 1 && !side && 3 * band_floats <= (size_t)B * g0.h * g0.w * LLICTI_PARAM_STRIDE) {
+            // Levels 4..1: the three bands' CNN outputs side by side in the buffer (each a quarter of what level 0 needs of it, or less),
+            // then ONE pairs launch for the three bands: 3 + 1 launches per level instead of 3 + 3.
+            PairsBands pb;
+            for (int band = 0; band < 3; ++band) {
+                float *pband = params + band * band_floats;
+                if (int rc = launch_band_params(c, fplanes, g, band, pband, s)) return rc;
+                pb.sg[band] = make_stage(g, band);
+                pb.params[band] = pband;
+                pb.pairs[band] = pairs + p.pair_base[lvl * 3 + band];
+            }
+            ProfSpan span(c, PROF_PAIRS, s);
+            const long np = (long)g.h * g.w;
+            cdf_pairs_bands_kernel<<<dim3((unsigned)((np + kPairsThreads - 1) / kPairsThreads), B, 3), kPairsThreads, 0, s>>>(planes, pb, mm, B);
+            HIPCHK(hipGetLastError());
+            continue;
+        }
         for (int band = 0; band < 3; ++band) {
             StageGeom sgb = make_stage(g, band);
             const long nc = (long)sgb.hc * sgb.wc;
