@@ -383,6 +383,39 @@ def test_rans_xwide_tail_seeds_and_chains_bitexact(torch_mod, codecs, oracle_wei
     assert np.array_equal(rec.cpu().numpy(), rgb)
 
 
+@pytest.mark.parametrize("mode_name", ["xrans3", "rans4", "ac"])
+def test_encoder_tuning_switches_bitexact(torch_mod, codecs, mode_name):
+    """The encoder's schedule switches change WHEN kernels run, never what they write: levels 4..1 on a side stream (`enc_side_levels`: the
+    per-band pairs launches instead of the one-launch-per-level form), level-0 sub-batches (`enc_chunk_images`), every CNN tile form
+    (`cnn_tile_rows` 16 / 8 / 4 / the round-3 rule) -- containers byte-identical to the default schedule's, decode lossless."""
+    from llicti_amd.codec import mode_of_name
+    torch = torch_mod
+    c = codecs("trainedlike")
+    rgb = make_batch("smooth", 3, 150, 131, seed0=321)
+    mode = mode_of_name(mode_name)
+    x = _dev(torch, rgb)
+    cont0, seg0 = c.encode(x, mode=mode)
+    c.check()
+    seg_h = seg0.cpu().numpy()
+    lens = seg_h.sum(axis=1)
+    ref = [cont0[b, :int(lens[b])].cpu().numpy().copy() for b in range(len(rgb))]
+    try:
+        for key, val in (("enc_side_levels", 1), ("enc_chunk_images", 1), ("enc_chunk_images", 2), ("cnn_tile_rows", 16), ("cnn_tile_rows", 8),
+                         ("cnn_tile_rows", 4), ("cnn_tile_rows", -1)):
+            c.set_tuning(key, val)
+            cont, seg = c.encode(x, mode=mode)
+            c.check()
+            assert np.array_equal(seg.cpu().numpy(), seg_h), (key, val)
+            for b in range(len(rgb)):
+                assert np.array_equal(cont[b, :int(lens[b])].cpu().numpy(), ref[b]), (key, val, b)
+            c.set_tuning(key, 0)
+    finally:
+        for key in ("enc_side_levels", "enc_chunk_images", "cnn_tile_rows"):
+            c.set_tuning(key, 0)
+    rec = _decode_poisoned(c, cont0, seg0, 150, 131, mode)
+    assert np.array_equal(rec.cpu().numpy(), rgb)
+
+
 def test_rans_v3_known_answer_hip(torch_mod, codecs):
     """The committed known-answer vectors of the rANS v3 container (tests/golden/rans_v3_vectors.npz, frozen by
     test_rans_v3_known_answer on the CPU): the HIP encoder reproduces the stored bytes, the HIP decoder turns the stored bytes
