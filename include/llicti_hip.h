@@ -11,9 +11,10 @@
  *   - every function returns 0 on success or a negative LLICTI_E* code; llicti_last_error() gives the
  *     message of the calling thread's last failure
  *   - nothing allocates device memory except llicti_create (status word, 1 MB of lift partials, streams and events
- *     of the AC decode pipeline), llicti_set_band_weights (weights) and the first whole-batch call of a new
- *     (B, H, W, mode) (stream descriptors of the plan, cached) -- all working memory comes from the caller-sized
- *     workspace (llicti_workspace_bytes)
+ *     of the AC decode pipeline), llicti_set_band_weights (weights) and a whole-batch call whose (mode, image sizes) the
+ *     context has not seen lately (the plan's per-image tables, 0.1 - 0.3 MB of device + pinned host memory from a pool of
+ *     blocks that are reused and never freed before llicti_destroy) -- all working memory comes from the caller-sized
+ *     workspace (llicti_workspace_bytes / llicti_workspace_bytes_v)
  *   - launches are asynchronous on `stream`; functions that return host-visible results say so and
  *     synchronise the stream themselves
  *   - one context per GPU / host thread; a context is not thread-safe and its calls must not overlap on different
@@ -23,10 +24,14 @@
  *   - every call makes the context's device current for its own duration and restores the caller's current device
  *   - calls that BLOCK the host: llicti_create / llicti_destroy / llicti_set_band_weights (device-wide synchronise:
  *     work in flight may still read the old weights), llicti_check_status and llicti_last_timing (they return
- *     host-visible results), and the FIRST whole-batch call of a new (B, H, W, mode) (builds and uploads the plan;
- *     the cache holds 16 plans, the 17th distinct shape synchronises the device and drops them all)
- *   - all images of one call share H x W (32 <= H, W <= 8160: the header stores h4, w4 as uint8,
- *     LLICTI_nets.py:347)
+ *     host-visible results).  A whole-batch call of a new (mode, image sizes) builds its plan on the host (tens of
+ *     microseconds) and enqueues ONE asynchronous upload of its tables on the call's stream: it does not synchronise the
+ *     device (the cache holds 32 plans, least recently used out first; a block that leaves it waits in the pool until its
+ *     last user has finished -- the reference's own test set has 119 image sizes among 500 images, interleaved)
+ *   - 32 <= H, W <= 8160 (the header stores h4, w4 as uint8, LLICTI_nets.py:347).  llicti_encode_images /
+ *     llicti_decode_images take B images of ONE size; llicti_encode_images_v / llicti_decode_images_v take a size per
+ *     image (the reference's test loader yields images of arbitrary sizes one at a time, dataloaders/image_dl.py:40-45):
+ *     same kernels, same bytes per image as a call of its own -- an image's container never depends on its batch
  *
  * Data layout in HBM
  *   rgb     uint8  [B][3][H][W]   planar
@@ -174,8 +179,9 @@ int llicti_ac_decode_u16cdf(llicti_ctx *ctx, const uint16_t *d_cdf, int Lp, int 
                                                   64: two streams per segment); ONE decoder lane per symbol, four wavefronts per stream: the fewest vector instructions
                                                   per symbol of the three (2 - 3.5 bytes per stream: 10 per 768x512 image are +0.0003 ... +0.0007 bpp over the reference format) */
 
-/* Bytes of device workspace the two calls below need for B images of H x W in `mode`. */
+/* Bytes of device workspace the calls below need for B images of H x W in `mode` (_v: of Hs[b] x Ws[b]). */
 size_t llicti_workspace_bytes(int B, int H, int W, int mode);
+size_t llicti_workspace_bytes_v(int B, const int *Hs, const int *Ws, int mode);
 /* Upper bound of the container size of ONE image: the minimum out_stride / in_stride. */
 size_t llicti_max_container_bytes(int H, int W);
 
@@ -188,6 +194,20 @@ int llicti_encode_images(llicti_ctx *ctx, const uint8_t *d_rgb, int B, int H, in
 int llicti_decode_images(llicti_ctx *ctx, const uint8_t *d_in, size_t in_stride, const int32_t *d_seg_len,
                          int B, int H, int W, int mode, void *d_workspace, size_t workspace_bytes,
                          uint8_t *d_rgb, void *stream);
+
+/* Batches of MIXED sizes (the reference's eval loop, agents/llicti_agent.py:122-164, meets a different H x W at almost every step;
+ * what it does one image at a time these calls do for B images at once).  Hs, Ws: host arrays of B sizes.  rgb_off: host array of B byte
+ * offsets into d_rgb, image b's uint8 [3][Hs[b]][Ws[b]] block at d_rgb + rgb_off[b]; NULL = the blocks tightly packed in call order.
+ * Containers as above: image b's at d_out + b*out_stride (out_stride >= llicti_max_container_bytes of the largest image), its 49 segment
+ * lengths in d_seg_len[b].  Image b's bytes equal those of llicti_encode_images(B = 1) on that image, whatever else is in the batch.
+ * rANS containers only: the reference-format container (LLICTI_MODE_AC) codes equal sizes per call (LLICTI_EINVAL otherwise). */
+int llicti_encode_images_v(llicti_ctx *ctx, const uint8_t *d_rgb, const size_t *rgb_off, int B, const int *Hs, const int *Ws, int mode,
+                           void *d_workspace, size_t workspace_bytes,
+                           uint8_t *d_out, size_t out_stride, int32_t *d_seg_len, void *stream);
+/* Hs[b] x Ws[b] must be the size container b's header describes (llicti_header_dims); a mismatch flags that image (llicti_image_status). */
+int llicti_decode_images_v(llicti_ctx *ctx, const uint8_t *d_in, size_t in_stride, const int32_t *d_seg_len,
+                           int B, const int *Hs, const int *Ws, int mode, void *d_workspace, size_t workspace_bytes,
+                           uint8_t *d_rgb, const size_t *rgb_off, void *stream);
 
 /* Synchronises `stream` and returns the latched device-side status of the calls issued since the
  * last check (LLICTI_OK, LLICTI_EFORMAT, LLICTI_ENOSPACE). */
@@ -229,9 +249,8 @@ int llicti_last_cnn_level_ms(llicti_ctx *ctx, float level_ms[LLICTI_NLEVELS]);
  * "ac_anchor_min_batch" (default 96): from this many images per call on,
  * llicti_decode_images decodes the AC container over anchor rows (every 8th table entry from cdf_anchor_kernel, the 8
  * entries of the located bucket evaluated by the decoding wavefront) instead of full table rows; values above the
- * default are clamped to it (the workspace is sized for the default).  "enc_chunk_images" (default 0 = never): llicti_encode_images
- * runs a (level, band) whose CNN outputs exceed 200 MB in sub-batches of this many images, so that the outputs of one CNN launch could
- * still be in the memory-side cache when the pairs kernel behind it reads them (measured on MI355X: no gain, hence off).
+ * default are clamped to it (the workspace is sized for the default).  "force_ragged" (default 0; 1: a batch of equal sizes takes the
+ * code path of a mixed-size batch too -- per-image tables, tile lists -- so that tests can run every case through both).
  * "enc_side_levels" (default 0; 1: llicti_encode_images runs levels 4..1 on an internal stream next to level 0's launches and joins it
  * before the entropy coder: -0.3 % of a step on MI355X, at the price of kernel traces whose side-queue durations include waiting). */
 int llicti_set_tuning(llicti_ctx *ctx, const char *key, int value);

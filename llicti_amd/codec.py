@@ -124,7 +124,9 @@ class HipCodec:
         _lib.check(self.L.llicti_create(C.byref(ctx), self.device.index))
         self.ctx = ctx
         self._ws = None
-        self._ws_key = None
+        self._ws_need = {}
+        self._ws_grown = False
+        self._mc = {}
         self.have_weights = False
 
     def close(self):
@@ -244,22 +246,40 @@ class HipCodec:
         return sym
 
     # ------------------------------------------------------------------ whole batch
-    def workspace(self, B, H, W, mode=MODE_AC):
-        key = (B, H, W, mode)
-        if self._ws_key != key:
-            n = self.L.llicti_workspace_bytes(B, H, W, mode)
-            if n == 0:
-                _lib.check(_lib.EINVAL)
-            self._ws = None
-            self._ws = torch.empty((n,), dtype=torch.uint8, device=self.device)
-            self._ws_key = key
-        return self._ws
-
-    def max_container_bytes(self, H, W):
-        n = self.L.llicti_max_container_bytes(H, W)
+    def _workspace_of(self, n):
+        """The cached workspace, grown to the RUNNING MAXIMUM of what the calls needed (a data set of many image sizes must not
+        re-allocate per call; the library validates the size it is given against what the call needs)."""
         if n == 0:
             _lib.check(_lib.EINVAL)
-        return int(n)
+        if self._ws is None or self._ws.numel() < n:
+            self._ws = None
+            self._ws = torch.empty((int(n * 1.25) if self._ws_grown else n,), dtype=torch.uint8, device=self.device)
+            self._ws_grown = True
+        return self._ws
+
+    def workspace(self, B, H, W, mode=MODE_AC):
+        key = (B, H, W, mode)
+        n = self._ws_need.get(key)
+        if n is None:
+            if len(self._ws_need) > 256:
+                self._ws_need.clear()
+            n = self._ws_need[key] = int(self.L.llicti_workspace_bytes(B, H, W, mode))
+        return self._workspace_of(n)
+
+    def workspace_v(self, Hs, Ws, mode):
+        Hs, Ws = np.ascontiguousarray(Hs, dtype=np.int32), np.ascontiguousarray(Ws, dtype=np.int32)
+        return self._workspace_of(int(self.L.llicti_workspace_bytes_v(len(Hs), _ptr(Hs), _ptr(Ws), mode)))
+
+    def max_container_bytes(self, H, W):
+        n = self._mc.get((H, W))
+        if n is None:
+            n = int(self.L.llicti_max_container_bytes(H, W))
+            if n == 0:
+                _lib.check(_lib.EINVAL)
+            if len(self._mc) > 1024:
+                self._mc.clear()
+            self._mc[(H, W)] = n
+        return n
 
     def encode(self, rgb, mode=MODE_AC, out=None, seg_len=None):
         """rgb uint8 [B,3,H,W] on this device -> (containers uint8 [B, stride], seg_len int32 [B,49]), async."""
@@ -284,6 +304,46 @@ class HipCodec:
             out = torch.empty((B, 3, H, W), dtype=torch.uint8, device=self.device)
         _lib.check(self.L.llicti_decode_images(self.ctx, _ptr(containers), containers.shape[1], _ptr(seg_len), B, H, W, mode,
                                                _ptr(ws), ws.numel(), _ptr(out), _stream_ptr(self.device)))
+        return out
+
+    # ---- batches of mixed sizes (llicti_encode_images_v / llicti_decode_images_v): images tightly packed in one flat uint8 buffer
+    @staticmethod
+    def flat_offsets(Hs, Ws):
+        """Byte offsets of the images' [3][H][W] blocks in the flat RGB buffer of a mixed-size batch (tightly packed), and its size."""
+        sizes = 3 * np.asarray(Hs, dtype=np.int64) * np.asarray(Ws, dtype=np.int64)
+        offs = np.concatenate(([0], np.cumsum(sizes)))
+        return offs[:-1], int(offs[-1])
+
+    def encode_v(self, rgb_flat, Hs, Ws, mode, out=None, seg_len=None):
+        """rgb_flat: uint8 device tensor holding B images of sizes Hs[b] x Ws[b] back to back ([3][H][W] each) -> (containers uint8
+        [B, stride], seg_len int32 [B, 49]), async.  Image b's bytes are those of encode() on that image alone."""
+        assert rgb_flat.dtype == torch.uint8 and rgb_flat.is_cuda and rgb_flat.dim() == 1 and rgb_flat.is_contiguous()
+        Hs, Ws = np.ascontiguousarray(Hs, dtype=np.int32), np.ascontiguousarray(Ws, dtype=np.int32)
+        B = len(Hs)
+        assert rgb_flat.numel() >= self.flat_offsets(Hs, Ws)[1]
+        ws = self.workspace_v(Hs, Ws, mode)
+        stride = max(self.max_container_bytes(int(h), int(w)) for h, w in set(zip(Hs.tolist(), Ws.tolist())))
+        if out is None:
+            out = torch.empty((B, stride), dtype=torch.uint8, device=self.device)
+        if seg_len is None:
+            seg_len = torch.zeros((B, NSEG), dtype=torch.int32, device=self.device)
+        assert out.shape[1] >= stride
+        _lib.check(self.L.llicti_encode_images_v(self.ctx, _ptr(rgb_flat), None, B, _ptr(Hs), _ptr(Ws), mode, _ptr(ws), ws.numel(),
+                                                 _ptr(out), out.shape[1], _ptr(seg_len), _stream_ptr(self.device)))
+        return out, seg_len
+
+    def decode_v(self, containers, seg_len, Hs, Ws, mode, out=None):
+        """device containers of B images of sizes Hs[b] x Ws[b] -> flat uint8 device tensor (the images back to back), async."""
+        Hs, Ws = np.ascontiguousarray(Hs, dtype=np.int32), np.ascontiguousarray(Ws, dtype=np.int32)
+        B = len(Hs)
+        assert containers.shape[0] == B
+        ws = self.workspace_v(Hs, Ws, mode)
+        total = self.flat_offsets(Hs, Ws)[1]
+        if out is None:
+            out = torch.empty((total,), dtype=torch.uint8, device=self.device)
+        assert out.numel() >= total
+        _lib.check(self.L.llicti_decode_images_v(self.ctx, _ptr(containers), containers.shape[1], _ptr(seg_len), B, _ptr(Hs), _ptr(Ws), mode,
+                                                 _ptr(ws), ws.numel(), _ptr(out), None, _stream_ptr(self.device)))
         return out
 
     def check(self):

@@ -142,10 +142,15 @@ constexpr int prio_step(int before, int after, int total)
     return -1;
 }
 
-template <int BAND, int TH = kTileHMax>
+// RAGGED = false: B images of ONE size (tile -> image, row, column by division; the image's arrays at b x their size) -- the form every
+// call with equal sizes runs.  RAGGED = true (llicti_encode_images_v / _decode_images_v with mixed sizes): the launch walks a TILE LIST --
+// tiles[t] = (image, tile row << 16 | tile column), image-major -- and takes each image's geometry and placement from gv[image]; the same
+// fmaf chain per position, so the outputs of an image do not depend on what else is in the batch.
+template <int BAND, int TH = kTileHMax, bool RAGGED = false>
 __global__ __launch_bounds__(CnnGeo<TH>::kThreads) void band_params_kernel(const float *__restrict__ fplanes, Geom g,
                                                                   const float *__restrict__ wpack,
-                                                                  float *__restrict__ params, int tiles_x, int tiles_y, int n_tiles)
+                                                                  float *__restrict__ params, int tiles_x, int tiles_y, int n_tiles,
+                                                                  const Geom *__restrict__ gv, const int2 *__restrict__ tiles)
 {
     using GEO = CnnGeo<TH>;
     constexpr int kCnnThreads = GEO::kThreads, kTileH = TH, kInRows = GEO::kInRows, kInPlane = GEO::kInPlane, kPP = GEO::kPP;
@@ -199,21 +204,48 @@ __global__ __launch_bounds__(CnnGeo<TH>::kThreads) void band_params_kernel(const
     // (deletion experiments: staging is ~6 % of the kernel).  Border tiles take the general path.
     // lane-dependent part: only the piece's phase t matters (row t or t + 1 of its 4-row group, column within the row)
     uint32_t lane_t[3];
+    if constexpr (!RAGGED) {
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const int thr = 48 - 16 * t;
-        const bool up = lane >= thr;
-        const int cidx = min(up ? lane - thr : lane + 16 * t, kInCols - 1);
-        lane_t[t] = (uint32_t)((((long)(2 * (t + (up ? 1 : 0))) * g.W + 2 * cidx) << g.lvl) * 4);
+        for (int t = 0; t < 3; ++t) {
+            const int thr = 48 - 16 * t;
+            const bool up = lane >= thr;
+            const int cidx = min(up ? lane - thr : lane + 16 * t, kInCols - 1);
+            lane_t[t] = (uint32_t)((((long)(2 * (t + (up ? 1 : 0))) * g.W + 2 * cidx) << g.lvl) * 4);
+        }
     }
 #endif
+    // The mixed-size form takes tile -> (image, tile row, tile column) from the list and the image's geometry from the table (wave-uniform:
+    // scalar loads), where it is needed -- in the staging and in the epilogue -- and does not keep it across the tile (the kernel is at its
+    // SGPR budget).  The equal-size form is, instruction for instruction, what it was before the list existed.
     auto stage = [&](int tile, float *dst) {
-        const int img = tile / (tiles_x * tiles_y);
-        const int trem = tile - img * (tiles_x * tiles_y);
-        const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+        int img, ty, tx;
+        Geom gl;                                                // (mixed sizes only)
+        if constexpr (RAGGED) {
+            const int2 t = tiles[tile];
+            img = __builtin_amdgcn_readfirstlane(t.x);
+            const int yx = __builtin_amdgcn_readfirstlane(t.y);
+            ty = yx >> 16; tx = yx & 0xFFFF;
+            gl = gv[img];
+        } else {
+            img = tile / (tiles_x * tiles_y);
+            const int trem = tile - img * (tiles_x * tiles_y);
+            ty = trem / tiles_x; tx = trem - ty * tiles_x;
+        }
+        const Geom &g_k = g;
+        const Geom &g = RAGGED ? gl : g_k;                      // (shadows the kernel's: this image's)
         const int i0 = ty * kTileH - 2, j0 = tx * kTileW - 2;
-        const float *base = fplanes + (long)img * 3 * g.plane;
+        const float *base = RAGGED ? fplanes + g.pix_off : fplanes + (long)img * 3 * g.plane;
 #if CNN_STAGE_FAST
+        uint32_t lt[3];                                         // mixed sizes: the row pitch is the image's, so the three per-lane offsets are recomputed per
+        if constexpr (RAGGED) {                                 // staged tile (~25 vector operations of a tile's ~10^5 cycles)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int thr = 48 - 16 * t;
+                const bool up = lane >= thr;
+                const int cidx = min(up ? lane - thr : lane + 16 * t, kInCols - 1);
+                lt[t] = (uint32_t)((((long)(2 * (t + (up ? 1 : 0))) * g.W + 2 * cidx) << g.lvl) * 4);
+            }
+        }
         // rows i0 .. i0 + kInRows - 1 and columns j0 .. j0 + kInCols - 1 of the band grid, all strictly inside it and below
         // the last row / column (where lazyDWT's odd-edge pad could apply)
         if (i0 >= 0 && i0 + kInRows - 1 <= g.h - 2 && j0 >= 0 && j0 + kInCols - 1 <= g.w - 2) {
@@ -225,7 +257,9 @@ __global__ __launch_bounds__(CnnGeo<TH>::kThreads) void band_params_kernel(const
                     const int pl = u / kPP, v = u - kPP * pl, q4 = v / 3, t = v - 3 * q4;
                     const int src = pl / 3, ci = pl - 3 * src;
                     const long uoff = ((long)ci * g.plane + (((long)(8 * q4 + src_oi(src)) * g.W + src_oj(src)) << g.lvl)) * 4;
-                    const uint32_t lo = (t == 0) ? lane_t[0] : (t == 1) ? lane_t[1] : lane_t[2];
+                    uint32_t lo;
+                    if constexpr (RAGGED) lo = (t == 0) ? lt[0] : (t == 1) ? lt[1] : lt[2];
+                    else lo = (t == 0) ? lane_t[0] : (t == 1) ? lane_t[1] : lane_t[2];
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(origin + uoff + lo),
                                                      (__attribute__((address_space(3))) void *)(dst + u * 64), 4, 0, 0);
                 }
@@ -261,9 +295,17 @@ __global__ __launch_bounds__(CnnGeo<TH>::kThreads) void band_params_kernel(const
     if (__builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_sleep(CNN_STAGGER);
 #endif
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int img = tile / (tiles_x * tiles_y);
-        const int trem = tile - img * (tiles_x * tiles_y);
-        const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+        int img, ty, tx;
+        if constexpr (RAGGED) {
+            const int2 t = tiles[tile];
+            img = __builtin_amdgcn_readfirstlane(t.x);
+            const int yx = __builtin_amdgcn_readfirstlane(t.y);
+            ty = yx >> 16; tx = yx & 0xFFFF;
+        } else {
+            img = tile / (tiles_x * tiles_y);
+            const int trem = tile - img * (tiles_x * tiles_y);
+            ty = trem / tiles_x; tx = trem - ty * tiles_x;
+        }
         const int i0 = ty * kTileH, j0 = tx * kTileW;
         float *lds_cur = lds_in + cur * (NPL * kInPlane);
 
@@ -495,7 +537,21 @@ __global__ __launch_bounds__(CnnGeo<TH>::kThreads) void band_params_kernel(const
 
         // D row 4q + r = output 4q + r of this head -> channel plane head * 16 + 4q + r of params[img][64][h * w] (numerics.hpp: ParRow).
         // A store instruction writes 16 consecutive positions (64 bytes) of four planes; plane 15 of a head does not exist (15 outputs).
-        {
+        if constexpr (RAGGED) {
+            const Geom gi = gv[img];                            // this image's
+            const long npos = (long)gi.h * gi.w;
+#pragma unroll
+            for (int n = 0; n < kNT; ++n) {
+                const int i = i0 + ((wave * kNT) >> 1) + (n >> 1), j = j0 + 16 * (n & 1) + px;
+                if (i < gi.h && j < gi.w) {
+                    float *dst = params + gi.par_off + (long)(head * 16 + 4 * q) * npos + (long)i * gi.w + j;
+                    dst[0] = a2[n][0];
+                    dst[npos] = a2[n][1];
+                    dst[2 * npos] = a2[n][2];
+                    if (q < 3) dst[3 * npos] = a2[n][3];
+                }
+            }
+        } else {
             const long npos = (long)g.h * g.w;
 #pragma unroll
             for (int n = 0; n < kNT; ++n) {

@@ -8,6 +8,12 @@ struct StageGeom {      // one (level, band): band grid, coded crop, full-res ad
     long plane;
     uint32_t wc_mul;    // n / wc for 0 <= n < 2^31 without a division: div_by_magic(n, wc_mul, wc_sh)
     int wc_sh;
+    // Per-image placement (whole-batch calls keep one StageGeom per image in a device table -- the images of a call may differ in size; a
+    // kernel-level entry point passes ONE by value and stage_at() derives these from the image index):
+    long img_off;       // first element of the image's [3][H][W] block in planes / fplanes
+    long par_off;       // first float of its [64][h * w] block in the CNN-output buffer of this (level, band)
+    long pair_off;      // first pair of its Y stream in the (level, band)'s pairs [clr][image][n] ...
+    long pair_cs;       // ... and the distance between two colour channels there (the images' coded positions together)
 };
 // exact unsigned division by an invariant divisor (Granlund / Montgomery, the 33-bit multiplier form), 1 <= d < 2^31,
 // 0 <= n < 2^31: l = ceil(log2 d), mul = floor(2^32 (2^l - d) / d) + 1, t = mulhi(n, mul), q = (t + ((n - t) >> 1)) >> (l - 1).
@@ -52,7 +58,18 @@ static StageGeom make_stage(const Geom &g, int band)
     coded_dims(g, band, &s.hc, &s.wc);
     s.oi = OI[band + 1]; s.oj = OJ[band + 1];
     div_magic((uint32_t)s.wc, &s.wc_mul, &s.wc_sh);
+    s.img_off = g.pix_off; s.par_off = g.par_off; s.pair_off = 0; s.pair_cs = 0;
     return s;
+}
+// image b's stage geometry: its entry of the call's table, or (kernel-level entry points: B images of one size, tight arrays) derived from b
+__device__ __forceinline__ StageGeom stage_at(const StageGeom &s, const StageGeom *__restrict__ sv, int b)
+{
+    if (sv) return sv[b];
+    StageGeom r = s;
+    r.img_off = (long)b * 3 * s.plane;
+    r.par_off = (long)b * LLICTI_PARAM_STRIDE * s.h * s.w;
+    r.pair_off = (long)b * s.hc * s.wc;
+    return r;
 }
 
 __device__ __forceinline__ void clr_range(const int32_t *mm, int clr, int &minv, int &maxv, int &shift)
@@ -65,8 +82,7 @@ __device__ __forceinline__ void clr_range(const int32_t *mm, int clr, int &minv,
 // encoder: thread per coded position; the two entries the coder reads, for Y, Co, Cg
 constexpr int kPairsThreads = 256;       // a workgroup walks 256 consecutive positions (1 KB of every channel plane); 64 ... 1024 measured: 0.61 / 0.62 / 0.60 / 0.64 / 0.69 ms per encode
 __device__ __forceinline__ void cdf_pairs_body(const int16_t *__restrict__ planes, const float *__restrict__ params,
-                                               const int32_t *__restrict__ minmax, const StageGeom &s,
-                                               uint32_t *__restrict__ pairs, int pair_batch)
+                                               const int32_t *__restrict__ minmax, const StageGeom &s, uint32_t *__restrict__ pairs)
 {
     // Channel-planar CNN outputs (numerics.hpp: ParRow): the 64 lanes of a wave walk 64 consecutive positions, so each of a thread's
     // 60 parameter loads is one fully coalesced 256-byte wave access -- no LDS staging (round 3 moved position-major rows through LDS).
@@ -74,14 +90,13 @@ __device__ __forceinline__ void cdf_pairs_body(const int16_t *__restrict__ plane
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int np = s.h * s.w;
     const int p0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 64;
-    if (p0 >= np) return;                                         // whole wave
-    const ParRow par = par_row(params, b, np, min(p0 + lane, np - 1));
+    if (p0 >= np) return;                                         // whole wave (a smaller image of a mixed batch: whole workgroups)
+    const ParRow par = par_row(params + s.par_off, 0, np, min(p0 + lane, np - 1));
     const int p = p0 + lane;
     const int i = p / s.w, j = p - i * s.w;
     if (p >= np || i >= s.hc || j >= s.wc) return;                // padded row / column of the band grid: not coded
-    const long nc = (long)s.hc * s.wc;
     const long n = (long)i * s.wc + j;
-    const long off = (long)b * 3 * s.plane + ((long)(2 * i + s.oi) << s.lvl) * s.W + ((long)(2 * j + s.oj) << s.lvl);
+    const long off = s.img_off + ((long)(2 * i + s.oi) << s.lvl) * s.W + ((long)(2 * j + s.oj) << s.lvl);
     const int vy = planes[off], vco = planes[off + s.plane], vcg = planes[off + 2 * s.plane];
     const float yv = (float)vy / 255.0f, cov = (float)vco / 255.0f;
     const int32_t *mm = minmax + 4 * b;
@@ -97,23 +112,23 @@ __device__ __forceinline__ void cdf_pairs_body(const int16_t *__restrict__ plane
         const uint32_t lo = cdf_entry(m, gr, sym);
         const uint32_t hi1 = cdf_entry(m, gr, min(sym + 1, gr.Lp - 2));     // unconditional (clamped): no divergent branch around ten erfc chains
         const uint32_t hi = (sym == gr.Lp - 2) ? 0u : hi1;
-        pairs[((long)clr * pair_batch + b) * nc + n] = (hi << 16) | lo;      // [clr][image of the whole batch][n]: a sub-batch launch passes the batch size and a shifted base
+        pairs[(long)clr * s.pair_cs + s.pair_off + n] = (hi << 16) | lo;      // [clr][image][n]
     }
 }
 __global__ __launch_bounds__(kPairsThreads) void cdf_pairs_kernel(const int16_t *__restrict__ planes, const float *__restrict__ params,
-                                                        const int32_t *__restrict__ minmax, StageGeom s,
-                                                        uint32_t *__restrict__ pairs, int pair_batch)
+                                                        const int32_t *__restrict__ minmax, StageGeom s, const StageGeom *__restrict__ sv,
+                                                        uint32_t *__restrict__ pairs)
 {
-    cdf_pairs_body(planes, params, minmax, s, pairs, pair_batch);
+    cdf_pairs_body(planes, params, minmax, stage_at(s, sv, blockIdx.y), pairs);
 }
 // The three bands of one level in ONE launch (blockIdx.z = band; the band grids of a level have the same size, the coded crops differ):
 // the encoder's levels 4..1, whose three CNN outputs fit side by side into the buffer level 0 needs anyway -- two launches fewer per level.
-struct PairsBands { StageGeom sg[3]; const float *params[3]; uint32_t *pairs[3]; };
+struct PairsBands { const StageGeom *sv[3]; const float *params[3]; uint32_t *pairs[3]; };      // sv: the band's per-image table
 __global__ __launch_bounds__(kPairsThreads) void cdf_pairs_bands_kernel(const int16_t *__restrict__ planes, PairsBands a,
-                                                              const int32_t *__restrict__ minmax, int pair_batch)
+                                                              const int32_t *__restrict__ minmax)
 {
     const int band = blockIdx.z;
-    cdf_pairs_body(planes, a.params[band], minmax, a.sg[band], a.pairs[band], pair_batch);
+    cdf_pairs_body(planes, a.params[band], minmax, a.sv[band][blockIdx.y], a.pairs[band]);
 }
 
 // decoder / seam export: full Lp-entry rows (entries >= Lp padded with 0xFFFF).  Persistent wavefronts, one

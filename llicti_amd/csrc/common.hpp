@@ -28,6 +28,17 @@ struct Geom {
     int B, H, W, lvl;
     int Hl, Wl, h, w, padH, padW;
     long plane;   // H*W
+    // Whole-batch calls keep one Geom PER IMAGE in a device table (the images of a call may differ in size: llicti_encode_images_v); these two
+    // fields are only meaningful there.  The kernel-level entry points pass one Geom by value and derive both from the image index.
+    long pix_off; // first element of the image's [3][H][W] block in planes / fplanes
+    long par_off; // first float of the image's [64][h * w] block in the CNN-output buffer of this level
+};
+// One image of a whole-batch call (device table, llicti_hip.hip: Plan).
+struct ImgGeo {
+    int H, W, h4, w4, padint, hdr_bytes;      // hdr_bytes = 17 + 3 h4 w4 (LLICTI_nets.py:347-350)
+    long plane;                               // H * W
+    long pix_off;                             // first element of the image's [3][H][W] block in planes / fplanes (workspace)
+    long rgb_off;                             // first byte of its [3][H][W] block in the caller's RGB buffer
 };
 static Geom make_geom(int B, int H, int W, int lvl)
 {
@@ -41,6 +52,7 @@ static Geom make_geom(int B, int H, int W, int lvl)
     g.padH = g.Hl & 1;
     g.padW = g.Wl & 1;
     g.plane = (long)H * W;
+    g.pix_off = 0; g.par_off = 0;
     return g;
 }
 static void coded_dims(const Geom &g, int band, int *hc, int *wc)

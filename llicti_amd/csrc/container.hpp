@@ -4,13 +4,14 @@
 
 // ------------------------------------------------------------------------------------------------ container kernels
 // encode: header segments straight into the container; seg_len[b][0..3]
-__global__ void header_write_kernel(const uint8_t *__restrict__ rgb, const int32_t *__restrict__ minmax, int H, int W,
-                                    int h4, int w4, int padint, int byte0, uint8_t *__restrict__ out, long out_stride,
-                                    int32_t *__restrict__ seg_len)
+__global__ void header_write_kernel(const uint8_t *__restrict__ rgb, const int32_t *__restrict__ minmax, const ImgGeo *__restrict__ iv,
+                                    int byte0, uint8_t *__restrict__ out, long out_stride, int32_t *__restrict__ seg_len)
 {
     const int b = blockIdx.x;
     uint8_t *o = out + (long)b * out_stride;
-    const long plane = (long)H * W;
+    const ImgGeo ig = iv[b];
+    const int W = ig.W, h4 = ig.h4, w4 = ig.w4, padint = ig.padint;
+    const long plane = ig.plane;
     if (threadIdx.x == 0) {
         o[0] = (uint8_t)byte0; o[1] = (uint8_t)h4; o[2] = (uint8_t)w4;          // LLICTI_nets.py:347 (AC: number of scales)
         const int32_t *mm = minmax + 4 * b;
@@ -22,7 +23,7 @@ __global__ void header_write_kernel(const uint8_t *__restrict__ rgb, const int32
     }
     for (int t = threadIdx.x; t < 3 * h4 * w4; t += blockDim.x) {                                        // :248-252, :350
         const int c = t / (h4 * w4), r = t - c * h4 * w4, i = r / w4, j = r - i * w4;
-        o[17 + t] = rgb[(long)b * 3 * plane + c * plane + (long)(32 * i) * W + 32 * j];
+        o[17 + t] = rgb[ig.rgb_off + c * plane + (long)(32 * i) * W + 32 * j];
     }
 }
 
@@ -46,13 +47,15 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ s
 
 // decode: parse + validate header, min/max -> minmax[b][4], DC band -> planes at stride 32
 __global__ void header_read_kernel(const uint8_t *__restrict__ in, long in_stride, const int32_t *__restrict__ seg_len,
-                                   int H, int W, int h4, int w4, int padint, int byte0, int16_t *__restrict__ planes,
+                                   const ImgGeo *__restrict__ iv, int byte0, int16_t *__restrict__ planes,
                                    float *__restrict__ fplanes, int32_t *__restrict__ minmax, int32_t *status)
 {
     const int b = blockIdx.x;
     const uint8_t *p = in + (long)b * in_stride;
     const int32_t *sl = seg_len + (long)b * LLICTI_NSEG;
-    const long plane = (long)H * W;
+    const ImgGeo ig = iv[b];
+    const int W = ig.W, h4 = ig.h4, w4 = ig.w4, padint = ig.padint;
+    const long plane = ig.plane;
     __shared__ int ok;
     __shared__ int sh_bad;
     __shared__ unsigned long long sh_tot;
@@ -93,7 +96,7 @@ __global__ void header_read_kernel(const uint8_t *__restrict__ in, long in_strid
         const int i = t / w4, j = t - i * w4;
         const int R = ok ? dc[t] : 128, G = ok ? dc[h4 * w4 + t] : 128, Bl = ok ? dc[2 * h4 * w4 + t] : 128;
         const int Co = R - Bl, tt = Bl + (Co >> 1), Cg = G - tt, Y = tt + (Cg >> 1) - 127;
-        const long off = (long)b * 3 * plane + (long)(32 * i) * W + 32 * j;
+        const long off = ig.pix_off + (long)(32 * i) * W + 32 * j;
         planes[off] = (int16_t)Y; planes[off + plane] = (int16_t)Co; planes[off + 2 * plane] = (int16_t)Cg;
         fplanes[off] = (float)Y / 255.0f; fplanes[off + plane] = (float)Co / 255.0f; fplanes[off + 2 * plane] = (float)Cg / 255.0f;
     }

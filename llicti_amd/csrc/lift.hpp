@@ -27,15 +27,20 @@ __global__ __launch_bounds__(64) void minmax_reduce_kernel(const int32_t *__rest
 template <int VEC>
 // zero != nullptr (the whole-batch encode, whose first kernel this is): the call's n_zero status words are cleared here, before any kernel that
 // can set them is launched, instead of by a launch of its own.
+// iv != nullptr (whole-batch calls): image b's size and placement come from the call's table (the images may differ in size); else B
+// images of `plane` pixels each, tightly packed in all three arrays.
 __global__ __launch_bounds__(256) void lift_kernel(const uint8_t *__restrict__ rgb, long plane, int16_t *__restrict__ planes,
-                                                   float *__restrict__ fplanes, int32_t *__restrict__ part, int32_t *__restrict__ zero, int n_zero)
+                                                   float *__restrict__ fplanes, int32_t *__restrict__ part, int32_t *__restrict__ zero, int n_zero,
+                                                   const ImgGeo *__restrict__ iv)
 {
     const int b = blockIdx.y;
     if (zero && blockIdx.x == 0 && b == 0)
         for (int i = threadIdx.x; i < n_zero; i += blockDim.x) zero[i] = 0;
-    const uint8_t *src = rgb + (long)b * 3 * plane;
-    int16_t *dst = planes + (long)b * 3 * plane;
-    float *fdst = fplanes + (long)b * 3 * plane;
+    long src_off = (long)b * 3 * plane, dst_off = src_off;
+    if (iv) { plane = iv[b].plane; src_off = iv[b].rgb_off; dst_off = iv[b].pix_off; }
+    const uint8_t *src = rgb + src_off;
+    int16_t *dst = planes + dst_off;
+    float *fdst = fplanes + dst_off;
     int mnCo = 32767, mnCg = 32767, mxCo = -32768, mxCg = -32768;
     for (long p = ((long)blockIdx.x * blockDim.x + threadIdx.x) * VEC; p < plane; p += (long)gridDim.x * blockDim.x * VEC) {
         uint8_t r[VEC], gch[VEC], bl[VEC];
@@ -96,15 +101,17 @@ __global__ __launch_bounds__(256) void lift_kernel(const uint8_t *__restrict__ r
 // kernel that can set them has finished -- instead of by a launch of its own: word 0 if set, and image b's word by the image's first block.
 __global__ __launch_bounds__(256) void unlift_kernel(const int16_t *__restrict__ planes, long plane, uint8_t *__restrict__ rgb,
                                                      const int32_t *__restrict__ status, int status_head, int32_t *__restrict__ latched,
-                                                     int32_t *__restrict__ img_latched)
+                                                     int32_t *__restrict__ img_latched, const ImgGeo *__restrict__ iv)
 {
     const int b = blockIdx.y;
     if (status && blockIdx.x == 0 && threadIdx.x == 0) {
         if (b == 0 && status[0] != 0) *latched = status[0];
         if (img_latched) img_latched[b] = status[status_head + b];
     }
-    const int16_t *src = planes + (long)b * 3 * plane;
-    uint8_t *dst = rgb + (long)b * 3 * plane;
+    long src_off = (long)b * 3 * plane, dst_off = src_off;
+    if (iv) { plane = iv[b].plane; src_off = iv[b].pix_off; dst_off = iv[b].rgb_off; }      // (lift_kernel: the call's per-image table)
+    const int16_t *src = planes + src_off;
+    uint8_t *dst = rgb + dst_off;
     for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < plane; p += (long)gridDim.x * blockDim.x) {
         const int Y = src[p] + 127, Co = src[plane + p], Cg = src[2 * plane + p];
         const int t = Y - (Cg >> 1);

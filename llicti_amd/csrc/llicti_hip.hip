@@ -46,22 +46,39 @@ using namespace llicti;
 #include "container.hpp"
 
 // ------------------------------------------------------------------------------------------------ context
-struct Plan {                 // workspace carving for (B, H, W)
-    int B = 0, H = 0, W = 0;
-    size_t off_lift_part, off_acstate;
-    long ac_cap_rows = 0;             // rows per image of one colour's chunk table buffer
-    size_t off_planes, off_fplanes, off_minmax, off_status, off_params, off_params2, off_pairs, off_slots, off_slot_len, off_tables;
-    size_t total;
-    std::vector<StreamDesc> desc;       // stage-major, image-minor: index (stage * B + b)
-    std::vector<long> slot_off;
-    std::vector<int32_t> slot_cap;
-    std::vector<long> pair_base;        // per (lvl, band): first pair of [clr][B][nc]
-    size_t max_container;
+// One whole-batch call's layout: the workspace carving and the per-image tables the kernels read.  The images of a call may differ in
+// size (llicti_encode_images_v / llicti_decode_images_v); llicti_encode_images / llicti_decode_images are the same code with B equal sizes.
+struct TileRun { size_t off = 0; int n_tiles = 0, TH = 0, gx = 0; };      // band-CNN launch of one (level, band) of a mixed-size plan: its tile list
+struct Plan {
+    int B = 0, ME = 0;
     int M = 0;                          // rANS streams per image (0: AC container only)
     int Q = 1;                          // 64-lane sub-chunks per stream step (2: wide streams of 128 lanes; 4: xwide streams of 256 lanes)
+    bool uniform = true;                // every image has the size of image 0: the band CNN runs its division form, the AC container is available
+    bool vec_ok = true;                 // every image's plane size and placement allow the lift's 4-pixel accesses
+    long lev_maxpos[LLICTI_NLEVELS];    // largest band grid (h * w) of a level
+    std::vector<long> key;              // (ME, B, tile-form tuning, H, W, rgb offset per image): what the cache compares
+    size_t off_lift_part, off_acstate;
+    long ac_cap_rows = 0;               // rows per image of one colour's chunk table buffer (AC decode)
+    size_t off_planes, off_fplanes, off_minmax, off_status, off_params, off_params2, off_pairs, off_slots, off_slot_len, off_tables;
+    size_t total = 0;
+    size_t rgb_bytes = 0;               // extent of the caller's RGB buffer
+    long max_plane = 0;                 // largest H * W of the batch
+    std::vector<ImgGeo> img;            // [B]
+    std::vector<Geom> geo;              // [level][B]
+    std::vector<StageGeom> sg;          // [level * 3 + band][B]
+    size_t lev_floats[LLICTI_NLEVELS];  // CNN outputs of one (level, band): 64 floats per band-grid position of every image
+    std::vector<StreamDesc> desc;       // stage-major, image-minor: index (stage * B + b)
+    std::vector<long> slot_off;         // AC container (uniform plans)
+    std::vector<int32_t> slot_cap;
+    long pair_base[LLICTI_NLEVELS * 3]; // per (lvl, band): first pair of [clr][image][n]
+    size_t max_container = 0;           // of the batch's largest image
     int rslot_cap = 0;
     std::vector<long> rslot_off;        // [B*M] byte offsets into the slots region
     size_t off_rinfo, off_rstate, off_rpos, off_rtail;
+    std::vector<int2> tiles;            // mixed-size plans: the tile lists of the 15 band-CNN launches, back to back
+    TileRun run[LLICTI_NLEVELS * 3];
+    // device copies (one block, see PlanBlock)
+    size_t d_img = 0, d_geo = 0, d_sg = 0, d_desc = 0, d_slot_off = 0, d_slot_cap = 0, d_rslot_off = 0, d_tiles = 0, d_total = 0;
 };
 
 // AC decode has two table forms.  Few images in flight (latency bound: every stream is one serial wave and the GPU is
@@ -76,22 +93,24 @@ static bool ac_use_anchors(int B, int min_batch = kAcAnchorBatch) { return B >= 
 constexpr int kMaxSub = 3;
 constexpr int kRansMaxStreams = 128;   // rANS streams per image: <= 32 one per segment, 64 / 128 grouped (rans_group())
 constexpr int kStatusHead = 16;       // status words in front of the per-image ones (common.hpp: image_status())
-struct PlanDev {                  // owns its device arrays: a plan that fails half-way through get_plan() frees what it took
+constexpr int kMaxPlans = 32;         // plans the context keeps (least recently used goes first)
+// Device + pinned host memory of one plan's tables.  Blocks are POOLED and never freed before llicti_destroy: a plan that leaves the cache
+// hands its block back, the next new plan takes any block whose last user has finished (hipEventQuery on `done`, recorded behind every call
+// that uses the block) -- so that a data set of many image sizes (the reference's own test set has 119 among 500 images) never makes the
+// library synchronise the device or call hipFree (which does) once it is warm.
+struct PlanBlock {
+    uint8_t *dev = nullptr, *host = nullptr;
+    size_t cap = 0;
+    hipEvent_t done = nullptr;        // behind the last call that used the block
+    hipEvent_t uploaded = nullptr;    // behind the table upload ...
+    hipStream_t up_stream = nullptr;  // ... on this stream: a call on another stream waits for it
+    bool used = false;                // `done` has been recorded at least once
+};
+struct PlanDev {
     Plan p;
-    StreamDesc *d_desc = nullptr;
-    long *d_slot_off = nullptr;
-    int32_t *d_slot_cap = nullptr;
-    long *d_rslot_off = nullptr;
-    PlanDev() = default;
-    PlanDev(const PlanDev &) = delete;
-    PlanDev &operator=(const PlanDev &) = delete;
-    ~PlanDev()
-    {
-        if (d_desc) (void)hipFree(d_desc);
-        if (d_slot_off) (void)hipFree(d_slot_off);
-        if (d_slot_cap) (void)hipFree(d_slot_cap);
-        if (d_rslot_off) (void)hipFree(d_rslot_off);
-    }
+    PlanBlock blk;
+    uint64_t last_use = 0;
+    template <class T> const T *dev(size_t off) const { return reinterpret_cast<const T *>(blk.dev + off); }
 };
 
 // profiling spans (llicti_set_profiling): what a pair of events brackets
@@ -102,7 +121,10 @@ struct llicti_ctx {
     int device = 0;
     float *d_pack[3] = { nullptr, nullptr, nullptr };
     bool have[3] = { false, false, false };
-    std::map<std::tuple<int, int, int, int>, struct PlanDev *> plans;   // (B, H, W, M) -> plan + its device arrays
+    std::map<std::vector<long>, struct PlanDev *> plans;   // Plan::key -> plan + its device tables (at most kMaxPlans, least recently used out first)
+    std::vector<PlanBlock> pool;      // table blocks of plans that left the cache, for the next new plan
+    uint64_t use_clock = 0;
+    int force_ragged = 0;             // llicti_set_tuning("force_ragged"): equal-size batches take the mixed-size code path too (tests)
     hipStream_t sub[kMaxSub] = { nullptr, nullptr, nullptr };    // internal streams of the AC decode pipeline ([0] unused: the caller's)
     hipEvent_t ev_ac[2][16] = {};      // AC decode pipeline: chunk c of Y / Co done
     hipEvent_t ev_ac_band = nullptr, ev_ac_end[2] = { nullptr, nullptr };
@@ -116,7 +138,6 @@ struct llicti_ctx {
     int cnn_tile_rows = 0;            // llicti_set_tuning("cnn_tile_rows"): 0 = choose per launch, 16 / 4 = force (tests, A/B)
     int enc_side_levels = 0;          // llicti_set_tuning("enc_side_levels"): 1 = encoder levels 4..1 on a side stream next to level 0, 0 = one queue (default)
     hipEvent_t ev_enc[2] = { nullptr, nullptr };
-    int enc_chunk_images = 0;         // llicti_set_tuning("enc_chunk_images"): encoder sub-batch of a (level, band) whose CNN outputs exceed 200 MB (0: never split; measured: no gain, profiles/r4/tried_encoder_subbatch.json)
     bool profiling = false;
     std::vector<hipEvent_t> ev;       // event pool of the profiling spans
     struct Span { hipEvent_t e0, e1; int cat, tag; };
@@ -199,77 +220,192 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static int stage_index(int lvl, int band, int clr) { return (LLICTI_NLEVELS - 1 - lvl) * 9 + band * 3 + clr; }   // scale 4..0
 
-// ME: streams per image, | 0x100 for wide (128-lane) streams, | 0x200 for xwide (256-lane) streams -- what mode_streams() returns and the
-// plan cache is keyed on
-static void build_plan(Plan &p, int B, int H, int W, int ME)
+static int pad_int(int H, int W)
+{
+    int v = 0;
+    for (int l = 0; l < LLICTI_NLEVELS; ++l) {
+        Geom g = make_geom(1, H, W, l);
+        v = 4 * v + 2 * g.padH + g.padW;       // LLICTI_nets.py:230
+    }
+    return v;
+}
+
+// Tile height of a band-CNN launch (16, 8 or 4 rows; one wavefront per row, so 16 / 8 / 4 wavefronts per workgroup): the form whose launch is
+// shortest under a two-parameter model of the persistent grid -- rounds = ceil(tiles / workgroups that fit the chip), a round = a fixed part
+// (halo rows, staging the head's weights, barrier) + a part per tile row; the constants are the measured 46 / 25 / 15 us of a band-2
+// tile of 16 / 8 / 4 rows.  Full launches come out at 16 rows; launches of one to three half-empty rounds (levels 3 and 4 of a batch
+// of 24) at 8; launches that cannot give every compute unit a workgroup (coarse levels of a single image) at 4.  Every form computes
+// each position with the same fmaf chains: the results do not depend on it (test_band_params_bitexact_and_golden runs all three).
+// count(th) = tiles of the launch in tiles of th rows (all images).  tile_rows: llicti_set_tuning("cnn_tile_rows").
+struct TileForm { int TH, gx; long n_tiles; };
+template <class COUNT>
+static TileForm choose_tile_form(int n_cu, int tile_rows, int band, COUNT &&count)
+{
+    auto plan_for = [&](int th, int *gx_out, long *tiles_out) -> double {
+        const long tiles = count(th);
+        const int per_cu = std::max(1, std::min(4, (160 * 1024) / cnn_lds_bytes(band, th)));
+        const long gx = std::max<long>(1, std::min<long>(tiles, (long)n_cu * per_cu / 4));
+        *gx_out = (int)gx; *tiles_out = tiles;
+        return (double)((tiles + gx - 1) / gx) * (4.7 + 2.6 * th);
+    };
+    TileForm f{ kTileHMax, 1, 0 };
+    if (tile_rows > 0) { f.TH = tile_rows; (void)plan_for(f.TH, &f.gx, &f.n_tiles); }
+    else if (tile_rows < 0) {                              // round 3's rule (A/B): 4 rows iff the 16-row tiles cannot fill the chip
+        f.TH = (4 * count(kTileHMax) < n_cu) ? kTileHSmall : kTileHMax;
+        (void)plan_for(f.TH, &f.gx, &f.n_tiles);
+    } else {
+        // Launches of one or two rounds of 16-row tiles (coarse levels, single images) are priced from a table instead: a launch's first
+        // round and its later ones per (band, form), measured on single-image launches (rocprofv3, tools/single_image_trace.py) -- the linear
+        // model is off exactly there: a 4-row tile of band 2 takes 21-25 us, not 15 (one wavefront per SIMD cannot keep the matrix pipe busy and
+        // 120 input channels are the longest layer 0), so three rounds of them lost to ONE round of 16-row tiles at level 1 of a lone image
+        // (75 against 47 us).  Band 0 fits two workgroups per compute unit: its rounds are priced as shared.
+        static const double kFirstUs[3][3] = { { 31.5, 18.1, 12.5 }, { 36.4, 20.8, 14.5 }, { 46.3, 26.2, 21.4 } };      // [band][16, 8, 4 rows]
+        static const double kLaterUs[3][3] = { { 31.0, 17.0, 11.0 }, { 36.4, 19.0, 11.2 }, { 46.0, 23.9, 25.2 } };
+        static const double kSharedUs[3] = { 61.3, 31.2, 16.7 };                                                            // band 0, two workgroups per CU
+        int gx16; long nt16;
+        (void)plan_for(kTileHMax, &gx16, &nt16);
+        const bool small_launch = (nt16 + gx16 - 1) / gx16 <= 2;
+        double best = 0;
+        int fi = 0;
+        for (int th : { kTileHMax, kTileHMid, kTileHSmall }) {
+            int gx_t; long nt;
+            double t = plan_for(th, &gx_t, &nt);
+            if (small_launch) {
+                const long rounds = (nt + gx_t - 1) / gx_t;
+                const bool shared = 4L * gx_t > n_cu;                      // more workgroups (4 heads) than compute units
+                t = shared ? 2.0 + rounds * kSharedUs[fi] : kFirstUs[band][fi] + (rounds - 1) * kLaterUs[band][fi];
+            }
+            if (th == kTileHMax || t < 0.995 * best) { best = t; f.TH = th; f.gx = gx_t; f.n_tiles = nt; }    // ties go to the larger form
+            ++fi;
+        }
+    }
+    return f;
+}
+
+// ME: streams per image, | 0x100 for wide (128-lane) streams, | 0x200 for xwide (256-lane) streams -- what mode_streams() returns.
+// Hs, Ws: B sizes; rgb_off: B byte offsets of the images in the caller's RGB buffer, or nullptr = tightly packed in call order.
+// n_cu, tile_rows: the band CNN's tile forms of a mixed-size plan are chosen (and its tile lists written) here.
+static void build_plan(Plan &p, int B, const int *Hs, const int *Ws, const size_t *rgb_off, int ME, int n_cu = 256, int tile_rows = 0, bool force_ragged = false)
 {
     const int M = ME & 0xFF, Q = 1 << (ME >> 8);
-    p.B = B; p.H = H; p.W = W; p.M = M; p.Q = Q;
-    const size_t plane = (size_t)H * W;
+    p.B = B; p.ME = ME; p.M = M; p.Q = Q;
+    p.uniform = !force_ragged;
+    for (int b = 1; b < B; ++b) if (Hs[b] != Hs[0] || Ws[b] != Ws[0]) p.uniform = false;
+    {
+        long pos = 0;
+        for (int b = 0; b < B; ++b) { if (rgb_off && (long)rgb_off[b] != pos) p.uniform = false; pos += 3L * Hs[b] * Ws[b]; }      // (the division form of the kernels assumes tightly packed images)
+    }
+    p.vec_ok = true;
+    p.key.clear();
+    p.key.reserve(3 + 3 * (size_t)B);
+    p.key.push_back(ME); p.key.push_back(B); p.key.push_back(tile_rows * 2 + (force_ragged ? 1 : 0));
+    // images: sizes, header constants, placement (mixed sizes: planes / fplanes blocks start at multiples of 64 elements; equal sizes: tightly
+    // packed, [B][3][H][W] -- what the division form of the band CNN and the AC container's kernels index)
+    p.img.assign(B, ImgGeo{});
+    long pix = 0, rgb_pos = 0;
+    p.max_plane = 0;
+    for (int b = 0; b < B; ++b) {
+        ImgGeo &ig = p.img[b];
+        ig.H = Hs[b]; ig.W = Ws[b];
+        const Geom g4 = make_geom(1, ig.H, ig.W, 4);
+        ig.h4 = g4.h; ig.w4 = g4.w; ig.padint = pad_int(ig.H, ig.W); ig.hdr_bytes = 17 + 3 * g4.h * g4.w;
+        ig.plane = (long)ig.H * ig.W;
+        ig.pix_off = pix;
+        pix += p.uniform ? 3 * ig.plane : (long)align_up((size_t)(3 * ig.plane), 64);
+        ig.rgb_off = rgb_off ? (long)rgb_off[b] : rgb_pos;
+        rgb_pos += 3 * ig.plane;
+        if ((ig.plane & 3) || (ig.rgb_off & 3)) p.vec_ok = false;
+        p.rgb_bytes = std::max(p.rgb_bytes, (size_t)(ig.rgb_off + 3 * ig.plane));
+        p.max_plane = std::max(p.max_plane, ig.plane);
+        p.key.push_back(ig.H); p.key.push_back(ig.W); p.key.push_back(ig.rgb_off);
+    }
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
     p.off_status = take(kStatusHead * sizeof(int32_t) + (size_t)B * sizeof(int32_t));   // [0]: the call's status; [kStatusHead + b]: image b's
     p.off_minmax = take((size_t)B * 4 * sizeof(int32_t));
     p.off_lift_part = take((size_t)kLiftMaxParts * 4 * sizeof(int32_t));
-    p.off_planes = take((size_t)B * 3 * plane * sizeof(int16_t));
-    p.off_fplanes = take((size_t)B * 3 * plane * sizeof(float));
-    Geom g0 = make_geom(B, H, W, 0);
-    p.off_params = take((size_t)B * g0.h * g0.w * LLICTI_PARAM_STRIDE * sizeof(float));
-    // pairs + slots
+    p.off_planes = take((size_t)pix * sizeof(int16_t));
+    p.off_fplanes = take((size_t)pix * sizeof(float));
+    // levels: geometry and the placement of every image's CNN outputs
+    p.geo.assign((size_t)LLICTI_NLEVELS * B, Geom{});
+    for (int lvl = 0; lvl < LLICTI_NLEVELS; ++lvl) {
+        size_t fl = 0;
+        p.lev_maxpos[lvl] = 0;
+        for (int b = 0; b < B; ++b) {
+            Geom g = make_geom(B, Hs[b], Ws[b], lvl);
+            p.lev_maxpos[lvl] = std::max(p.lev_maxpos[lvl], (long)g.h * g.w);
+            g.pix_off = p.img[b].pix_off;
+            g.par_off = (long)fl;
+            fl += (size_t)g.h * g.w * LLICTI_PARAM_STRIDE;
+            p.geo[(size_t)lvl * B + b] = g;
+        }
+        p.lev_floats[lvl] = fl;
+    }
+    p.off_params = take(std::max(p.lev_floats[0], 3 * p.lev_floats[1]) * sizeof(float));
+    // stages: pairs, streams, AC slots
+    p.sg.assign((size_t)LLICTI_NLEVELS * 3 * B, StageGeom{});
     p.desc.assign((size_t)LLICTI_NSTREAMS * B, StreamDesc{});
-    p.slot_off.assign((size_t)LLICTI_NSTREAMS * B, 0);
-    p.slot_cap.assign((size_t)LLICTI_NSTREAMS * B, 0);
-    p.pair_base.assign(LLICTI_NLEVELS * 3, 0);
+    if (M == 0) { p.slot_off.assign((size_t)LLICTI_NSTREAMS * B, 0); p.slot_cap.assign((size_t)LLICTI_NSTREAMS * B, 0); }
     long pair_pos = 0, slot_pos = 0;
-    size_t container = 17;
-    Geom g4 = make_geom(B, H, W, 4);
-    container += 3 * (size_t)g4.h * g4.w;
+    std::vector<size_t> container(B);
+    for (int b = 0; b < B; ++b) container[b] = (size_t)p.img[b].hdr_bytes;
     for (int lvl = LLICTI_NLEVELS - 1; lvl >= 0; --lvl) {
-        Geom g = make_geom(B, H, W, lvl);
         for (int band = 0; band < 3; ++band) {
-            int hc, wc;
-            coded_dims(g, band, &hc, &wc);
-            const long nc = (long)hc * wc;
+            StageGeom *sgr = &p.sg[(size_t)(lvl * 3 + band) * B];
+            long cs = 0;
+            for (int b = 0; b < B; ++b) {
+                sgr[b] = make_stage(p.geo[(size_t)lvl * B + b], band);
+                sgr[b].pair_off = cs;
+                cs += (long)sgr[b].hc * sgr[b].wc;
+            }
+            for (int b = 0; b < B; ++b) sgr[b].pair_cs = cs;
             p.pair_base[lvl * 3 + band] = pair_pos;
             for (int clr = 0; clr < 3; ++clr) {
                 const int st = stage_index(lvl, band, clr);
-                const int cap = (int)align_up((size_t)(2 * nc + 8 + 16), 16);   // <= 16 bits per symbol + termination + zero pad
                 for (int b = 0; b < B; ++b) {
+                    const long nc = (long)sgr[b].hc * sgr[b].wc;
                     StreamDesc &d = p.desc[(size_t)st * B + b];
-                    d.pair_off = pair_pos + ((long)clr * B + b) * nc;
-                    d.out_off = slot_pos;
+                    d.pair_off = pair_pos + (long)clr * cs + sgr[b].pair_off;
                     d.n = (int)nc;
-                    d.cap = cap - 16;
-                    p.slot_off[(size_t)st * B + b] = slot_pos;
-                    p.slot_cap[(size_t)st * B + b] = cap;
-                    slot_pos += cap;
+                    if (M == 0) {
+                        const int cap = (int)align_up((size_t)(2 * nc + 8 + 16), 16);   // <= 16 bits per symbol + termination + zero pad
+                        d.out_off = slot_pos;
+                        d.cap = cap - 16;
+                        p.slot_off[(size_t)st * B + b] = slot_pos;
+                        p.slot_cap[(size_t)st * B + b] = cap;
+                        slot_pos += cap;
+                    }
+                    container[b] += (size_t)(2 * nc + 8);
                 }
-                container += (size_t)(2 * nc + 8);
             }
-            pair_pos += 3L * B * nc;
+            pair_pos += 3 * cs;
         }
     }
-    p.max_container = align_up(container + 64 * 45, 16);
+    p.max_container = 0;
+    for (int b = 0; b < B; ++b) p.max_container = std::max(p.max_container, align_up(container[b] + 64 * 45, 16));
     p.off_pairs = take((size_t)pair_pos * sizeof(uint32_t));
     if (M > 0) {
         // worst case of one stream: every symbol emits 16 bits; chunks are dealt round-robin, so a
-        // stream gets at most ceil(nchunks / M) chunks of every stage
-        long syms = 0;
+        // stream gets at most ceil(nchunks / M) chunks of every stage (sized for the batch's largest image)
         const int L = 64 * Q;
-        for (int st = 0; st < LLICTI_NSTREAMS; ++st) {
-            const long nchunks = (p.desc[(size_t)st * B].n + L - 1) / L;
-            syms += (nchunks + M - 1) / M * L;
-        }
         const int pay_bytes = Q * RansGeo<1>::kPayBytes;
-        p.rslot_cap = (int)align_up((size_t)(2 * syms + 4 + 8 + pay_bytes + 16 + 64), 64);   // + T, the 31-bit states, slack, zero pad
+        p.rslot_cap = 0;
+        for (int b = 0; b < B; ++b) {
+            long syms = 0, all_syms = 0;
+            for (int st = 0; st < LLICTI_NSTREAMS; ++st) {
+                const long n = p.desc[(size_t)st * B + b].n;
+                const long nchunks = (n + L - 1) / L;
+                syms += (nchunks + M - 1) / M * L;
+                all_syms += (n + 63) / 64 * 64;
+            }
+            p.rslot_cap = std::max(p.rslot_cap, (int)align_up((size_t)(2 * syms + 4 + 8 + pay_bytes + 16 + 64), 64));   // + T, the 31-bit states, slack, zero pad
+            // container bound: the streams together hold every symbol once (<= 16 bits each, whole chunks), plus per stream T | pad, the
+            // 64 final states, a table entry (M > 32) and the byte the bit region rounds up to
+            p.max_container = std::max(p.max_container, align_up((size_t)p.img[b].hdr_bytes + (size_t)(2 * all_syms) + (size_t)M * (2 + pay_bytes + 4 + 4) + 64, 16));
+        }
         p.rslot_off.assign((size_t)B * M, 0);
         for (long i = 0; i < (long)B * M; ++i) p.rslot_off[i] = (long)i * p.rslot_cap;
-        slot_pos = std::max<long>(slot_pos, (long)B * M * p.rslot_cap);
-        // container bound: the streams together hold every symbol once (<= 16 bits each, whole chunks), plus per stream T | pad, the
-        // 64 final states, a table entry (M > 32) and the byte the bit region rounds up to
-        long all_syms = 0;
-        for (int st = 0; st < LLICTI_NSTREAMS; ++st) all_syms += (p.desc[(size_t)st * B].n + 63) / 64 * 64;
-        p.max_container = std::max(p.max_container, align_up((size_t)(17 + 3 * g4.h * g4.w) + (size_t)(2 * all_syms) + (size_t)M * (2 + pay_bytes + 4 + 4) + 64, 16));
+        slot_pos = (long)B * M * p.rslot_cap;
     }
     p.off_slots = take((size_t)slot_pos);
     const size_t ns = (size_t)B * std::max(M, 32);
@@ -278,28 +414,57 @@ static void build_plan(Plan &p, int B, int H, int W, int ME)
     p.off_rpos = take(ns * sizeof(uint32_t));
     p.off_rtail = take(ns * sizeof(uint32_t));
     p.off_slot_len = take((size_t)LLICTI_NSTREAMS * B * sizeof(int32_t));
-    int hc0, wc0;
-    coded_dims(g0, 1, &hc0, &wc0);
-    for (int lvl = 0; lvl < LLICTI_NLEVELS; ++lvl) {
-        Geom gl = make_geom(B, H, W, lvl);
-        for (int band = 0; band < 3; ++band) {
-            int hcl, wcl;
-            coded_dims(gl, band, &hcl, &wcl);
-            p.ac_cap_rows = std::max(p.ac_cap_rows, ac_chunk_rows((long)hcl * wcl));
-        }
+    // AC decode (equal sizes only): one chunk buffer per colour channel -- full rows (512 x uint16) or anchor rows (kAnchorRow bytes), see ac_use_anchors()
+    size_t tables_bytes = 0;
+    p.ac_cap_rows = 0;
+    if (M == 0) {
+        for (int st = 0; st < LLICTI_NSTREAMS; ++st) p.ac_cap_rows = std::max(p.ac_cap_rows, ac_chunk_rows((long)p.desc[(size_t)st * B].n));
+        tables_bytes = (size_t)3 * B * p.ac_cap_rows * (ac_use_anchors(B) ? (size_t)kAnchorRow : (size_t)512 * sizeof(uint16_t));
     }
-    // one chunk buffer per colour channel: full rows (512 x uint16) or anchor rows (kAnchorRow bytes), see ac_use_anchors()
-    const size_t tables_bytes = (size_t)3 * B * p.ac_cap_rows * (ac_use_anchors(B) ? (size_t)kAnchorRow : (size_t)512 * sizeof(uint16_t));
-    p.off_tables = take(tables_bytes);
     {   // a second, quarter-size buffer for the CNN outputs of levels >= 1 (llicti_set_tuning("enc_side_levels"): the encoder's coarse levels
-        // on a side stream).  Only the encoder uses it and only the AC DECODER uses the chunk tables, so it shares their bytes where they suffice.
-        Geom g1 = make_geom(B, H, W, 1);
-        const size_t need = (size_t)B * g1.h * g1.w * LLICTI_PARAM_STRIDE * sizeof(float);
-        p.off_params2 = (tables_bytes >= need) ? p.off_tables : (size_t)-1;      // no room (anchor-row tables of a very large batch): the switch is ignored there
+        // on a side stream).  Only the encoder uses it and only the AC DECODER uses the chunk tables, so the two share their bytes.
+        tables_bytes = std::max(tables_bytes, p.lev_floats[1] * sizeof(float));
+        p.off_tables = take(tables_bytes);
+        p.off_params2 = p.off_tables;
     }
     static_assert(kAnchorRow <= 1024, "anchor rows must fit the full-row buffer");
     p.off_acstate = take((size_t)3 * B * 8 * sizeof(uint32_t));
     p.total = o;
+    // mixed sizes: the band CNN's tile lists (image-major, rows, columns: the order the division form walks)
+    p.tiles.clear();
+    for (int k = 0; k < LLICTI_NLEVELS * 3; ++k) p.run[k] = TileRun{};
+    if (!p.uniform) {
+        for (int lvl = 0; lvl < LLICTI_NLEVELS; ++lvl) {
+            const Geom *gl = &p.geo[(size_t)lvl * B];
+            auto count = [&](int th) -> long {
+                long t = 0;
+                for (int b = 0; b < B; ++b) t += (long)((gl[b].w + kTileW - 1) / kTileW) * ((gl[b].h + th - 1) / th);
+                return t;
+            };
+            for (int band = 0; band < 3; ++band) {
+                const TileForm f = choose_tile_form(n_cu, tile_rows, band, count);
+                TileRun &r = p.run[lvl * 3 + band];
+                r.off = p.tiles.size(); r.n_tiles = (int)std::min<long>(f.n_tiles, 0x7FFFFFFFL); r.TH = f.TH; r.gx = f.gx;
+                for (int b = 0; b < B; ++b) {
+                    const int tx_n = (gl[b].w + kTileW - 1) / kTileW, ty_n = (gl[b].h + f.TH - 1) / f.TH;
+                    for (int ty = 0; ty < ty_n; ++ty)
+                        for (int tx = 0; tx < tx_n; ++tx) p.tiles.push_back(make_int2(b, (ty << 16) | tx));
+                }
+            }
+        }
+    }
+    // the device block: every table at a 256-byte boundary
+    size_t d = 0;
+    auto dtake = [&](size_t bytes) { size_t r = d; d = align_up(d + bytes, 256); return r; };
+    p.d_img = dtake(p.img.size() * sizeof(ImgGeo));
+    p.d_geo = dtake(p.geo.size() * sizeof(Geom));
+    p.d_sg = dtake(p.sg.size() * sizeof(StageGeom));
+    p.d_desc = dtake(p.desc.size() * sizeof(StreamDesc));
+    p.d_slot_off = dtake(p.slot_off.size() * sizeof(long));
+    p.d_slot_cap = dtake(p.slot_cap.size() * sizeof(int32_t));
+    p.d_rslot_off = dtake(p.rslot_off.size() * sizeof(long));
+    p.d_tiles = dtake(p.tiles.size() * sizeof(int2));
+    p.d_total = d;
 }
 
 // mode: 0 = AC container (torchac-compatible, the reference's format); 0x100 | M = rANS container (v3) with M
@@ -335,24 +500,39 @@ static int rans_streams_of_byte0(int b0)      // -> M (| 0x100 for wide, | 0x200
     return (v == 30 ? 32 : v == 31 ? 64 : v - 15) | 0x200;
 }
 
-extern "C" size_t llicti_workspace_bytes(int B, int H, int W, int mode)
+static int check_dims_v(int B, const int *Hs, const int *Ws)
+{
+    if (B < 1 || !Hs || !Ws) return fail(LLICTI_EINVAL, "bad batch: B=%d (need B>=1 and the sizes of every image)", B);
+    for (int b = 0; b < B; ++b)
+        if (Hs[b] < 32 || Ws[b] < 32 || Hs[b] > 8160 || Ws[b] > 8160) return fail(LLICTI_EINVAL, "bad shape of image %d: H=%d W=%d (need 32<=H,W<=8160)", b, Hs[b], Ws[b]);
+    return 0;
+}
+extern "C" size_t llicti_workspace_bytes_v(int B, const int *Hs, const int *Ws, int mode)
 {
     const int ME = mode_streams(mode);
-    if (check_dims(B, H, W) || ME < 0) return 0;
-    Plan p;
-    build_plan(p, B, H, W, ME);
-    return p.total;
+    if (check_dims_v(B, Hs, Ws) || ME < 0) return 0;
+    Plan p, q;
+    build_plan(p, B, Hs, Ws, nullptr, ME);
+    build_plan(q, B, Hs, Ws, nullptr, ME, 256, 0, true);      // (llicti_set_tuning("force_ragged"): image blocks at 64-element boundaries)
+    return std::max(p.total, q.total);
+}
+extern "C" size_t llicti_workspace_bytes(int B, int H, int W, int mode)
+{
+    if (check_dims(B, H, W)) return 0;
+    std::vector<int> Hs(B, H), Ws(B, W);
+    return llicti_workspace_bytes_v(B, Hs.data(), Ws.data(), mode);
 }
 extern "C" size_t llicti_max_container_bytes(int H, int W)
 {
     if (check_dims(1, H, W)) return 0;
     Plan p, q;
-    build_plan(p, 1, H, W, 32);     // covers the AC container and M <= 32 ...
-    build_plan(q, 1, H, W, kRansMaxStreams);     // ... and the many-stream latency modes (more per-stream slack)
-    Plan w, x;
-    build_plan(w, 1, H, W, 14 | 0x100);          // ... and wide ...
-    build_plan(x, 1, H, W, 64 | 0x200);          // ... and xwide streams (larger state blocks)
-    return std::max(std::max(p.max_container, q.max_container), std::max(w.max_container, x.max_container));
+    build_plan(p, 1, &H, &W, nullptr, 32);     // covers the AC container and M <= 32 ...
+    build_plan(q, 1, &H, &W, nullptr, kRansMaxStreams);     // ... and the many-stream latency modes (more per-stream slack)
+    Plan a, w, x;
+    build_plan(a, 1, &H, &W, nullptr, 0);
+    build_plan(w, 1, &H, &W, nullptr, 14 | 0x100);          // ... and wide ...
+    build_plan(x, 1, &H, &W, nullptr, 64 | 0x200);          // ... and xwide streams (larger state blocks)
+    return std::max(std::max(std::max(p.max_container, q.max_container), std::max(w.max_container, x.max_container)), a.max_container);
 }
 
 extern "C" int llicti_create(llicti_ctx **out, int device)
@@ -391,15 +571,13 @@ extern "C" int llicti_create(llicti_ctx **out, int device)
     for (int k = 0; k < 2; ++k) HIPCHK(hipEventCreateWithFlags(&c->ev_enc[k], hipEventDisableTiming));
     for (int i = 1; i < kMaxSub; ++i) HIPCHK(hipStreamCreateWithFlags(&c->sub[i], hipStreamNonBlocking));
     // the band CNN stages a whole head (up to 86 KB) in LDS
-    HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(0)));
-    HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(1)));
-    HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(2)));
-    HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<0, kTileHMid>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(0, kTileHMid)));
-    HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<1, kTileHMid>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(1, kTileHMid)));
-    HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<2, kTileHMid>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(2, kTileHMid)));
-    HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<0, kTileHSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(0, kTileHSmall)));
-    HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<1, kTileHSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(1, kTileHSmall)));
-    HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<2, kTileHSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(2, kTileHSmall)));
+#define LLICTI_CNN_ATTR(BAND, TH_) \
+    HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<BAND, TH_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(BAND, TH_))); \
+    HIPCHK(hipFuncSetAttribute((const void *)band_params_kernel<BAND, TH_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cnn_lds_bytes(BAND, TH_)))
+    LLICTI_CNN_ATTR(0, kTileHMax); LLICTI_CNN_ATTR(1, kTileHMax); LLICTI_CNN_ATTR(2, kTileHMax);
+    LLICTI_CNN_ATTR(0, kTileHMid); LLICTI_CNN_ATTR(1, kTileHMid); LLICTI_CNN_ATTR(2, kTileHMid);
+    LLICTI_CNN_ATTR(0, kTileHSmall); LLICTI_CNN_ATTR(1, kTileHSmall); LLICTI_CNN_ATTR(2, kTileHSmall);
+#undef LLICTI_CNN_ATTR
     *out = c;
     return LLICTI_OK;
 }
@@ -411,7 +589,15 @@ extern "C" int llicti_destroy(llicti_ctx *c)
     DeviceGuard guard(c);
     (void)hipDeviceSynchronize();
     for (int b = 0; b < 3; ++b) if (c->d_pack[b]) hipFree(c->d_pack[b]);
-    for (auto &kv : c->plans) delete kv.second;
+    for (auto &kv : c->plans) { c->pool.push_back(kv.second->blk); delete kv.second; }
+    c->plans.clear();
+    for (PlanBlock &bk : c->pool) {
+        if (bk.dev) (void)hipFree(bk.dev);
+        if (bk.host) (void)hipHostFree(bk.host);
+        if (bk.done) (void)hipEventDestroy(bk.done);
+        if (bk.uploaded) (void)hipEventDestroy(bk.uploaded);
+    }
+    c->pool.clear();
     for (int i = 0; i < kMaxSub; ++i) {
         if (c->sub[i]) hipStreamDestroy(c->sub[i]);
     }
@@ -449,6 +635,13 @@ extern "C" int llicti_set_band_weights(llicti_ctx *c, int band, int K0, const fl
     return LLICTI_OK;
 }
 
+// every cached plan back to the block pool (no device work: the blocks wait there for their last users)
+static void drop_plans(llicti_ctx *c)
+{
+    for (auto &kv : c->plans) { c->pool.push_back(kv.second->blk); delete kv.second; }
+    c->plans.clear();
+}
+
 extern "C" int llicti_set_tuning(llicti_ctx *c, const char *key, int value)
 {
     if (!c || !key) return fail(LLICTI_EINVAL, "set_tuning: null argument");
@@ -460,6 +653,7 @@ extern "C" int llicti_set_tuning(llicti_ctx *c, const char *key, int value)
     if (!strcmp(key, "cnn_tile_rows")) {
         if (value != 0 && value != kTileHMax && value != kTileHMid && value != kTileHSmall && value != -1)
             return fail(LLICTI_EINVAL, "set_tuning: cnn_tile_rows must be 0 (automatic), %d, %d or %d (-1: round 3's rule, 16 or 4)", kTileHMax, kTileHMid, kTileHSmall);
+        if (c->cnn_tile_rows != value) drop_plans(c);       // (a mixed-size plan holds the tile lists of the forms chosen when it was built)
         c->cnn_tile_rows = value;
         return LLICTI_OK;
     }
@@ -468,9 +662,9 @@ extern "C" int llicti_set_tuning(llicti_ctx *c, const char *key, int value)
         c->enc_side_levels = value;
         return LLICTI_OK;
     }
-    if (!strcmp(key, "enc_chunk_images")) {
-        if (value < 0) return fail(LLICTI_EINVAL, "set_tuning: enc_chunk_images must be >= 0");
-        c->enc_chunk_images = value;
+    if (!strcmp(key, "force_ragged")) {
+        if (value < 0 || value > 1) return fail(LLICTI_EINVAL, "set_tuning: force_ragged must be 0 or 1");
+        c->force_ragged = value;
         return LLICTI_OK;
     }
     return fail(LLICTI_EINVAL, "set_tuning: unknown key '%s'", key);
@@ -485,89 +679,66 @@ extern "C" int llicti_set_profiling(llicti_ctx *c, int enable)
 
 // ------------------------------------------------------------------------------------------------ launches
 // part: scratch of kLiftMaxParts x 4 int32 (the workspace's for the whole-batch calls, the context's for llicti_lift_u8)
-static int launch_lift(const uint8_t *d_rgb, int B, int H, int W, int16_t *planes, float *fplanes, int32_t *mm, int32_t *part, hipStream_t s,
-                       int32_t *zero = nullptr, int n_zero = 0)
+static int launch_lift(const uint8_t *d_rgb, int B, long plane, bool vec_ok, int16_t *planes, float *fplanes, int32_t *mm, int32_t *part, hipStream_t s,
+                       int32_t *zero = nullptr, int n_zero = 0, const ImgGeo *iv = nullptr)
 {
-    const long plane = (long)H * W;
-    const bool vec = (plane % 4 == 0) && (((uintptr_t)d_rgb | (uintptr_t)planes | (uintptr_t)fplanes) % 16 == 0);
+    // plane: H * W (with a table: of the batch's largest image -- it sizes the grid); vec_ok: every image's plane size and placement allow
+    // 4-pixel accesses
+    const bool vec = vec_ok && (plane % 4 == 0) && (((uintptr_t)d_rgb | (uintptr_t)planes | (uintptr_t)fplanes) % 16 == 0);
     const long want = vec ? (plane / 4 + 255) / 256 : (plane + 255) / 256;
     const int gx = (int)std::max<long>(1, std::min<long>(std::min<long>(want, std::max(8, 4096 / B)), kLiftMaxParts / B));
     if ((long)B * gx > kLiftMaxParts) return fail(LLICTI_EINVAL, "lift: batch of %d images exceeds the partials scratch", B);
-    if (vec) lift_kernel<4><<<dim3(gx, B), 256, 0, s>>>(d_rgb, plane, planes, fplanes, part, zero, n_zero);
-    else lift_kernel<1><<<dim3(gx, B), 256, 0, s>>>(d_rgb, plane, planes, fplanes, part, zero, n_zero);
+    if (vec) lift_kernel<4><<<dim3(gx, B), 256, 0, s>>>(d_rgb, plane, planes, fplanes, part, zero, n_zero, iv);
+    else lift_kernel<1><<<dim3(gx, B), 256, 0, s>>>(d_rgb, plane, planes, fplanes, part, zero, n_zero, iv);
     minmax_reduce_kernel<<<B, 64, 0, s>>>(part, gx, mm);
     HIPCHK(hipGetLastError());
     return 0;
 }
 
-static int launch_band_params(llicti_ctx *c, const float *fplanes, const Geom &g, int band, float *params, hipStream_t s)
+// One band-CNN launch.  Equal sizes (tiles == nullptr): B images of g's size, tile -> image by division; mixed sizes: the plan's tile list of
+// this (level, band) and its per-image geometry table, form and grid chosen when the plan was built.
+static int launch_band_params(llicti_ctx *c, const float *fplanes, const Geom &g, int band, float *params, hipStream_t s,
+                              const Geom *gv = nullptr, const int2 *tiles = nullptr, const TileRun *run = nullptr)
 {
     if (!c->have[band]) return fail(LLICTI_ENOWEIGHTS, "band %d weights not set", band);
-    // Tile height (16, 8 or 4 rows; one wavefront per row, so 16 / 8 / 4 wavefronts per workgroup): the form whose launch is shortest
-    // under a two-parameter model of the persistent grid -- rounds = ceil(tiles / workgroups that fit the chip), a round = a fixed part
-    // (halo rows, staging the head's weights, barrier) + a part per tile row; the constants are the measured 46 / 25 / 15 us of a band-2
-    // tile of 16 / 8 / 4 rows.  Full launches come out at 16 rows; launches of one to three half-empty rounds (levels 3 and 4 of a batch
-    // of 24) at 8; launches that cannot give every compute unit a workgroup (coarse levels of a single image) at 4.  Every form computes
-    // each position with the same fmaf chains: the results do not depend on it (test_band_params_bitexact_and_golden runs all three).
     const int tiles_x = (g.w + kTileW - 1) / kTileW;
-    auto plan_for = [&](int th, int *gx_out, long *tiles_out) -> double {
-        const long tiles = (long)g.B * tiles_x * ((g.h + th - 1) / th);
-        const int per_cu = std::max(1, std::min(4, (160 * 1024) / cnn_lds_bytes(band, th)));
-        const long gx = std::max<long>(1, std::min<long>(tiles, (long)c->n_cu * per_cu / 4));
-        *gx_out = (int)gx; *tiles_out = tiles;
-        return (double)((tiles + gx - 1) / gx) * (4.7 + 2.6 * th);
-    };
-    int TH = kTileHMax, gx = 1;
-    long n_tiles_l = 0;
-    if (c->cnn_tile_rows > 0) { TH = c->cnn_tile_rows; (void)plan_for(TH, &gx, &n_tiles_l); }
-    else if (c->cnn_tile_rows < 0) {                       // round 3's rule (A/B): 4 rows iff the 16-row tiles cannot fill the chip
-        const long tiles16 = (long)g.B * tiles_x * ((g.h + kTileHMax - 1) / kTileHMax);
-        TH = (4 * tiles16 < c->n_cu) ? kTileHSmall : kTileHMax;
-        (void)plan_for(TH, &gx, &n_tiles_l);
-    } else {
-        // Launches of one or two rounds of 16-row tiles (coarse levels, single images) are priced from a table instead: a launch's first
-        // round and its later ones per (band, form), measured on single-image launches (rocprofv3, tools/single_image_trace.py) -- the linear
-        // model is off exactly there: a 4-row tile of band 2 takes 21-25 us, not 15 (one wavefront per SIMD cannot keep the matrix pipe busy and
-        // 120 input channels are the longest layer 0), so three rounds of them lost to ONE round of 16-row tiles at level 1 of a lone image
-        // (75 against 47 us).  Band 0 fits two workgroups per compute unit: its rounds are priced as shared.
-        static const double kFirstUs[3][3] = { { 31.5, 18.1, 12.5 }, { 36.4, 20.8, 14.5 }, { 46.3, 26.2, 21.4 } };      // [band][16, 8, 4 rows]
-        static const double kLaterUs[3][3] = { { 31.0, 17.0, 11.0 }, { 36.4, 19.0, 11.2 }, { 46.0, 23.9, 25.2 } };
-        static const double kSharedUs[3] = { 61.3, 31.2, 16.7 };                                                            // band 0, two workgroups per CU
-        int gx16; long nt16;
-        (void)plan_for(kTileHMax, &gx16, &nt16);
-        const bool small_launch = (nt16 + gx16 - 1) / gx16 <= 2;
-        double best = 0;
-        int fi = 0;
-        for (int th : { kTileHMax, kTileHMid, kTileHSmall }) {
-            int gx_t; long nt;
-            double t = plan_for(th, &gx_t, &nt);
-            if (small_launch) {
-                const long rounds = (nt + gx_t - 1) / gx_t;
-                const bool shared = 4L * gx_t > c->n_cu;                   // more workgroups (4 heads) than compute units
-                t = shared ? 2.0 + rounds * kSharedUs[fi] : kFirstUs[band][fi] + (rounds - 1) * kLaterUs[band][fi];
-            }
-            if (th == kTileHMax || t < 0.995 * best) { best = t; TH = th; gx = gx_t; n_tiles_l = nt; }    // ties go to the larger form
-            ++fi;
-        }
+    int TH, gx;
+    long n_tiles_l;
+    if (tiles) { TH = run->TH; gx = run->gx; n_tiles_l = run->n_tiles; }
+    else {
+        const TileForm f = choose_tile_form(c->n_cu, c->cnn_tile_rows, band, [&](int th) { return (long)g.B * tiles_x * ((g.h + th - 1) / th); });
+        TH = f.TH; gx = f.gx; n_tiles_l = f.n_tiles;
     }
     const int tiles_y = (g.h + TH - 1) / TH;
-    if (n_tiles_l > 0x7FFFFFFFL) return fail(LLICTI_EINVAL, "band_params: too many tiles");
+    if (n_tiles_l > 0x7FFFFFFFL || n_tiles_l < 1) return fail(LLICTI_EINVAL, "band_params: bad tile count");
     const int n_tiles = (int)n_tiles_l;
     const int lds_bytes = cnn_lds_bytes(band, TH);
     const int kCnnThreads = 64 * TH;
     dim3 grid((unsigned)gx, 4);
     ProfSpan span(c, PROF_CNN, s, g.lvl);
-    switch (band + (TH == kTileHSmall ? 3 : TH == kTileHMid ? 6 : 0)) {
-    case 0: band_params_kernel<0><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[0], params, tiles_x, tiles_y, n_tiles); break;
-    case 1: band_params_kernel<1><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[1], params, tiles_x, tiles_y, n_tiles); break;
-    case 2: band_params_kernel<2><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[2], params, tiles_x, tiles_y, n_tiles); break;
-    case 3: band_params_kernel<0, kTileHSmall><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[0], params, tiles_x, tiles_y, n_tiles); break;
-    case 4: band_params_kernel<1, kTileHSmall><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[1], params, tiles_x, tiles_y, n_tiles); break;
-    case 5: band_params_kernel<2, kTileHSmall><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[2], params, tiles_x, tiles_y, n_tiles); break;
-    case 6: band_params_kernel<0, kTileHMid><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[0], params, tiles_x, tiles_y, n_tiles); break;
-    case 7: band_params_kernel<1, kTileHMid><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[1], params, tiles_x, tiles_y, n_tiles); break;
-    default: band_params_kernel<2, kTileHMid><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[2], params, tiles_x, tiles_y, n_tiles); break;
+#define LLICTI_CNN_LAUNCH(BAND, TH_, RAG) band_params_kernel<BAND, TH_, RAG><<<grid, kCnnThreads, lds_bytes, s>>>(fplanes, g, c->d_pack[BAND], params, tiles_x, tiles_y, n_tiles, gv, tiles)
+    const int form = band + (TH == kTileHSmall ? 3 : TH == kTileHMid ? 6 : 0) + (tiles ? 9 : 0);
+    switch (form) {
+    case 0: LLICTI_CNN_LAUNCH(0, kTileHMax, false); break;
+    case 1: LLICTI_CNN_LAUNCH(1, kTileHMax, false); break;
+    case 2: LLICTI_CNN_LAUNCH(2, kTileHMax, false); break;
+    case 3: LLICTI_CNN_LAUNCH(0, kTileHSmall, false); break;
+    case 4: LLICTI_CNN_LAUNCH(1, kTileHSmall, false); break;
+    case 5: LLICTI_CNN_LAUNCH(2, kTileHSmall, false); break;
+    case 6: LLICTI_CNN_LAUNCH(0, kTileHMid, false); break;
+    case 7: LLICTI_CNN_LAUNCH(1, kTileHMid, false); break;
+    case 8: LLICTI_CNN_LAUNCH(2, kTileHMid, false); break;
+    case 9: LLICTI_CNN_LAUNCH(0, kTileHMax, true); break;
+    case 10: LLICTI_CNN_LAUNCH(1, kTileHMax, true); break;
+    case 11: LLICTI_CNN_LAUNCH(2, kTileHMax, true); break;
+    case 12: LLICTI_CNN_LAUNCH(0, kTileHSmall, true); break;
+    case 13: LLICTI_CNN_LAUNCH(1, kTileHSmall, true); break;
+    case 14: LLICTI_CNN_LAUNCH(2, kTileHSmall, true); break;
+    case 15: LLICTI_CNN_LAUNCH(0, kTileHMid, true); break;
+    case 16: LLICTI_CNN_LAUNCH(1, kTileHMid, true); break;
+    default: LLICTI_CNN_LAUNCH(2, kTileHMid, true); break;
     }
+#undef LLICTI_CNN_LAUNCH
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -578,7 +749,7 @@ extern "C" int llicti_lift_u8(llicti_ctx *c, const uint8_t *d_rgb, int B, int H,
     if (!c || !d_rgb || !d_planes || !d_fplanes || !d_minmax) return fail(LLICTI_EINVAL, "lift: null pointer");
     DeviceGuard guard(c);
     if (check_dims(B, H, W)) return LLICTI_EINVAL;
-    return launch_lift(d_rgb, B, H, W, d_planes, d_fplanes, d_minmax, c->d_lift_part, (hipStream_t)stream);
+    return launch_lift(d_rgb, B, (long)H * W, true, d_planes, d_fplanes, d_minmax, c->d_lift_part, (hipStream_t)stream);
 }
 
 extern "C" int llicti_unlift_u8(llicti_ctx *c, const int16_t *d_planes, int B, int H, int W, uint8_t *d_rgb, void *stream)
@@ -588,7 +759,7 @@ extern "C" int llicti_unlift_u8(llicti_ctx *c, const int16_t *d_planes, int B, i
     if (check_dims(B, H, W)) return LLICTI_EINVAL;
     const long plane = (long)H * W;
     const int gx = (int)std::min<long>((plane + 255) / 256, 1024);
-    unlift_kernel<<<dim3(gx, B), 256, 0, (hipStream_t)stream>>>(d_planes, plane, d_rgb, nullptr, 0, nullptr, nullptr);
+    unlift_kernel<<<dim3(gx, B), 256, 0, (hipStream_t)stream>>>(d_planes, plane, d_rgb, nullptr, 0, nullptr, nullptr, nullptr);
     HIPCHK(hipGetLastError());
     return LLICTI_OK;
 }
@@ -633,13 +804,14 @@ extern "C" int llicti_selfinfo_f32(llicti_ctx *c, const float *d_fplanes, const 
     return LLICTI_OK;
 }
 
-// pair_batch: images of the whole batch (the [clr][image][n] layout of `pairs`); g.B may be a sub-batch whose pointers the caller has shifted
+// kernel-level entry point: B images of one size, pairs [clr][B][n]
 static int launch_cdf_pairs(const int16_t *planes, const float *params, const int32_t *mm, const Geom &g, int band,
-                            uint32_t *pairs, int pair_batch, hipStream_t s)
+                            uint32_t *pairs, hipStream_t s)
 {
     StageGeom sg = make_stage(g, band);
+    sg.pair_cs = (long)g.B * sg.hc * sg.wc;
     const long np = (long)sg.h * sg.w;                    // the kernel walks the band grid (rows of CNN outputs are contiguous there)
-    cdf_pairs_kernel<<<dim3((unsigned)((np + kPairsThreads - 1) / kPairsThreads), g.B), kPairsThreads, 0, s>>>(planes, params, mm, sg, pairs, pair_batch);
+    cdf_pairs_kernel<<<dim3((unsigned)((np + kPairsThreads - 1) / kPairsThreads), g.B), kPairsThreads, 0, s>>>(planes, params, mm, sg, nullptr, pairs);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -689,7 +861,7 @@ extern "C" int llicti_cdf_pairs_u32(llicti_ctx *c, const int16_t *d_planes, cons
     if (check_dims(B, H, W)) return LLICTI_EINVAL;
     if (lvl < 0 || lvl >= LLICTI_NLEVELS || band < 0 || band > 2) return fail(LLICTI_EINVAL, "cdf_pairs: bad level/band");
     Geom g = make_geom(B, H, W, lvl);
-    return launch_cdf_pairs(d_planes, d_params, d_minmax, g, band, d_pairs, B, (hipStream_t)stream);
+    return launch_cdf_pairs(d_planes, d_params, d_minmax, g, band, d_pairs, (hipStream_t)stream);
 }
 
 extern "C" int llicti_ac_encode_u16cdf(llicti_ctx *c, const uint16_t *d_cdf, int Lp, int row_stride, const int16_t *d_sym,
@@ -724,32 +896,93 @@ extern "C" int llicti_ac_decode_u16cdf(llicti_ctx *c, const uint16_t *d_cdf, int
 }
 
 // ------------------------------------------------------------------------------------------------ whole batch
-static int get_plan(llicti_ctx *c, int B, int H, int W, int ME, PlanDev **out)      // ME: mode_streams() (streams | 0x100 for wide streams)
+// A block of >= need bytes for a new plan's tables: one from the pool whose last user has finished, else a new one.  Never hipFree
+// (which synchronises the device) before llicti_destroy; the pool is bounded by kMaxPlans + the blocks in flight.
+static int acquire_block(llicti_ctx *c, size_t need, PlanBlock *out)
 {
-    auto key = std::make_tuple(B, H, W, ME);
+    int pick = -1, busy_fit = -1;
+    for (int i = 0; i < (int)c->pool.size(); ++i) {
+        PlanBlock &bk = c->pool[i];
+        if (bk.cap < need) continue;
+        if (!bk.used || hipEventQuery(bk.done) == hipSuccess) { if (pick < 0 || bk.cap < c->pool[pick].cap) pick = i; }
+        else if (busy_fit < 0) busy_fit = i;
+    }
+    if (pick < 0 && busy_fit >= 0 && c->pool.size() >= 16) {      // plenty of blocks, all still in flight: wait for the oldest one's user (a stream-level wait)
+        HIPCHK(hipEventSynchronize(c->pool[busy_fit].done));
+        pick = busy_fit;
+    }
+    if (pick >= 0) {
+        *out = c->pool[pick];
+        c->pool.erase(c->pool.begin() + pick);
+        out->used = false;
+        return 0;
+    }
+    PlanBlock bk;
+    size_t cap = 256 << 10;
+    while (cap < need) cap *= 2;
+    bk.cap = cap;
+    if (hipMalloc(&bk.dev, cap) != hipSuccess) return fail(LLICTI_EHIP, "plan tables: hipMalloc(%zu) failed", cap);
+    if (hipHostMalloc(&bk.host, cap, hipHostMallocDefault) != hipSuccess) { (void)hipFree(bk.dev); return fail(LLICTI_EHIP, "plan tables: hipHostMalloc(%zu) failed", cap); }
+    if (hipEventCreateWithFlags(&bk.done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&bk.uploaded, hipEventDisableTiming) != hipSuccess) {
+        (void)hipFree(bk.dev); (void)hipHostFree(bk.host);
+        if (bk.done) (void)hipEventDestroy(bk.done);
+        return fail(LLICTI_EHIP, "plan tables: hipEventCreate failed");
+    }
+    *out = bk;
+    return 0;
+}
+
+// The plan of a batch: cached by (mode, sizes, placement).  A miss builds the tables on the host, copies them into a pinned block and
+// enqueues ONE asynchronous upload on the call's stream -- no device synchronisation, no allocation once the pool is warm.
+static int get_plan(llicti_ctx *c, int B, const int *Hs, const int *Ws, const size_t *rgb_off, int ME, hipStream_t s, PlanDev **out)
+{
+    std::vector<long> key;
+    key.reserve(3 + 3 * (size_t)B);
+    key.push_back(ME); key.push_back(B); key.push_back(c->cnn_tile_rows * 2 + (c->force_ragged ? 1 : 0));
+    {
+        long pos = 0;
+        for (int b = 0; b < B; ++b) { key.push_back(Hs[b]); key.push_back(Ws[b]); key.push_back(rgb_off ? (long)rgb_off[b] : pos); pos += 3L * Hs[b] * Ws[b]; }
+    }
     auto it = c->plans.find(key);
-    if (it != c->plans.end()) { *out = it->second; return 0; }
-    if (c->plans.size() >= 16) {      // bounded cache: drop everything (plans are cheap to rebuild)
-        HIPCHK(hipDeviceSynchronize());
-        for (auto &kv : c->plans) delete kv.second;
-        c->plans.clear();
+    if (it != c->plans.end()) {
+        PlanDev *pd = it->second;
+        pd->last_use = ++c->use_clock;
+        if (pd->blk.up_stream != s) HIPCHK(hipStreamWaitEvent(s, pd->blk.uploaded, 0));      // (uploaded on another stream: order behind it)
+        *out = pd;
+        return 0;
     }
-    std::unique_ptr<PlanDev> pd(new PlanDev());       // an early return below (HIPCHK) frees the plan and what it allocated
-    build_plan(pd->p, B, H, W, ME);
-    if (!pd->p.rslot_off.empty()) {
-        // the table holds B * p.M entries (p.M = ME & 0xFF), never B * ME
-        const size_t nb = pd->p.rslot_off.size() * sizeof(long);
-        if (pd->p.rslot_off.size() != (size_t)B * pd->p.M) return fail(LLICTI_EINVAL, "plan: stream slot table has %zu entries, expected %d x %d", pd->p.rslot_off.size(), B, pd->p.M);
-        HIPCHK(hipMalloc(&pd->d_rslot_off, nb));
-        HIPCHK(hipMemcpy(pd->d_rslot_off, pd->p.rslot_off.data(), nb, hipMemcpyHostToDevice));
+    std::unique_ptr<PlanDev> pd(new PlanDev());
+    Plan &p = pd->p;
+    build_plan(p, B, Hs, Ws, rgb_off, ME, c->n_cu, c->cnn_tile_rows, c->force_ragged != 0);
+    if (p.key != key) return fail(LLICTI_EINVAL, "plan: key mismatch");
+    if (!p.rslot_off.empty() && p.rslot_off.size() != (size_t)B * p.M)
+        return fail(LLICTI_EINVAL, "plan: stream slot table has %zu entries, expected %d x %d", p.rslot_off.size(), B, p.M);
+    if (int rc = acquire_block(c, p.d_total, &pd->blk)) return rc;
+    uint8_t *h = pd->blk.host;
+    auto put = [&](size_t off, const void *src, size_t n) { if (n) memcpy(h + off, src, n); };
+    put(p.d_img, p.img.data(), p.img.size() * sizeof(ImgGeo));
+    put(p.d_geo, p.geo.data(), p.geo.size() * sizeof(Geom));
+    put(p.d_sg, p.sg.data(), p.sg.size() * sizeof(StageGeom));
+    put(p.d_desc, p.desc.data(), p.desc.size() * sizeof(StreamDesc));
+    put(p.d_slot_off, p.slot_off.data(), p.slot_off.size() * sizeof(long));
+    put(p.d_slot_cap, p.slot_cap.data(), p.slot_cap.size() * sizeof(int32_t));
+    put(p.d_rslot_off, p.rslot_off.data(), p.rslot_off.size() * sizeof(long));
+    put(p.d_tiles, p.tiles.data(), p.tiles.size() * sizeof(int2));
+    bool ok = hipMemcpyAsync(pd->blk.dev, h, p.d_total, hipMemcpyHostToDevice, s) == hipSuccess;
+    ok = ok && hipEventRecord(pd->blk.uploaded, s) == hipSuccess;
+    ok = ok && hipEventRecord(pd->blk.done, s) == hipSuccess;      // (so that the block is never recycled in front of its own upload)
+    pd->blk.up_stream = s;
+    pd->blk.used = true;
+    if (!ok) { c->pool.push_back(pd->blk); return fail(LLICTI_EHIP, "plan tables: upload failed"); }
+    p.tiles.clear(); p.tiles.shrink_to_fit();                      // (the host copy of the largest table is not needed again)
+    if ((int)c->plans.size() >= kMaxPlans) {                       // least recently used out; its block waits in the pool for its last user
+        auto lru = c->plans.begin();
+        for (auto jt = c->plans.begin(); jt != c->plans.end(); ++jt) if (jt->second->last_use < lru->second->last_use) lru = jt;
+        c->pool.push_back(lru->second->blk);
+        delete lru->second;
+        c->plans.erase(lru);
     }
-    const size_t n = (size_t)LLICTI_NSTREAMS * B;
-    HIPCHK(hipMalloc(&pd->d_desc, n * sizeof(StreamDesc)));
-    HIPCHK(hipMalloc(&pd->d_slot_off, n * sizeof(long)));
-    HIPCHK(hipMalloc(&pd->d_slot_cap, n * sizeof(int32_t)));
-    HIPCHK(hipMemcpy(pd->d_desc, pd->p.desc.data(), n * sizeof(StreamDesc), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(pd->d_slot_off, pd->p.slot_off.data(), n * sizeof(long), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(pd->d_slot_cap, pd->p.slot_cap.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+    pd->last_use = ++c->use_clock;
     *out = pd.get();
     c->plans[key] = pd.release();
     return 0;
@@ -767,16 +1000,6 @@ __global__ void latch_status_kernel(const int32_t *status, int32_t *latched, int
 {
     if (threadIdx.x == 0 && *status != 0) *latched = *status;
     if (img_latched) for (int b = threadIdx.x; b < B; b += blockDim.x) img_latched[b] = status[kStatusHead + b];
-}
-
-static int pad_int(int H, int W)
-{
-    int v = 0;
-    for (int l = 0; l < LLICTI_NLEVELS; ++l) {
-        Geom g = make_geom(1, H, W, l);
-        v = 4 * v + 2 * g.padH + g.padW;       // LLICTI_nets.py:230
-    }
-    return v;
 }
 
 // The profiled extent of one whole-batch call: the closing event is recorded on EVERY way out (an early error return
@@ -799,41 +1022,52 @@ struct CallScope {
     CallScope &operator=(const CallScope &) = delete;
 };
 
-extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, int H, int W, int mode,
-                                    void *d_workspace, size_t workspace_bytes,
-                                    uint8_t *d_out, size_t out_stride, int32_t *d_seg_len, void *stream)
+// marks the plan's table block as in use behind everything the call enqueued (get_plan: blocks are recycled, never freed)
+struct PlanUse {
+    PlanDev *pd; hipStream_t s;
+    ~PlanUse() { if (pd && hipEventRecord(pd->blk.done, s) == hipSuccess) pd->blk.used = true; }
+};
+
+static int encode_batch(llicti_ctx *c, const uint8_t *d_rgb, const size_t *rgb_off, int B, const int *Hs, const int *Ws, int mode,
+                        void *d_workspace, size_t workspace_bytes, uint8_t *d_out, size_t out_stride, int32_t *d_seg_len, void *stream)
 {
     if (!c || !d_rgb || !d_workspace || !d_out || !d_seg_len) return fail(LLICTI_EINVAL, "encode_images: null pointer");
-    if (check_dims(B, H, W)) return LLICTI_EINVAL;
+    if (check_dims_v(B, Hs, Ws)) return LLICTI_EINVAL;
     const int ME = mode_streams(mode);
     if (ME < 0) return fail(LLICTI_EINVAL, "encode_images: unknown mode 0x%x", mode);
     const int M = ME & 0xFF, Q = 1 << (ME >> 8);
     for (int b = 0; b < 3; ++b) if (!c->have[b]) return fail(LLICTI_ENOWEIGHTS, "band %d weights not set", b);
     DeviceGuard guard(c);
+    hipStream_t s = (hipStream_t)stream;
     PlanDev *pd = nullptr;
-    if (int rc = get_plan(c, B, H, W, ME, &pd)) return rc;
+    if (int rc = get_plan(c, B, Hs, Ws, rgb_off, ME, s, &pd)) return rc;
+    PlanUse use{ pd, s };
     const Plan &p = pd->p;
+    if (!p.uniform && M == 0) return fail(LLICTI_EINVAL, "encode_images: a batch of mixed sizes needs a rANS container (the reference-format container codes equal sizes per call)");
     if (workspace_bytes < p.total) return fail(LLICTI_ENOSPACE, "encode_images: workspace %zu < %zu", workspace_bytes, p.total);
     if (out_stride < p.max_container) return fail(LLICTI_ENOSPACE, "encode_images: out_stride %zu < %zu", out_stride, p.max_container);
-    hipStream_t s = (hipStream_t)stream;
     uint8_t *ws = (uint8_t *)d_workspace;
     int16_t *planes = (int16_t *)(ws + p.off_planes);
     float *fplanes = (float *)(ws + p.off_fplanes);
     int32_t *mm = (int32_t *)(ws + p.off_minmax);
     int32_t *status = (int32_t *)(ws + p.off_status);
-    float *params = (float *)(ws + p.off_params);
     uint32_t *pairs = (uint32_t *)(ws + p.off_pairs);
     uint8_t *slots = ws + p.off_slots;
     int32_t *slot_len = (int32_t *)(ws + p.off_slot_len);
+    const ImgGeo *d_img = pd->dev<ImgGeo>(p.d_img);
+    const Geom *d_geo = pd->dev<Geom>(p.d_geo);
+    const StageGeom *d_sg = pd->dev<StageGeom>(p.d_sg);
+    const StreamDesc *d_desc = pd->dev<StreamDesc>(p.d_desc);
+    const long *d_rslot_off = pd->dev<long>(p.d_rslot_off);
+    const int2 *d_tiles = p.uniform ? nullptr : pd->dev<int2>(p.d_tiles);
 
     CallScope call(c, s);
-    Geom g4 = make_geom(B, H, W, 4);
     const int byte0 = M ? rans_byte0(M, Q) : LLICTI_NLEVELS;
     {
         ProfSpan span(c, PROF_MISC, s);
         // (the lift is the call's first kernel and sets no status: it clears the call's status words on the way)
-        if (int rc = launch_lift(d_rgb, B, H, W, planes, fplanes, mm, (int32_t *)(ws + p.off_lift_part), s, status, kStatusHead + B)) return rc;
-        header_write_kernel<<<B, 256, 0, s>>>(d_rgb, mm, H, W, g4.h, g4.w, pad_int(H, W), byte0, d_out, (long)out_stride, d_seg_len);
+        if (int rc = launch_lift(d_rgb, B, p.max_plane, p.vec_ok, planes, fplanes, mm, (int32_t *)(ws + p.off_lift_part), s, status, kStatusHead + B, d_img)) return rc;
+        header_write_kernel<<<B, 256, 0, s>>>(d_rgb, mm, d_img, byte0, d_out, (long)out_stride, d_seg_len);
     }
     // The encoder has no dependency between stages: every (level, band) reads only original pixels.  With llicti_set_tuning("enc_side_levels", 1)
     // levels 4..1 (twelve CNN + twelve pairs launches, a quarter of the work) run on a side stream next to level 0's, with their own
@@ -842,83 +1076,88 @@ extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, 
     // launch's ramp-down under the other's ramp-up.  Measured (profiles/r4/ab_encoder_side_stream.json): -0.5 ... -4 % per encode, 10.75 ->
     // 10.68 ms at B = 24 -- 0.3 % of a step, for which every kernel trace of the run shows the side queue's launches with the time they
     // spend waiting for a compute unit inside their durations.  Off by default: the per-kernel evidence is worth more than 0.07 ms.
-    const bool side = c->enc_side_levels != 0 && !c->profiling && p.off_params2 != (size_t)-1;      // (the profiling spans assume one queue)
-    float *params2 = side ? (float *)(ws + p.off_params2) : nullptr;
+    const bool side = c->enc_side_levels != 0 && !c->profiling;      // (the profiling spans assume one queue)
     hipStream_t s2 = side ? c->sub[1] : s;
     if (side) {
         HIPCHK(hipEventRecord(c->ev_enc[0], s));      // lift and header are done
         HIPCHK(hipStreamWaitEvent(s2, c->ev_enc[0], 0));
     }
     for (int lvl = LLICTI_NLEVELS - 1; lvl >= 0; --lvl) {
-        Geom g = make_geom(B, H, W, lvl);
+        const Geom &g = p.geo[(size_t)lvl * B];                         // image 0's (equal sizes: every image's)
+        const Geom *gv = p.uniform ? nullptr : d_geo + (size_t)lvl * B;
         hipStream_t s = (lvl >= 1) ? s2 : (hipStream_t)stream;          // (shadows the call's stream inside the loop)
-        float *params = (lvl >= 1 && side) ? params2 : (float *)(ws + p.off_params);
-        // A launch's CNN outputs are read once, by the pairs kernel right behind it: at level 0 of a large batch they are 25 MB per image
-        // (604 MB for 24 images), far more than the 256 MB the chip's memory-side cache holds, and the pairs kernel is then bound by
-        // reading them back from HBM.  In sub-batches of `enc_chunk_images` the CNN outputs of one launch stay cache-resident.
-        const long par_bytes_img = (long)g.h * g.w * LLICTI_PARAM_STRIDE * sizeof(float);
-        const int chunk = (c->enc_chunk_images > 0 && (long)B * par_bytes_img > (200L << 20)) ? std::min(B, c->enc_chunk_images) : B;
-        const size_t band_floats = (size_t)B * g.h * g.w * LLICTI_PARAM_STRIDE;
-        const Geom g0 = make_geom(B, H, W, 0);
-        if (lvl >= 1 && !side && 3 * band_floats <= (size_t)B * g0.h * g0.w * LLICTI_PARAM_STRIDE) {
+        float *params = (lvl >= 1 && side) ? (float *)(ws + p.off_params2) : (float *)(ws + p.off_params);
+        const unsigned pairs_gx = (unsigned)((p.lev_maxpos[lvl] + kPairsThreads - 1) / kPairsThreads);
+        if (lvl >= 1 && !side) {
             // Levels 4..1: the three bands' CNN outputs side by side in the buffer (each a quarter of what level 0 needs of it, or less),
             // then ONE pairs launch for the three bands: 3 + 1 launches per level instead of 3 + 3.
             PairsBands pb;
             for (int band = 0; band < 3; ++band) {
-                float *pband = params + band * band_floats;
-                if (int rc = launch_band_params(c, fplanes, g, band, pband, s)) return rc;
-                pb.sg[band] = make_stage(g, band);
+                float *pband = params + band * p.lev_floats[lvl];
+                if (int rc = launch_band_params(c, fplanes, g, band, pband, s, gv, d_tiles ? d_tiles + p.run[lvl * 3 + band].off : nullptr, &p.run[lvl * 3 + band])) return rc;
+                pb.sv[band] = d_sg + (size_t)(lvl * 3 + band) * B;
                 pb.params[band] = pband;
                 pb.pairs[band] = pairs + p.pair_base[lvl * 3 + band];
             }
             ProfSpan span(c, PROF_PAIRS, s);
-            const long np = (long)g.h * g.w;
-            cdf_pairs_bands_kernel<<<dim3((unsigned)((np + kPairsThreads - 1) / kPairsThreads), B, 3), kPairsThreads, 0, s>>>(planes, pb, mm, B);
+            cdf_pairs_bands_kernel<<<dim3(pairs_gx, B, 3), kPairsThreads, 0, s>>>(planes, pb, mm);
             HIPCHK(hipGetLastError());
             continue;
         }
         for (int band = 0; band < 3; ++band) {
-            StageGeom sgb = make_stage(g, band);
-            const long nc = (long)sgb.hc * sgb.wc;
-            for (int b0 = 0; b0 < B; b0 += chunk) {
-                Geom gs = g;
-                gs.B = std::min(chunk, B - b0);
-                if (int rc = launch_band_params(c, fplanes + (long)b0 * 3 * g.plane, gs, band, params, s)) return rc;
-                ProfSpan span(c, PROF_PAIRS, s);
-                if (int rc = launch_cdf_pairs(planes + (long)b0 * 3 * g.plane, params, mm + 4 * b0, gs, band,
-                                              pairs + p.pair_base[lvl * 3 + band] + (long)b0 * nc, B, s)) return rc;
-            }
+            // (a launch's CNN outputs are read once, by the pairs kernel right behind it; cutting level 0 into sub-batches whose outputs stay in
+            // the memory-side cache was measured and bought nothing: profiles/r4/tried_encoder_subbatch.json)
+            if (int rc = launch_band_params(c, fplanes, g, band, params, s, gv, d_tiles ? d_tiles + p.run[lvl * 3 + band].off : nullptr, &p.run[lvl * 3 + band])) return rc;
+            ProfSpan span(c, PROF_PAIRS, s);
+            const StageGeom *sv = d_sg + (size_t)(lvl * 3 + band) * B;
+            cdf_pairs_kernel<<<dim3(pairs_gx, B), kPairsThreads, 0, s>>>(planes, params, mm, p.sg[(size_t)(lvl * 3 + band) * B], sv, pairs + p.pair_base[lvl * 3 + band]);
+            HIPCHK(hipGetLastError());
         }
     }
     if (side) {
         HIPCHK(hipEventRecord(c->ev_enc[1], s2));
         HIPCHK(hipStreamWaitEvent(s, c->ev_enc[1], 0));
     }
-    const int hdr_bytes = 17 + 3 * g4.h * g4.w;
     if (M == 0) {
         ProfSpan span(c, PROF_AC, s);
         const int n_streams = LLICTI_NSTREAMS * B;
-        ac_encode_pairs_kernel<<<n_streams, 64, 0, s>>>(pairs, pd->d_desc, n_streams, slots, slot_len, status);
-        pack_kernel<<<dim3(LLICTI_NSTREAMS, B), 256, 0, s>>>(slots, pd->d_slot_off, slot_len, B, hdr_bytes, d_out, (long)out_stride, d_seg_len, status);
+        ac_encode_pairs_kernel<<<n_streams, 64, 0, s>>>(pairs, d_desc, n_streams, slots, slot_len, status);
+        pack_kernel<<<dim3(LLICTI_NSTREAMS, B), 256, 0, s>>>(slots, pd->dev<long>(p.d_slot_off), slot_len, B, p.img[0].hdr_bytes, d_out, (long)out_stride, d_seg_len, status);
     } else {
         ProfSpan span(c, PROF_RANS_ENC, s);
         int32_t *rinfo = (int32_t *)(ws + p.off_rinfo);
-        const StageGeom sgl = make_stage(make_geom(B, H, W, 0), 2);      // the last stage: an xwide stream's seed symbols are read from its pixels
-        if (Q == 4) rans_encode_kernel<4><<<B * M, 256, 0, s>>>(pairs, pd->d_desc, B, M, slots, pd->d_rslot_off, p.rslot_cap, rinfo, status, sgl, planes, mm);
-        else if (Q == 2) rans_encode_kernel<2><<<B * M, 128, 0, s>>>(pairs, pd->d_desc, B, M, slots, pd->d_rslot_off, p.rslot_cap, rinfo, status, sgl, planes, mm);
-        else rans_encode_kernel<1><<<B * M, 64, 0, s>>>(pairs, pd->d_desc, B, M, slots, pd->d_rslot_off, p.rslot_cap, rinfo, status, sgl, planes, mm);
-        rans_pack_kernel<<<dim3(M, B), 256, 0, s>>>(slots, pd->d_rslot_off, rinfo, M, hdr_bytes, d_out, (long)out_stride, d_seg_len, status);
+        const StageGeom *sglv = d_sg + (size_t)(0 * 3 + 2) * B;      // the last stage: an xwide stream's seed symbols are read from its pixels
+        if (Q == 4) rans_encode_kernel<4><<<B * M, 256, 0, s>>>(pairs, d_desc, B, M, slots, d_rslot_off, p.rslot_cap, rinfo, status, sglv, planes, mm);
+        else if (Q == 2) rans_encode_kernel<2><<<B * M, 128, 0, s>>>(pairs, d_desc, B, M, slots, d_rslot_off, p.rslot_cap, rinfo, status, sglv, planes, mm);
+        else rans_encode_kernel<1><<<B * M, 64, 0, s>>>(pairs, d_desc, B, M, slots, d_rslot_off, p.rslot_cap, rinfo, status, sglv, planes, mm);
+        rans_pack_kernel<<<dim3(M, B), 256, 0, s>>>(slots, d_rslot_off, rinfo, M, d_img, d_out, (long)out_stride, d_seg_len, status);
     }
     latch_status_kernel<<<1, 64, 0, s>>>(status, c->d_status, nullptr, 0);
     HIPCHK(hipGetLastError());
     return LLICTI_OK;
 }
 
-static int decode_batch(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in_stride, const int32_t *d_seg_len,
-                        int B, int H, int W, int M, uint8_t *ws, uint8_t *d_rgb, hipStream_t s)
+extern "C" int llicti_encode_images_v(llicti_ctx *c, const uint8_t *d_rgb, const size_t *rgb_off, int B, const int *Hs, const int *Ws, int mode,
+                                      void *d_workspace, size_t workspace_bytes,
+                                      uint8_t *d_out, size_t out_stride, int32_t *d_seg_len, void *stream)
 {
-    const int Q = pd->p.Q;
+    return encode_batch(c, d_rgb, rgb_off, B, Hs, Ws, mode, d_workspace, workspace_bytes, d_out, out_stride, d_seg_len, stream);
+}
+
+extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, int H, int W, int mode,
+                                    void *d_workspace, size_t workspace_bytes,
+                                    uint8_t *d_out, size_t out_stride, int32_t *d_seg_len, void *stream)
+{
+    if (check_dims(B, H, W)) return LLICTI_EINVAL;
+    std::vector<int> Hs(B, H), Ws(B, W);
+    return encode_batch(c, d_rgb, nullptr, B, Hs.data(), Ws.data(), mode, d_workspace, workspace_bytes, d_out, out_stride, d_seg_len, stream);
+}
+
+static int decode_stages(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in_stride, const int32_t *d_seg_len,
+                         uint8_t *ws, uint8_t *d_rgb, hipStream_t s)
+{
     const Plan &p = pd->p;
+    const int B = p.B, M = p.M, Q = p.Q;
     int16_t *planes = (int16_t *)(ws + p.off_planes);
     float *fplanes = (float *)(ws + p.off_fplanes);
     int32_t *mm = (int32_t *)(ws + p.off_minmax);
@@ -928,57 +1167,63 @@ static int decode_batch(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t 
     uint8_t *tables = ws + p.off_tables;
     uint32_t *acstate = (uint32_t *)(ws + p.off_acstate);
     int32_t *slot_len = (int32_t *)(ws + p.off_slot_len);
+    const ImgGeo *d_img = pd->dev<ImgGeo>(p.d_img);
+    const Geom *d_geo = pd->dev<Geom>(p.d_geo);
+    const StageGeom *d_sg = pd->dev<StageGeom>(p.d_sg);
+    const long *d_rslot_off = pd->dev<long>(p.d_rslot_off);
+    const int2 *d_tiles = p.uniform ? nullptr : pd->dev<int2>(p.d_tiles);
 
     zero_words_kernel<<<(kStatusHead + B + 255) / 256, 256, 0, s>>>(status, kStatusHead + B);
-    Geom g4 = make_geom(B, H, W, 4);
     const int byte0 = M ? rans_byte0(M, Q) : LLICTI_NLEVELS;
     uint32_t *rstate = (uint32_t *)(ws + p.off_rstate);
     uint32_t *rpos = (uint32_t *)(ws + p.off_rpos);
     uint32_t *rtail = (uint32_t *)(ws + p.off_rtail);
     {
         ProfSpan span(c, PROF_MISC, s);
-        header_read_kernel<<<B, 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, H, W, g4.h, g4.w, pad_int(H, W), byte0, planes, fplanes, mm, status);
+        header_read_kernel<<<B, 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, d_img, byte0, planes, fplanes, mm, status);
         if (M == 0) {
-            unpack_kernel<<<dim3(LLICTI_NSTREAMS, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, B, slots, pd->d_slot_off, pd->d_slot_cap, slot_len, status);
+            unpack_kernel<<<dim3(LLICTI_NSTREAMS, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, B, slots, pd->dev<long>(p.d_slot_off), pd->dev<int32_t>(p.d_slot_cap), slot_len, status);
         } else {
             rans_unpack_kernel<<<dim3(M, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, M, 2 + Q * RansGeo<1>::kPayBytes,
-                                                          slots, pd->d_rslot_off, p.rslot_cap, rpos, status);
-            if (Q == 4) rans_init_kernel<4><<<B * M, 64, 0, s>>>(slots, pd->d_rslot_off, M, rstate, rpos, rtail, status);
-            else if (Q == 2) rans_init_kernel<2><<<B * M, 64, 0, s>>>(slots, pd->d_rslot_off, M, rstate, rpos, rtail, status);
-            else rans_init_kernel<1><<<B * M, 64, 0, s>>>(slots, pd->d_rslot_off, M, rstate, rpos, rtail, status);
+                                                          slots, d_rslot_off, p.rslot_cap, rpos, status);
+            if (Q == 4) rans_init_kernel<4><<<B * M, 64, 0, s>>>(slots, d_rslot_off, M, rstate, rpos, rtail, status);
+            else if (Q == 2) rans_init_kernel<2><<<B * M, 64, 0, s>>>(slots, d_rslot_off, M, rstate, rpos, rtail, status);
+            else rans_init_kernel<1><<<B * M, 64, 0, s>>>(slots, d_rslot_off, M, rstate, rpos, rtail, status);
         }
     }
     // 45 dependent stages (LLICTI_nets.py:440-498): CNN of band b needs bands < b of this level, Co needs Y, Cg needs Y, Co
     for (int lvl = LLICTI_NLEVELS - 1; lvl >= 0; --lvl) {
-        Geom g = make_geom(B, H, W, lvl);
+        const Geom &g = p.geo[(size_t)lvl * B];                         // image 0's (equal sizes: every image's)
+        const Geom *gv = p.uniform ? nullptr : d_geo + (size_t)lvl * B;
         for (int band = 0; band < 3; ++band) {
-            if (int rc = launch_band_params(c, fplanes, g, band, params, s)) return rc;
-            StageGeom sg = make_stage(g, band);
-            const long nc = (long)sg.hc * sg.wc;
+            if (int rc = launch_band_params(c, fplanes, g, band, params, s, gv, d_tiles ? d_tiles + p.run[lvl * 3 + band].off : nullptr, &p.run[lvl * 3 + band])) return rc;
+            const StageGeom *sgv = d_sg + (size_t)(lvl * 3 + band) * B;
             if (M > 0) {
                 const int last = (lvl == 0 && band == 2) ? 1 : 0;      // the last stage's tail symbols are decoded by rans_tail_kernel
                 {
                 ProfSpan span(c, PROF_RANS_STAGE, s);
                 if (Q == 4) {
-                    rans_decode_stage_lane_kernel<4><<<B * M, 256, 0, s>>>(params, sg, M, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status, c->d_phi_lut);
+                    rans_decode_stage_lane_kernel<4><<<B * M, 256, 0, s>>>(params, sgv, M, slots, d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status, c->d_phi_lut);
                 } else if (Q == 2) {
-                    rans_decode_stage_pair_kernel<<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, c->d_phi_lut, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status);
+                    rans_decode_stage_pair_kernel<<<B * M, 64 * kRansWaves, 0, s>>>(params, sgv, M, c->d_phi_lut, slots, d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status);
                 } else {
-                    rans_decode_stage_kernel<<<B * M, 64 * kRansWaves, 0, s>>>(params, sg, M, c->d_phi_lut, slots, pd->d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status);
+                    rans_decode_stage_kernel<<<B * M, 64 * kRansWaves, 0, s>>>(params, sgv, M, c->d_phi_lut, slots, d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status);
                 }
                 }
                 if (last) {
                     ProfSpan span(c, PROF_RANS_TAIL, s);
-                    if (Q == 4) rans_tail_kernel<4><<<B * M, 64 * (1 + kTailAhead) * kTailChains<4>, 0, s>>>(params, sg, M, rstate, rpos, rtail, planes, fplanes, mm, status);
-                    else if (Q == 2) rans_tail_kernel<2><<<B * M, 64 * (1 + kTailAhead), 0, s>>>(params, sg, M, rstate, rpos, rtail, planes, fplanes, mm, status);
-                    else rans_tail_kernel<1><<<B * M, 64 * (1 + kTailAhead), 0, s>>>(params, sg, M, rstate, rpos, rtail, planes, fplanes, mm, status);
+                    if (Q == 4) rans_tail_kernel<4><<<B * M, 64 * (1 + kTailAhead) * kTailChains<4>, 0, s>>>(params, sgv, M, rstate, rpos, rtail, planes, fplanes, mm, status);
+                    else if (Q == 2) rans_tail_kernel<2><<<B * M, 64 * (1 + kTailAhead), 0, s>>>(params, sgv, M, rstate, rpos, rtail, planes, fplanes, mm, status);
+                    else rans_tail_kernel<1><<<B * M, 64 * (1 + kTailAhead), 0, s>>>(params, sgv, M, rstate, rpos, rtail, planes, fplanes, mm, status);
                 }
             }
             if (M == 0) {
-                // Y, Co, Cg of this band as a pipeline over chunks of the stage: chunk c of Co needs only chunk c
+                // (equal sizes only)  Y, Co, Cg of this band as a pipeline over chunks of the stage: chunk c of Co needs only chunk c
                 // of Y (mean update from the SAME pixel, LLICTI_nets.py:474-477), chunk c of Cg only chunk c of
                 // Y and Co.  Three HIP streams; tables are built per chunk into one buffer per colour; the coder
                 // state of a stream travels between its chunk launches in `acstate`.
+                const StageGeom sg = make_stage(g, band);
+                const long nc = (long)sg.hc * sg.wc;
                 const int C = ac_chunks(nc);
                 const long rows = ac_chunk_rows(nc);
                 hipStream_t q[3] = { s, c->sub[1], c->sub[2] };
@@ -1020,52 +1265,67 @@ static int decode_batch(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t 
             }
         }
     }
-    const long plane = (long)H * W;
-    const int gx = (int)std::min<long>((plane + 255) / 256, 1024);
+    const int gx = (int)std::min<long>((p.max_plane + 255) / 256, 1024);
     {
         ProfSpan span(c, PROF_MISC, s);
         // (the call's status words are latched into the context's by this kernel: the workspace is the caller's, it may be gone or reused by the
         // time the words are read)
-        unlift_kernel<<<dim3(gx, B), 256, 0, s>>>(planes, plane, d_rgb, status, kStatusHead, c->d_status, c->d_img_status);
+        unlift_kernel<<<dim3(gx, B), 256, 0, s>>>(planes, p.max_plane, d_rgb, status, kStatusHead, c->d_status, c->d_img_status, d_img);
     }
     HIPCHK(hipGetLastError());
     return 0;
 }
 
-extern "C" int llicti_decode_images(llicti_ctx *c, const uint8_t *d_in, size_t in_stride, const int32_t *d_seg_len,
-                                    int B, int H, int W, int mode, void *d_workspace, size_t workspace_bytes,
-                                    uint8_t *d_rgb, void *stream)
+static int decode_batch(llicti_ctx *c, const uint8_t *d_in, size_t in_stride, const int32_t *d_seg_len, int B, const int *Hs, const int *Ws,
+                        int mode, void *d_workspace, size_t workspace_bytes, uint8_t *d_rgb, const size_t *rgb_off, void *stream)
 {
     if (!c || !d_in || !d_seg_len || !d_workspace || !d_rgb) return fail(LLICTI_EINVAL, "decode_images: null pointer");
-    if (check_dims(B, H, W)) return LLICTI_EINVAL;
+    if (check_dims_v(B, Hs, Ws)) return LLICTI_EINVAL;
     const int ME = mode_streams(mode);
     if (ME < 0) return fail(LLICTI_EINVAL, "decode_images: unknown mode 0x%x", mode);
-    const int M = ME & 0xFF;
     for (int b = 0; b < 3; ++b) if (!c->have[b]) return fail(LLICTI_ENOWEIGHTS, "band %d weights not set", b);
     DeviceGuard guard(c);
-    {
-        const Geom g4c = make_geom(B, H, W, 4);
-        if (in_stride < (size_t)(17 + 3 * g4c.h * g4c.w))
-            return fail(LLICTI_EINVAL, "decode_images: in_stride %zu is smaller than the %d header bytes of a %dx%d image", in_stride, 17 + 3 * g4c.h * g4c.w, W, H);
-    }
-    PlanDev *pd = nullptr;
-    if (int rc = get_plan(c, B, H, W, ME, &pd)) return rc;
-    if (workspace_bytes < pd->p.total)
-        return fail(LLICTI_ENOSPACE, "decode_images: workspace %zu < %zu", workspace_bytes, pd->p.total);
     hipStream_t s = (hipStream_t)stream;
+    PlanDev *pd = nullptr;
+    if (int rc = get_plan(c, B, Hs, Ws, rgb_off, ME, s, &pd)) return rc;
+    PlanUse use{ pd, s };
+    const Plan &p = pd->p;
+    if (!p.uniform && p.M == 0) return fail(LLICTI_EINVAL, "decode_images: a batch of mixed sizes needs a rANS container (the reference-format container codes equal sizes per call)");
+    for (int b = 0; b < B; ++b)
+        if (in_stride < (size_t)p.img[b].hdr_bytes)
+            return fail(LLICTI_EINVAL, "decode_images: in_stride %zu is smaller than the %d header bytes of a %dx%d image", in_stride, p.img[b].hdr_bytes, Ws[b], Hs[b]);
+    if (workspace_bytes < p.total)
+        return fail(LLICTI_ENOSPACE, "decode_images: workspace %zu < %zu", workspace_bytes, p.total);
     uint8_t *ws = (uint8_t *)d_workspace;
 
     c->img_status_n = 0;
     if (c->img_status_cap < B) {          // grows rarely (a larger batch than any before): blocking is fine here
         HIPCHK(hipDeviceSynchronize());
         if (c->d_img_status) { (void)hipFree(c->d_img_status); c->d_img_status = nullptr; c->img_status_cap = 0; }
-        HIPCHK(hipMalloc(&c->d_img_status, (size_t)B * sizeof(int32_t)));
-        c->img_status_cap = B;
+        const int cap = std::max(B, 64);
+        HIPCHK(hipMalloc(&c->d_img_status, (size_t)cap * sizeof(int32_t)));
+        c->img_status_cap = cap;
     }
     CallScope call(c, s);
-    if (int rc = decode_batch(c, pd, d_in, in_stride, d_seg_len, B, H, W, M, ws, d_rgb, s)) return rc;
+    if (int rc = decode_stages(c, pd, d_in, in_stride, d_seg_len, ws, d_rgb, s)) return rc;
     c->img_status_n = B;
     return LLICTI_OK;
+}
+
+extern "C" int llicti_decode_images_v(llicti_ctx *c, const uint8_t *d_in, size_t in_stride, const int32_t *d_seg_len,
+                                      int B, const int *Hs, const int *Ws, int mode, void *d_workspace, size_t workspace_bytes,
+                                      uint8_t *d_rgb, const size_t *rgb_off, void *stream)
+{
+    return decode_batch(c, d_in, in_stride, d_seg_len, B, Hs, Ws, mode, d_workspace, workspace_bytes, d_rgb, rgb_off, stream);
+}
+
+extern "C" int llicti_decode_images(llicti_ctx *c, const uint8_t *d_in, size_t in_stride, const int32_t *d_seg_len,
+                                    int B, int H, int W, int mode, void *d_workspace, size_t workspace_bytes,
+                                    uint8_t *d_rgb, void *stream)
+{
+    if (check_dims(B, H, W)) return LLICTI_EINVAL;
+    std::vector<int> Hs(B, H), Ws(B, W);
+    return decode_batch(c, d_in, in_stride, d_seg_len, B, Hs.data(), Ws.data(), mode, d_workspace, workspace_bytes, d_rgb, nullptr, stream);
 }
 
 extern "C" int llicti_check_status(llicti_ctx *c, void *stream)

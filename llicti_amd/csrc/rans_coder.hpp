@@ -120,7 +120,7 @@ template <int Q>
 __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__restrict__ pairs, const StreamDesc *__restrict__ desc,
                                                          int B, int M, uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
                                                          int rslot_cap, int32_t *__restrict__ rinfo, int32_t *status,
-                                                         StageGeom sgl, const int16_t *__restrict__ planes, const int32_t *__restrict__ minmax)
+                                                         const StageGeom *__restrict__ sglv, const int16_t *__restrict__ planes, const int32_t *__restrict__ minmax)
 {
     using GEO = RansGeo<Q>;
     constexpr int L = GEO::kLanes;
@@ -136,6 +136,7 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
     __shared__ __attribute__((aligned(16))) int sh_tot[2][Q][4];       // a round's four bit totals per sub-chunk (ping-pong by round parity)
     const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M;
     const int tid = threadIdx.x, lane = tid & 63, wq = tid >> 6;      // wavefront wq codes sub-chunk wq (stream lanes 64 wq .. 64 wq + 63)
+    const StageGeom sgl = sglv[b];                  // the image's last stage (level 0, band x10): an xwide stream's seed symbols are read from its pixels
     uint8_t *slot = slots + rslot_off[sidx];
     uint32_t *out32 = reinterpret_cast<uint32_t *>(slot + 4);
     const int cap_dw = (rslot_cap - 4 - GEO::kPayBytes - 8) >> 2;      // dwords the bit region may take
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
                 const int q = cnt - 1 - j;
                 const int n = L * (m + (q / L) * M) + (q % L);
                 const int pi = div_wc(sgl, n), pj = n - pi * sgl.wc;
-                int sv = (int)planes[((long)b * 3 + 2) * sgl.plane + ((long)(2 * pi + sgl.oi) << sgl.lvl) * sgl.W + ((long)(2 * pj + sgl.oj) << sgl.lvl)] + shift;
+                int sv = (int)planes[sgl.img_off + 2 * sgl.plane + ((long)(2 * pi + sgl.oi) << sgl.lvl) * sgl.W + ((long)(2 * pj + sgl.oj) << sgl.lvl)] + shift;
                 if (sv < 0 || sv >= A) { bad = 1; sv = 0; }
                 uint32_t mul = 1;
                 for (int e = 0; e < lane; ++e) mul *= (uint32_t)A;
@@ -605,7 +606,7 @@ __device__ __forceinline__ int group_cdf_entry_fast(const CompFast &A, const Com
     return (int)__builtin_rintf(dpp_sum5(term_fast(A, pt), term_fast(B, pt)) * scale) + i;
 }
 
-__global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(const float *__restrict__ params, StageGeom sg, int M,
+__global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(const float *__restrict__ params, const StageGeom *__restrict__ sgv, int M,
                                                                const float2 *__restrict__ phi_lut,
                                                                const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
                                                                int rslot_cap, uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos,
@@ -617,6 +618,7 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
     __shared__ float2 sh_lut[kPhiLutN];          // the hint's normal CDF (term_lut)
     const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const StageGeom sg = sgv[b];                 // the image's own stage geometry (the images of a call may differ in size)
     const int nc = sg.hc * sg.wc;
     const int nchunks = (nc + 63) >> 6;
     if (nchunks <= m) return;                    // whole workgroup
@@ -645,7 +647,7 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
     const Grid gr = make_grid(minv, maxv);
     const int max_symbol = gr.Lp - 2;
     const float fbase = (float)minv - 0.5f;
-    const long img = (long)b * 3 * sg.plane;
+    const long img = sg.img_off;
     const int mA = lane & 3;                                            // component A of this lane; component B is 4 (read from lane 3 only)
     const int gsym = 16 * wave + (lane >> 2);                           // symbol (lane of the stream) this 4-lane group resolves
     const int gbit = lane & ~3;                                         // ballot bit of the group's first lane
@@ -657,7 +659,7 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
         Raw r;
         const int n = min(64 * (m + k * M) + gsym, nc - 1);          // clamped: the loads are unconditional
         const int i = div_wc(sg, n), j = n - i * sg.wc;          // multiply-shift: a runtime division costs ~25 of the step's ~900 instructions
-        const ParRow par = par_row(params, b, (long)sg.h * sg.w, (long)i * sg.w + j);
+        const ParRow par = par_row(params + sg.par_off, 0, (long)sg.h * sg.w, (long)i * sg.w + j);
         r.off = img + ((long)(2 * i + sg.oi) << sg.lvl) * sg.W + ((long)(2 * j + sg.oj) << sg.lvl);
         r.sgA = par[5 * clr + mA]; r.muA = par[16 + 5 * clr + mA]; r.wkA = par[32 + 5 * clr + mA];
         r.sgB = par[5 * clr + 4];  r.muB = par[16 + 5 * clr + 4];  r.wkB = par[32 + 5 * clr + 4];
@@ -846,7 +848,7 @@ __device__ __forceinline__ uint32_t pair_swap_u(uint32_t v)
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
 }
 
-__global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_pair_kernel(const float *__restrict__ params, StageGeom sg, int M,
+__global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_pair_kernel(const float *__restrict__ params, const StageGeom *__restrict__ sgv, int M,
                                                                const float2 *__restrict__ phi_lut,
                                                                const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
                                                                int rslot_cap, uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos,
@@ -859,6 +861,7 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_pair_kernel
     __shared__ float2 sh_lut[kPhiLutN];          // the hint's normal CDF (term_lut)
     const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const StageGeom sg = sgv[b];                 // the image's own stage geometry (the images of a call may differ in size)
     const int nc = sg.hc * sg.wc;
     const int nchunks = (nc + L - 1) / L;
     if (nchunks <= m) return;                    // whole workgroup
@@ -887,7 +890,7 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_pair_kernel
     const Grid gr = make_grid(minv, maxv);
     const int max_symbol = gr.Lp - 2;
     const float fbase = (float)minv - 0.5f;
-    const long img = (long)b * 3 * sg.plane;
+    const long img = sg.img_off;
     const int pl = lane & 1;                                            // lane of the pair
     const bool odd = pl != 0;
     const int gsym = 32 * wave + (lane >> 1);                           // stream lane (0 .. 127) this pair resolves
@@ -899,7 +902,7 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_pair_kernel
         Raw r;
         const int n = min(L * (m + k * M) + gsym, nc - 1);           // clamped: the loads are unconditional
         const int i = div_wc(sg, n), j = n - i * sg.wc;
-        const ParRow par = par_row(params, b, (long)sg.h * sg.w, (long)i * sg.w + j);
+        const ParRow par = par_row(params + sg.par_off, 0, (long)sg.h * sg.w, (long)i * sg.w + j);
         r.off = img + ((long)(2 * i + sg.oi) << sg.lvl) * sg.W + ((long)(2 * j + sg.oj) << sg.lvl);
         r.y = r.co = 0.0f;
 #pragma unroll
@@ -1089,7 +1092,7 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_pair_kernel
 // from which every lane knows where its bits start.  The stream's bits come from an LDS ring of 512 dwords (a step takes at most
 // 128), refilled 128 dwords at a time: requested at the end of a step, stored at the end of the next, used after the barrier that follows.
 template <int Q>
-__global__ __launch_bounds__(64 * Q) void rans_decode_stage_lane_kernel(const float *__restrict__ params, StageGeom sg, int M,
+__global__ __launch_bounds__(64 * Q) void rans_decode_stage_lane_kernel(const float *__restrict__ params, const StageGeom *__restrict__ sgv, int M,
                                                                const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
                                                                int rslot_cap, uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos,
                                                                const uint32_t *__restrict__ rtail,
@@ -1113,6 +1116,7 @@ __global__ __launch_bounds__(64 * Q) void rans_decode_stage_lane_kernel(const fl
     __shared__ float2 sh_lut[kLutN];
     const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;      // tid = lane of the stream
+    const StageGeom sg = sgv[b];                 // the image's own stage geometry (the images of a call may differ in size)
     const int nc = sg.hc * sg.wc;
     const int nchunks = (nc + L - 1) / L;
     if (nchunks <= m) return;                    // whole workgroup
@@ -1140,14 +1144,14 @@ __global__ __launch_bounds__(64 * Q) void rans_decode_stage_lane_kernel(const fl
     const Grid gr = make_grid(minv, maxv);
     const int max_symbol = gr.Lp - 2;
     const float fbase = (float)minv - 0.5f;
-    const long img = (long)b * 3 * sg.plane;
+    const long img = sg.img_off;
     const long npos = (long)sg.h * sg.w;
     struct Raw { float sg[5], mu[5], wk[5], a0[5], a1[5], y, co; long off; bool on; };
     auto fetch = [&](int k) -> Raw {
         Raw r;
         const int n = min(L * (m + k * M) + tid, nc - 1);            // clamped: the loads are unconditional
         const int i = div_wc(sg, n), j = n - i * sg.wc;
-        const ParRow prw = par_row(params, b, npos, (long)i * sg.w + j);
+        const ParRow prw = par_row(params + sg.par_off, 0, npos, (long)i * sg.w + j);
         r.off = img + ((long)(2 * i + sg.oi) << sg.lvl) * sg.W + ((long)(2 * j + sg.oj) << sg.lvl);
         r.y = r.co = 0.0f;
 #pragma unroll
@@ -1317,7 +1321,7 @@ constexpr int kTailAhead = 3;                    // symbols per round = preparin
 template <int Q> constexpr int kTailChains = kSeeded<Q> ? 2 : 1;      // xwide: two chains, each with its own coder + preparing wavefronts
 
 template <int Q>
-__global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_tail_kernel(const float *__restrict__ params, StageGeom sg, int M,
+__global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_tail_kernel(const float *__restrict__ params, const StageGeom *__restrict__ sgv, int M,
                                                        const uint32_t *__restrict__ rstate, const uint32_t *__restrict__ rpos,
                                                        const uint32_t *__restrict__ rtail,
                                                        int16_t *__restrict__ planes, float *__restrict__ fplanes,
@@ -1335,6 +1339,7 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_t
     // role 0: the chain's coder.  A workgroup's wavefronts go to the four SIMDs round robin: with two chains the coders are wavefronts 0 and 1 (their
     // own SIMD each, shared with one preparing wavefront), not 0 and 4 (the same SIMD, taking turns at its issue port)
     const int chain = wave % NCH, role = wave / NCH;
+    const StageGeom sg = sgv[b];                 // the image's own stage geometry (the images of a call may differ in size)
     const int nc = sg.hc * sg.wc;
     const int cnt = rans_stream_count(nc, m, M, L);
     const int rt = (int)(rtail[sidx] & 0xFFFFu);
@@ -1353,7 +1358,7 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_t
     const int Tc = max(Tall - NS, 0);                   // coded symbols; the one with index idx (j = nch ns + idx from the stream's end) is on chain idx % nch
     const int T = live ? (Tc + nch - 1 - chain) / nch : 0;      // this chain's
     const int R = ((Tc + nch - 1) / nch + kTailAhead - 1) / kTailAhead;      // rounds (chain 0 has the most symbols)
-    const long img = (long)b * 3 * sg.plane;
+    const long img = sg.img_off;
     const int mc = lane % 5, we = lane / 5;
     auto pixel_of = [&](int j) -> long {                 // the stream's j-th symbol from its end
         const int q = min(max(cnt - 1 - j, 0), max(cnt - 1, 0));
@@ -1370,7 +1375,7 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_t
             Row r;
             const long pp = pixel_of(nch * ns + chain + nch * (T - 1 - t));
             const int pi = (int)(pp >> 32), pj = (int)(uint32_t)pp;
-            const ParRow src = par_row(params, b, (long)sg.h * sg.w, (long)pi * sg.w + pj);
+            const ParRow src = par_row(params + sg.par_off, 0, (long)sg.h * sg.w, (long)pi * sg.w + pj);
             r.off = img + ((long)(2 * pi + sg.oi) << sg.lvl) * sg.W + ((long)(2 * pj + sg.oj) << sg.lvl);
             r.sg = src[10 + mc]; r.mu = src[16 + 10 + mc]; r.wk = src[32 + 10 + mc];      // the Cg channel's sigma, mu, weight ...
             r.bb = src[48 + 5 + mc]; r.dd = src[48 + 10 + mc];                                // ... and its cross-channel factors
@@ -1570,10 +1575,11 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_t
 __host__ __device__ __forceinline__ int rans_group(int M) { return M > 32 ? M / 32 : 1; }
 
 __global__ __launch_bounds__(256) void rans_pack_kernel(const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
-                                                        const int32_t *__restrict__ rinfo, int M, int hdr_bytes,
+                                                        const int32_t *__restrict__ rinfo, int M, const ImgGeo *__restrict__ iv,
                                                         uint8_t *__restrict__ out, long out_stride, int32_t *__restrict__ seg_len, int32_t *status)
 {
     const int m = blockIdx.x, b = blockIdx.y;
+    const int hdr_bytes = iv[b].hdr_bytes;
     const int G = rans_group(M), sg = m / G;
     long dst = hdr_bytes + (G > 1 ? 4L * G * (sg + 1) : 0);
     for (int k = 0; k < m; ++k) dst += rinfo[2 * (b * M + k) + 1];

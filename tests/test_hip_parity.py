@@ -386,8 +386,9 @@ def test_rans_xwide_tail_seeds_and_chains_bitexact(torch_mod, codecs, oracle_wei
 @pytest.mark.parametrize("mode_name", ["xrans3", "rans4", "ac"])
 def test_encoder_tuning_switches_bitexact(torch_mod, codecs, mode_name):
     """The encoder's schedule switches change WHEN kernels run, never what they write: levels 4..1 on a side stream (`enc_side_levels`: the
-    per-band pairs launches instead of the one-launch-per-level form), level-0 sub-batches (`enc_chunk_images`), every CNN tile form
-    (`cnn_tile_rows` 16 / 8 / 4 / the round-3 rule) -- containers byte-identical to the default schedule's, decode lossless."""
+    per-band pairs launches instead of the one-launch-per-level form), the mixed-size code path on an equal-size batch (`force_ragged`: per-image
+    tables, tile lists), every CNN tile form (`cnn_tile_rows` 16 / 8 / 4 / the round-3 rule), alone and with the tile lists -- containers
+    byte-identical to the default schedule's, decode lossless."""
     from llicti_amd.codec import mode_of_name
     torch = torch_mod
     c = codecs("trainedlike")
@@ -400,17 +401,21 @@ def test_encoder_tuning_switches_bitexact(torch_mod, codecs, mode_name):
     lens = seg_h.sum(axis=1)
     ref = [cont0[b, :int(lens[b])].cpu().numpy().copy() for b in range(len(rgb))]
     try:
-        for key, val in (("enc_side_levels", 1), ("enc_chunk_images", 1), ("enc_chunk_images", 2), ("cnn_tile_rows", 16), ("cnn_tile_rows", 8),
-                         ("cnn_tile_rows", 4), ("cnn_tile_rows", -1)):
-            c.set_tuning(key, val)
-            cont, seg = c.encode(x, mode=mode)
-            c.check()
-            assert np.array_equal(seg.cpu().numpy(), seg_h), (key, val)
-            for b in range(len(rgb)):
-                assert np.array_equal(cont[b, :int(lens[b])].cpu().numpy(), ref[b]), (key, val, b)
-            c.set_tuning(key, 0)
+        for ragged in ((0, 1) if mode_name != "ac" else (0,)):      # (the reference-format container codes equal sizes only: no tile lists there)
+            c.set_tuning("force_ragged", ragged)
+            for key, val in (("enc_side_levels", 0), ("enc_side_levels", 1), ("cnn_tile_rows", 16), ("cnn_tile_rows", 8), ("cnn_tile_rows", 4), ("cnn_tile_rows", -1)):
+                c.set_tuning(key, val)
+                cont, seg = c.encode(x, mode=mode)
+                c.check()
+                assert np.array_equal(seg.cpu().numpy(), seg_h), (ragged, key, val)
+                for b in range(len(rgb)):
+                    assert np.array_equal(cont[b, :int(lens[b])].cpu().numpy(), ref[b]), (ragged, key, val, b)
+                if key == "cnn_tile_rows":
+                    rec = _decode_poisoned(c, cont0, seg0, 150, 131, mode)      # the decoder's launches in that form too
+                    assert np.array_equal(rec.cpu().numpy(), rgb), (ragged, key, val)
+                c.set_tuning(key, 0)
     finally:
-        for key in ("enc_side_levels", "enc_chunk_images", "cnn_tile_rows"):
+        for key in ("enc_side_levels", "force_ragged", "cnn_tile_rows"):
             c.set_tuning(key, 0)
     rec = _decode_poisoned(c, cont0, seg0, 150, 131, mode)
     assert np.array_equal(rec.cpu().numpy(), rgb)
@@ -1382,3 +1387,165 @@ def test_integration_md_binding_runs(torch_mod, tmp_path):
     out = ns["forward_hip"](hip.ctx, xp)
     mine = model.forward(xp)
     assert len(out) == 5 and all(torch.equal(a, b) for a, b in zip(out, mine))
+
+
+# ------------------------------------------------------------------------------------------------ batches of mixed sizes
+def _flat(rgbs):
+    return np.concatenate([r.reshape(-1) for r in rgbs])
+
+
+def _split(flat, Hs, Ws):
+    out, pos = [], 0
+    for h, w in zip(Hs, Ws):
+        out.append(flat[pos:pos + 3 * h * w].reshape(3, h, w))
+        pos += 3 * h * w
+    return out
+
+
+MIXED_SHAPES = [(150, 131), (96, 160), (67, 93), (150, 131), (33, 64), (224, 96), (32, 32), (97, 351)]      # odd sizes, both pad flags, a repeat, portrait and landscape
+
+
+@pytest.mark.parametrize("mode_name", ["xrans3", "xrans10", "wrans4", "rans8", "rans64"])
+@pytest.mark.parametrize("wname", ["trainedlike", "rand1337"])
+def test_mixed_size_batch_equals_single_image_and_oracle(torch_mod, codecs, oracle_weights, mode_name, wname):
+    """llicti_encode_images_v / llicti_decode_images_v (the reference's test loader yields a different H x W at almost every step,
+    dataloaders/image_dl.py:40-45; agents/llicti_agent.py:122-164 codes them one at a time): every image of a mixed-size batch has exactly the
+    bytes of its own single-image encode, three of them are compared with the CPU oracle, and the batch decodes losslessly on a poisoned
+    workspace -- in every kind of rANS stream (64 / 128 / 256 lanes, grouped segments)."""
+    from llicti_amd.codec import container_to_bytestream_list, mode_of_name, _mode_wide
+    from oracle import oracle as orc
+    torch = torch_mod
+    c = codecs(wname)
+    mode = mode_of_name(mode_name)
+    kinds = ["smooth", "noise"]
+    rgbs = [make_image(kinds[i % 2], h, w, 700 + i) for i, (h, w) in enumerate(MIXED_SHAPES)]
+    Hs, Ws = [h for h, _ in MIXED_SHAPES], [w for _, w in MIXED_SHAPES]
+    flat = _dev(torch, _flat(rgbs))
+    cont, seg = c.encode_v(flat, Hs, Ws, mode)
+    c.check()
+    cont_h, seg_h = cont.cpu().numpy(), seg.cpu().numpy()
+    W_o = oracle_weights(wname)
+    for b, rgb in enumerate(rgbs):
+        c1, s1 = c.encode(_dev(torch, rgb[None]), mode=mode)
+        c.check()
+        n = int(seg_h[b].sum())
+        assert np.array_equal(seg_h[b], s1[0].cpu().numpy()), b
+        assert np.array_equal(cont_h[b, :n], c1[0, :n].cpu().numpy()), b
+        if b in (0, 2, 7):
+            assert container_to_bytestream_list(cont_h[b], seg_h[b]) == orc.encode_image_rans(rgb, W_o, mode & 0xFF, wide=_mode_wide(mode)), b
+    c.poison_workspace()
+    rec = c.decode_v(cont, seg, Hs, Ws, mode)
+    c.check()
+    assert not c.image_status(len(rgbs)).any()
+    for b, (r, rgb) in enumerate(zip(_split(rec.cpu().numpy(), Hs, Ws), rgbs)):
+        assert np.array_equal(r, rgb), b
+    # ... and a container written by a mixed-size call decodes in a call of its own (and the other way round)
+    one = c.decode(cont[5:6].contiguous(), seg[5:6].contiguous(), Hs[5], Ws[5], mode=mode)
+    c.check()
+    assert np.array_equal(one.cpu().numpy()[0], rgbs[5])
+
+
+def test_mixed_size_batch_eval_set_shapes(torch_mod, codecs, oracle_weights):
+    """A batch at the sizes the reference's own test set has (tests/golden/eval_shapes.json: the 500 sizes its eval log prints, 119 distinct,
+    interleaved): 12 consecutive images of it in xrans8 -- bytes of image 0, 5 and 11 equal the oracle's, the rest equal their single-image
+    encodes, lossless on a poisoned workspace; then the next 12 through the same context (a new plan: no stale tables)."""
+    import json
+    import os
+    from conftest import GOLDEN
+    from llicti_amd.codec import container_to_bytestream_list, mode_of_name
+    from oracle import oracle as orc
+    torch = torch_mod
+    shapes = json.load(open(os.path.join(GOLDEN, "eval_shapes.json")))["shapes"]
+    c = codecs("trainedlike")
+    W_o = oracle_weights("trainedlike")
+    mode = mode_of_name("xrans8")
+    for k0 in (404, 416):
+        sh = shapes[k0:k0 + 12]
+        Hs, Ws = [h for h, _ in sh], [w for _, w in sh]
+        rgbs = [make_image("smooth" if i % 3 else "noise", h, w, 900 + k0 + i) for i, (h, w) in enumerate(sh)]
+        cont, seg = c.encode_v(_dev(torch, _flat(rgbs)), Hs, Ws, mode)
+        c.check()
+        cont_h, seg_h = cont.cpu().numpy(), seg.cpu().numpy()
+        for b, rgb in enumerate(rgbs):
+            if b in (0, 5, 11) and k0 == 404:
+                assert container_to_bytestream_list(cont_h[b], seg_h[b]) == orc.encode_image_rans(rgb, W_o, 8, wide=2), b
+            else:
+                c1, s1 = c.encode(_dev(torch, rgb[None]), mode=mode)
+                n = int(seg_h[b].sum())
+                assert np.array_equal(seg_h[b], s1[0].cpu().numpy()) and np.array_equal(cont_h[b, :n], c1[0, :n].cpu().numpy()), b
+        c.poison_workspace()
+        rec = c.decode_v(cont, seg, Hs, Ws, mode)
+        c.check()
+        for b, (r, rgb) in enumerate(zip(_split(rec.cpu().numpy(), Hs, Ws), rgbs)):
+            assert np.array_equal(r, rgb), (k0, b)
+
+
+def test_mixed_size_batch_rejects_reference_format_and_bad_sizes(torch_mod, codecs):
+    """The reference-format container codes equal sizes per call (its decoder's chunk pipeline is sized per stage): a mixed-size call in it
+    is LLICTI_EINVAL, not a wrong result; so is a size outside 32 .. 8160; a decode whose sizes do not match the headers flags those images."""
+    from llicti_amd import _lib
+    from llicti_amd.codec import MODE_AC, mode_of_name
+    torch = torch_mod
+    c = codecs("trainedlike")
+    rgbs = [make_image("smooth", 64, 96, 1), make_image("smooth", 96, 64, 2)]
+    flat = _dev(torch, _flat(rgbs))
+    with pytest.raises(_lib.LlictiError) as e:
+        c.encode_v(flat, [64, 96], [96, 64], MODE_AC)
+    assert e.value.code == _lib.EINVAL
+    with pytest.raises(_lib.LlictiError):
+        c.encode_v(flat, [64, 16], [96, 64], mode_of_name("xrans2"))
+    # equal sizes through the _v entry are fine in the reference format (same bytes as encode())
+    two = [make_image("smooth", 64, 96, 1), make_image("noise", 64, 96, 2)]
+    cv, sv = c.encode_v(_dev(torch, _flat(two)), [64, 64], [96, 96], MODE_AC)
+    cu, su = c.encode(_dev(torch, np.stack(two)), mode=MODE_AC)
+    c.check()
+    assert torch.equal(sv, su)
+    for b in range(2):
+        n = int(su[b].sum())
+        assert torch.equal(cv[b, :n], cu[b, :n])
+    # swapped sizes at decode: both images flagged, no fault
+    mode = mode_of_name("xrans2")
+    cont, seg = c.encode_v(flat, [64, 96], [96, 64], mode)
+    c.check()
+    c.decode_v(cont, seg, [96, 64], [64, 96], mode)
+    with pytest.raises(_lib.LlictiError) as e:
+        c.check()
+    assert e.value.code == _lib.EFORMAT
+    assert (c.image_status(2) == _lib.EFORMAT).all()
+
+
+def test_many_sizes_no_device_sync_and_plan_reuse(torch_mod, codecs):
+    """80 different (batch composition, size) plans through one context -- more than the plan cache holds (32) -- round-trip losslessly, a
+    size that left the cache comes back with the same bytes, and the calls never block on the device once the table blocks are pooled: the
+    host returns from an encode enqueued behind 50 ms of other work on the stream long before that work ends."""
+    import time
+    from llicti_amd.codec import mode_of_name
+    torch = torch_mod
+    c = codecs("trainedlike")
+    mode = mode_of_name("xrans2")
+    first = None
+    for k in range(80):
+        h, w = 32 + 3 * k, 40 + 2 * (k % 17)
+        rgb = make_image("smooth", h, w, k)[None]
+        cont, seg = c.encode(_dev(torch, rgb), mode=mode)
+        rec = c.decode(cont, seg, h, w, mode=mode)
+        assert np.array_equal(rec.cpu().numpy(), rgb), k
+        if k == 0:
+            first = (cont[0, :int(seg[0].sum())].cpu().numpy().copy(), rgb)
+    c.check()
+    cont, seg = c.encode(_dev(torch, first[1]), mode=mode)
+    assert np.array_equal(cont[0, :int(seg[0].sum())].cpu().numpy(), first[0])
+    # a new size enqueued behind a long-running kernel: the call must return while that kernel is still running
+    a = torch.randn(8192, 8192, device="cuda:0")
+    x = _dev(torch, make_image("smooth", 333, 77, 5)[None])
+    torch.cuda.synchronize()
+    for _ in range(6):
+        a = a @ a * 1e-4
+    t1 = time.perf_counter()
+    cont, seg = c.encode(x, mode=mode)
+    rec = c.decode(cont, seg, 333, 77, mode=mode)
+    t2 = time.perf_counter()
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    assert (t3 - t2) > 4 * (t2 - t1), f"the calls blocked on the device: enqueue {t2 - t1:.4f} s, remaining GPU work {t3 - t2:.4f} s"
+    assert np.array_equal(rec.cpu().numpy()[0], make_image("smooth", 333, 77, 5))
