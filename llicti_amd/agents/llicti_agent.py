@@ -137,21 +137,26 @@ class LLICTIAgent:
 
     @torch.no_grad()
     def eval_model_batched(self, eval_batch):
-        """eval_model for throughput: consecutive test images of one size are coded `eval_batch` at a time through
-        LLICTI.encode_batch_async / decode_batch_async -- the same bytestream_lists, rates, lossless check and per-image log lines as
-        the one-image loop (llicti_agent.py:122-164), in the same order.  The loop is software-pipelined one batch deep: while the GPU
-        encodes batch k + 1 the host cuts batch k's containers into bytestream_lists, books their rates and packs them again for the
-        decoder, so neither side waits for the other; uploads and downloads run on the model's copy streams, next to the kernels.  Enc/Dec-Times of an
-        image are its batch's GPU time (HIP events around the enqueued calls on the compute stream) divided by the batch size.  With config.keep_streams the lists stay in self.results."""
+        """eval_model for throughput: the test images are coded `eval_batch` at a time, IN THE ORDER THE LOADER YIELDS THEM AND WHATEVER THEIR
+        SIZES (the reference's loader yields batch-1 images of arbitrary size, dataloaders/image_dl.py:40-45; its own 500-image test set has
+        119 sizes, interleaved) through LLICTI.encode_batch_async / decode_batch_async on a list of images -- the same bytestream_lists,
+        rates, lossless check and per-image log lines as the one-image loop (llicti_agent.py:122-164), in the same order.  (In the
+        reference-format container, which codes one size per call, a batch closes where the size changes.)  The loop is software-pipelined
+        one batch deep: while the GPU encodes batch k + 1 the host cuts batch k's containers into bytestream_lists, books their rates and
+        packs them again for the decoder, so neither side waits for the other; uploads and downloads run on the model's copy streams, next
+        to the kernels.  Enc/Dec-Times of an image are its batch's GPU time (HIP events around the enqueued calls on the compute stream,
+        the encode's behind the wait for its upload) times the image's share of the batch's pixels.  With config.keep_streams the lists
+        stay in self.results."""
         self.model.eval()
         self.results = []
         keep = bool(self.config["keep_streams"]) if "keep_streams" in self.config else False
         stream = torch.cuda.current_stream(self.device)
+        one_size = self.model.mode is not None and self.model.mode == 0          # reference format: equal sizes per call
 
         def batches():
             cur = []
             for rgb in _iter_test_images_u8(self.config):
-                if cur and (rgb.shape != cur[0].shape or len(cur) == eval_batch):
+                if cur and (len(cur) == eval_batch or (one_size and rgb.shape != cur[0].shape)):
                     yield cur
                     cur = []
                 cur.append(rgb)
@@ -160,27 +165,31 @@ class LLICTIAgent:
 
         def start_encode(imgs, slot):
             B = len(imgs)
-            host = self.model._pinned(("rgb_in", slot), (B,) + imgs[0].shape, torch.uint8)
-            np.stack(imgs, out=host.numpy())
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            enc = self.model.encode_batch_async(host, slot=slot)        # (pinned host tensor: uploaded on the model's copy stream)
+            up, _ = self.model._copy_streams(self.device)
+            enc = self.model.encode_batch_async(imgs, slot=slot)        # list of uint8 host arrays: staged in pinned memory, uploaded on the model's copy stream
             e1.record(stream)
-            return {"enc": enc, "e_enc": (e0, e1), "B": B, "H": imgs[0].shape[1], "W": imgs[0].shape[2]}
+            return {"enc": enc, "e_enc": (enc.t0 if enc.t0 is not None else e0, e1), "B": B, "Hs": enc.Hs, "Ws": enc.Ws}
 
         def finish(job, idx0):
             """host half of a batch: lists, rates, decode enqueue; then (synchronising) the lossless check and the log lines"""
             enc = job["enc"]
             lists = enc.lists(check=False)
-            numel = 3 * job["H"] * job["W"]
-            rates = [self.compr_loss.forward(numel, bl) for bl in lists]
+            rates = [self.compr_loss.forward(3 * h * w, bl) for bl, h, w in zip(lists, job["Hs"], job["Ws"])]
             d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             d0.record(stream)
-            rec = self.model.decode_batch_async(lists, self.device, slot=job["slot"])
-            err = (torch.maximum(rec, enc.rgb) - torch.minimum(rec, enc.rgb)).amax(dim=(1, 2, 3)).to(torch.int16)    # per image, = max|x - x_reco| * 255 (uint8 arithmetic: half the bytes of an int16 difference)
+            rec, _, _ = self.model.decode_batch_async(lists, self.device, slot=job["slot"], flat=True)
+            n = rec.numel()
+            diff = torch.maximum(rec, enc.rgb[:n]) - torch.minimum(rec, enc.rgb[:n])    # |x - x_reco| * 255 in uint8 arithmetic, the images back to back
+            offs, _ = enc.codec.flat_offsets(job["Hs"], job["Ws"])
+            if len(set(zip(job["Hs"], job["Ws"]))) == 1:
+                err = diff.view(job["B"], -1).amax(dim=1).to(torch.int16)
+            else:
+                err = torch.stack([diff[int(o):int(o) + 3 * h * w].amax() for o, h, w in zip(offs, job["Hs"], job["Ws"])]).to(torch.int16)
             d1.record(stream)
-            err_h = self.model._pinned(("err", job["slot"]), (job["B"],), torch.int16)
+            err_h = self.model._pinned(("err", job["slot"]), 2 * job["B"])[:2 * job["B"]].view(torch.int16)
             err_h.copy_(err, non_blocking=True)                # read in report() behind its own event: no wait for later batches
+            self.model._pinned_mark(("err", job["slot"]), stream)
             ev = torch.cuda.Event()
             ev.record(stream)
             return {"job": job, "lists": lists, "rates": rates, "err": err_h, "ev": ev, "e_dec": (d0, d1), "idx0": idx0}
@@ -191,13 +200,16 @@ class LLICTIAgent:
             err = fin["err"].numpy().astype(np.float64)
             enc_ms = job["e_enc"][0].elapsed_time(job["e_enc"][1])
             dec_ms = fin["e_dec"][0].elapsed_time(fin["e_dec"][1])
+            pix = float(sum(h * w for h, w in zip(job["Hs"], job["Ws"])))
             for b in range(job["B"]):
                 bl, rate1_list = fin["lists"][b], fin["rates"][b]
+                H, W = job["Hs"][b], job["Ws"][b]
                 self.test_logger(rate1_list)                   # llicti_agent.py:140
-                bpsp = sum(len(s) * 8 for row in bl for s in row) / (3 * job["H"] * job["W"])
-                enc_t, dec_t = enc_ms / 1e3 / job["B"], dec_ms / 1e3 / job["B"]
-                self._log_image(fin["idx0"] + b, job["H"], job["W"], bpsp, enc_t, dec_t, float(err[b]))
-                r = {"idx": fin["idx0"] + b, "H": job["H"], "W": job["W"], "bpsp": bpsp, "enc_s": enc_t, "dec_s": dec_t,
+                bpsp = sum(len(s) * 8 for row in bl for s in row) / (3 * H * W)
+                share = H * W / pix
+                enc_t, dec_t = enc_ms / 1e3 * share, dec_ms / 1e3 * share
+                self._log_image(fin["idx0"] + b, H, W, bpsp, enc_t, dec_t, float(err[b]))
+                r = {"idx": fin["idx0"] + b, "H": H, "W": W, "bpsp": bpsp, "enc_s": enc_t, "dec_s": dec_t,
                      "max_abs_err": float(err[b]), "rates": rate1_list, "batch": job["B"]}
                 if keep:
                     r["bytestream_list"] = bl

@@ -22,19 +22,46 @@ MODE_AC = 0                      # the reference's container: 45 torchac-algorit
 
 
 MAX_STREAMS_IN_BUDGET = 10       # an xwide v3 stream (seeded tail chains, two where they pay) costs ~2-4 bytes: 10 per 768x512 image are +0.0003 (noise) ... +0.0008 (an image drawn from the model) bpp over the reference-format container
+XWIDE_MIN_TAIL = 2048            # last-stage symbols a 256-lane stream needs for its tail to fill the 7,936-bit payload its initial states carry (the format's cap is 2,047 tail symbols)
+NARROW_MIN_TAIL = 512            # ... and a 64-lane stream for its 1,984 bits
 
 
-def auto_streams(B, n_cu=256):
+def streams_in_budget(H, W):
+    """xwide streams per image that keep the container within +0.001 bpp of the reference-format one for an H x W image (measured with the
+    CPU oracle over sizes 32x32 ... 768x512, smooth / model-drawn / noise content: tests/test_oracle_golden.py::test_auto_container_budget_by_size).
+    Two limits.  BYTES: the M streams of an image cost about 7 M - 25 bytes more than the reference format's 45 range-coder terminations,
+    and 0.001 bpp are H W / 8000 bytes.  PAYLOAD: a stream's 256 initial states carry 992 bytes that only the stream's own share of the LAST
+    stage's symbols can fill (its tail): with fewer than ~2,048 of them per stream what is left is pure waste -- a 96x128 image in ten xwide
+    streams is 25 % larger than in the reference format.  0: no xwide stream fits (use a 64-lane stream or the reference format)."""
+    nc_last = (H // 2) * (W // 2)                 # coded positions of level 0, band x10
+    return max(0, min(MAX_STREAMS_IN_BUDGET, nc_last // XWIDE_MIN_TAIL, int((H * W / 8000.0 + 25.0) / 7.0)))
+
+
+def auto_streams(B, n_cu=256, sizes=None):
     """Streams per image of the throughput container for a batch of B images: as many as keep ONE decoder workgroup per stream on its
     own compute unit (B * M <= CUs: a second workgroup on a CU slows both by 1.4x, so more streams than that buy nothing) and stay
-    inside the north star's 0.001 bpp (<= 10 per 768x512 image).  24 images on a 256-CU MI355X: 10; 32 images (configs[4] per GPU): 8."""
-    return max(1, min(MAX_STREAMS_IN_BUDGET, n_cu // max(1, B)))
+    inside the north star's 0.001 bpp -- at most 10 per 768x512 image, fewer for smaller ones (streams_in_budget; `sizes`: the (H, W) of the
+    batch's images, the smallest one decides).  24 images of 768x512 on a 256-CU MI355X: 10; 32 images (configs[4] per GPU): 8."""
+    m = max(1, min(MAX_STREAMS_IN_BUDGET, n_cu // max(1, B)))
+    if sizes:
+        m = min(m, min(streams_in_budget(h, w) for h, w in sizes))
+    return m
 
 
-def auto_container(B, n_cu=256):
+def auto_container(B, n_cu=256, sizes=None):
     """Name of the throughput container for B images per call: xwide streams (256 lanes, one decoder lane per symbol -- lanes are nearly
-    free in bytes, 0.06 bit each; streams are not, ~2-3.5 bytes each), auto_streams(B) of them per image."""
-    return f"xrans{auto_streams(B, n_cu)}"
+    free in bytes, 0.06 bit each; streams are not, ~2-3.5 bytes each), auto_streams(B) of them per image.  With `sizes` (the (H, W) of the
+    images): small images get fewer streams, below ~90x90 pixels one 64-lane stream ("rans1"), below ~45x45 the reference format ("ac";
+    a batch of MIXED sizes stays in "rans1", the reference format codes one size per call) -- so that the container stays within +0.001 bpp
+    of the reference-format one at every size.  What no size rule can see is the CONTENT: a source cheaper than ~3.9 bits per symbol in the
+    last stage (2,047 tail symbols cannot fill 7,936 bits) wastes part of every xwide stream's payload whatever the size -- DESIGN section 8."""
+    m = auto_streams(B, n_cu, sizes)
+    if m >= 1:
+        return f"xrans{m}"
+    nc_last = min((h // 2) * (w // 2) for h, w in sizes)
+    if nc_last >= NARROW_MIN_TAIL or len(set(sizes)) > 1:
+        return "rans1"
+    return "ac"
 
 
 def MODE_RANS(M=8, wide=False):

@@ -107,7 +107,7 @@ class LLICTI(nn.Module):
         # (llicti_amd.codec.auto_container: xwide rANS streams, one decoder workgroup per stream and compute unit)
         self.container = str(config["container"]) if "container" in config else "ac"
         self.mode = None if self.container == "auto" else mode_of_name(self.container)
-        self._stage = {}                # pinned host staging buffers of the batched path, by (tag, shape)
+        self._stage = {}                # pinned host staging buffers of the batched path, by (tag, slot): [buffer, event behind its last copy]
         self._xfer = {}                 # (upload, download) copy streams of the batched path, by device index
 
     # ------------------------------------------------------------------ plumbing
@@ -158,22 +158,30 @@ class LLICTI(nn.Module):
         lists, x_ycocg = self.compress_batch(x)
         return lists[0], x_ycocg
 
-    def mode_for_batch(self, B, device=None):
-        """Container mode of a call with B images: the configured one, or for "auto" the throughput container for that batch size."""
+    def mode_for_batch(self, B, device=None, sizes=None):
+        """Container mode of a call with B images (of `sizes` [(H, W), ...] where known): the configured one, or for "auto" the throughput
+        container for that batch -- streams per image limited by the compute units AND by the smallest image's byte budget."""
         if self.mode is not None:
             return self.mode
         dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-        return mode_of_name(auto_container(B, torch.cuda.get_device_properties(dev).multi_processor_count))
+        return mode_of_name(auto_container(B, torch.cuda.get_device_properties(dev).multi_processor_count, sizes=sizes))
 
-    def _pinned(self, tag, shape, dtype):
-        key = (tag, tuple(shape), dtype)
-        t = self._stage.get(key)
-        if t is None:
-            if len(self._stage) >= 16:
-                self._stage.clear()
-            t = torch.empty(shape, dtype=dtype).pin_memory()
-            self._stage[key] = t
-        return t
+    def _pinned(self, key, nbytes):
+        """Pinned host staging buffer (flat uint8, at least nbytes, grown to the running maximum) of `key` = (tag, slot).  The buffer's last
+        asynchronous copy -- _pinned_mark() records an event behind it -- has finished when this returns: the host may rewrite it."""
+        ent = self._stage.get(key)
+        if ent is not None and ent[1] is not None:
+            ent[1].synchronize()
+            ent[1] = None
+        if ent is None or ent[0].numel() < nbytes:
+            ent = self._stage[key] = [torch.empty((int(nbytes * (1.25 if ent is not None else 1.0)),), dtype=torch.uint8).pin_memory(), None]
+        return ent[0]
+
+    def _pinned_mark(self, key, stream):
+        """An asynchronous copy from / into the buffer of `key` has just been enqueued on `stream`."""
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        self._stage[key][1] = ev
 
     @torch.no_grad()
     def compress_batch(self, x):
@@ -183,39 +191,75 @@ class LLICTI(nn.Module):
 
     @torch.no_grad()
     def encode_batch_async(self, x, want_ycocg=False, slot=0):
-        """Enqueue the encode of a batch and the download of its containers (pinned host buffers, only the bytes in use); returns an
-        EncodedBatch whose lists() waits for the download and cuts the containers into the reference's bytestream_lists.  Nothing here
-        blocks the host: a caller can enqueue the next batch before it converts this one (LLICTIAgent.eval_model with eval_batch > 1).
-        `slot` selects one of the staging buffer sets (two batches in flight need two)."""
-        codec = self.codec(x.device if x.is_cuda else None)
-        cur = torch.cuda.current_stream(codec.device)
-        up, down = self._copy_streams(codec.device)
-        xu = self._to_u8(x)
-        if xu.is_cuda:
-            rgb = xu.to(codec.device).contiguous()
-        else:
-            # host input (pinned by the caller for a true async copy): uploaded on the copy stream, so that it runs under whatever the
-            # compute stream is doing (the previous batch's decode); the compute stream waits for it, nothing else does
+        """Enqueue the encode of a batch and the download of its containers (pinned host buffers); returns an EncodedBatch whose lists() waits
+        for the download and cuts the containers into the reference's bytestream_lists.  Nothing here blocks the host: a caller can enqueue
+        the next batch before it converts this one (LLICTIAgent.eval_model with eval_batch > 1).  `slot` selects one of the staging buffer
+        sets (two batches in flight need two).
+        x: a tensor [B,3,H,W] (float32 in {k/255} or uint8; host or device), or a LIST of B uint8 host arrays [3,H_b,W_b] whose sizes may
+        differ (the reference's test loader yields arbitrary sizes, dataloaders/image_dl.py:40-45): one call, one upload, one download."""
+        if isinstance(x, (list, tuple)):
+            imgs = [np.ascontiguousarray(a) for a in x]
+            for a in imgs:
+                if a.dtype != np.uint8 or a.ndim != 3 or a.shape[0] != 3:
+                    raise ValueError("a list batch holds uint8 [3, H, W] arrays")
+            codec = self.codec(None)
+            Hs, Ws = [int(a.shape[1]) for a in imgs], [int(a.shape[2]) for a in imgs]
+            offs, total = codec.flat_offsets(Hs, Ws)
+            host = self._pinned(("rgb_in", slot), total)
+            hv = host.numpy()
+            for a, o in zip(imgs, offs):
+                hv[int(o):int(o) + a.size] = a.reshape(-1)
+            cur = torch.cuda.current_stream(codec.device)
+            up, down = self._copy_streams(codec.device)
             with torch.cuda.stream(up):
-                rgb = xu.to(codec.device, non_blocking=True).contiguous()
+                rgb = host[:total].to(codec.device, non_blocking=True)
+            self._pinned_mark(("rgb_in", slot), up)
             cur.wait_stream(up)
             rgb.record_stream(cur)
-        B, _, H, W = rgb.shape
-        mode = self.mode_for_batch(B, codec.device)
-        cont, seg = codec.encode(rgb, mode=mode)
-        x_ycocg = codec.lift(rgb)[1] if want_ycocg else None     # x_ycocg = (YCoCg - [127,0,0]) / 255 (LLICTI_nets.py:143-144)
-        seg_h = self._pinned(("seg", slot), (B, NSEG), torch.int32)
-        cont_h = self._pinned(("cont_out", slot), tuple(cont.shape), torch.uint8)
+            t0 = torch.cuda.Event(enable_timing=True)              # the compute stream has the batch: what follows is encode time, not upload wait
+            t0.record(cur)
+            B = len(imgs)
+            mode = self.mode_for_batch(B, codec.device, sizes=list(zip(Hs, Ws)))
+            cont, seg = codec.encode_v(rgb, Hs, Ws, mode)
+            x_ycocg = None
+        else:
+            t0 = None
+            codec = self.codec(x.device if x.is_cuda else None)
+            cur = torch.cuda.current_stream(codec.device)
+            up, down = self._copy_streams(codec.device)
+            xu = self._to_u8(x)
+            if xu.is_cuda:
+                rgb = xu.to(codec.device).contiguous()
+            else:
+                # host input (pinned by the caller for a true async copy): uploaded on the copy stream, so that it runs under whatever the
+                # compute stream is doing (the previous batch's decode); the compute stream waits for it, nothing else does
+                with torch.cuda.stream(up):
+                    rgb = xu.to(codec.device, non_blocking=True).contiguous()
+                cur.wait_stream(up)
+                rgb.record_stream(cur)
+            B, _, H, W = rgb.shape
+            Hs, Ws = [H] * B, [W] * B
+            mode = self.mode_for_batch(B, codec.device, sizes=[(H, W)])
+            cont, seg = codec.encode(rgb, mode=mode)
+            # x_ycocg = (YCoCg - [127,0,0]) / 255 (LLICTI_nets.py:143-144): the float planes the reference hands back beside the streams
+            x_ycocg = codec.lift(rgb)[1] if want_ycocg else None
+        nb = cont.numel()
+        seg_h = self._pinned(("seg", slot), B * NSEG * 4)[:B * NSEG * 4].view(torch.int32).view(B, NSEG)
+        cont_h = self._pinned(("cont_out", slot), nb)[:nb].view(tuple(cont.shape))
         # the download runs on its own stream behind the encode: the compute stream goes straight on to the next enqueued call
         down.wait_stream(cur)
         with torch.cuda.stream(down):
             seg_h.copy_(seg, non_blocking=True)
-            cont_h.copy_(cont, non_blocking=True)                  # one contiguous copy of the container strides
+            cont_h.copy_(cont, non_blocking=True)                  # one contiguous copy of the container strides (bytes past a container's own length: undefined)
             ev = torch.cuda.Event()
             ev.record(down)
+        self._pinned_mark(("seg", slot), down)
+        self._pinned_mark(("cont_out", slot), down)
         cont.record_stream(down)
         seg.record_stream(down)
-        return EncodedBatch(codec, rgb, cont_h, seg_h, ev, x_ycocg, mode)
+        enc = EncodedBatch(codec, rgb, cont_h, seg_h, ev, x_ycocg, mode, Hs, Ws)
+        enc.t0 = t0
+        return enc
 
     def _copy_streams(self, device):
         """(upload, download) HIP streams of a device for the batched calls' transfers (created once): PCIe copies next to the kernels, not
@@ -227,9 +271,17 @@ class LLICTI(nn.Module):
 
     @torch.no_grad()
     def decompres(self, bytestream_list, devc=None, xorg=None):
-        """bytestream_list -> float32 [1,3,H,W] (LLICTI_nets.py:161-179)."""
-        out = self.decompres_batch([bytestream_list], devc)
-        return out
+        """bytestream_list -> float32 [1,3,H,W] (LLICTI_nets.py:161-179).  xorg: the reference's diagnostic (:167-171) -- the float planes
+        compress() returned; the decoded planes are compared with them on the device and a difference of a grey level or more is reported."""
+        rgb = self.decode_batch_async([bytestream_list], devc)
+        codec = self.codec()
+        codec.check()
+        if xorg is not None:
+            planes = codec.lift(rgb)[1]                            # (YCoCg - [127,0,0]) / 255 of the decoded image, as compress() returns it
+            maxx_abserr = float((xorg.to(planes.device) - planes).abs().max()) * 255
+            if maxx_abserr >= 1.0:                                 # LLICTI_nets.py:169-171
+                print("Error: Decoded YCoCg img does NOT match original YCoCg image perfectly! The maximum of absolute error is {:.4f}".format(maxx_abserr))
+        return rgb.to(torch.float32) / 255           # LLICTI_nets.py:87
 
     @torch.no_grad()
     def decompres_batch(self, lists, devc=None):
@@ -238,28 +290,33 @@ class LLICTI(nn.Module):
         return rgb.to(torch.float32) / 255           # LLICTI_nets.py:87
 
     @torch.no_grad()
-    def decode_batch_async(self, lists, devc=None, slot=0):
-        """bytestream_lists of B same-size images -> uint8 [B,3,H,W] on the device, enqueued (upload from a pinned buffer + decode);
-        device-side failures are reported by codec().check() / image_status()."""
+    def decode_batch_async(self, lists, devc=None, slot=0, flat=False):
+        """bytestream_lists of B images -> uint8 [B,3,H,W] on the device, enqueued (upload from a pinned buffer + decode); device-side
+        failures are reported by codec().check() / image_status().  The images of a call share a container kind; in a rANS container their
+        SIZES may differ -- then (or with flat=True) the result is (flat uint8 device tensor, Hs, Ws): the images back to back, [3][H][W] each."""
         codec = self.codec(devc if (devc is not None and torch.device(devc).type == "cuda") else None)
-        dims = None
+        Hs, Ws, mode = [], [], None
         for bl in lists:
             if len(bl) != 6 or any(len(r) != 9 for r in bl):
                 raise ValueError("bytestream_list must be 6 lists of 9 byte strings")
             if len(bl[0][0]) != 3 or len(bl[0][1]) != 12 or len(bl[0][2]) != 2:
                 raise ValueError("malformed header streams")
             hdr = bytes(bl[0][0]) + bytes(bl[0][1]) + bytes(bl[0][2])
-            mode = mode_of_header(hdr[0])               # AC container: hdr[0] == num_scales (LLICTI_nets.py:424)
-            d = header_dims(hdr) + (mode,)
-            if dims is None:
-                dims = d
-            elif d != dims:
-                raise ValueError("all images of one decompres_batch call must have the same size and container")
-        H, W, mode = dims
+            m = mode_of_header(hdr[0])                  # AC container: hdr[0] == num_scales (LLICTI_nets.py:424)
+            H, W = header_dims(hdr)
+            if mode is None:
+                mode = m
+            elif m != mode:
+                raise ValueError("all images of one decompres_batch call must be in the same container")
+            Hs.append(H)
+            Ws.append(W)
         B = len(lists)
-        stride = codec.max_container_bytes(H, W)
-        cont_h = self._pinned(("cont_in", slot), (B, stride), torch.uint8)
-        seg_h = self._pinned(("seg_in", slot), (B, NSEG), torch.int32)
+        mixed = any(h != Hs[0] or w != Ws[0] for h, w in zip(Hs, Ws))
+        if mixed and mode == MODE_AC:
+            raise ValueError("images of different sizes in the reference-format container decode one size per call")
+        stride = max(codec.max_container_bytes(h, w) for h, w in set(zip(Hs, Ws)))
+        cont_h = self._pinned(("cont_in", slot), B * stride)[:B * stride].view(B, stride)
+        seg_h = self._pinned(("seg_in", slot), B * NSEG * 4)[:B * NSEG * 4].view(torch.int32).view(B, NSEG)
         cont_np, seg_np = cont_h.numpy(), seg_h.numpy()
         for i, bl in enumerate(lists):
             pos, k = 0, 0
@@ -278,19 +335,25 @@ class LLICTI(nn.Module):
         with torch.cuda.stream(up):
             cont_d = cont_h.to(codec.device, non_blocking=True)  # one contiguous copy; bytes past a container's own length are never read (validated lengths)
             seg_d = seg_h.to(codec.device, non_blocking=True)
+        self._pinned_mark(("cont_in", slot), up)
+        self._pinned_mark(("seg_in", slot), up)
         cur.wait_stream(up)
         cont_d.record_stream(cur)
         seg_d.record_stream(cur)
-        return codec.decode(cont_d, seg_d, H, W, mode=mode)
+        if mixed or flat:
+            return codec.decode_v(cont_d, seg_d, Hs, Ws, mode), Hs, Ws
+        return codec.decode(cont_d, seg_d, Hs[0], Ws[0], mode=mode)
 
 
 class EncodedBatch:
     """Handle of one enqueued batch encode (LLICTI.encode_batch_async): the device input, the pinned host copies of the containers and
     their segment lengths, and the event recorded behind the download."""
 
-    def __init__(self, codec, rgb, cont_h, seg_h, ev, x_ycocg, mode):
+    def __init__(self, codec, rgb, cont_h, seg_h, ev, x_ycocg, mode, Hs=None, Ws=None):
         self.codec, self.rgb, self.cont_h, self.seg_h, self.ev = codec, rgb, cont_h, seg_h, ev
         self.x_ycocg, self.mode = x_ycocg, mode
+        self.Hs, self.Ws = Hs, Ws           # per image (a list batch: rgb is the flat device buffer, the images back to back)
+        self.t0 = None                      # list batches: timing event on the compute stream behind the wait for the upload
         self._lists = None
 
     def lists(self, check=True):

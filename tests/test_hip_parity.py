@@ -641,31 +641,36 @@ def test_agent_eval_model(torch_mod, caplog):
 
 
 def test_agent_batched_eval_equals_unbatched(torch_mod, tmp_path, caplog, oracle_weights):
-    """LLICTIAgent.eval_model with config.eval_batch groups consecutive same-size test images and codes them through the
-    batched, software-pipelined path (LLICTI.encode_batch_async / decode_batch_async, config.container = "auto").  Its bytestream_lists
-    equal, image by image, what the one-image loop writes in the same container, and the oracle's for one image; per-image log lines,
-    rates and the lossless check are the same; a size change inside the data set closes a batch; an in-memory data set works."""
+    """LLICTIAgent.eval_model with config.eval_batch codes `eval_batch` CONSECUTIVE test images per call, WHATEVER THEIR SIZES (the
+    reference's loader yields arbitrary sizes one at a time, dataloaders/image_dl.py:40-45), through the batched, software-pipelined path
+    (LLICTI.encode_batch_async / decode_batch_async on lists of images -> llicti_encode_images_v / llicti_decode_images_v).  Its
+    bytestream_lists equal, image by image, what the one-image loop writes in the same container, and the oracle's for two images; per-image
+    log lines (in order), rates and the lossless check are the same.  container "auto" picks, per batch, the container its smallest image
+    allows; in the reference-format container a batch closes where the size changes; an in-memory data set works."""
     import logging
     from oracle import oracle as orc
     from llicti_amd import fileio
     from llicti_amd.agents.llicti_agent import LLICTIAgent
     from llicti_amd.codec import auto_container, mode_of_header, mode_of_name
     from llicti_amd.config import default_config
+    torch = torch_mod
     caplog.set_level(logging.INFO)
-    # 7 + 2 + 1 images of three sizes as files (the reference's test loader reads a directory): batches 3, 3, 1 | 2 | 1
-    imgs = [make_image("noise" if i % 2 else "smooth", 96, 128, 400 + i) for i in range(7)] + \
-           [make_image("smooth", 67, 93, 410 + i) for i in range(2)] + [make_image("noise", 128, 96, 420)]
+    # 10 images of six sizes, interleaved, as files (the reference's test loader reads a directory): batches of 3, 3, 3, 1
+    sizes = [(96, 128), (96, 128), (67, 93), (128, 96), (96, 128), (150, 131), (67, 93), (150, 131), (97, 351), (96, 128)]
+    imgs = [make_image("noise" if i % 2 else "smooth", h, w, 400 + i) for i, (h, w) in enumerate(sizes)]
     for i, im in enumerate(imgs):
         fileio.write_image(str(tmp_path / f"img_{i:02d}.ppm"), im)
-    cname = auto_container(3)
-    assert cname == auto_container(1) == "xrans10"
-    a_b = LLICTIAgent(default_config(test_data=str(tmp_path), eval_batch=3, container="auto", keep_streams=True))
+    cname = "xrans2"
+    a_b = LLICTIAgent(default_config(test_data=str(tmp_path), eval_batch=3, container=cname, keep_streams=True))
     res_b = a_b.run()
-    n_lines = sum("Check: Decoded img matches original" in r.message for r in caplog.records)
     a_u = LLICTIAgent(default_config(test_data=str(tmp_path), container=cname, keep_streams=True))
     res_u = a_u.run()
-    assert len(res_b) == len(res_u) == 10 and n_lines == 10
-    assert [r["batch"] for r in res_b] == [3, 3, 3, 3, 3, 3, 1, 2, 2, 1]
+    import re
+    lines = [r.message for r in caplog.records if "Check: Decoded img matches original" in r.message]
+    assert len(res_b) == len(res_u) == 10 and len(lines) == 20
+    heads = [tuple(int(v) for v in re.match(r"\s*(\d+)\s+(\d+)x\s*(\d+) ", ln).groups()) for ln in lines]
+    assert heads[:10] == heads[10:] == [(i, h, w) for i, (h, w) in enumerate(sizes)]      # both runs: one line per image, in the loader's order
+    assert [r["batch"] for r in res_b] == [3] * 9 + [1]
     for rb, ru, im in zip(res_b, res_u, imgs):
         assert (rb["idx"], rb["H"], rb["W"]) == (ru["idx"], ru["H"], ru["W"]) == (rb["idx"], im.shape[1], im.shape[2])
         assert rb["bytestream_list"] == ru["bytestream_list"]
@@ -673,16 +678,29 @@ def test_agent_batched_eval_equals_unbatched(torch_mod, tmp_path, caplog, oracle
         assert rb["max_abs_err"] == 0.0 and ru["max_abs_err"] < 1e-3
         assert mode_of_header(rb["bytestream_list"][0][0][0]) == mode_of_name(cname)
     W_o = oracle_weights("rand1337")                     # the agent's seed-1337 default init (no checkpoint in the test directory)
-    for i in (4, 8):
-        assert res_b[i]["bytestream_list"] == orc.encode_image_rans(imgs[i], W_o, mode_of_name(cname) & 0xFF, 2)
+    for i in (2, 8):
+        assert res_b[i]["bytestream_list"] == orc.encode_image_rans(imgs[i], W_o, 2, 2)
     # ... and both runs logged the same mean rate table ("te" rows, loggers/rate.py) -- once each
     tables = [r.message for r in caplog.records if "scl4->" in r.message]
     assert len(tables) == 2 and tables[0].split("(")[0:-1] == tables[1].split("(")[0:-1]      # identical but for the trailing time stamp
-    # in-memory data set, default (reference-format) container, batch of 4: equals the one-image reference-format path
+    # container "auto": per batch, what its smallest image allows (ten 256-lane streams on a 96x128 image are +5 bpp)
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    a_a = LLICTIAgent(default_config(test_data=imgs, eval_batch=4, container="auto", keep_streams=True))
+    res_a = a_a.run()
+    assert len(res_a) == 10 and all(r["max_abs_err"] == 0.0 for r in res_a)
+    for k0 in (0, 4, 8):
+        want = auto_container(len(sizes[k0:k0 + 4]), n_cu, sizes=sizes[k0:k0 + 4])
+        assert want in ("xrans1", "rans1"), want
+        for r in res_a[k0:k0 + 4]:
+            assert mode_of_header(r["bytestream_list"][0][0][0]) == mode_of_name(want)
+    assert auto_container(24, n_cu, sizes=[(512, 768)] * 24) == auto_container(24, n_cu) == "xrans10"
+    # in-memory data set, default (reference-format) container, batch of 4: a batch closes where the size changes; equals the oracle
     a_m = LLICTIAgent(default_config(test_data=imgs[:4], eval_batch=4, keep_streams=True))
     res_m = a_m.run()
     assert len(res_m) == 4 and all(r["max_abs_err"] == 0.0 for r in res_m)
+    assert [r["batch"] for r in res_m] == [2, 2, 1, 1]
     assert res_m[1]["bytestream_list"] == orc.encode_image(imgs[1], W_o)
+    assert res_m[2]["bytestream_list"] == orc.encode_image(imgs[2], W_o)
 
 
 def test_cli_file_roundtrip(torch_mod, tmp_path, capsys):

@@ -452,3 +452,26 @@ def test_torch_cpu_path_roundtrip(case, wname, oracle_weights):
     n_t = sum(len(s) for s in streams)
     n_o = sum(len(x) for row in orc.encode_image(rgb, W)[1:] for x in row)
     assert abs(n_t - n_o) <= max(8, n_o // 1000)
+
+
+@pytest.mark.parametrize("size", [(32, 32), (48, 64), (64, 96), (96, 128), (128, 192), (192, 256)])
+def test_auto_container_budget_by_size(size, oracle_weights):
+    """`container = "auto"` (llicti_amd.codec.auto_container with the image sizes) must stay inside the north star's budget at EVERY
+    size, not only at 768x512: a 256-lane stream whose share of the last stage cannot fill its 992-byte payload wastes what is left (a 96x128
+    image in xrans10 is 25 % larger than in the reference format).  For natural-like and model-drawn content the container the rule picks is
+    at most 0.001 bpp LARGER than the reference-format container of the same image (it may be smaller: no 45 range-coder terminations)."""
+    from helpers import make_image, make_sampled_image
+    from llicti_amd.codec import _mode_wide, auto_container, mode_of_name
+    H, W = size
+    W_o = oracle_weights("trainedlike")
+    name = auto_container(1, 256, sizes=[size])
+    assert auto_container(24, 256, sizes=[size, (512, 768)]) != "ac"        # the reference format codes one size per call
+    for img in (make_image("smooth", H, W, 11), make_sampled_image(H, W, 3)):
+        ac = sum(len(s) for row in orc.encode_image(img, W_o) for s in row)
+        if name == "ac":
+            continue
+        mode = mode_of_name(name)
+        bl = orc.encode_image_rans(img, W_o, mode & 0xFF, _mode_wide(mode))
+        assert np.array_equal(orc.decode_image_rans(bl, W_o), img)
+        got = sum(len(s) for row in bl for s in row)
+        assert 8.0 * (got - ac) / (H * W) <= 0.001, (name, got, ac)
