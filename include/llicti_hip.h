@@ -209,6 +209,12 @@ int llicti_decode_images_v(llicti_ctx *ctx, const uint8_t *d_in, size_t in_strid
                            int B, const int *Hs, const int *Ws, int mode, void *d_workspace, size_t workspace_bytes,
                            uint8_t *d_rgb, const size_t *rgb_off, void *stream);
 
+/* Where llicti_encode_images / llicti_decode_images of B images of H x W in `mode` keep the YCoCg-R planes inside the caller's workspace
+ * (byte offsets): int16 [B][3][H][W] (Y - 127, Co, Cg) and float32 [B][3][H][W] = planes / 255 -- the second is the `x_ycocg` the
+ * reference's compress() returns beside the streams (LLICTI_nets.py:143-144, :159), so a caller that wants it reads it from the workspace
+ * behind the encode instead of lifting the image a second time.  Valid until the next whole-batch call on that workspace. */
+int llicti_workspace_planes(llicti_ctx *ctx, int B, int H, int W, int mode, size_t *off_planes, size_t *off_fplanes);
+
 /* Synchronises `stream` and returns the latched device-side status of the calls issued since the
  * last check (LLICTI_OK, LLICTI_EFORMAT, LLICTI_ENOSPACE). */
 int llicti_check_status(llicti_ctx *ctx, void *stream);
@@ -254,6 +260,11 @@ int llicti_last_cnn_level_ms(llicti_ctx *ctx, float level_ms[LLICTI_NLEVELS]);
  * "enc_side_levels" (default 0; 1: llicti_encode_images runs levels 4..1 on an internal stream next to level 0's launches and joins it
  * before the entropy coder: -0.3 % of a step on MI355X, at the price of kernel traces whose side-queue durations include waiting). */
 int llicti_set_tuning(llicti_ctx *ctx, const char *key, int value);
+/* What the whole-batch calls have cost the host / device since llicti_create: "device_syncs" (hipDeviceSynchronize inside a whole-batch call),
+ * "device_allocs" (hipMalloc inside one), "plan_builds" / "plan_hits" (calls whose (mode, sizes) were new / cached), "block_waits" (a new plan
+ * had to wait for the last user of a pooled table block), "plans_cached", "blocks_pooled".  A warm context coding batch after batch of ever new
+ * image sizes adds to plan_builds only (tests/test_hip_parity.py::test_many_sizes_no_device_sync_and_plan_reuse). */
+int llicti_get_counter(llicti_ctx *ctx, const char *name, long *value);
 /* enable / disable the per-kernel event timing above (off by default: it adds event records). */
 int llicti_set_profiling(llicti_ctx *ctx, int enable);
 

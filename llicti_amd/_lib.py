@@ -72,6 +72,8 @@ _SIGS = {
     "llicti_last_timing_detail": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, C.POINTER(_i)]),
     "llicti_last_cnn_level_ms": (_i, [_vp, C.POINTER(C.c_float)]),
     "llicti_set_profiling": (_i, [_vp, _i]),
+    "llicti_get_counter": (_i, [_vp, C.c_char_p, C.POINTER(_l)]),
+    "llicti_workspace_planes": (_i, [_vp, _i, _i, _i, _i, C.POINTER(_sz), C.POINTER(_sz)]),
     "llicti_set_tuning": (_i, [_vp, C.c_char_p, _i]),
 }
 EXPORTS = sorted(_SIGS)

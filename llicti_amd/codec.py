@@ -385,6 +385,21 @@ class HipCodec:
     def set_tuning(self, key, value):
         _lib.check(self.L.llicti_set_tuning(self.ctx, key.encode(), int(value)))
 
+    def encoded_fplanes(self, B, H, W, mode):
+        """float32 [B,3,H,W] = (YCoCg-R - [127,0,0]) / 255 of the batch the LAST encode() / decode() of this shape and mode worked on, copied out of
+        the workspace (llicti_workspace_planes): the `x_ycocg` of the reference's compress() without a second lift.  Enqueued on the
+        current stream, behind that call."""
+        o16, o32 = C.c_size_t(), C.c_size_t()
+        _lib.check(self.L.llicti_workspace_planes(self.ctx, B, H, W, mode, C.byref(o16), C.byref(o32)))
+        n = B * 3 * H * W * 4
+        return self._ws[o32.value:o32.value + n].view(torch.float32).view(B, 3, H, W).clone()
+
+    def counter(self, name):
+        """llicti_get_counter: "device_syncs", "device_allocs", "plan_builds", "plan_hits", "block_waits", "plans_cached", "blocks_pooled"."""
+        v = C.c_long()
+        _lib.check(self.L.llicti_get_counter(self.ctx, name.encode(), C.byref(v)))
+        return int(v.value)
+
     def set_profiling(self, on=True):
         _lib.check(self.L.llicti_set_profiling(self.ctx, int(bool(on))))
 

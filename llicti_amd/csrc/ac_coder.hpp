@@ -82,13 +82,6 @@ struct AcEnc {
     }
 };
 
-struct StreamDesc {     // one arithmetic-coded stream of the whole-batch encoder
-    long pair_off;      // first (c_low, c_high) pair, in uint32 units
-    long out_off;       // slot offset in bytes
-    int n;              // symbols
-    int cap;            // slot capacity in bytes
-};
-
 __global__ __launch_bounds__(64) void ac_encode_pairs_kernel(const uint32_t *__restrict__ pairs, const StreamDesc *__restrict__ desc,
                                                              int n_streams, uint8_t *__restrict__ slots,
                                                              int32_t *__restrict__ slot_len, int32_t *status)

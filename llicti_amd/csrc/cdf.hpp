@@ -3,64 +3,6 @@
 #pragma once
 
 // ------------------------------------------------------------------------------------------------ CDF kernels
-struct StageGeom {      // one (level, band): band grid, coded crop, full-res addressing
-    int B, H, W, lvl, h, w, hc, wc, oi, oj;
-    long plane;
-    uint32_t wc_mul;    // n / wc for 0 <= n < 2^31 without a division: div_by_magic(n, wc_mul, wc_sh)
-    int wc_sh;
-    // Per-image placement (whole-batch calls keep one StageGeom per image in a device table -- the images of a call may differ in size; a
-    // kernel-level entry point passes ONE by value and stage_at() derives these from the image index):
-    long img_off;       // first element of the image's [3][H][W] block in planes / fplanes
-    long par_off;       // first float of its [64][h * w] block in the CNN-output buffer of this (level, band)
-    long pair_off;      // first pair of its Y stream in the (level, band)'s pairs [clr][image][n] ...
-    long pair_cs;       // ... and the distance between two colour channels there (the images' coded positions together)
-};
-// exact unsigned division by an invariant divisor (Granlund / Montgomery, the 33-bit multiplier form), 1 <= d < 2^31,
-// 0 <= n < 2^31: l = ceil(log2 d), mul = floor(2^32 (2^l - d) / d) + 1, t = mulhi(n, mul), q = (t + ((n - t) >> 1)) >> (l - 1).
-// d == 1 has no 33-bit form with a non-negative shift: it is encoded as (mul, sh) = (0, -1) and div_by_magic() returns n.
-static void div_magic(uint32_t d, uint32_t *mul, int *sh)
-{
-    int l = 0;
-    while ((1ull << l) < d) ++l;                                   // l = ceil(log2 d)
-    if (l == 0) { *mul = 0; *sh = -1; return; }                     // d == 1
-    *mul = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
-    *sh = l - 1;
-}
-__host__ __device__ __forceinline__ uint32_t div_by_magic(uint32_t n, uint32_t mul, int sh)
-{
-    if (sh < 0) return n;
-#if defined(__HIP_DEVICE_COMPILE__)
-    const uint32_t t = __umulhi(n, mul);
-#else
-    const uint32_t t = (uint32_t)(((uint64_t)n * mul) >> 32);
-#endif
-    return (t + ((n - t) >> 1)) >> sh;
-}
-__device__ __forceinline__ int div_wc(const StageGeom &s, int n) { return (int)div_by_magic((uint32_t)n, s.wc_mul, s.wc_sh); }
-// host self-test (llicti_selftest): every divisor of the format's range against '/', at the values where a magic division breaks first
-static int selftest_div_magic()
-{
-    for (uint32_t d = 1; d <= 8192; ++d) {
-        uint32_t mul; int sh;
-        div_magic(d, &mul, &sh);
-        const uint32_t probes[] = { 0u, 1u, d - 1, d, d + 1, 2 * d - 1, 2 * d, 4080u * 4080u - 1, 4080u * 4080u, (1u << 24) - 1, (1u << 24) + d,
-                                    0x7FFFFFFFu / d * d - 1, 0x7FFFFFFFu / d * d, 0x7FFFFFFFu };
-        for (uint32_t n : probes) if ((n >> 31) == 0 && div_by_magic(n, mul, sh) != n / d) return (int)d;
-        for (uint32_t k = 0; k < 4096; ++k) { const uint32_t n = k * 524287u + d; if ((n >> 31) == 0 && div_by_magic(n, mul, sh) != n / d) return (int)d; }
-    }
-    return 0;
-}
-static StageGeom make_stage(const Geom &g, int band)
-{
-    static const int OI[4] = { 0, 1, 0, 1 }, OJ[4] = { 0, 1, 1, 0 };
-    StageGeom s;
-    s.B = g.B; s.H = g.H; s.W = g.W; s.lvl = g.lvl; s.h = g.h; s.w = g.w; s.plane = g.plane;
-    coded_dims(g, band, &s.hc, &s.wc);
-    s.oi = OI[band + 1]; s.oj = OJ[band + 1];
-    div_magic((uint32_t)s.wc, &s.wc_mul, &s.wc_sh);
-    s.img_off = g.pix_off; s.par_off = g.par_off; s.pair_off = 0; s.pair_cs = 0;
-    return s;
-}
 // image b's stage geometry: its entry of the call's table, or (kernel-level entry points: B images of one size, tight arrays) derived from b
 __device__ __forceinline__ StageGeom stage_at(const StageGeom &s, const StageGeom *__restrict__ sv, int b)
 {
@@ -241,7 +183,6 @@ __global__ __launch_bounds__(64 * kTabWaves) void cdf_table_kernel(const int16_t
 // writes 208 instead of 528 / 1024 bytes per symbol:
 //   row n (kAnchorRow bytes):  [0, 128)   uint16 anchor[l] = entry[min(8 l, Lp - 1)],  l = 0 .. 63
 //                              [128, 208) float4 (mu + cross-channel update, 1 / max(sigma, bound), normalised weight, 0) x 5
-constexpr int kAnchorRow = 208;
 
 __global__ __launch_bounds__(64 * kTabWaves) void cdf_anchor_kernel(const int16_t *__restrict__ planes, const float *__restrict__ params,
                                                                     const int32_t *__restrict__ minmax, StageGeom s, int clr,

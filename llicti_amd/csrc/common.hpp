@@ -1,19 +1,8 @@
 // common.hpp -- errors, geometry and small device helpers shared by every kernel file.
 // Part of the single translation unit llicti_hip.hip (included in order; not a stand-alone header).
 #pragma once
+#include "host_types.hpp"
 
-// ------------------------------------------------------------------------------------------------ errors
-static thread_local std::string g_err;
-static int fail(int code, const char *fmt, ...)
-{
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    g_err = buf;
-    return code;
-}
 #define HIPCHK(x)                                                                                    \
     do {                                                                                             \
         hipError_t e_ = (x);                                                                         \
@@ -23,43 +12,6 @@ static int fail(int code, const char *fmt, ...)
 extern "C" const char *llicti_last_error(void) { return g_err.c_str(); }
 extern "C" const char *llicti_version(void) { return "llicti_hip 0.5 (gfx950, numerics spec v1, rANS container v3; params channel-planar, xwide streams with seeded tail chains)"; }
 
-// ------------------------------------------------------------------------------------------------ geometry
-struct Geom {
-    int B, H, W, lvl;
-    int Hl, Wl, h, w, padH, padW;
-    long plane;   // H*W
-    // Whole-batch calls keep one Geom PER IMAGE in a device table (the images of a call may differ in size: llicti_encode_images_v); these two
-    // fields are only meaningful there.  The kernel-level entry points pass one Geom by value and derive both from the image index.
-    long pix_off; // first element of the image's [3][H][W] block in planes / fplanes
-    long par_off; // first float of the image's [64][h * w] block in the CNN-output buffer of this level
-};
-// One image of a whole-batch call (device table, llicti_hip.hip: Plan).
-struct ImgGeo {
-    int H, W, h4, w4, padint, hdr_bytes;      // hdr_bytes = 17 + 3 h4 w4 (LLICTI_nets.py:347-350)
-    long plane;                               // H * W
-    long pix_off;                             // first element of the image's [3][H][W] block in planes / fplanes (workspace)
-    long rgb_off;                             // first byte of its [3][H][W] block in the caller's RGB buffer
-};
-static Geom make_geom(int B, int H, int W, int lvl)
-{
-    Geom g;
-    g.B = B; g.H = H; g.W = W; g.lvl = lvl;
-    const int st = 1 << lvl;
-    g.Hl = (H + st - 1) / st;
-    g.Wl = (W + st - 1) / st;
-    g.h = (g.Hl + 1) / 2;
-    g.w = (g.Wl + 1) / 2;
-    g.padH = g.Hl & 1;
-    g.padW = g.Wl & 1;
-    g.plane = (long)H * W;
-    g.pix_off = 0; g.par_off = 0;
-    return g;
-}
-static void coded_dims(const Geom &g, int band, int *hc, int *wc)
-{
-    *hc = (band == 0 || band == 2) ? g.h - g.padH : g.h;   // LLICTI_nets.py:396-397
-    *wc = (band == 0 || band == 1) ? g.w - g.padW : g.w;
-}
 extern "C" int llicti_level_geom(int H, int W, int lvl, int band, int *Hl, int *Wl, int *h, int *w,
                                  int *padH, int *padW, int *hc, int *wc)
 {
@@ -77,11 +29,7 @@ extern "C" int llicti_level_geom(int H, int W, int lvl, int band, int *Hl, int *
     if (wc) *wc = b;
     return LLICTI_OK;
 }
-static int check_dims(int B, int H, int W)
-{
-    if (B < 1 || H < 32 || W < 32 || H > 8160 || W > 8160) return fail(LLICTI_EINVAL, "bad shape B=%d H=%d W=%d (need B>=1, 32<=H,W<=8160)", B, H, W);
-    return 0;
-}
+
 
 // source sub-bands in lazyDWT cat order x00, x11, x01, x10 (LLICTI_nets.py:241); band b predicts source b+1
 // (row, column) phase of source s: (0,0), (1,1), (0,1), (1,0) -- computed, not looked up: a table load inside

@@ -6,7 +6,6 @@
 // Per-image min / max of Co and Cg in two steps without atomics: every workgroup of lift_kernel leaves its four
 // partial values in part[b][blockIdx.x][4], one small workgroup per image folds them.  (Thousands of atomicMin /
 // atomicMax on the same 16 bytes of an image serialise at the memory side: 150 of the kernel's 180 us.)
-constexpr int kLiftMaxParts = 65536;        // entries of the partials scratch: B * gridDim.x <= this
 
 __global__ __launch_bounds__(64) void minmax_reduce_kernel(const int32_t *__restrict__ part, int gx, int32_t *__restrict__ mm)
 {

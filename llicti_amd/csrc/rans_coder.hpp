@@ -17,43 +17,6 @@
 //     is left with those states after the last stage, reassembles the tail stream and decodes its T symbols serially.
 // Cost over the ideal code length: ~6 bytes per stream (v2: ~60) -- ten streams are within 0.001 bpp of the AC container.
 // Stream bytes:  u16 (T | pad << 11) | bit region, read DOWN from its top minus pad unused bits | L x 31-bit final states.
-constexpr int kRansStateBits = 31;
-constexpr int kRansTailMax = 2047;
-// A stream has 64 Q lanes: Q = 1, Q = 2 ("wide" streams: two 64-symbol sub-chunks per step, decoded two lanes per symbol by
-// rans_decode_stage_pair_kernel, at the price of a tail twice as long) or Q = 4 ("xwide": 256 lanes, decoded ONE lane per symbol by
-// rans_decode_stage_lane_kernel, four wavefronts per stream).  Symbol n of a stage sits in chunk n / 64Q.
-template <int Q> struct RansGeo {
-    static constexpr int kLanes = 64 * Q;
-    static constexpr int kPayBits = kLanes * kRansStateBits;      // 1984 / 3968 / 7936: what the initial states carry (the tail stream)
-    static constexpr int kPayBytes = kPayBits / 8;                // 248 / 496 / 992
-    static constexpr int kPayDw = (kPayBits + 31) / 32;           // 62 / 124 / 248
-    static constexpr int kMinStream = 2 + kPayBytes;              // T | pad, (empty bit region), states
-};
-constexpr int kRansPayBytesMax = RansGeo<4>::kPayBytes;
-constexpr int kPhiLutN = 2048;                   // the lane decoder's hint table (llicti_ctx::d_phi_lut)
-constexpr double kPhiLutZ = 6.0;
-// xwide streams (Q = 4) only -- the older stream kinds keep their bytes.  A rANS chain ends in a 32-bit state of which only what the symbols put
-// in is information: a coder that starts from an empty state wastes ~31 bits.  And the tail is serial.  So an xwide stream's tail is coded by up to
-// TWO single-state coders ("chains") sharing the payload, none starting empty (spec: oracle/llicti_oracle.c, RANS_SEED_LANES; two chains where
-// symbols are expensive, one where the model predicts them well and a second final state would cost more than its seed saves: the encoder's
-// integer rule on the stream's last 64 symbols, bit 14 of the stream's first u16 = one chain):
-//   seeds    A = number of symbol values of the image's Cg channel, n = rans_seed_count(A) = the largest count with A^n <= 2^31 (<= 31); counting
-//            the stream's symbols from its end (j = 0 the last), chain A starts from 2^31 | sum sym(i) A^i (i < n), chain B from that of sym(n + i):
-//            2 n symbols that are never coded (three each for the full range of 511: ~3 bytes a stream; ten 256-lane streams an image cost what
-//            five cost before);
-//   chains   symbol j >= 2 n goes to chain A if j is even, B if odd, j ascending, while used_A + used_B + bits(j) + 64 <= payload bits;
-//   payload  [0, 32) A's final state, A's fields from bit 32 up in the decoder's reading order; the top 32 bits B's final state, B's fields below
-//            it read downwards; zeros between.  The states sit at fixed places: no search for the payload's highest set bit.
-template <int Q> constexpr bool kSeeded = (Q == 4);
-constexpr int kSeedMax = 31;
-__host__ __device__ __forceinline__ int rans_seed_count(int A, uint32_t &pw)      // n and A^n
-{
-    int n = 0;
-    uint64_t p = 1;
-    while (n < kSeedMax && p * (uint64_t)A <= (1ull << 31)) { p *= (uint64_t)A; ++n; }
-    pw = (uint32_t)p;
-    return n;
-}
 
 __device__ __forceinline__ int lanes_below(uint64_t mask)
 {
@@ -70,16 +33,6 @@ __device__ __forceinline__ int wave_incl_scan(int v)
     v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);      // lane 15 of rows 0 / 2 -> rows 1 / 3
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);      // lane 31 -> rows 2, 3
     return v;
-}
-
-// symbols of stream m in a stage of nc symbols (chunks of L symbols m, m + M, ...; only the stage's last chunk can be partial)
-__host__ __device__ __forceinline__ int rans_stream_count(int nc, int m, int M, int L)
-{
-    const int nchunks = (nc + L - 1) / L;
-    if (nchunks <= m) return 0;
-    const int K = (nchunks - m + M - 1) / M;
-    const int last = m + (K - 1) * M;
-    return L * K - ((last == nchunks - 1 && (nc % L)) ? L - (nc % L) : 0);
 }
 
 // encoder renormalisation: the smallest n with (x >> n) < freq << 16, x in [2^31, 2^32), 1 <= freq <= 2^16
@@ -1569,10 +1522,6 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_t
         if ((bad || tc != 0) && lane == 0) flag_image(status, b, LLICTI_EFORMAT);
     }
 }
-
-// M <= 32: stream m is segment 4 + m of the container.  M = 64 / 128 (latency modes for single / large images; the reference's list
-// has 45 stream slots): G = M / 32 streams share segment 4 + m / G = G little-endian u32 stream lengths, then the G streams.
-__host__ __device__ __forceinline__ int rans_group(int M) { return M > 32 ? M / 32 : 1; }
 
 __global__ __launch_bounds__(256) void rans_pack_kernel(const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
                                                         const int32_t *__restrict__ rinfo, int M, const ImgGeo *__restrict__ iv,

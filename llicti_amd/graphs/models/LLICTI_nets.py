@@ -241,8 +241,9 @@ class LLICTI(nn.Module):
             Hs, Ws = [H] * B, [W] * B
             mode = self.mode_for_batch(B, codec.device, sizes=[(H, W)])
             cont, seg = codec.encode(rgb, mode=mode)
-            # x_ycocg = (YCoCg - [127,0,0]) / 255 (LLICTI_nets.py:143-144): the float planes the reference hands back beside the streams
-            x_ycocg = codec.lift(rgb)[1] if want_ycocg else None
+            # x_ycocg = (YCoCg - [127,0,0]) / 255 (LLICTI_nets.py:143-144): the float planes the reference hands back beside the streams -- the encode
+            # has just computed them: copied out of its workspace, not lifted a second time
+            x_ycocg = codec.encoded_fplanes(B, H, W, mode) if want_ycocg else None
         nb = cont.numel()
         seg_h = self._pinned(("seg", slot), B * NSEG * 4)[:B * NSEG * 4].view(torch.int32).view(B, NSEG)
         cont_h = self._pinned(("cont_out", slot), nb)[:nb].view(tuple(cont.shape))

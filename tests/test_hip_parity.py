@@ -597,8 +597,9 @@ def test_malformed_container_rejected(torch_mod, codecs):
     assert np.array_equal(rec.cpu().numpy(), rgb)
 
 
-def test_reference_api_roundtrip(torch_mod):
-    """graphs.models.LLICTI_nets.LLICTI: compress / decompres with the reference's container and seeded init."""
+def test_reference_api_roundtrip(torch_mod, capsys):
+    """graphs.models.LLICTI_nets.LLICTI: compress / decompres with the reference's container and seeded init; `x_ycocg` (read back from the
+    encoder's workspace, no second lift) equals the reference's; decompres(..., xorg=) runs the reference's diagnostic (LLICTI_nets.py:167-171)."""
     torch = torch_mod
     from llicti_amd.config import default_config
     from llicti_amd.graphs.models.LLICTI_nets import LLICTI
@@ -613,7 +614,12 @@ def test_reference_api_roundtrip(torch_mod):
     g = load_case("noise_67x93_rand")           # same image, same seeded weights as the fixture
     assert bl[0][1] == g["hdr_minmax"].tobytes() and bl[0][3] == g["hdr_dc"].tobytes()
     assert np.array_equal(x_ycocg.cpu().numpy()[0], g["x_ycocg_f32"])
-    x_reco = model.decompres(bl, torch.device("cuda:0"))
+    x_reco = model.decompres(bl, torch.device("cuda:0"), xorg=x_ycocg)
+    assert "does NOT match" not in capsys.readouterr().out
+    bad = x_ycocg.clone()
+    bad[0, 1, 5, 7] += 2.0 / 255
+    model.decompres(bl, torch.device("cuda:0"), xorg=bad)
+    assert "Decoded YCoCg img does NOT match original YCoCg image perfectly! The maximum of absolute error is 2.0000" in capsys.readouterr().out
     assert float(((x - x_reco) * 255).abs().max()) < 0.5          # the reference's own check (llicti_agent.py:151-152)
     assert np.array_equal((x_reco * 255).round().to(torch.uint8).cpu().numpy()[0], rgb)   # and exact as integers
     W_o = orc.Weights(pack_state_dict(model.state_dict()))
@@ -1553,6 +1559,18 @@ def test_many_sizes_no_device_sync_and_plan_reuse(torch_mod, codecs):
     c.check()
     cont, seg = c.encode(_dev(torch, first[1]), mode=mode)
     assert np.array_equal(cont[0, :int(seg[0].sum())].cpu().numpy(), first[0])
+    # the library's own account: from here on ever new sizes cost plan builds and nothing else -- no device synchronisation, no allocation
+    before = {k: c.counter(k) for k in ("device_syncs", "device_allocs", "plan_builds", "block_waits")}
+    for k in range(60):
+        sh = [(40 + 2 * k + 3 * b, 50 + k + 5 * b) for b in range(3)]
+        rgbs = [make_image("noise", h, w, 10 * k + b) for b, (h, w) in enumerate(sh)]
+        cont, seg = c.encode_v(_dev(torch, _flat(rgbs)), [h for h, _ in sh], [w for _, w in sh], mode)
+        rec = c.decode_v(cont, seg, [h for h, _ in sh], [w for _, w in sh], mode)
+    c.check()
+    assert np.array_equal(rec.cpu().numpy(), _flat(rgbs))
+    after = {k: c.counter(k) for k in before}
+    assert after["plan_builds"] == before["plan_builds"] + 60 and c.counter("plans_cached") <= 32
+    assert after["device_syncs"] == before["device_syncs"] and after["device_allocs"] == before["device_allocs"], (before, after)
     # a new size enqueued behind a long-running kernel: the call must return while that kernel is still running
     a = torch.randn(8192, 8192, device="cuda:0")
     x = _dev(torch, make_image("smooth", 333, 77, 5)[None])

@@ -324,3 +324,16 @@ def test_synth_images_are_the_fixture_generators():
         assert np.array_equal(synth.make_image(kind, H, W, seed), make_image(kind, H, W, seed))
     with pytest.raises(ValueError):
         synth.make_image("photo", 32, 32, 0)
+
+
+def test_host_plan_logic_driver(tmp_path):
+    """The library's HOST logic (llicti_amd/csrc/host_types.hpp, cnn_pack.hpp, host_plan.hpp: plan building for equal and mixed sizes,
+    container tags, size bounds, header parsing, the CNN weight pack) has no HIP dependency: g++ compiles tests/sanitize_host.cpp against it
+    and the driver checks every plan's internal consistency over the shapes and modes the suite uses.  (tests/sanitize_host.sh runs the same
+    driver under AddressSanitizer + UBSan; here it is built plain, so that the CPU suite needs no sanitizer runtime.)"""
+    import subprocess
+    exe = tmp_path / "sanitize_host"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", str(exe), os.path.join(ROOT, "tests", "sanitize_host.cpp")])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "clean" in out.stdout

@@ -46,6 +46,11 @@ def per_launch(prefix):
     iv, av, bz = (sum(agg[k].get(c, 0) for k in ks) for c in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES"))
     if iv:
         d["valu_insts_per_launch"] = iv / n
+        if gui:
+            # the chip issues one wave64 vector instruction per SIMD every 2 cycles: 1,024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+            cyc = gui / 8.0 / n
+            d["cycles_per_launch"] = cyc
+            d["valu_issue_frac"] = (iv / n) / (cyc * 1024 * 0.5)
     return d
 
 
