@@ -911,6 +911,18 @@ def main(argv=None):
                               "bpp_delta_vs_ac_container": round(8.0 * (r["bytes"] - ac_bytes) / (B * H * W), 5)})
         legs_out["m_sweep"] = {"workload": f"{B}x{W}x{H}, rANS container with M streams per image", "modes": sweep}
         legs.free()
+        # (2b) the N = 8 run's per-GPU workload (configs[4]: 32 images per GPU, its own container) on ONE GPU: what an 8-GPU value has to be divided
+        #      by for a like-for-like scaling efficiency (the driver's N = 1 point is the batch of 24)
+        try:
+            b32 = torch.from_numpy(make_batch(32, H, W, seed0=0)).to(dev)
+            r32 = legs.run(b32, mode_of(default_container(32, torch.cuda.get_device_properties(dev).multi_processor_count)), reps=3)
+            r32["container"] = default_container(32, torch.cuda.get_device_properties(dev).multi_processor_count)
+            r32["workload"] = f"32x{W}x{H} on ONE GPU: the per-GPU batch of bench.py --gpus 8 (BASELINE.json configs[4]); N = 8 efficiency like for like = value(N = 8) / (8 x this)"
+            legs_out["batch32_single_gpu"] = r32
+            del b32
+        except Exception as e:
+            legs_out["batch32_single_gpu"] = {"skipped": repr(e)[:200]}
+        legs.free()
         # (3) configs[1]: ONE 768x512 image
         one = rgb[:1].contiguous()
         legs_out["single_image"] = {"workload": f"1x{W}x{H} (BASELINE.json configs[1])",

@@ -16,58 +16,84 @@ import torch
 
 from ..graphs.losses.rate_dist import CompressionRLossList, TrainRLossList
 from ..graphs.models.LLICTI_nets import LLICTI
+from .. import shard
 from ..loggers.rate import RateLogger
 from ..weights import load_reference_state_dict
 
 
-def _iter_test_images_u8(config):
-    """The test images as uint8 [3,H,W] host arrays (the batched eval path uploads uint8: a quarter of the float32 bytes)."""
+def _iter_test_images_u8(config, rank=0, world=1, with_index=False):
+    """The test images as uint8 [3,H,W] host arrays (the batched eval path uploads uint8: a quarter of the float32 bytes).  With several
+    ranks (SURVEY section 8e): image i of the data set belongs to rank i mod world -- a rank reads and yields only its own, in order;
+    with_index: (index in the whole data set, image) pairs."""
     src = config.test_data
+
+    def out(i, rgb):
+        return (i, rgb) if with_index else rgb
     if not isinstance(src, str):                       # an in-memory data set: any iterable of uint8 [3,H,W] arrays
-        for rgb in src:
+        for i, rgb in enumerate(src):
+            if i % world != rank:
+                continue
             rgb = np.asarray(rgb)
             if rgb.dtype != np.uint8 or rgb.ndim != 3 or rgb.shape[0] != 3:
                 raise ValueError("in-memory test_data must yield uint8 [3, H, W] arrays")
-            yield rgb
+            yield out(i, rgb)
         return
     if src.startswith("synthetic:"):
         H, W, N = (int(v) for v in src.split(":")[1].split("x"))
-        for i in range(N):
-            yield np.random.default_rng(i).integers(0, 256, size=(3, H, W), dtype=np.uint8)
+        for i in range(rank, N, world):
+            yield out(i, np.random.default_rng(i).integers(0, 256, size=(3, H, W), dtype=np.uint8))
         return
     from ..fileio import read_image
-    for f in sorted(f for f in os.listdir(src) if f.lower().endswith((".png", ".jpg", ".ppm"))):
-        yield read_image(os.path.join(src, f))
+    files = sorted(f for f in os.listdir(src) if f.lower().endswith((".png", ".jpg", ".ppm")))
+    for i in range(rank, len(files), world):
+        yield out(i, read_image(os.path.join(src, files[i])))
 
 
-def _iter_test_images(config, device):
+def _iter_test_images(config, device, rank=0, world=1, with_index=False):
     """Test loader, batch 1, no crop (dataloaders/image_dl.py:40-45, :106-111): float32 1x3xHxW = uint8/255.
     `test_data` is a directory of .png/.jpg/.ppm, "synthetic:HxWxN" (seeded uniform RGB) or an in-memory
     iterable of uint8 [3,H,W] arrays."""
-    for rgb in _iter_test_images_u8(config):
-        yield torch.from_numpy(rgb.astype(np.float32) / np.float32(255)).unsqueeze(0).to(device)
+    for i, rgb in _iter_test_images_u8(config, rank, world, with_index=True):
+        x = torch.from_numpy(rgb.astype(np.float32) / np.float32(255)).unsqueeze(0).to(device)
+        yield (i, x) if with_index else x
 
 
 class LLICTIAgent:
-    def __init__(self, config):
+    """One process per GPU.  Started alone it is the reference's agent (agents/base.py:21-25: a single device).  Started by
+    `python -m torch.distributed.run --nproc-per-node G ...` (RANK / LOCAL_RANK / WORLD_SIZE in the environment) the G agents shard the
+    test set: image i -> rank i mod G, weights read once by rank 0 and broadcast (RCCL), no collective on the hot path,
+    ONE all_gather of the per-image records at the end; rank 0 prints the reference's per-image lines in index order and the rate table
+    -- the log of a 1-GPU run (llicti_amd/shard.py; tests/test_distributed_cpu.py::test_agent_two_ranks_equal_one_rank)."""
+
+    def __init__(self, config, model=None):
         self.config = config
         self.logger = logging.getLogger("Agent")
         self.cuda = torch.cuda.is_available() and bool(config.cuda)
-        if not self.cuda:
-            raise RuntimeError("LLICTIAgent (MI355X hot path) needs a GPU: there is no CPU fallback")
-        torch.cuda.set_device(config.gpu_device)
-        self.device = torch.device("cuda", config.gpu_device)
+        if model is None:
+            if not self.cuda:
+                raise RuntimeError("LLICTIAgent (MI355X hot path) needs a GPU: there is no CPU fallback")
+            n_dev = max(1, torch.cuda.device_count())
+            local = int(os.environ.get("LOCAL_RANK", "-1"))
+            gpu = config.gpu_device if local < 0 else local % n_dev      # under the launcher: one rank per GPU
+            torch.cuda.set_device(gpu)
+            self.device = torch.device("cuda", gpu)
+        else:
+            self.device = torch.device("cpu")          # an injected model (tests: the multi-rank plumbing without a GPU)
+        self.rank, self.world = shard.init_from_env(self.device)
         torch.manual_seed(config.seed)              # base.py:21-28 (one seed for the default init)
         assert config.wtr_type in ("lazydwt", "x")
-        self.model = LLICTI(config).to(self.device)
+        self.model = LLICTI(config).to(self.device) if model is None else model
         self.compr_loss = CompressionRLossList()
         self.train_loss = TrainRLossList()             # llicti_agent.py:22 (used by validate, :96)
         self.valid_logger = RateLogger()               # llicti_agent.py:39
         self.test_logger = RateLogger()                # llicti_agent.py:40
         self.results = []
-        if config.mode in ("test", "validate", "debug", "eval_model"):
+        if config.mode in ("test", "validate", "debug", "eval_model") and self.rank == 0 and model is None:
             self.load_checkpoint("model_best.pth.tar")
-        self.model_size_estimation()                   # llicti_agent.py:46
+        if self.world > 1 and isinstance(self.model, torch.nn.Module):
+            shard.broadcast_module_state(self.model, self.device)      # rank 0's weights (a checkpoint is read once), 0.79 MB
+        if isinstance(self.model, torch.nn.Module):
+            self.model_size_estimation()               # llicti_agent.py:46
 
     def load_checkpoint(self, filename):
         """base.py:51-81: a missing checkpoint is tolerated (the run continues with the seeded init)."""
@@ -124,6 +150,45 @@ class LLICTIAgent:
         rate, rate2 = self.valid_logger.display(lr=0.0, typ="va")
         return float(rate + rate2)
 
+    def _emit(self, idx, H, W, bl, rate1_list, enc_time, dec_time, maxx_abserr, batch=1, keep=False):
+        """One coded image: alone, book its rates and print its line now (llicti_agent.py:140, :154-162); as one rank of several, keep its
+        record -- rank 0 prints every rank's lines in index order after the gather (_finish_sharded)."""
+        nbytes = [len(s) for row in bl for s in row]
+        bpsp = sum(nbytes) * 8 / (3 * H * W)
+        r = {"idx": idx, "H": H, "W": W, "bpsp": bpsp, "enc_s": enc_time, "dec_s": dec_time, "max_abs_err": maxx_abserr, "rates": rate1_list, "batch": batch}
+        if keep:
+            r["bytestream_list"] = bl
+        self.results.append(r)
+        if self.world == 1:
+            self.test_logger(rate1_list)
+            self._log_image(idx, H, W, bpsp, enc_time, dec_time, maxx_abserr)
+        else:
+            self._records.append([float(idx), float(H), float(W), float(enc_time), float(dec_time), float(maxx_abserr)] + [float(n) for n in nbytes])
+        return r
+
+    def _finish_sharded(self):
+        """Several ranks: ONE all_gather of the per-image records (index, size, times, error, the 54 stream lengths); rank 0 books the rates and
+        prints the lines of ALL images in index order, then the table -- byte for byte the log of a one-rank run but for the times."""
+        if self.world == 1:
+            if self.results:
+                self.test_logger.display(lr=0.0, typ="te")     # mean scale x band x channel table (llicti_agent.py:164)
+            return self.results
+        coll_dev = self.device if (self.device.type == "cuda" and torch.distributed.get_backend() == "nccl") else "cpu"
+        rec = shard.gather_records(self._records, 6 + 54, device=coll_dev)
+        self.all_results = []
+        if self.rank == 0:
+            for row in sorted(rec.tolist(), key=lambda r: r[0]):
+                idx, H, W = int(row[0]), int(row[1]), int(row[2])
+                lens = [int(v) for v in row[6:]]
+                rate1_list = [[n * 8 / (3 * H * W) * 3 for n in lens[9 * k:9 * k + 9]] for k in range(6)]    # CompressionRLossList on the lengths
+                self.test_logger(rate1_list)
+                bpsp = sum(lens) * 8 / (3 * H * W)
+                self._log_image(idx, H, W, bpsp, row[3], row[4], row[5])
+                self.all_results.append({"idx": idx, "H": H, "W": W, "bpsp": bpsp, "enc_s": row[3], "dec_s": row[4], "max_abs_err": row[5], "rates": rate1_list})
+            if self.all_results:
+                self.test_logger.display(lr=0.0, typ="te")
+        return self.results
+
     def _log_image(self, idx, H, W, bpsp, enc_time, dec_time, maxx_abserr):
         """The reference's per-image line (llicti_agent.py:154-162), unchanged."""
         print_text = "{:3d} {:3d}x{:3d} ".format(idx, H, W)
@@ -148,20 +213,22 @@ class LLICTIAgent:
         the encode's behind the wait for its upload) times the image's share of the batch's pixels.  With config.keep_streams the lists
         stay in self.results."""
         self.model.eval()
-        self.results = []
+        self.results, self._records = [], []
         keep = bool(self.config["keep_streams"]) if "keep_streams" in self.config else False
         stream = torch.cuda.current_stream(self.device)
         one_size = self.model.mode is not None and self.model.mode == 0          # reference format: equal sizes per call
 
         def batches():
-            cur = []
-            for rgb in _iter_test_images_u8(self.config):
+            """(indices in the whole data set, images): this rank's images (all of them when it is alone), eval_batch at a time"""
+            cur, ids = [], []
+            for i, rgb in _iter_test_images_u8(self.config, self.rank, self.world, with_index=True):
                 if cur and (len(cur) == eval_batch or (one_size and rgb.shape != cur[0].shape)):
-                    yield cur
-                    cur = []
+                    yield ids, cur
+                    cur, ids = [], []
                 cur.append(rgb)
+                ids.append(i)
             if cur:
-                yield cur
+                yield ids, cur
 
         def start_encode(imgs, slot):
             B = len(imgs)
@@ -192,7 +259,7 @@ class LLICTIAgent:
             self.model._pinned_mark(("err", job["slot"]), stream)
             ev = torch.cuda.Event()
             ev.record(stream)
-            return {"job": job, "lists": lists, "rates": rates, "err": err_h, "ev": ev, "e_dec": (d0, d1), "idx0": idx0}
+            return {"job": job, "lists": lists, "rates": rates, "err": err_h, "ev": ev, "e_dec": (d0, d1)}
 
         def report(fin):
             job = fin["job"]
@@ -204,41 +271,29 @@ class LLICTIAgent:
             for b in range(job["B"]):
                 bl, rate1_list = fin["lists"][b], fin["rates"][b]
                 H, W = job["Hs"][b], job["Ws"][b]
-                self.test_logger(rate1_list)                   # llicti_agent.py:140
-                bpsp = sum(len(s) * 8 for row in bl for s in row) / (3 * H * W)
                 share = H * W / pix
-                enc_t, dec_t = enc_ms / 1e3 * share, dec_ms / 1e3 * share
-                self._log_image(fin["idx0"] + b, H, W, bpsp, enc_t, dec_t, float(err[b]))
-                r = {"idx": fin["idx0"] + b, "H": H, "W": W, "bpsp": bpsp, "enc_s": enc_t, "dec_s": dec_t,
-                     "max_abs_err": float(err[b]), "rates": rate1_list, "batch": job["B"]}
-                if keep:
-                    r["bytestream_list"] = bl
-                self.results.append(r)
+                self._emit(job["ids"][b], H, W, bl, rate1_list, enc_ms / 1e3 * share, dec_ms / 1e3 * share, float(err[b]), batch=job["B"], keep=keep)
 
-        idx, k, pending, prev_fin = 0, 0, None, None
-        for imgs in batches():
+        k, pending, prev_fin = 0, None, None
+        for ids, imgs in batches():
             job = start_encode(imgs, k & 1)                    # GPU: encode batch k ...
-            job["slot"] = k & 1
+            job["slot"], job["ids"] = k & 1, ids
             if pending is not None:                            # ... host: lists / rates / repack of batch k - 1, decode k - 1 enqueued behind encode k
                 if prev_fin is not None:
                     report(prev_fin)
-                prev_fin = finish(pending, pending["idx0"])
-            job["idx0"] = idx
-            idx += job["B"]
+                prev_fin = finish(pending, None)
             pending = job
             k += 1
         if pending is not None:
             if prev_fin is not None:
                 report(prev_fin)
-            prev_fin = finish(pending, pending["idx0"])
+            prev_fin = finish(pending, None)
         if prev_fin is not None:
             report(prev_fin)
         # device-side failures (malformed container, overflow) are latched in the context: one check at the end -- a check per batch
         # would synchronise the whole stream and undo the pipelining; a failed image shows up in its own log line (max error) anyway
         self.model.codec().check()
-        if self.results:
-            self.test_logger.display(lr=0.0, typ="te")
-        return self.results
+        return self._finish_sharded()
 
     @torch.no_grad()
     def eval_model(self):
@@ -246,30 +301,23 @@ class LLICTIAgent:
         if eval_batch > 1:
             return self.eval_model_batched(eval_batch)
         self.model.eval()
-        self.results = []
-        for batch_idx, x in enumerate(_iter_test_images(self.config, self.device)):
-            torch.cuda.synchronize()
+        self.results, self._records = [], []
+        keep = bool(self.config["keep_streams"]) if "keep_streams" in self.config else False
+        sync = torch.cuda.synchronize if self.device.type == "cuda" else (lambda: None)
+        for batch_idx, x in _iter_test_images(self.config, self.device, self.rank, self.world, with_index=True):
+            sync()
             t0 = time.time()
             bytestream_list, xorg = self.model.compress(x)
-            torch.cuda.synchronize()
+            sync()
             enc_time = time.time() - t0
             rate1_list = self.compr_loss.forward(torch.numel(x), bytestream_list)
-            self.test_logger(rate1_list)               # llicti_agent.py:140
-            total = sum(len(s) * 8 for row in bytestream_list for s in row)
             t0 = time.time()
             x_reco = self.model.decompres(bytestream_list, self.device)
-            torch.cuda.synchronize()
+            sync()
             dec_time = time.time() - t0
             maxx_abserr = float(((x - x_reco) * 255).abs().max())
-            bpsp = total / torch.numel(x)
-            self._log_image(batch_idx, x.shape[2], x.shape[3], bpsp, enc_time, dec_time, maxx_abserr)
-            self.results.append({"idx": batch_idx, "H": int(x.shape[2]), "W": int(x.shape[3]), "bpsp": bpsp,
-                                 "enc_s": enc_time, "dec_s": dec_time, "max_abs_err": maxx_abserr, "rates": rate1_list})
-            if "keep_streams" in self.config and self.config["keep_streams"]:
-                self.results[-1]["bytestream_list"] = bytestream_list
-        if self.results:
-            self.test_logger.display(lr=0.0, typ="te")     # mean scale x band x channel table (llicti_agent.py:164)
-        return self.results
+            self._emit(batch_idx, int(x.shape[2]), int(x.shape[3]), bytestream_list, rate1_list, enc_time, dec_time, maxx_abserr, keep=keep)
+        return self._finish_sharded()
 
     def finalize(self):
         self.logger.info("Please wait while finalizing the operation.. Thank you")

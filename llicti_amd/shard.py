@@ -85,3 +85,60 @@ def per_rank_report(elapsed_s, pcie_elapsed_s, pixels_per_step, steps, identitie
                      "pcie_inclusive_mpix_s": round(pixels_per_step / tp / 1e6, 3) if tp > 0 else None})
     ts = [t for t in elapsed_s if t > 0]
     return rows, (round(max(ts) / min(ts), 4) if ts else None)
+
+
+# ---------------------------------------------------------------------- the eval driver over several ranks
+def init_from_env(device=None, backend=None):
+    """Join the job `python -m torch.distributed.run` started (RANK / WORLD_SIZE / MASTER_* in the environment) unless a process group exists
+    already; returns (rank, world).  Call it BEFORE anything touches the GPU in this process only for the launch itself -- the launcher has
+    done that; here the group is created on the device the rank will use (backend "nccl" = RCCL over xGMI on GPUs, "gloo" on CPU)."""
+    import os
+    if dist.is_available() and dist.is_initialized():
+        return world_info()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1
+    on_gpu = device is not None and torch.device(device).type == "cuda"
+    backend = backend or ("nccl" if on_gpu else "gloo")
+    dist.init_process_group(backend, **({"device_id": torch.device(device)} if backend == "nccl" else {}))
+    return world_info()
+
+
+def broadcast_module_state(module, device=None):
+    """One broadcast from rank 0 of everything `module.state_dict()` holds (0.79 MB for LLICTI: parameters and buffers flattened into one float32
+    buffer): a checkpoint is read once, by rank 0, and every rank codes with exactly its weights.  No-op without a process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    sd = module.state_dict()
+    keys = sorted(k for k, v in sd.items() if torch.is_tensor(v) and v.numel() > 0)
+    if not keys:
+        return 0
+    dev = device if device is not None else sd[keys[0]].device
+    flat = torch.cat([sd[k].detach().to(device=dev, dtype=torch.float32).reshape(-1) for k in keys])
+    dist.broadcast(flat, src=0)
+    pos = 0
+    with torch.no_grad():
+        for k in keys:
+            n = sd[k].numel()
+            sd[k].copy_(flat[pos:pos + n].reshape(sd[k].shape).to(sd[k].dtype))
+            pos += n
+    return int(flat.numel())
+
+
+def gather_records(rows, width, device=None):
+    """One all_gather of the ranks' per-image records: `rows` = list of `width` floats per image this rank coded -> the records of ALL ranks
+    (float64 [n_total, width], rank-major; the caller sorts by its index column).  Ranks may hold different numbers of images."""
+    dev = device if device is not None else "cpu"
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return torch.tensor(rows, dtype=torch.float64).reshape(-1, width)
+    world = dist.get_world_size()
+    n = torch.tensor([len(rows)], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    cap = max(int(c.item()) for c in counts)
+    mine = torch.zeros((max(cap, 1), width), dtype=torch.float64, device=dev)
+    if rows:
+        mine[:len(rows)] = torch.tensor(rows, dtype=torch.float64, device=dev).reshape(-1, width)
+    outs = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(outs, mine)
+    return torch.cat([o[:int(c.item())].cpu() for o, c in zip(outs, counts)], dim=0)

@@ -151,3 +151,105 @@ def test_distinct_device_accounting():
     assert rows[0]["mpix_s"] == 1.0 and rows[1]["mpix_s"] == 0.5 and strag == 2.0
     assert rows[0]["pci"] == "0000:01:01" and rows[1]["pci"] is None
     assert shard.gather_per_rank([1.5, 2.5]) == [[1.5, 2.5]]           # world = 1: no process group needed
+
+
+# ------------------------------------------------------------------------------------------------ LLICTIAgent.eval_model over several ranks
+class _StubModel(torch.nn.Module):
+    """Stands in for the device codec in the agent's multi-rank plumbing (no GPU here): stream lengths are a deterministic function of the
+    image AND of a weight, so a rank that coded with other weights than rank 0's, or an image booked under the wrong index, changes the log."""
+
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.zeros(4))
+        self.register_buffer("bound", torch.zeros(1))
+        self.mode = 0
+        self._last = None
+
+    def compress(self, x):
+        key = int(float(x.double().sum()) * 255) + int(float(self.w.sum()))
+        h4, w4 = (x.shape[2] + 31) // 32, (x.shape[3] + 31) // 32
+        rows = [[bytes([5, h4, w4]), bytes(12), bytes(2), bytes(3 * h4 * w4), b"", b"", b"", b"", b""]]
+        for s in range(5):
+            rows.append([bytes((key * (9 * s + k + 3)) % 97 + 1) for k in range(9)])
+        self._last = x
+        return rows, None
+
+    def decompres(self, bytestream_list, devc=None, xorg=None):
+        return self._last.clone()
+
+
+def _agent_log_lines(agent_logger_names=("Agent", "Rate Loss")):
+    import io
+    import logging
+    buf = io.StringIO()
+    h = logging.StreamHandler(buf)
+    h.setFormatter(logging.Formatter("%(name)s|%(message)s"))
+    for n in agent_logger_names:
+        lg = logging.getLogger(n)
+        lg.setLevel(logging.INFO)
+        lg.addHandler(h)
+    return buf
+
+
+def _strip_times(text):
+    import re
+    text = re.sub(r"Enc/Dec-Times:[0-9.]+/[0-9.]+", "Enc/Dec-Times:T/T", text)
+    return re.sub(r"\(\d\d:\d\d:\d\d\)", "(clock)", text)
+
+
+def _agent_images():
+    return [make_image("noise", 32 + 8 * (i % 3), 40 + 4 * (i % 4), seed=300 + i) for i in range(7)]
+
+
+def _agent_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank)})
+    from llicti_amd.agents.llicti_agent import LLICTIAgent
+    from llicti_amd.config import default_config
+    buf = _agent_log_lines()
+    model = _StubModel()
+    if rank == 0:
+        with torch.no_grad():
+            model.w.fill_(2.5)                       # "the checkpoint", read by rank 0 only
+    agent = LLICTIAgent(default_config(test_data=_agent_images()), model=model)
+    assert (agent.rank, agent.world) == (rank, world)
+    assert float(model.w.sum()) == 10.0              # every rank codes with rank 0's weights (one broadcast)
+    res = agent.run()
+    assert [r["idx"] for r in res] == list(range(rank, 7, world))
+    with open(os.path.join(outdir, f"log{rank}.txt"), "w") as f:
+        f.write(buf.getvalue())
+    if rank == 0:
+        np.save(os.path.join(outdir, "all.npy"), np.array([[r["idx"], r["H"], r["W"], r["bpsp"]] for r in agent.all_results]))
+    dist.destroy_process_group()
+
+
+def test_agent_two_ranks_equal_one_rank():
+    """SURVEY section 8(e) through the API: LLICTIAgent.eval_model started as two ranks (gloo here, RCCL on GPUs) shards the test set image i ->
+    rank i mod 2, takes rank 0's weights by one broadcast, gathers the per-image records once, and rank 0 logs exactly what a one-rank run logs
+    -- the reference's per-image lines in index order and the rate table (but for the wall-clock fields); the other rank logs no image line."""
+    from llicti_amd.agents.llicti_agent import LLICTIAgent
+    from llicti_amd.config import default_config
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    buf = _agent_log_lines()
+    model = _StubModel()
+    with torch.no_grad():
+        model.w.fill_(2.5)
+    one = LLICTIAgent(default_config(test_data=_agent_images()), model=model)
+    res1 = one.run()
+    for n in ("Agent", "Rate Loss"):
+        import logging
+        logging.getLogger(n).handlers = [h for h in logging.getLogger(n).handlers if getattr(h, "stream", None) is not buf]
+    log1 = _strip_times(buf.getvalue())
+    assert len(res1) == 7 and log1.count("Check: Decoded img matches original") == 7
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_agent_worker, args=(world, _free_port(), d), nprocs=world, join=True)
+        log_r0 = _strip_times(open(os.path.join(d, "log0.txt")).read())
+        log_r1 = open(os.path.join(d, "log1.txt")).read()
+        allr = np.load(os.path.join(d, "all.npy"))
+    pick = lambda t: [ln for ln in t.splitlines() if ln.startswith("Agent|") and "bpsp=" in ln] + [t[t.index("Rate Loss|"):]]      # noqa: E731
+    assert pick(log_r0) == pick(log1)                   # lines in index order + the table: identical
+    assert "bpsp=" not in log_r1 and "Rate Loss|" not in log_r1
+    assert [int(v) for v in allr[:, 0]] == list(range(7))
+    assert np.allclose(allr[:, 3], [r["bpsp"] for r in res1])
