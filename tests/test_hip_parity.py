@@ -1585,3 +1585,50 @@ def test_many_sizes_no_device_sync_and_plan_reuse(torch_mod, codecs):
     t3 = time.perf_counter()
     assert (t3 - t2) > 4 * (t2 - t1), f"the calls blocked on the device: enqueue {t2 - t1:.4f} s, remaining GPU work {t3 - t2:.4f} s"
     assert np.array_equal(rec.cpu().numpy()[0], make_image("smooth", 333, 77, 5))
+
+
+@pytest.mark.parametrize("name", ["smooth11_trainedlike", "noise0_rand1337"])
+def test_full_size_params_and_tables_vs_reference(torch_mod, codecs, name):
+    """levels 1 and 0 of FULL-SIZE 768x512 images on the HIP kernels against the reference's own numbers
+    (tests/golden/fullsize_samples.npz: LLICTIEntropyModel4.get_params outputs and int16 table entries at ~160 positions per (level, band)
+    -- image corners and borders, both sides of the MFMA kernel's tile seams, interior -- generated from the reference-owned code by
+    tests/golden/make_fixture_fullsize_samples.py): interpolator outputs within 1e-5 (north star), table entries within +-1 (trained-like
+    weights) / +-40 (sigma-floor seed-1337 weights) counts, symbols exact."""
+    import json
+    import os
+    from conftest import GOLDEN
+    torch = torch_mod
+    z = np.load(os.path.join(GOLDEN, "fullsize_samples.npz"))
+    meta = json.loads(bytes(z["meta_json"]).decode())
+    m = meta[name]
+    c = codecs(m["weights"])
+    rgb = make_image(m["kind"], m["H"], m["W"], m["seed"])
+    planes, fplanes, mm = c.lift(_dev(torch, rgb[None]))
+    mm_h = mm[0].cpu().numpy()
+    planes_h = planes[0].cpu().numpy()
+    ent_tol = 1 if m["weights"] == "trainedlike" else 40
+    worst = 0.0
+    for lvl in (1, 0):
+        for band in range(3):
+            tag = f"{name}_l{lvl}_b{band}"
+            pos = z[tag + "_pos"].astype(np.int64)
+            p64 = c.band_params(fplanes, lvl, band)
+            got = c.params60(p64)[0].cpu().numpy()[pos[:, 0], pos[:, 1]]
+            err = float(np.abs(got - z[tag + "_params"]).max())
+            worst = max(worst, err)
+            assert err < PARAM_TOL, (tag, err)
+            oi, oj = [(1, 1), (0, 1), (1, 0)][band]
+            w_band = got.shape and p64.shape[3]
+            for clr in range(3):
+                tab = c.cdf_tables(planes, p64, mm, lvl, band, clr, row_stride=512)[0].cpu().numpy().view(np.uint16)     # [hc * wc, 512]
+                shift = 127 if clr == 0 else -int(mm_h[clr - 1])
+                Lp = meta[f"{tag}_c{clr}_Lp"]
+                sym = planes_h[clr][((2 * pos[:, 0] + oi) << lvl), ((2 * pos[:, 1] + oj) << lvl)].astype(np.int64) + shift
+                assert np.array_equal(sym, z[f"{tag}_c{clr}_sym"].astype(np.int64)), (tag, clr)
+                rows = tab[pos[:, 0] * w_band + pos[:, 1]]                      # 768x512: the coded crop is the band grid
+                idx = z[f"{tag}_c{clr}_idx"].astype(np.int64)
+                val = z[f"{tag}_c{clr}_val"].astype(np.int64)
+                keep = idx < Lp - 1                                            # (the last entry wraps to 0 and is ignored by the coder)
+                d = np.abs(np.take_along_axis(rows.astype(np.int64), idx, axis=1) - val)[keep]
+                assert d.max() <= ent_tol, (tag, clr, int(d.max()))
+    print(f"{name}: max |params - reference| = {worst:.2e}")

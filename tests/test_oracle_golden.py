@@ -475,3 +475,51 @@ def test_auto_container_budget_by_size(size, oracle_weights):
         assert np.array_equal(orc.decode_image_rans(bl, W_o), img)
         got = sum(len(s) for row in bl for s in row)
         assert 8.0 * (got - ac) / (H * W) <= 0.001, (name, got, ac)
+
+
+def _fullsize_samples():
+    import json
+    import os
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "fullsize_samples.npz"))
+    meta = json.loads(bytes(z["meta_json"]).decode())
+    return z, meta
+
+
+_ALL_LB = tuple((l, b) for l in (1, 0) for b in range(3))
+
+
+@pytest.mark.parametrize("name,levels", [("smooth11_trainedlike", _ALL_LB), ("noise0_rand1337", _ALL_LB)])
+def test_full_size_samples_vs_reference(name, levels, oracle_weights):
+    """the reference's own get_params outputs and int16 table entries at ~160 positions per (level, band) of FULL-SIZE 768x512
+    images (tests/golden/fullsize_samples.npz: corners, borders, tile seams, interior; generated by make_fixture_fullsize_samples.py from the
+    reference-owned code) against the oracle: parameters within 1e-5 (north star), table entries within the stated +-1 (trained-like
+    weights) / +-40 (sigma-floor seed-1337 weights) counts, symbols exact.  (-m gpu runs the same samples on the HIP kernels:
+    tests/test_hip_parity.py::test_full_size_params_and_tables_vs_reference.)"""
+    from helpers import make_image
+    z, meta = _fullsize_samples()
+    m = meta[name]
+    W = oracle_weights(m["weights"])
+    rgb = make_image(m["kind"], m["H"], m["W"], m["seed"])
+    planes, mm = orc.lift(rgb)
+    ent_tol = 1 if m["weights"] == "trainedlike" else 40
+    for lvl, band in levels:
+        tag = f"{name}_l{lvl}_b{band}"
+        pos = z[tag + "_pos"].astype(np.int64)
+        params = orc.band_params(planes, lvl, band, W)                       # [h, w, 60]
+        got = params[pos[:, 0], pos[:, 1]]
+        assert np.abs(got - z[tag + "_params"]).max() < 1e-5, (tag, np.abs(got - z[tag + "_params"]).max())
+        oi, oj = [(1, 1), (0, 1), (1, 0)][band]
+        for clr in range(3):
+            minv = -127 if clr == 0 else int(mm[clr])
+            maxv = 128 if clr == 0 else int(mm[3 + clr])
+            shift = 127 if clr == 0 else -minv
+            for k, (i, j) in enumerate(pos):
+                R, Cc = (2 * i + oi) << lvl, (2 * j + oj) << lvl
+                assert int(planes[clr, R, Cc]) + shift == int(z[f"{tag}_c{clr}_sym"][k])
+                row = orc.cdf_row(params[i, j], clr, np.float32(planes[0, R, Cc]) / np.float32(255), np.float32(planes[1, R, Cc]) / np.float32(255), minv, maxv)
+                assert len(row) == meta[f"{tag}_c{clr}_Lp"]
+                idx = z[f"{tag}_c{clr}_idx"][k].astype(np.int64)
+                keep = idx < len(row) - 1                                     # (the last entry wraps to 0 and is ignored by the coder)
+                d = np.abs(row[idx[keep]].astype(np.int64) - z[f"{tag}_c{clr}_val"][k][keep].astype(np.int64))
+                assert d.max() <= ent_tol, (tag, clr, k, d.max())

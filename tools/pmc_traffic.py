@@ -62,7 +62,7 @@ if not isinstance(res["command"], dict):
     res["command"] = {"bench": res["command"]}
 label = sys.argv[3] if len(sys.argv) > 3 else "bench"
 res["command"][label] = ("python3 tools/bench_table.py" if label == "table" else
-                         "python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --no-ac-leg") + " (one rocprofv3 --pmc pass per counter group)"
+                         "python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --no-ac-leg --no-pcie-legs") + " (one rocprofv3 --pmc pass per counter group)"
 prefs = ("cdf_table_kernel",) if label == "table" else ("band_params_kernel", "rans_decode_stage_kernel", "rans_decode_stage_pair_kernel", "rans_decode_stage_lane_kernel", "rans_tail_kernel", "cdf_pairs_kernel", "lift_kernel", "cdf_table_kernel", "cdf_anchor_kernel",
              "ac_decode_kernel", "rans_encode_kernel", "ac_encode_pairs_kernel")
 for pref in prefs:
