@@ -160,7 +160,8 @@ int llicti_ac_decode_u16cdf(llicti_ctx *ctx, const uint16_t *d_cdf, int Lp, int 
  * build (BASELINE.json north_star: "torchac replaced by a HIP rANS coder"): header byte 0 = bit 7 (rANS) | bit 3 (format v3; the
  * retired v2 tag has it clear and is rejected with LLICTI_EFORMAT) | bit 6 (extended) | v in bits 5,4,2,1,0 with M = v + 1; extended:
  * v = 0 / 1 = 64 / 128 streams (latency modes), v = 2 .. 15 = v - 1 wide streams (LLICTI_MODE_RANS_WIDE), v = 16 .. 31 = xwide streams
- * (LLICTI_MODE_RANS_X); then M independent
+ * (LLICTI_MODE_RANS_X; round 3 had v = 16 .. 31 mean 15 .. 30 WIDE streams -- no container outside a test ever used them; one that did now reads
+ * as xwide and fails with LLICTI_EFORMAT, its streams being shorter than an xwide state block); then M independent
  * L-way interleaved rANS streams per image (L = 64 lanes, 128 for wide, 256 for xwide streams; segments 4 .. 4+M-1, the other stream segments
  * empty), same CDFs and symbols, decodable L*M symbols at a time.  States live in [2^31, 2^32) and renormalise bit by bit (the coder loses
  * ~2^-16 of a symbol's length, like the range coder); a stream = u16 (T | pad << 11) | bit region | L x 31-bit final

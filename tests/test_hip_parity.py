@@ -1411,6 +1411,17 @@ def test_integration_md_binding_runs(torch_mod, tmp_path):
     out = ns["forward_hip"](hip.ctx, xp)
     mine = model.forward(xp)
     assert len(out) == 5 and all(torch.equal(a, b) for a, b in zip(out, mine))
+    # section 4: a batch of mixed sizes in one call (llicti_encode_images_v / llicti_decode_images_v); each image's bytes == the packaged path's
+    mixed = next(b for b in blocks if "def compress_mixed_hip" in b)
+    exec(compile(mixed, "INTEGRATION.md#mixed", "exec"), ns)
+    imgs = [make_image("smooth", h, w, 30 + i) for i, (h, w) in enumerate([(72, 104), (97, 130), (64, 200)])]
+    cont, seg = ns["compress_mixed_hip"](hip.ctx, [torch.from_numpy(a).to("cuda:0") for a in imgs], 0x500 | 2)
+    m2 = LLICTI(default_config(container="xrans2")).to("cuda:0").eval()
+    m2.load_state_dict(model.state_dict())
+    from llicti_amd.codec import container_to_bytestream_list
+    for b, a in enumerate(imgs):
+        want, _ = m2.compress(torch.from_numpy(a[None]).to("cuda:0"))
+        assert container_to_bytestream_list(cont[b].cpu().numpy(), seg[b].cpu().numpy()) == want, b
 
 
 # ------------------------------------------------------------------------------------------------ batches of mixed sizes
