@@ -10,7 +10,7 @@
     } while (0)
 
 extern "C" const char *llicti_last_error(void) { return g_err.c_str(); }
-extern "C" const char *llicti_version(void) { return "llicti_hip 0.5 (gfx950, numerics spec v1, rANS container v3; params channel-planar, xwide streams with seeded tail chains)"; }
+extern "C" const char *llicti_version(void) { return "llicti_hip 0.6 (gfx950, numerics spec v1, rANS container v3; xwide streams with seeded tail chains of up to 8,191 symbols; batches of mixed sizes)"; }
 
 extern "C" int llicti_level_geom(int H, int W, int lvl, int band, int *Hl, int *Wl, int *h, int *w,
                                  int *padH, int *padW, int *hc, int *wc)

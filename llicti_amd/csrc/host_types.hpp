@@ -154,7 +154,9 @@ constexpr int kLiftMaxParts = 65536;        // entries of the partials scratch: 
 constexpr int kAnchorRow = 208;
 
 constexpr int kRansStateBits = 31;
-constexpr int kRansTailMax = 2047;
+constexpr int kRansTailMax = 2047;          // tail symbols of a 64- / 128-lane stream (the 11-bit T field)
+constexpr int kRansTailMaxX = 8191;         // ... of an xwide stream (round 5): its T field has a twelfth bit (bit 15 of the stream's first u16), and
+constexpr int kRansTailEscX = 4095;         // ... T >= 4,095 is written as 4,095 in the field + the count itself as a u16 behind the states
 // A stream has 64 Q lanes: Q = 1, Q = 2 ("wide" streams: two 64-symbol sub-chunks per step, decoded two lanes per symbol by
 // rans_decode_stage_pair_kernel, at the price of a tail twice as long) or Q = 4 ("xwide": 256 lanes, decoded ONE lane per symbol by
 // rans_decode_stage_lane_kernel, four wavefronts per stream).  Symbol n of a stage sits in chunk n / 64Q.

@@ -114,7 +114,8 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
         // they run in blocks of 32 steps, record (field, bits) of every step in symbol order and their states of the last block, and meet at a
         // barrier after each block; the first block that overshoots the payload ends the recursion, and where exactly the sequential rule stops
         // -- T -- and where each field goes are prefix sums over the records, done by all 256 threads.
-        uint32_t *sh_fld = sh_win;                      // (the ring is not in use yet; zeroed again below)
+        __shared__ uint32_t sh_fld[kRansTailMaxX + 1];  // (field, bits) of every tail step, in symbol order: up to 8,191 of them (round 5: a tail of 2,047 symbols
+                                                        // fills the 7,936-bit payload only at 3.9 bits per symbol; the trained model's last stage costs 1.7)
         __shared__ uint32_t sh_xs[2][34];
         __shared__ int sh_used[2][2], sh_scan[2][4], sh_cut[3];
         const uint32_t *pl = pairs + dl.pair_off;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
         }
         tail_single = (nch == 1);
         const int NS = min(nch * ns, cnt);
-        const int ncod = max(min(cnt, kRansTailMax) - nch * ns, 0);        // candidates j = nch ns + idx, idx < ncod; chain c takes idx = nch i + c
+        const int ncod = max(min(cnt, kRansTailMaxX) - nch * ns, 0);       // candidates j = nch ns + idx, idx < ncod; chain c takes idx = nch i + c
         const int n_own = (wq < nch) ? (ncod + nch - 1 - wq) / nch : 0;
         const int nblk = ((ncod + nch - 1) / nch + 31) >> 5;               // chain A's steps, in blocks
         uint32_t xc = 1u << 31;
@@ -191,54 +192,82 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
             if (sh_used[blk & 1][0] + sh_used[blk & 1][1] + 32 * nch > GEO::kPayBits || blk + 1 >= nblk) break;
         }
         const int nrun = min(32 * nch * (blk + 1), ncod);     // records there are
-        // thread tid: records 8 tid .. 8 tid + 7 (2048 >= the tail's maximum): bits of chain A / chain B before each of them
-        auto onb = [&](int e) -> bool { return nch == 2 && (e & 1); };      // record 8 tid + e belongs to chain B
-        int nbv[8], sa = 0, sb = 0;
+        // Where the sequential rule stops (tcod) and where each field goes are prefix sums over the records: thread tid takes records
+        // 2048 q + 8 tid .. + 7 of quarter q (one quarter covers the 2,047 symbols every tail had before round 5; a long tail of a cheap source has up to
+        // four), the chains' bit counts before a quarter carried over from the quarters in front of it.
+        auto onb = [&](int e) -> bool { return nch == 2 && (e & 1); };      // record 2048 q + 8 tid + e belongs to chain B (2048 and 8 are even)
+        const int nq = (nrun + 2047) >> 11;
+        int nbv[8];
         uint32_t fv[8];
+        int base_a = 0, base_b = 0;                     // bits of chain A / chain B in the quarters before the current one
+        // exclusive prefixes (ea, eb) of this thread's records of quarter q; leaves the quarter's totals in tot_a / tot_b.  Two barriers.
+        auto scan_quarter = [&](int q, int &ea, int &eb, int &tot_a, int &tot_b) {
+            int sa = 0, sb = 0;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int idx = 8 * tid + e;
-            const uint32_t r = (idx < nrun) ? sh_fld[idx] : 0u;
-            nbv[e] = (int)(r >> 16); fv[e] = r & 0xFFFFu;
-            if (onb(e)) sb += nbv[e]; else sa += nbv[e];
-        }
-        const int ia = wave_incl_scan(sa), ib = wave_incl_scan(sb);
-        if (lane == 63) { sh_scan[0][wq] = ia; sh_scan[1][wq] = ib; }
+            for (int e = 0; e < 8; ++e) {
+                const int idx = 2048 * q + 8 * tid + e;
+                const uint32_t r = (idx < nrun) ? sh_fld[idx] : 0u;
+                nbv[e] = (int)(r >> 16); fv[e] = r & 0xFFFFu;
+                if (onb(e)) sb += nbv[e]; else sa += nbv[e];
+            }
+            const int ia = wave_incl_scan(sa), ib = wave_incl_scan(sb);
+            __syncthreads();                            // (the previous use of sh_scan has been read)
+            if (lane == 63) { sh_scan[0][wq] = ia; sh_scan[1][wq] = ib; }
+            __syncthreads();
+            ea = base_a + ia - sa; eb = base_b + ib - sb;
+            tot_a = 0; tot_b = 0;
+            for (int w2 = 0; w2 < 4; ++w2) {
+                if (w2 < wq) { ea += sh_scan[0][w2]; eb += sh_scan[1][w2]; }
+                tot_a += sh_scan[0][w2]; tot_b += sh_scan[1][w2];
+            }
+        };
         if (tid == 0) sh_cut[0] = nrun;
         __syncthreads();
-        int ea = ia - sa, eb = ib - sb;                 // exclusive
-        for (int w2 = 0; w2 < wq; ++w2) { ea += sh_scan[0][w2]; eb += sh_scan[1][w2]; }
-        {
+        for (int q = 0; q < nq; ++q) {                  // 1. the first record that does not fit
+            int ea, eb, ta, tb2;
+            scan_quarter(q, ea, eb, ta, tb2);
             int ca = ea, cb = eb, first = 0x7FFFFFFF;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                if (ca + cb + nbv[e] + 32 * nch > GEO::kPayBits && first == 0x7FFFFFFF) first = 8 * tid + e;
+                if (ca + cb + nbv[e] + 32 * nch > GEO::kPayBits && first == 0x7FFFFFFF) first = 2048 * q + 8 * tid + e;
                 if (onb(e)) cb += nbv[e]; else ca += nbv[e];
             }
             if (first != 0x7FFFFFFF) atomicMin(&sh_cut[0], first);
+            base_a += ta; base_b += tb2;
         }
         __syncthreads();
         const int tcod = sh_cut[0];                     // coded symbols: the sequential rule's stop
-        {
+        base_a = 0; base_b = 0;
+        if (tid == 0 && tcod == nrun) { sh_cut[1] = -1; sh_cut[2] = -1; }
+        for (int q = 0; q < nq; ++q) {                  // 2. the chains' bits up to there
+            int ea, eb, ta, tb2;
+            scan_quarter(q, ea, eb, ta, tb2);
             int ca = ea, cb = eb;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                if (8 * tid + e == tcod) { sh_cut[1] = ca; sh_cut[2] = cb; }
+                if (2048 * q + 8 * tid + e == tcod) { sh_cut[1] = ca; sh_cut[2] = cb; }
                 if (onb(e)) cb += nbv[e]; else ca += nbv[e];
             }
+            base_a += ta; base_b += tb2;
         }
         __syncthreads();
+        if (tid == 0 && sh_cut[1] < 0) { sh_cut[1] = base_a; sh_cut[2] = base_b; }      // every record fits: the totals
+        __syncthreads();
         const int used_a = sh_cut[1], used_b = sh_cut[2];
-        {
+        base_a = 0; base_b = 0;
+        for (int q = 0; q < nq; ++q) {                  // 3. the fields to their places: chain A's upwards from bit 32 in the decoder's reading order, chain B's below its state
+            int ea, eb, ta, tb2;
+            scan_quarter(q, ea, eb, ta, tb2);
             int ca = ea, cb = eb;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                if (8 * tid + e < tcod) {
+                if (2048 * q + 8 * tid + e < tcod) {
                     const int pos = onb(e) ? GEO::kPayBits - 32 - used_b + cb : 32 + used_a - ca - nbv[e];
                     lds_or_bits(sh_pay, pos, nbv[e], fv[e]);
                 }
                 if (onb(e)) cb += nbv[e]; else ca += nbv[e];
             }
+            base_a += ta; base_b += tb2;
         }
         if (tid == 0) {
             sh_pay[0] = sh_xs[0][(tcod + nch - 1) / nch - 32 * blk];
@@ -418,10 +447,15 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
         uint8_t *fs = slot + 4 + nbytes;
         for (int t = tid; t < GEO::kPayBytes; t += 64 * Q) fs[t] = (uint8_t)(sh_pay[t >> 2] >> (8 * (t & 3)));
     }
+    // xwide streams: the T field has a twelfth bit (bit 15), and a tail of 4,095 symbols or more is written as 4,095 with the count itself as a u16
+    // behind the states (oracle/llicti_oracle.h, "stream")
+    const bool t_esc = kSeeded<Q> && T >= kRansTailEscX;
     if (tid == 0) {
-        const int t16 = T | ((8 * nbytes - bp) << 11) | (tail_single << 14);      // pad: unused (zero) bits on top of the region's last byte
+        const int Tf = t_esc ? kRansTailEscX : T;
+        const int t16 = (Tf & 0x7FF) | ((8 * nbytes - bp) << 11) | (tail_single << 14) | ((Tf >> 11) << 15);      // pad: unused (zero) bits on top of the region's last byte
         slot[2] = (uint8_t)(t16 & 0xFF); slot[3] = (uint8_t)(t16 >> 8);
-        rinfo[2 * sidx] = 2; rinfo[2 * sidx + 1] = (bad == 2) ? 0 : 2 + nbytes + GEO::kPayBytes;      // overflowed slot (never with the plan's sizing): nothing to pack, ENOSPACE is latched
+        if (t_esc && !over) { uint8_t *te = slot + 4 + nbytes + GEO::kPayBytes; te[0] = (uint8_t)(T & 0xFF); te[1] = (uint8_t)(T >> 8); }
+        rinfo[2 * sidx] = 2; rinfo[2 * sidx + 1] = (bad == 2) ? 0 : 2 + nbytes + GEO::kPayBytes + (t_esc ? 2 : 0);      // overflowed slot (never with the plan's sizing): nothing to pack, ENOSPACE is latched
     }
     if (bad) atomicExch(&status[0], bad == 1 ? LLICTI_EFORMAT : LLICTI_ENOSPACE);
 }
@@ -437,13 +471,18 @@ __global__ __launch_bounds__(64) void rans_init_kernel(const uint8_t *__restrict
     const int sidx = blockIdx.x, lane = threadIdx.x;
     const uint8_t *slot = slots + rslot_off[sidx];
     const int n = (int)rpos[sidx];                                 // >= GEO::kMinStream
-    const int nbytes = n - 2 - GEO::kPayBytes;
     const int t16 = slot[2] | (slot[3] << 8);
-    int T = t16 & 0x7FF;
+    int T = (t16 & 0x7FF) | (kSeeded<Q> ? (t16 >> 15) << 11 : 0);  // xwide: bit 15 is the field's twelfth bit ...
+    const bool t_esc = kSeeded<Q> && T == kRansTailEscX;           // ... and 4,095 says: the count follows the states as a u16
+    int nbytes = n - 2 - GEO::kPayBytes - (t_esc ? 2 : 0);
     const int pad = (t16 >> 11) & 7;
     bool bad = false;
     const int single = kSeeded<Q> ? (t16 >> 14) & 1 : 0;           // xwide: one tail chain instead of two
-    if ((t16 >> (kSeeded<Q> ? 15 : 14)) || (nbytes == 0 && pad)) { bad = true; T = 0; }
+    if ((!kSeeded<Q> && (t16 >> 14)) || nbytes < 0 || (nbytes == 0 && pad)) { bad = true; T = 0; nbytes = max(nbytes, 0); }
+    if (t_esc && !bad) {
+        T = slot[2 + n - 2] | (slot[2 + n - 1] << 8);               // (the stream sits at slot + 2)
+        if (T < kRansTailEscX || T > kRansTailMaxX) { bad = true; T = 0; }
+    }
     const int cur = bad ? 0 : 8 * nbytes - pad;
     const uint8_t *fs = slot + 4 + nbytes;
 #pragma unroll

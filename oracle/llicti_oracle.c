@@ -783,7 +783,9 @@ typedef struct { long n; uint32_t *clow, *chigh; int16_t *sym; } stage_syms_t;
 #define RANS_MAX_LANES  256                             /* lanes of a stream: 64, 128 ("wide": two 64-symbol chunks per step) or 256 ("xwide": four) */
 #define RANS_STATE_BITS 31                              /* a lane state is 2^31 | 31 bits */
 #define RANS_MAX_PAY_BITS (RANS_MAX_LANES * RANS_STATE_BITS)   /* what the initial states carry (the tail stream): 1984 / 3968 / 7936 bits */
-#define RANS_TAIL_MAX   2047
+#define RANS_TAIL_MAX   2047                            /* tail symbols of a 64- / 128-lane stream (the 11-bit T field) */
+#define RANS_TAIL_MAX_X 8191                            /* ... of an xwide stream, whose T field has a 12th bit (bit 15 of the u16): T < 4095 as it is, */
+#define RANS_TAIL_ESC_X 4095                            /* ... T >= 4095 as the escape 4095 in the field + the count itself as a u16 behind the states */
 /* xwide streams (256 lanes) only -- the older kinds keep their bytes.  Their tail is coded by TWO single-state coders ("chains") that share the
  * payload, and neither starts from an empty state:
  *   seeds    with A = the number of symbol values of the image's Cg channel (max - min + 1) and n = the largest count with A^n <= 2^31 (at most
@@ -791,7 +793,9 @@ typedef struct { long n; uint32_t *clow, *chigh; int16_t *sym; } stage_syms_t;
  *            starts from 2^31 | sum sym(i) A^i over i < n and chain B from the same of sym(n + i) (symbol INDICES, raw, radix A; a stream shorter
  *            than 2 n symbols leaves the missing digits zero): the 31 bits an empty start state wastes carry n symbols that are never coded;
  *   chains   symbol j >= 2 n is pushed on chain A if j is even, on chain B if it is odd, j ascending (the decoder pops j descending), while
- *            used_A + used_B + bits(j) + 64 <= payload bits; T = the first j that does not fit (or the stream's length, or 2047);
+ *            used_A + used_B + bits(j) + 64 <= payload bits; T = the first j that does not fit (or the stream's length, or 8191: a payload of
+ *            7936 bits is filled by 2047 symbols only if they cost 3.9 bits each -- the trained model on natural images spends 1.7 there,
+ *            reference log exp_debug.log.1:2682 -- so an xwide tail may be up to RANS_TAIL_MAX_X symbols long);
  *   payload  bits [0, 32) = A's final state; A's bit fields from bit 32 UPWARDS in the order the decoder reads them (last pushed first); B's
  *            final state in the top 32 bits, B's fields below it, read DOWNWARDS (last pushed on top); what lies between is zero.
  * Two chains because the tail is serial: the decoder runs them on two wavefronts, the encoder too. */
@@ -874,10 +878,10 @@ static long rans_tail_encode_x(const stage_syms_t *sl, int m, int M, long cnt, i
         }
     }
     const long j0 = j;                                         /* first coded symbol: nch ns (or the stream's end) */
-    uint32_t fld[RANS_TAIL_MAX];
-    uint8_t fnb[RANS_TAIL_MAX];
+    static __thread uint32_t fld[RANS_TAIL_MAX_X];
+    static __thread uint8_t fnb[RANS_TAIL_MAX_X];
     long used[2] = { 0, 0 };
-    for (; j < cnt && j < RANS_TAIL_MAX; ++j) {
+    for (; j < cnt && j < RANS_TAIL_MAX_X; ++j) {
         const long q = cnt - 1 - j;
         const long n = (long)L * (m + (q / L) * M) + (q % L);
         const uint32_t lo = sl->clow[n], freq = sl->chigh[n] - lo;
@@ -1031,7 +1035,8 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
         if (rc < 0) break;
         const long nbytes = (bp + 7) / 8;
         const long padb = 8 * nbytes - bp;               /* unused (zero) bits on top of the region's last byte */
-        const long bytes = 2 + nbytes + PAY_BITS / 8;
+        const int t_esc = (L == RANS_SEED_LANES && T >= RANS_TAIL_ESC_X);   /* xwide, very long tail: T field = 4095, the count itself as a u16 behind the states */
+        const long bytes = 2 + nbytes + PAY_BITS / 8 + (t_esc ? 2 : 0);
         if (pos + bytes + 4 * G > cap) { rc = -1; break; }
         if (G > 1) {
             /* M = 64 / 128: segment m / G = G little-endian u32 stream lengths, then its G streams */
@@ -1039,12 +1044,14 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
             uint8_t *tab = out + pos - seg_len[4 + m / G] + 4 * (m % G);
             tab[0] = (uint8_t)(bytes & 0xFF); tab[1] = (uint8_t)((bytes >> 8) & 0xFF); tab[2] = (uint8_t)((bytes >> 16) & 0xFF); tab[3] = (uint8_t)(bytes >> 24);
         }
-        const long t16 = T | (padb << 11) | ((long)single << 14);
+        const long Tf = t_esc ? RANS_TAIL_ESC_X : T;         /* 11 bits, or (xwide) 12: the twelfth is bit 15 */
+        const long t16 = (Tf & 0x7FF) | (padb << 11) | ((long)single << 14) | ((Tf >> 11) << 15);
         out[pos] = (uint8_t)(t16 & 0xFF); out[pos + 1] = (uint8_t)(t16 >> 8);
         memcpy(out + pos + 2, bits, nbytes);
         uint8_t *fs = out + pos + 2 + nbytes;
         memset(fs, 0, PAY_BITS / 8);
         for (int l = 0; l < L; ++l) put_bits(fs, (long)RANS_STATE_BITS * l, RANS_STATE_BITS, x[l] & 0x7FFFFFFFu);
+        if (t_esc) { fs[PAY_BITS / 8] = (uint8_t)(T & 0xFF); fs[PAY_BITS / 8 + 1] = (uint8_t)(T >> 8); }
         pos += bytes;
         seg_len[4 + m / G] += (int32_t)bytes;
     }
@@ -1114,9 +1121,15 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
             const uint8_t *sp = in + pos;
             const int t16 = sp[0] | (sp[1] << 8);
             const int padb = (t16 >> 11) & 7;
-            const long nbytes = len - 2 - PAY_BITS / 8;
-            if ((t16 >> 15) || (((t16 >> 14) & 1) && L != RANS_SEED_LANES) || (nbytes == 0 && padb)) { free(x); free(bitsp); free(cur); free(T); return -3; }
-            T[m] = (t16 & 0x7FF) | (((t16 >> 14) & 1) << 16);         /* bit 16: the xwide stream's tail has one chain, not two */
+            long Tv = (t16 & 0x7FF) | (L == RANS_SEED_LANES ? ((long)(t16 >> 15) << 11) : 0);      /* xwide: bit 15 is the field's twelfth bit */
+            const int t_esc = (L == RANS_SEED_LANES && Tv == RANS_TAIL_ESC_X);                    /* ... and 4095 says: the length follows the states */
+            const long nbytes = len - 2 - PAY_BITS / 8 - (t_esc ? 2 : 0);
+            if (((t16 >> 15) && L != RANS_SEED_LANES) || (((t16 >> 14) & 1) && L != RANS_SEED_LANES) || nbytes < 0 || (nbytes == 0 && padb)) { free(x); free(bitsp); free(cur); free(T); return -3; }
+            if (t_esc) {
+                Tv = (long)sp[len - 2] | ((long)sp[len - 1] << 8);
+                if (Tv < RANS_TAIL_ESC_X || Tv > RANS_TAIL_MAX_X) { free(x); free(bitsp); free(cur); free(T); return -3; }
+            }
+            T[m] = Tv | ((long)((t16 >> 14) & 1) << 16);         /* bit 16: the xwide stream's tail has one chain, not two */
             bitsp[m] = sp + 2;
             cur[m] = 8 * nbytes - padb;                               /* number of data bits */
             const uint8_t *fs = sp + 2 + nbytes;

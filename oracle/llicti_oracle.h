@@ -140,7 +140,7 @@ long orc_stream_pairs(const int16_t *planes, int H, int W, const int16_t minmax[
  *              count with A^n <= 2^31 (at most 31) and j counting the stream's symbols from its end (j = 0 the last): chain A starts from
  *              2^31 | sum sym(i) A^i (i < n), chain B from the same of sym(n + i) -- symbol INDICES, raw; missing symbols = zero digits -- so the
  *              ~31 bits an empty start state wastes carry n symbols that are never coded.  Symbol j >= 2 n is pushed on chain A if j is even,
- *              on B if odd, j ascending, while used_A + used_B + bits(j) + 64 <= 7936; T = the first j that does not fit (<= 2047, <= cnt).
+ *              on B if odd, j ascending, while used_A + used_B + bits(j) + 64 <= 7936; T = the first j that does not fit (<= 8191, <= cnt).
  *              Payload: bits [0, 32) A's final state, A's bit fields from bit 32 UP in the decoder's reading order (last pushed first); the
  *              top 32 bits B's final state, B's fields below it, read DOWN; zeros between.  Checks: both states have their leading one, the
  *              cursors do not cross, the bits between them are zero, each chain ends at a seed below A^n whose digits beyond the stream's
@@ -150,8 +150,13 @@ long orc_stream_pairs(const int16_t *planes, int H, int W, const int16_t minmax[
  *              64 symbols (k of them): two chains iff the stream has 2 n symbols and n * sum(16 - floor(log2 freq)) / k >= 32 + n / 2 (integer
  *              form: 2 n sum >= k (64 + n)), and says so in bit 14 of the stream's first u16 (1 = ONE chain).  One chain: n seed symbols, every
  *              coded symbol on chain A, stop rule with 32 instead of 64, no state on top; the payload above A's fields is zero.
- *   stream     u16 LE (T | pad << 11 | single << 14: bit 14 only in xwide streams, bit 15 zero) | bit region, LSB first, ceil(bits / 8) bytes, pad = unused zero bits on
- *              top of its last byte | L x 31-bit final states (low 31 bits of x_l at bit 31 l; 248 / 496 / 992 bytes).
+ *   stream     u16 LE (T | pad << 11 | single << 14: bit 14 only in xwide streams, bit 15 zero -- xwide: T's twelfth bit) | bit region, LSB first, ceil(bits / 8) bytes, pad = unused zero bits on
+ *              top of its last byte | L x 31-bit final states (low 31 bits of x_l at bit 31 l; 248 / 496 / 992 bytes) | xwide streams only
+ *              (round 5): the T field has a twelfth bit, bit 15 of the u16 (T < 4095 costs nothing), and a tail of 4095 symbols or more is
+ *              written as 4095 in the field with the count itself, 4095 .. 8191, as a u16 LE behind the states.  (A source cheaper than
+ *              7936 / 2047 = 3.9 bits per last-stage symbol cannot fill a 256-lane payload with 2047 symbols -- the rest of the 992 bytes was
+ *              waste; the trained model on natural images spends 1.7 bits there.  The 64- and 128-lane kinds keep T <= 2047, bit 15 zero: their
+ *              payloads hold 1984 / 3968 bits.)
  * Cost over the ideal code length: ~6 bytes per stream that has symbols (v2: ~60; wide: ~6.5; xwide: ~2-3.5), an empty stream 250 / 498 / 994.
  * M: streams per image, | 0x100 for wide streams, | 0x200 for xwide streams.  Returns total bytes or <0. */
 long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *wts, int M,

@@ -32,8 +32,14 @@ for case in range(N):
     H, W = int(rng.integers(32, 161)), int(rng.integers(32, 201))
     B = int(rng.integers(1, 4))
     kind = ("noise", "smooth", "flat", "binary", "narrow")[int(rng.integers(0, 5))]
+    big = kind in ("flat", "binary", "narrow") and rng.integers(0, 4) == 0      # round 5: cheap content, large enough for xwide tails beyond 2,047 / 4,095 symbols
+    if big:
+        H, W = int(rng.integers(200, 361)), int(rng.integers(250, 421))
+    mixed = bool(rng.integers(0, 2))               # round 5: the images of the call differ in size (llicti_encode_images_v; rANS containers)
+    sizes = [(H, W)] + [((int(rng.integers(32, 161)), int(rng.integers(32, 201))) if mixed else (H, W)) for _ in range(B - 1)]
     imgs = []
     for b in range(B):
+        H, W = sizes[b]
         seed = int(rng.integers(0, 2 ** 31))
         if kind in ("noise", "smooth"):
             imgs.append(make_image(kind, H, W, seed))
@@ -44,33 +50,49 @@ for case in range(N):
             imgs.append(np.broadcast_to(np.random.default_rng(seed).integers(0, 256, (3, 1, 1), dtype=np.uint8), (3, H, W)).copy())
         else:
             imgs.append(np.random.default_rng(seed).choice(np.array([0, 255], np.uint8), size=(3, H, W)))
-    rgb = np.stack(imgs)
+    H, W = sizes[0]
     M = int(rng.choice([0, 1, 2, 3, 4, 8, 10, 11, 16, 32, 64, 128, -1, -5, -10, -14, -1001, -1003, -1009, -1014, -1032, -1064]))     # negative: |M| wide streams, |M| - 1000 xwide streams
-    if XWIDE_ONLY: M = int(rng.choice([-1001, -1002, -1003, -1005, -1009, -1010, -1014, -1032, -1064]))
+    if XWIDE_ONLY or big: M = int(rng.choice([-1001, -1002, -1003, -1005, -1009, -1010, -1014, -1032, -1064] if not big else [-1001, -1002, -1003]))
     wide = 0 if M >= 0 else (2 if M <= -1000 else 1)
     M = abs(M) % 1000
     mode = MODE_AC if M == 0 else MODE_RANS(M, wide)
-    tag = f"case {case}: {wname} x{scale} {kind} B={B} {W}x{H} M={M}{('', ' wide', ' xwide')[wide]}"
+    if M == 0 and len(set(sizes)) > 1:             # the reference-format container codes one size per call
+        sizes = [sizes[0]] * B
+        imgs = [imgs[0]] + [np.random.default_rng(int(rng.integers(0, 2 ** 31))).integers(0, 256, (3,) + sizes[0], dtype=np.uint8) for _ in range(B - 1)]
+    ragged = len(set(sizes)) > 1
+    tag = f"case {case}: {wname} x{scale} {kind}{' big' if big else ''} B={B} {'x'.join(f'{w}x{h}' for h, w in sizes) if ragged else f'{W}x{H}'} M={M}{('', ' wide', ' xwide')[wide]}"
     codec = HipCodec("cuda:0")
     codec.load_state_dict(sd)
     W_o = orc.Weights(pack_state_dict(sd))
-    x = torch.from_numpy(rgb).cuda()
-    cont, seg = codec.encode(x, mode=mode)
-    codec.check()
-    codec.workspace(B, H, W, mode)
-    codec.poison_workspace()                       # the decode must not find the encoder's planes in the workspace
-    rec = codec.decode(cont, seg, H, W, mode=mode)
-    codec.check()
-    assert torch.equal(rec, x), "ROUND TRIP " + tag
+    Hs, Ws = [h for h, _ in sizes], [w for _, w in sizes]
+    if ragged or (M != 0 and rng.integers(0, 4) == 0):          # (equal sizes through the _v entry now and then)
+        flat = torch.from_numpy(np.concatenate([a.reshape(-1) for a in imgs])).cuda()
+        cont, seg = codec.encode_v(flat, Hs, Ws, mode)
+        codec.check()
+        codec.poison_workspace()                   # the decode must not find the encoder's planes in the workspace
+        rec = codec.decode_v(cont, seg, Hs, Ws, mode)
+        codec.check()
+        assert torch.equal(rec, flat), "ROUND TRIP " + tag
+    else:
+        x = torch.from_numpy(np.stack(imgs)).cuda()
+        cont, seg = codec.encode(x, mode=mode)
+        codec.check()
+        codec.workspace(B, H, W, mode)
+        codec.poison_workspace()
+        rec = codec.decode(cont, seg, H, W, mode=mode)
+        codec.check()
+        assert torch.equal(rec, x), "ROUND TRIP " + tag
     ch, sh = cont.cpu().numpy(), seg.cpu().numpy()
     for b in range(B):
-        ref = orc.encode_image(rgb[b], W_o) if M == 0 else orc.encode_image_rans(rgb[b], W_o, M, wide)
+        ref = orc.encode_image(imgs[b], W_o) if M == 0 else orc.encode_image_rans(imgs[b], W_o, M, wide)
         assert container_to_bytestream_list(ch[b], sh[b]) == ref, "BYTES " + tag + f" image {b}"
+    if ragged: counts["mixed_size_calls"] += 1
+    if big: counts["big_cheap_images"] += 1
     codec.close()
     counts[f"container:{'ac' if M == 0 else ('rans%d', 'wrans%d', 'xrans%d')[wide] % M}"] += 1
     counts[f"kind:{kind}"] += 1
     counts[f"weights:{wname}x{scale}"] += 1
-    pixels += B * H * W
+    pixels += sum(h * w for h, w in sizes)
     if case % 10 == 9:
         print(f"{case + 1} cases ok ({time.time() - t0:.0f} s); last: {tag}", flush=True)
 print("fuzz ok:", N, "cases")

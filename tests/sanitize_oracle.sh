@@ -43,6 +43,24 @@ for wname in ("trainedlike", "rand1337"):
                 except RuntimeError:
                     pass
         print(wname, kind, H, Wd, "ok", flush=True)
+# round 5: xwide tails beyond 2,047 symbols (12-bit T field, escape) -- a cheap model-drawn source and a flat image large enough for 8,191 tail symbols
+sys.path.insert(0, "$ROOT/tests")
+from test_oracle_golden import _cheap_case
+for kind in ("sharp", "single"):
+    sd, Wc, img = _cheap_case(kind)
+    for M in (1, 3):
+        bl = orc.encode_image_rans(img, Wc, M, 2)
+        assert np.array_equal(orc.decode_image_rans(bl, Wc), img), (kind, M)
+        for trial in range(3):
+            rows = [list(r) for r in bl]
+            b = bytearray(rows[1][0]); b[(0, 1, len(b) - 1)[trial]] ^= 0x80; rows[1][0] = bytes(b)      # T's low / high byte (bit 15!), the escape's count
+            try:
+                orc.decode_image_rans(rows, Wc)
+            except RuntimeError:
+                pass
+    print("long tails", kind, "ok", flush=True)
+flat = np.full((3, 256, 384), 77, np.uint8)
+assert np.array_equal(orc.decode_image_rans(orc.encode_image_rans(flat, W, 2, 2), W), flat)
 print("sanitizer run clean")
 PY
 LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0 python3 "$OUT/run.py"

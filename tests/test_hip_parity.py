@@ -1643,3 +1643,48 @@ def test_full_size_params_and_tables_vs_reference(torch_mod, codecs, name):
                 d = np.abs(np.take_along_axis(rows.astype(np.int64), idx, axis=1) - val)[keep]
                 assert d.max() <= ent_tol, (tag, clr, int(d.max()))
     print(f"{name}: max |params - reference| = {worst:.2e}")
+
+
+@pytest.mark.parametrize("kind", ["sharp", "single", "flat"])
+def test_rans_xwide_long_tail_bitexact(torch_mod, kind):
+    """Round 5: xwide tails longer than 2,047 symbols (cheap sources: the 12-bit T field and the escape up to 8,191; see
+    tests/test_oracle_golden.py::test_rans_xwide_long_tail) -- HIP bytes == oracle bytes, lossless on a poisoned workspace, alone, as a
+    batch, and inside a batch of mixed sizes next to ordinary images; a flat image (symbols that cost nothing: tails at the cap) too."""
+    from test_oracle_golden import _cheap_case
+    from llicti_amd.codec import HipCodec, container_to_bytestream_list, mode_of_name
+    from oracle import oracle as orc
+    torch = torch_mod
+    sd, W_o, img = _cheap_case("sharp" if kind == "flat" else kind)
+    if kind == "flat":
+        img = np.full((3, 256, 384), 77, np.uint8)
+    c = HipCodec("cuda:0")
+    try:
+        c.load_state_dict(sd)
+        for name, M in (("xrans1", 1), ("xrans2", 2), ("xrans5", 5)):
+            mode = mode_of_name(name)
+            x = _dev(torch, np.stack([img, img[:, ::-1].copy()]))
+            cont, seg = c.encode(x, mode=mode)
+            c.check()
+            want = orc.encode_image_rans(img, W_o, M, 2)
+            got = container_to_bytestream_list(cont[0].cpu().numpy(), seg[0].cpu().numpy())
+            assert got == want, (kind, name)
+            Tf = [((s[0] | (s[1] << 8)) & 0x7FF) | (((s[0] | (s[1] << 8)) >> 15) << 11) for s in got[1][:M]]
+            if name == "xrans1":
+                assert Tf[0] >= 2048, Tf
+                if kind != "sharp":
+                    assert Tf[0] == 4095, Tf                           # the escape
+            rec = _decode_poisoned(c, cont, seg, img.shape[1], img.shape[2], mode)
+            assert np.array_equal(rec.cpu().numpy(), x.cpu().numpy())
+        mode = mode_of_name("xrans2")
+        rgbs = [make_image("smooth", 150, 131, 1), img, make_image("noise", 67, 93, 2)]
+        Hs, Ws = [r.shape[1] for r in rgbs], [r.shape[2] for r in rgbs]
+        cont, seg = c.encode_v(_dev(torch, _flat(rgbs)), Hs, Ws, mode)
+        c.check()
+        assert container_to_bytestream_list(cont[1].cpu().numpy(), seg[1].cpu().numpy()) == orc.encode_image_rans(img, W_o, 2, 2)
+        c.poison_workspace()
+        rec = c.decode_v(cont, seg, Hs, Ws, mode)
+        c.check()
+        for r, rgb in zip(_split(rec.cpu().numpy(), Hs, Ws), rgbs):
+            assert np.array_equal(r, rgb)
+    finally:
+        c.close()

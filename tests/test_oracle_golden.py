@@ -523,3 +523,69 @@ def test_full_size_samples_vs_reference(name, levels, oracle_weights):
                 keep = idx < len(row) - 1                                     # (the last entry wraps to 0 and is ignored by the coder)
                 d = np.abs(row[idx[keep]].astype(np.int64) - z[f"{tag}_c{clr}_val"][k][keep].astype(np.int64))
                 assert d.max() <= ent_tol, (tag, clr, k, d.max())
+
+
+def _cheap_case(kind):
+    """(state_dict, image) of a source far cheaper than 3.9 bits per last-stage symbol -- the class the trained model on natural images belongs to
+    (its last stage's Cg: 1.7 bits per symbol, reference log exp_debug.log.1:2682) and none of the other fixtures does.  The image is DRAWN FROM THE
+    MODEL (the reference-format decoder fed random bytes, as helpers.make_sampled_image) of a sharpened copy of the trained-like weights:
+      "sharp"   sigma biases x 0.15: ~3.6 bits per symbol -- tails of ~2,200 symbols (the 12-bit T field);
+      "single"  ONE live mixture component of sigma 0.6 grey levels: ~1.4 bits per symbol -- tails beyond 4,095 symbols (the escape)."""
+    import os
+    from conftest import GOLDEN
+    from helpers import make_image
+    from llicti_amd.weights import pack_state_dict
+    sd = dict(np.load(os.path.join(GOLDEN, "weights_trainedlike.npz")))
+    for k in list(sd):
+        if k.endswith("layers1toL.2.bias"):
+            b = sd[k].copy()
+            if kind == "sharp":
+                b[0:15] *= 0.15
+            else:
+                b[0:15] = 0.6 / 255.0
+                b[30:45] = np.tile(np.array([1.0, 1e-7, 1e-7, 1e-7, 1e-7], np.float32), 3)
+            sd[k] = b
+        if k.endswith("layers1toL.2.weight") and kind == "single":
+            w = sd[k].copy()
+            w[0:15] = 0.0
+            w[30:45] = 0.0
+            sd[k] = w
+    W = orc.Weights(pack_state_dict(sd))
+    H, Wd = 256, 384
+    bl = orc.encode_image(make_image("smooth", H, Wd, 11), W)
+    rng = np.random.default_rng(5)
+    bl = [list(bl[0])] + [[rng.integers(0, 256, len(x), dtype=np.uint8).tobytes() for x in row] for row in bl[1:]]
+    return sd, W, orc.decode_image(bl, W)
+
+
+@pytest.mark.parametrize("kind", ["sharp", "single"])
+def test_rans_xwide_long_tail(kind):
+    """Round 5: an xwide stream's 7,936-bit payload is filled by its tail symbols -- 2,047 of them (the old cap) do that only for a source of 3.9
+    bits per symbol or more; the reference's trained model spends 1.7 bits on the last stage's Cg symbols (exp_debug.log.1:2682), where every
+    256-lane stream wasted ~560 bytes (xrans10: +0.11 bpp).  Now the T field of an xwide stream has 12 bits and an escape up to 8,191 symbols:
+    cheap sources round-trip, their streams say T >= 2,048 ("single": the escape), and a stream costs a few bytes over the reference format, not
+    the ~500 of an unfilled payload ("sharp" at 768x512 before: +0.015 bpp at xrans10)."""
+    sd, W, img = _cheap_case(kind)
+    H, Wd = img.shape[1:]
+    ac_bl = orc.encode_image(img, W)
+    ac = sum(len(s) for row in ac_bl for s in row)
+    bits_last = 8.0 * len(ac_bl[5][8]) / (H * Wd / 4)
+    assert bits_last < 3.9, bits_last
+    for M in (1, 2, 4):
+        bl = orc.encode_image_rans(img, W, M, 2)
+        assert np.array_equal(orc.decode_image_rans(bl, W), img)
+        t16 = [s[0] | (s[1] << 8) for s in bl[1][:M]]
+        Tf = [(t & 0x7FF) | ((t >> 15) << 11) for t in t16]
+        assert all(t >= 2048 for t in Tf), Tf
+        if kind == "single":
+            assert all(t == 4095 for t in Tf), Tf                  # the escape: T itself behind the states
+            assert all(4095 <= (s[-2] | (s[-1] << 8)) <= 8191 for s in bl[1][:M])
+        got = sum(len(s) for row in bl for s in row)
+        assert got - ac <= 6 * M, (kind, M, got, ac, bits_last)            # a few bytes per stream (the escape: 2 of them), not the ~500 of an unfilled payload
+        if M <= 2:
+            assert 8.0 * (got - ac) / (H * Wd) <= 0.001, (kind, M, got, ac)
+    # the 64- and 128-lane kinds are as they were: T <= 2,047, bit 15 zero
+    for wide in (0, 1):
+        bl = orc.encode_image_rans(img, W, 2, wide)
+        assert np.array_equal(orc.decode_image_rans(bl, W), img)
+        assert all(((s[0] | (s[1] << 8)) >> 15) == 0 for s in bl[1][:2])
