@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""What the throughput containers cost -- bytes and time -- on a CHEAP source (round 5): 24 x 768x512 images DRAWN FROM THE MODEL (the reference-format
+decoder on the GPU fed random bytes behind the headers of a noise batch) of a sharpened copy of the trained-like weights:
+  "sharp"  sigma biases x 0.15 (~3.6 bits per last-stage symbol),  "single"  one live mixture component of sigma 0.6 grey levels (~1.5 bits; the
+  reference's trained model on natural images: 1.7, exp_debug.log.1:2682).
+Per container: bytes against the reference-format container of the same batch, encode / decode rate, and the decode's kernel groups (the tail is
+serial: two chains of up to 4,096 symbols each).  Usage: python tools/probe_cheap_content.py [out.json]"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from llicti_amd.codec import MODE_AC, HipCodec, mode_of_name  # noqa: E402
+
+B, H, W = 24, 512, 768
+dev = torch.device("cuda", 0)
+
+
+def cheap_sd(kind):
+    sd = dict(np.load(os.path.join(ROOT, "tests", "golden", "weights_trainedlike.npz")))
+    for k in list(sd):
+        if k.endswith("layers1toL.2.bias"):
+            b = sd[k].copy()
+            if kind == "sharp":
+                b[0:15] *= 0.15
+            else:
+                b[0:15] = 0.6 / 255.0
+                b[30:45] = np.tile(np.array([1.0, 1e-7, 1e-7, 1e-7, 1e-7], np.float32), 3)
+            sd[k] = b
+        if k.endswith("layers1toL.2.weight") and kind == "single":
+            w = sd[k].copy()
+            w[0:15] = 0.0
+            w[30:45] = 0.0
+            sd[k] = w
+    return sd
+
+
+out = {"workload": f"{B}x{W}x{H} images drawn from the model (sharpened trained-like weights), one MI355X"}
+for kind in ("sharp", "single"):
+    codec = HipCodec(dev)
+    codec.load_state_dict(cheap_sd(kind))
+    x0 = torch.from_numpy(np.stack([np.random.default_rng(i).integers(0, 256, (3, H, W), dtype=np.uint8) for i in range(B)])).to(dev)
+    cont, seg = codec.encode(x0, mode=MODE_AC)
+    codec.check()
+    ch, sh = cont.cpu().numpy().copy(), seg.cpu().numpy()
+    rng = np.random.default_rng(1)
+    for b in range(B):
+        h0 = int(sh[b, :4].sum())
+        n = int(sh[b].sum())
+        ch[b, h0:n] = rng.integers(0, 256, n - h0, dtype=np.uint8)
+    x = codec.decode(torch.from_numpy(ch).to(dev), seg, H, W, mode=MODE_AC)        # the decoder fed random bits emits symbols with the model's own probabilities
+    torch.cuda.synchronize()
+    res = {}
+    ac_bytes = None
+    for name in ("ac", "xrans10", "wrans10", "rans10", "xrans8"):
+        mode = mode_of_name(name)
+        c, s = codec.encode(x, mode=mode)
+        codec.check()
+        codec.poison_workspace()
+        r = codec.decode(c, s, H, W, mode=mode)
+        codec.check()
+        assert torch.equal(r, x), (kind, name)
+        reps = 1 if name == "ac" else 3
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(reps):
+            codec.encode(x, mode=mode, out=c, seg_len=s)
+        torch.cuda.synchronize(); te = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            codec.decode(c, s, H, W, mode=mode, out=r)
+        torch.cuda.synchronize(); td = (time.perf_counter() - t0) / reps
+        nbytes = int(s.sum().item())
+        if name == "ac":
+            ac_bytes = nbytes
+            sh2 = s.cpu().numpy()
+            res["bits_per_symbol_last_stage_cg"] = round(8.0 * float(sh2[:, 48].mean()) / (H * W / 4), 3)
+            res["bpp"] = round(8.0 * nbytes / (B * H * W), 4)
+        row = {"encdec_mpix_s": round(B * H * W / (te + td) / 1e6, 1), "enc_ms": round(te * 1e3, 3), "dec_ms": round(td * 1e3, 3),
+               "bpp_delta_vs_ac_container": round(8.0 * (nbytes - ac_bytes) / (B * H * W), 5)}
+        if name != "ac":
+            codec.set_profiling(True)
+            codec.decode(c, s, H, W, mode=mode, out=r)
+            torch.cuda.synchronize()
+            cat, _ = codec.last_timing_detail()
+            codec.set_profiling(False)
+            row["decode_kernel_ms"] = {k: round(v, 3) for k, v in cat.items() if v > 0}
+            t16 = c[0, int(s[0, :4].sum()):int(s[0, :4].sum()) + 2].cpu().numpy()
+            tf = int(t16[0]) | (int(t16[1]) << 8)
+            row["T_field_stream0"] = (tf & 0x7FF) | ((tf >> 15) << 11) if name.startswith("x") else tf & 0x7FF
+        res[name] = row
+    out[kind] = res
+    codec.close()
+print(json.dumps(out, indent=1))
+if len(sys.argv) > 1:
+    json.dump(out, open(sys.argv[1], "w"), indent=1)
