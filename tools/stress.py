@@ -51,6 +51,35 @@ run(24, 512, 768, MODE_RANS(10), "bench batch, narrow streams (rans10)")
 run(7, 1055, 2049, MODE_RANS(11, wide=2), "odd-size images, 11 xwide streams")
 run(5, 1055, 2049, MODE_RANS(7, wide=1), "odd-size images, 7 wide streams")
 run(2, 2160, 3840, MODE_AC, "two 4K images, AC container")
+def run_mixed(n, mode, name, big=False):
+    """round 5: a batch of MIXED sizes at the sizes of the reference's own test set (or, big: large odd sizes incl. the format's widest)"""
+    shapes = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "eval_shapes.json")))["shapes"]
+    sh = [(2160, 3840), (1055, 2049), (33, 8160), (8160, 33), (4097, 1031), (512, 768)] if big else shapes[100:100 + n]
+    Hs, Ws = [h for h, _ in sh], [w for _, w in sh]
+    g = torch.Generator(device="cuda").manual_seed(n)
+    flat = torch.randint(0, 256, (sum(3 * h * w for h, w in sh),), dtype=torch.uint8, device="cuda", generator=g)
+    codec.workspace_v(Hs, Ws, mode)
+    torch.cuda.synchronize(); t0 = time.time()
+    cont, seg = codec.encode_v(flat, Hs, Ws, mode)
+    codec.check(); torch.cuda.synchronize(); t1 = time.time()
+    codec.poison_workspace()
+    torch.cuda.synchronize(); t1b = time.time()
+    rec = codec.decode_v(cont, seg, Hs, Ws, mode)
+    codec.check(); torch.cuda.synchronize(); t2 = time.time()
+    ok = bool(torch.equal(rec, flat))
+    mp = sum(h * w for h, w in sh) / 1e6
+    print(f"{name}: {len(sh)} images, {mp:.1f} MPix ok={ok} enc {mp/(t1-t0):.1f} MPix/s dec {mp/(t2-t1b):.1f} MPix/s workspace {codec._ws.numel()/2**30:.2f} GiB", flush=True)
+    assert ok
+    results.append({"case": name, "images": len(sh), "megapixels": round(mp, 2), "lossless": ok, "enc_mpix_s": round(mp / (t1 - t0), 1), "dec_mpix_s": round(mp / (t2 - t1b), 1),
+                    "bpp": round(8.0 * float(seg.sum()) / (mp * 1e6), 4), "workspace_GiB": round(codec._ws.numel() / 2**30, 2)})
+    del flat, cont, seg, rec
+    codec._ws = None
+    torch.cuda.empty_cache()
+run_mixed(24, MODE_RANS(8, wide=2), "24 images at the reference's eval-set sizes, mixed (xrans8)")
+run_mixed(24, MODE_RANS(8, wide=2), "same, warm")
+run_mixed(256, MODE_RANS(1, wide=2), "256 images at the reference's eval-set sizes in ONE call (xrans1)")
+run_mixed(6, MODE_RANS(14, wide=2), "six large odd sizes incl. 33x8160 and 8160x33 in one call (xrans14)", big=True)
+run_mixed(6, MODE_RANS(32), "the same six in 32 narrow streams (rans32)", big=True)
 if len(sys.argv) > 1:
     json.dump({"tool": "tools/stress.py", "note": "single runs incl. first-call plan set-up unless marked warm; decode on a poisoned workspace", "runs": results},
               open(sys.argv[1], "w"), indent=1)
