@@ -99,7 +99,7 @@ def init_from_env(device=None, backend=None):
     if world <= 1:
         return 0, 1
     on_gpu = device is not None and torch.device(device).type == "cuda"
-    backend = backend or ("nccl" if on_gpu else "gloo")
+    backend = backend or os.environ.get("LLICTI_DIST_BACKEND") or ("nccl" if on_gpu else "gloo")      # (the variable: rehearsals of several ranks on ONE GPU need gloo)
     dist.init_process_group(backend, **({"device_id": torch.device(device)} if backend == "nccl" else {}))
     return world_info()
 
@@ -114,6 +114,8 @@ def broadcast_module_state(module, device=None):
     if not keys:
         return 0
     dev = device if device is not None else sd[keys[0]].device
+    if dist.get_backend() == "gloo":
+        dev = "cpu"
     flat = torch.cat([sd[k].detach().to(device=dev, dtype=torch.float32).reshape(-1) for k in keys])
     dist.broadcast(flat, src=0)
     pos = 0

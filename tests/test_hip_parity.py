@@ -1350,9 +1350,52 @@ def test_bench_two_ranks_aggregate(torch_mod):
     assert d["meets_north_star"] is False and d["config"]["sharding"] == "images/2gpu"
 
 
+def test_agent_two_ranks_on_gpu_equal_one_rank(torch_mod, tmp_path):
+    """SURVEY section 8(e) through the API on the GPU: `LLICTIAgent.eval_model` started by torch.distributed.run as two ranks (RCCL with one rank
+    per GPU when two are visible; on a one-GPU box gloo with both ranks on the one GPU -- a rehearsal of the plumbing, not scaling) against the same
+    script started alone: rank 0's log -- the per-image lines of all nine images in index order and the rate table -- and the gathered records
+    (sizes, bpsp, lossless check) are those of the one-rank run, one image at a time and batched."""
+    import json
+    import os
+    import re
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    torch = torch_mod
+    two = torch.cuda.device_count() >= 2
+    script = os.path.join(ROOT, "tools", "agent_ranks_demo.py")
+
+    def strip(t):
+        t = re.sub(r"Enc/Dec-Times:[0-9.]+/[0-9.]+", "Enc/Dec-Times:T/T", t)
+        return re.sub(r"\(\d\d:\d\d:\d\d\)", "(clock)", t)
+
+    for eb in (1, 4):
+        one = tmp_path / f"one{eb}.json"
+        p = subprocess.run([sys.executable, script, str(one), str(eb)], capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        env = dict(os.environ)
+        if not two:
+            env["LLICTI_DIST_BACKEND"] = "gloo"
+        out2 = tmp_path / f"two{eb}.json"
+        p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", str(port), script, str(out2), str(eb)], capture_output=True, text=True, timeout=900, env=env)
+        assert p.returncode == 0, p.stderr[-3000:]
+        a, b = json.load(open(one)), json.load(open(out2))
+        assert a["world"] == 1 and b["world"] == 2 and b["own"] == [0, 2, 4, 6, 8]
+        assert [r[:3] for r in b["records"]] == [r[:3] for r in a["records"]] and all(r[4] < 1e-3 for r in b["records"])     # (float32 uint8/255 on host vs device division)
+        assert np.allclose([r[3] for r in b["records"]], [r[3] for r in a["records"]])
+        pick = lambda t: [ln for ln in strip(t).splitlines() if ln.startswith("Agent|") and "bpsp=" in ln] + [strip(t)[strip(t).index("Rate Loss|"):]]      # noqa: E731
+        assert pick(b["log"]) == pick(a["log"]), eb
+
+
 def test_plan_cache_eviction(torch_mod, codecs):
-    """More than 16 distinct (B, H, W, mode) shapes through one context: the plan cache drops everything at the 17th
-    (documented: that call synchronises the device) and every shape still round-trips, including one seen before."""
+    """More distinct (B, H, W, mode) shapes through one context than it has seen before at once: every shape round-trips, including one seen
+    before (round 5: the cache holds 32 plans, least recently used out first, on pooled table blocks -- no device synchronisation;
+    test_many_sizes_no_device_sync_and_plan_reuse goes past 32)."""
     from llicti_amd.codec import MODE_RANS
     torch = torch_mod
     c = codecs("trainedlike")
