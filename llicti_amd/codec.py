@@ -295,7 +295,13 @@ class HipCodec:
 
     def workspace_v(self, Hs, Ws, mode):
         Hs, Ws = np.ascontiguousarray(Hs, dtype=np.int32), np.ascontiguousarray(Ws, dtype=np.int32)
-        return self._workspace_of(int(self.L.llicti_workspace_bytes_v(len(Hs), _ptr(Hs), _ptr(Ws), mode)))
+        key = (Hs.tobytes(), Ws.tobytes(), mode)
+        n = self._ws_need.get(key)
+        if n is None:
+            if len(self._ws_need) > 256:
+                self._ws_need.clear()
+            n = self._ws_need[key] = int(self.L.llicti_workspace_bytes_v(len(Hs), _ptr(Hs), _ptr(Ws), mode))
+        return self._workspace_of(n)
 
     def max_container_bytes(self, H, W):
         n = self._mc.get((H, W))
