@@ -1731,3 +1731,54 @@ def test_rans_xwide_long_tail_bitexact(torch_mod, kind):
             assert np.array_equal(r, rgb)
     finally:
         c.close()
+
+
+def test_mixed_size_batch_caller_placed_rgb(torch_mod, codecs):
+    """llicti_encode_images_v / llicti_decode_images_v with caller-chosen byte offsets of the images in the RGB buffer (`rgb_off`: gaps between the
+    images, unaligned starts, a different order in memory than in the call): the containers are those of the tightly packed call, the decoder
+    writes every image to its own place and nothing between them; equal sizes at caller-chosen offsets take the table path too."""
+    import ctypes as C
+    from llicti_amd import _lib
+    from llicti_amd.codec import NSEG, _ptr, _stream_ptr, mode_of_name
+    torch = torch_mod
+    c = codecs("trainedlike")
+    mode = mode_of_name("xrans3")
+    for shapes in ([(150, 131), (67, 93), (96, 160), (33, 65)], [(96, 160)] * 3):
+        rgbs = [make_image("smooth" if i % 2 else "noise", h, w, 40 + i) for i, (h, w) in enumerate(shapes)]
+        Hs, Ws = np.array([h for h, _ in shapes], np.int32), np.array([w for _, w in shapes], np.int32)
+        B = len(rgbs)
+        cont0, seg0 = c.encode_v(_dev(torch, _flat(rgbs)), Hs, Ws, mode)
+        c.check()
+        # placement: image b at a caller-chosen offset -- reversed order in memory, odd gaps (not multiples of 4: the lift falls back to byte accesses)
+        sizes = [r.size for r in rgbs]
+        offs, pos = [0] * B, 13
+        for b in reversed(range(B)):
+            offs[b] = pos
+            pos += sizes[b] + 7 + 3 * b
+        total = pos + 5
+        host = np.full(total, 0xEE, np.uint8)
+        for b, r in enumerate(rgbs):
+            host[offs[b]:offs[b] + sizes[b]] = r.reshape(-1)
+        buf = _dev(torch, host)
+        off_arr = np.array(offs, dtype=np.uint64)
+        ws = c.workspace_v(Hs, Ws, mode)
+        stride = cont0.shape[1]
+        cont = torch.empty((B, stride), dtype=torch.uint8, device="cuda:0")
+        seg = torch.zeros((B, NSEG), dtype=torch.int32, device="cuda:0")
+        _lib.check(c.L.llicti_encode_images_v(c.ctx, _ptr(buf), _ptr(off_arr), B, _ptr(Hs), _ptr(Ws), mode, _ptr(ws), ws.numel(), _ptr(cont), stride,
+                                              _ptr(seg), _stream_ptr(c.device)))
+        c.check()
+        assert torch.equal(seg, seg0)
+        for b in range(B):
+            n = int(seg0[b].sum())
+            assert torch.equal(cont[b, :n], cont0[b, :n]), b
+        out = torch.full((total,), 0x55, dtype=torch.uint8, device="cuda:0")
+        c.poison_workspace()
+        _lib.check(c.L.llicti_decode_images_v(c.ctx, _ptr(cont), stride, _ptr(seg), B, _ptr(Hs), _ptr(Ws), mode, _ptr(ws), ws.numel(), _ptr(out),
+                                              _ptr(off_arr), _stream_ptr(c.device)))
+        c.check()
+        got = out.cpu().numpy()
+        want = np.full(total, 0x55, np.uint8)
+        for b, r in enumerate(rgbs):
+            want[offs[b]:offs[b] + sizes[b]] = r.reshape(-1)
+        assert np.array_equal(got, want)                      # every image at its place, the gaps untouched
