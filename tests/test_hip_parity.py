@@ -1782,3 +1782,52 @@ def test_mixed_size_batch_caller_placed_rgb(torch_mod, codecs):
         for b, r in enumerate(rgbs):
             want[offs[b]:offs[b] + sizes[b]] = r.reshape(-1)
         assert np.array_equal(got, want)                      # every image at its place, the gaps untouched
+
+
+def test_mixed_size_entry_points_reject_misuse(torch_mod, codecs):
+    """llicti_encode_images_v / llicti_decode_images_v: a workspace or an output stride smaller than the batch needs is LLICTI_ENOSPACE (never a
+    write past the buffer), null size arrays / B = 0 / an unknown mode are LLICTI_EINVAL, a container whose header names another size than the
+    call flags that image only -- and the context keeps working afterwards."""
+    from llicti_amd import _lib
+    from llicti_amd.codec import NSEG, _ptr, _stream_ptr, mode_of_name
+    torch = torch_mod
+    c = codecs("trainedlike")
+    mode = mode_of_name("xrans2")
+    shapes = [(96, 160), (150, 131), (67, 93)]
+    rgbs = [make_image("smooth", h, w, 60 + i) for i, (h, w) in enumerate(shapes)]
+    Hs, Ws = np.array([h for h, _ in shapes], np.int32), np.array([w for _, w in shapes], np.int32)
+    flat = _dev(torch, _flat(rgbs))
+    ws = c.workspace_v(Hs, Ws, mode)
+    need = int(c.L.llicti_workspace_bytes_v(3, _ptr(Hs), _ptr(Ws), mode))
+    stride = max(c.max_container_bytes(h, w) for h, w in shapes)
+    cont = torch.empty((3, stride), dtype=torch.uint8, device="cuda:0")
+    seg = torch.zeros((3, NSEG), dtype=torch.int32, device="cuda:0")
+    st = _stream_ptr(c.device)
+
+    def enc(B=3, hs=Hs, wsz=Ws, m=mode, wbytes=None, ostride=stride):
+        return c.L.llicti_encode_images_v(c.ctx, _ptr(flat), None, B, _ptr(hs) if hs is not None else None, _ptr(wsz) if wsz is not None else None, m,
+                                          _ptr(ws), need if wbytes is None else wbytes, _ptr(cont), ostride, _ptr(seg), st)
+    assert enc(wbytes=need - 256) == _lib.ENOSPACE
+    assert enc(ostride=c.max_container_bytes(67, 93)) == _lib.ENOSPACE          # fits the smallest image only
+    assert enc(B=0) == _lib.EINVAL and enc(hs=None) == _lib.EINVAL and enc(m=0x700 | 3) == _lib.EINVAL
+    bad = Hs.copy()
+    bad[1] = 9000
+    assert enc(hs=bad) == _lib.EINVAL
+    assert enc() == 0
+    c.check()
+    # decode with image 1 declared as another size: that image is flagged, the others decode
+    H2, W2 = Hs.copy(), Ws.copy()
+    H2[1], W2[1] = 131, 150
+    offs, total = c.flat_offsets(H2, W2)
+    out = torch.empty((total,), dtype=torch.uint8, device="cuda:0")
+    wsb = c.workspace_v(H2, W2, mode)
+    _lib.check(c.L.llicti_decode_images_v(c.ctx, _ptr(cont), stride, _ptr(seg), 3, _ptr(H2), _ptr(W2), mode, _ptr(wsb), wsb.numel(), _ptr(out), None, st))
+    with pytest.raises(_lib.LlictiError):
+        c.check()
+    stat = c.image_status(3)
+    assert stat[1] == _lib.EFORMAT and stat[0] == 0 and stat[2] == 0
+    got = _split(out.cpu().numpy(), H2, W2)
+    assert np.array_equal(got[0], rgbs[0]) and np.array_equal(got[2], rgbs[2])
+    rec = c.decode_v(cont, seg, Hs, Ws, mode)
+    c.check()
+    assert np.array_equal(rec.cpu().numpy(), _flat(rgbs))
