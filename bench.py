@@ -276,7 +276,6 @@ class Legs:
 
     def free(self):
         self.codec._ws = None
-        self.codec._ws_key = None
         self.torch.cuda.empty_cache()
 
 

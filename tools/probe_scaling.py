@@ -45,7 +45,7 @@ def run(B, mode, reps):
          "encdec_mpix_s": round(mp / (te + td), 1), "bytes_per_image": float(seg.sum().item()) / B,
          "workspace_GiB": round(codec._ws.numel() / 2**30, 2)}
     del rgb, cont, seg, rec
-    codec._ws = None; codec._ws_key = None
+    codec._ws = None
     torch.cuda.empty_cache()
     return r
 

@@ -32,7 +32,7 @@ def run(B, H, W, mode, name):
     results.append({"case": name, "B": B, "W": W, "H": H, "lossless": ok, "enc_mpix_s": round(mp / (t1 - t0), 1), "dec_mpix_s": round(mp / (t2 - t1b), 1),
                     "bpp": round(8.0 * float(seg.sum()) / (B * H * W), 4), "workspace_GiB": round(codec._ws.numel() / 2**30, 2)})
     del rgb, cont, seg, rec
-    codec._ws = None; codec._ws_key = None
+    codec._ws = None
     torch.cuda.empty_cache()
 run(256, 512, 768, MODE_RANS(8, wide=2), "configs[4] batch on one GPU (xrans8: the per-GPU container of configs[4])")
 run(256, 512, 768, MODE_RANS(8, wide=2), "same, warm")
