@@ -74,7 +74,6 @@ static void check_plan(const Plan &p, int B, const int *Hs, const int *Ws, int M
         REQUIRE(p.off_slots + (size_t)(p.rslot_off.back() + p.rslot_cap) <= p.off_rinfo);
         REQUIRE(p.d_rslot_off + p.rslot_off.size() * sizeof(long) <= p.d_total);
     } else {
-        REQUIRE(p.uniform || true);
         REQUIRE(p.slot_off.size() == (size_t)45 * B && p.off_slots + (size_t)(p.slot_off.back() + p.slot_cap.back()) <= p.off_rinfo);
     }
     for (int b = 0; b < B; ++b) REQUIRE(p.max_container >= (size_t)p.img[b].hdr_bytes);
