@@ -563,7 +563,7 @@ def api_path_leg(torch, dev, B, H, W, n_images=240):
     return out
 
 
-def api_path_mixed_leg(torch, dev, B, n_images=500):
+def api_path_mixed_leg(torch, dev, B, n_images=500, balance=True):
     """the drop-in API on the reference's OWN eval workload -- 500 images at the sizes its test set has, in the order its loader
     yields them (tests/golden/eval_shapes.json: parsed out of the reference's eval log, 119 distinct sizes, interleaved; the images themselves
     are not in the reference tree, so the content is the bench's uniform noise) -- through LLICTIAgent.eval_model with eval_batch = B and
@@ -580,7 +580,7 @@ def api_path_mixed_leg(torch, dev, B, n_images=500):
     out = {"workload": f"{len(shapes)} uniform-noise RGB images at the sizes and in the order of the reference's own test set ({len(set(map(tuple, shapes)))} distinct sizes, "
                        f"{pix / 1e6:.1f} MPix) through LLICTIAgent.eval_model, eval_batch = {B}, container auto, wall clock incl. transfers, container <-> bytestream_list, "
                        "rates, lossless check, log lines"}
-    agent = LLICTIAgent(default_config(test_data=imgs[:3 * B], eval_batch=B, container="auto"))
+    agent = LLICTIAgent(default_config(test_data=imgs[:3 * B], eval_batch=B, container="auto", balance_streams=balance))
     agent.run()                                                   # warm-up: workspaces, pinned staging buffers, table blocks
     agent.config["test_data"] = imgs
     torch.cuda.synchronize()
@@ -590,6 +590,8 @@ def api_path_mixed_leg(torch, dev, B, n_images=500):
     dt = time.perf_counter() - t0
     assert len(res) == len(shapes) and all(r["max_abs_err"] == 0.0 for r in res)
     assert [(r["H"], r["W"]) for r in res] == [tuple(s) for s in shapes]              # in order
+    out["stream_counts"] = ("per image, in proportion to its pixels (llicti_amd.codec.balanced_modes -> llicti_encode_images_vm)" if balance else
+                            "one count for the batch (its smallest image's budget)")
     out["mixed_batches"] = {"mpix_s": round(pix / dt / 1e6, 2), "wall_s": round(dt, 4), "ms_per_image": round(dt / len(shapes) * 1e3, 3),
                             "bpsp": round(float(np.mean([r["bpsp"] for r in res])), 5),
                             "gpu_enc_ms_per_image": round(float(np.mean([r["enc_s"] for r in res])) * 1e3, 3),

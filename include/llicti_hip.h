@@ -183,6 +183,7 @@ int llicti_ac_decode_u16cdf(llicti_ctx *ctx, const uint16_t *d_cdf, int Lp, int 
 /* Bytes of device workspace the calls below need for B images of H x W in `mode` (_v: of Hs[b] x Ws[b]). */
 size_t llicti_workspace_bytes(int B, int H, int W, int mode);
 size_t llicti_workspace_bytes_v(int B, const int *Hs, const int *Ws, int mode);
+size_t llicti_workspace_bytes_vm(int B, const int *Hs, const int *Ws, const int *modes);      /* one mode per image, see llicti_encode_images_vm */
 /* Upper bound of the container size of ONE image: the minimum out_stride / in_stride. */
 size_t llicti_max_container_bytes(int H, int W);
 
@@ -205,6 +206,17 @@ int llicti_decode_images(llicti_ctx *ctx, const uint8_t *d_in, size_t in_stride,
 int llicti_encode_images_v(llicti_ctx *ctx, const uint8_t *d_rgb, const size_t *rgb_off, int B, const int *Hs, const int *Ws, int mode,
                            void *d_workspace, size_t workspace_bytes,
                            uint8_t *d_out, size_t out_stride, int32_t *d_seg_len, void *stream);
+/* ... with a container mode PER IMAGE (host array of B modes): rANS containers of one lane kind whose STREAM COUNTS may differ -- every image's header
+ * carries its own count.  What it is for: a stage of the decoder takes as long as its longest stream, and in a batch of mixed sizes that is a
+ * stream of the largest image; with counts in proportion to the images' sizes (llicti_amd.codec.balanced_modes) all streams are equally long,
+ * and every image stays inside its own byte budget (a 768x768 image affords 14 streams, a 352x768 one 8).  Image b's bytes are those of
+ * llicti_encode_images(B = 1) on it in modes[b]. */
+int llicti_encode_images_vm(llicti_ctx *ctx, const uint8_t *d_rgb, const size_t *rgb_off, int B, const int *Hs, const int *Ws, const int *modes,
+                            void *d_workspace, size_t workspace_bytes,
+                            uint8_t *d_out, size_t out_stride, int32_t *d_seg_len, void *stream);
+int llicti_decode_images_vm(llicti_ctx *ctx, const uint8_t *d_in, size_t in_stride, const int32_t *d_seg_len,
+                            int B, const int *Hs, const int *Ws, const int *modes, void *d_workspace, size_t workspace_bytes,
+                            uint8_t *d_rgb, const size_t *rgb_off, void *stream);
 /* Hs[b] x Ws[b] must be the size container b's header describes (llicti_header_dims); a mismatch flags that image (llicti_image_status). */
 int llicti_decode_images_v(llicti_ctx *ctx, const uint8_t *d_in, size_t in_stride, const int32_t *d_seg_len,
                            int B, const int *Hs, const int *Ws, int mode, void *d_workspace, size_t workspace_bytes,

@@ -59,6 +59,9 @@ _SIGS = {
     "llicti_ac_decode_u16cdf": (_i, [_vp, _vp, _i, _i, _vp, _l, _vp, _i, _l, _vp, _vp]),
     "llicti_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "llicti_workspace_bytes_v": (_sz, [_i, _vp, _vp, _i]),
+    "llicti_workspace_bytes_vm": (_sz, [_i, _vp, _vp, _vp]),
+    "llicti_encode_images_vm": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp]),
+    "llicti_decode_images_vm": (_i, [_vp, _vp, _sz, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     "llicti_encode_images_v": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp, _sz, _vp, _vp]),
     "llicti_decode_images_v": (_i, [_vp, _vp, _sz, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp, _vp, _vp]),
     "llicti_max_container_bytes": (_sz, [_i, _i]),

@@ -34,14 +34,14 @@ def streams_in_budget(H, W):
     stage's symbols can fill (its tail): with fewer than ~2,048 of them per stream what is left is pure waste -- a 96x128 image in ten xwide
     streams is 25 % larger than in the reference format.  0: no xwide stream fits (use a 64-lane stream or the reference format)."""
     nc_last = (H // 2) * (W // 2)                 # coded positions of level 0, band x10
-    return max(0, min(MAX_STREAMS_IN_BUDGET, nc_last // XWIDE_MIN_TAIL, int((H * W / 8000.0 + 25.0) / 7.0)))
+    return max(0, min(14, nc_last // XWIDE_MIN_TAIL, int((H * W / 8000.0 + 25.0) / 7.0)))      # (14: the most xwide streams a container tag can say, one per segment)
 
 
 def auto_streams(B, n_cu=256, sizes=None):
     """Streams per image of the throughput container for a batch of B images: as many as keep ONE decoder workgroup per stream on its
     own compute unit (B * M <= CUs: a second workgroup on a CU slows both by 1.4x, so more streams than that buy nothing) and stay
     inside the north star's 0.001 bpp -- at most 10 per 768x512 image, fewer for smaller ones (streams_in_budget; `sizes`: the (H, W) of the
-    batch's images, the smallest one decides).  24 images of 768x512 on a 256-CU MI355X: 10; 32 images (configs[4] per GPU): 8."""
+    batch's images, the smallest one decides; balanced_modes() gives every image of a mixed batch its own count instead).  24 images of 768x512 on a 256-CU MI355X: 10; 32 images (configs[4] per GPU): 8."""
     m = max(1, min(MAX_STREAMS_IN_BUDGET, n_cu // max(1, B)))
     if sizes:
         m = min(m, min(streams_in_budget(h, w) for h, w in sizes))
@@ -62,6 +62,26 @@ def auto_container(B, n_cu=256, sizes=None):
     if nc_last >= NARROW_MIN_TAIL or len(set(sizes)) > 1:
         return "rans1"
     return "ac"
+
+
+def balanced_modes(sizes, n_cu=256, wide=2):
+    """Container modes for the images of ONE call of mixed sizes (llicti_encode_images_vm): xwide streams, their number per image in proportion to
+    the image's pixels -- so that all streams of the call are equally long (a decoder stage takes as long as its longest stream) -- with at most
+    `n_cu` streams in all (one decoder workgroup per stream and compute unit) and every image inside its own byte budget (streams_in_budget).  An
+    image too small for an xwide stream makes the whole call fall back to one 64-lane stream per image."""
+    budgets = [streams_in_budget(h, w) for h, w in sizes]
+    if min(budgets) < 1:
+        return [MODE_RANS(1)] * len(sizes)
+    pix = [h * w for h, w in sizes]
+    total = min(n_cu, sum(budgets))
+    Ms = [max(1, min(b, int(total * p / sum(pix)))) for b, p in zip(budgets, pix)]
+    while sum(Ms) < total:                          # what the rounding left over: to the image whose streams are longest
+        cand = [i for i in range(len(Ms)) if Ms[i] < budgets[i]]
+        if not cand:
+            break
+        i = max(cand, key=lambda k: pix[k] / Ms[k])
+        Ms[i] += 1
+    return [MODE_RANS(m, wide=wide) for m in Ms]
 
 
 def MODE_RANS(M=8, wide=False):
@@ -293,14 +313,26 @@ class HipCodec:
             n = self._ws_need[key] = int(self.L.llicti_workspace_bytes(B, H, W, mode))
         return self._workspace_of(n)
 
+    @staticmethod
+    def _modes_arg(mode, B):
+        """mode: one int, or one per image -> (int or None, int32 array or None)"""
+        if isinstance(mode, (int, np.integer)):
+            return int(mode), None
+        m = np.ascontiguousarray(mode, dtype=np.int32)
+        assert m.shape == (B,)
+        return (int(m[0]), None) if (m == m[0]).all() else (None, m)
+
     def workspace_v(self, Hs, Ws, mode):
         Hs, Ws = np.ascontiguousarray(Hs, dtype=np.int32), np.ascontiguousarray(Ws, dtype=np.int32)
-        key = (Hs.tobytes(), Ws.tobytes(), mode)
+        one, per = self._modes_arg(mode, len(Hs))
+        key = (Hs.tobytes(), Ws.tobytes(), one if per is None else per.tobytes())
         n = self._ws_need.get(key)
         if n is None:
             if len(self._ws_need) > 256:
                 self._ws_need.clear()
-            n = self._ws_need[key] = int(self.L.llicti_workspace_bytes_v(len(Hs), _ptr(Hs), _ptr(Ws), mode))
+            n = int(self.L.llicti_workspace_bytes_v(len(Hs), _ptr(Hs), _ptr(Ws), one)) if per is None else \
+                int(self.L.llicti_workspace_bytes_vm(len(Hs), _ptr(Hs), _ptr(Ws), _ptr(per)))
+            self._ws_need[key] = n
         return self._workspace_of(n)
 
     def max_container_bytes(self, H, W):
@@ -361,8 +393,13 @@ class HipCodec:
         if seg_len is None:
             seg_len = torch.zeros((B, NSEG), dtype=torch.int32, device=self.device)
         assert out.shape[1] >= stride
-        _lib.check(self.L.llicti_encode_images_v(self.ctx, _ptr(rgb_flat), None, B, _ptr(Hs), _ptr(Ws), mode, _ptr(ws), ws.numel(),
-                                                 _ptr(out), out.shape[1], _ptr(seg_len), _stream_ptr(self.device)))
+        one, per = self._modes_arg(mode, B)         # one mode for the call, or one per image (stream counts may differ: llicti_encode_images_vm)
+        if per is None:
+            _lib.check(self.L.llicti_encode_images_v(self.ctx, _ptr(rgb_flat), None, B, _ptr(Hs), _ptr(Ws), one, _ptr(ws), ws.numel(),
+                                                     _ptr(out), out.shape[1], _ptr(seg_len), _stream_ptr(self.device)))
+        else:
+            _lib.check(self.L.llicti_encode_images_vm(self.ctx, _ptr(rgb_flat), None, B, _ptr(Hs), _ptr(Ws), _ptr(per), _ptr(ws), ws.numel(),
+                                                      _ptr(out), out.shape[1], _ptr(seg_len), _stream_ptr(self.device)))
         return out, seg_len
 
     def decode_v(self, containers, seg_len, Hs, Ws, mode, out=None):
@@ -375,8 +412,13 @@ class HipCodec:
         if out is None:
             out = torch.empty((total,), dtype=torch.uint8, device=self.device)
         assert out.numel() >= total
-        _lib.check(self.L.llicti_decode_images_v(self.ctx, _ptr(containers), containers.shape[1], _ptr(seg_len), B, _ptr(Hs), _ptr(Ws), mode,
-                                                 _ptr(ws), ws.numel(), _ptr(out), None, _stream_ptr(self.device)))
+        one, per = self._modes_arg(mode, B)
+        if per is None:
+            _lib.check(self.L.llicti_decode_images_v(self.ctx, _ptr(containers), containers.shape[1], _ptr(seg_len), B, _ptr(Hs), _ptr(Ws), one,
+                                                     _ptr(ws), ws.numel(), _ptr(out), None, _stream_ptr(self.device)))
+        else:
+            _lib.check(self.L.llicti_decode_images_vm(self.ctx, _ptr(containers), containers.shape[1], _ptr(seg_len), B, _ptr(Hs), _ptr(Ws), _ptr(per),
+                                                      _ptr(ws), ws.numel(), _ptr(out), None, _stream_ptr(self.device)))
         return out
 
     def check(self):

@@ -5,11 +5,12 @@
 // ------------------------------------------------------------------------------------------------ container kernels
 // encode: header segments straight into the container; seg_len[b][0..3]
 __global__ void header_write_kernel(const uint8_t *__restrict__ rgb, const int32_t *__restrict__ minmax, const ImgGeo *__restrict__ iv,
-                                    int byte0, uint8_t *__restrict__ out, long out_stride, int32_t *__restrict__ seg_len)
+                                    uint8_t *__restrict__ out, long out_stride, int32_t *__restrict__ seg_len)
 {
     const int b = blockIdx.x;
     uint8_t *o = out + (long)b * out_stride;
     const ImgGeo ig = iv[b];
+    const int byte0 = ig.byte0;
     const int W = ig.W, h4 = ig.h4, w4 = ig.w4, padint = ig.padint;
     const long plane = ig.plane;
     if (threadIdx.x == 0) {
@@ -47,13 +48,14 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ s
 
 // decode: parse + validate header, min/max -> minmax[b][4], DC band -> planes at stride 32
 __global__ void header_read_kernel(const uint8_t *__restrict__ in, long in_stride, const int32_t *__restrict__ seg_len,
-                                   const ImgGeo *__restrict__ iv, int byte0, int16_t *__restrict__ planes,
+                                   const ImgGeo *__restrict__ iv, int16_t *__restrict__ planes,
                                    float *__restrict__ fplanes, int32_t *__restrict__ minmax, int32_t *status)
 {
     const int b = blockIdx.x;
     const uint8_t *p = in + (long)b * in_stride;
     const int32_t *sl = seg_len + (long)b * LLICTI_NSEG;
     const ImgGeo ig = iv[b];
+    const int byte0 = ig.byte0;
     const int W = ig.W, h4 = ig.h4, w4 = ig.w4, padint = ig.padint;
     const long plane = ig.plane;
     __shared__ int ok;

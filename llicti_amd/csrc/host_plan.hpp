@@ -14,7 +14,9 @@
 struct TileRun { size_t off = 0; int n_tiles = 0, TH = 0, gx = 0; };      // band-CNN launch of one (level, band) of a mixed-size plan: its tile list
 struct Plan {
     int B = 0, ME = 0;
-    int M = 0;                          // rANS streams per image (0: AC container only)
+    int M = 0;                          // rANS streams per image (0: AC container only); images of a call may differ: the largest count
+    int nstreams = 0;                   // ... and the streams of all images together (sref)
+    std::vector<StreamRef> sref;        // [nstreams]: stream -> (image, stream of the image, its count, its first stream)
     int Q = 1;                          // 64-lane sub-chunks per stream step (2: wide streams of 128 lanes; 4: xwide streams of 256 lanes)
     bool uniform = true;                // every image has the size of image 0: the band CNN runs its division form, the AC container is available
     bool vec_ok = true;                 // every image's plane size and placement allow the lift's 4-pixel accesses
@@ -41,7 +43,7 @@ struct Plan {
     std::vector<TileRef> tiles;            // mixed-size plans: the tile lists of the 15 band-CNN launches, back to back
     TileRun run[LLICTI_NLEVELS * 3];
     // device copies (one block, see PlanBlock)
-    size_t d_img = 0, d_geo = 0, d_sg = 0, d_desc = 0, d_slot_off = 0, d_slot_cap = 0, d_rslot_off = 0, d_tiles = 0, d_total = 0;
+    size_t d_img = 0, d_geo = 0, d_sg = 0, d_desc = 0, d_slot_off = 0, d_slot_cap = 0, d_rslot_off = 0, d_tiles = 0, d_sref = 0, d_total = 0;
 };
 
 // AC decode has two table forms.  Few images in flight (latency bound: every stream is one serial wave and the GPU is
@@ -129,9 +131,16 @@ static TileForm choose_tile_form(int n_cu, int tile_rows, int band, COUNT &&coun
 // ME: streams per image, | 0x100 for wide (128-lane) streams, | 0x200 for xwide (256-lane) streams -- what mode_streams() returns.
 // Hs, Ws: B sizes; rgb_off: B byte offsets of the images in the caller's RGB buffer, or nullptr = tightly packed in call order.
 // n_cu, tile_rows: the band CNN's tile forms of a mixed-size plan are chosen (and its tile lists written) here.
-static void build_plan(Plan &p, int B, const int *Hs, const int *Ws, const size_t *rgb_off, int ME, int n_cu = 256, int tile_rows = 0, bool force_ragged = false)
+static int rans_byte0(int M, int Q);
+
+// Ms: B stream counts (rANS containers: the images of a call may have different ones -- every header carries its own -- so that larger images
+// get more streams and a stage launch does not wait for its largest image), or nullptr = ME's count for every image.
+static void build_plan(Plan &p, int B, const int *Hs, const int *Ws, const size_t *rgb_off, int ME, int n_cu = 256, int tile_rows = 0, bool force_ragged = false,
+                       const int *Ms = nullptr)
 {
-    const int M = ME & 0xFF, Q = 1 << (ME >> 8);
+    const int Q = 1 << (ME >> 8);
+    int M = ME & 0xFF;
+    if (Ms && M > 0) { M = 0; for (int b = 0; b < B; ++b) M = std::max(M, Ms[b]); }
     p.B = B; p.ME = ME; p.M = M; p.Q = Q;
     p.uniform = !force_ragged;
     for (int b = 1; b < B; ++b) if (Hs[b] != Hs[0] || Ws[b] != Ws[0]) p.uniform = false;
@@ -141,8 +150,9 @@ static void build_plan(Plan &p, int B, const int *Hs, const int *Ws, const size_
     }
     p.vec_ok = true;
     p.key.clear();
-    p.key.reserve(3 + 3 * (size_t)B);
+    p.key.reserve(3 + 4 * (size_t)B);
     p.key.push_back(ME); p.key.push_back(B); p.key.push_back(tile_rows * 2 + (force_ragged ? 1 : 0));
+    auto m_of = [&](int b) -> int { return (Ms && (ME & 0xFF) > 0) ? Ms[b] : (ME & 0xFF); };
     // images: sizes, header constants, placement (mixed sizes: planes / fplanes blocks start at multiples of 64 elements; equal sizes: tightly
     // packed, [B][3][H][W] -- what the division form of the band CNN and the AC container's kernels index)
     p.img.assign(B, ImgGeo{});
@@ -161,7 +171,9 @@ static void build_plan(Plan &p, int B, const int *Hs, const int *Ws, const size_
         if ((ig.plane & 3) || (ig.rgb_off & 3)) p.vec_ok = false;
         p.rgb_bytes = std::max(p.rgb_bytes, (size_t)(ig.rgb_off + 3 * ig.plane));
         p.max_plane = std::max(p.max_plane, ig.plane);
-        p.key.push_back(ig.H); p.key.push_back(ig.W); p.key.push_back(ig.rgb_off);
+        ig.M = m_of(b);
+        ig.byte0 = ig.M ? rans_byte0(ig.M, Q) : LLICTI_NLEVELS;
+        p.key.push_back(ig.H); p.key.push_back(ig.W); p.key.push_back(ig.rgb_off); p.key.push_back(ig.M);
     }
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
@@ -228,31 +240,37 @@ static void build_plan(Plan &p, int B, const int *Hs, const int *Ws, const size_
     p.max_container = 0;
     for (int b = 0; b < B; ++b) p.max_container = std::max(p.max_container, align_up(container[b] + 64 * 45, 16));
     p.off_pairs = take((size_t)pair_pos * sizeof(uint32_t));
+    p.sref.clear();
+    p.nstreams = 0;
     if (M > 0) {
         // worst case of one stream: every symbol emits 16 bits; chunks are dealt round-robin, so a
-        // stream gets at most ceil(nchunks / M) chunks of every stage (sized for the batch's largest image)
+        // stream gets at most ceil(nchunks / M) chunks of every stage (one capacity for all: the largest any image's streams need)
         const int L = 64 * Q;
         const int pay_bytes = Q * RansGeo<1>::kPayBytes;
         p.rslot_cap = 0;
         for (int b = 0; b < B; ++b) {
+            const int Mb = p.img[b].M;
             long syms = 0, all_syms = 0;
             for (int st = 0; st < LLICTI_NSTREAMS; ++st) {
                 const long n = p.desc[(size_t)st * B + b].n;
                 const long nchunks = (n + L - 1) / L;
-                syms += (nchunks + M - 1) / M * L;
+                syms += (nchunks + Mb - 1) / Mb * L;
                 all_syms += (n + 63) / 64 * 64;
             }
             p.rslot_cap = std::max(p.rslot_cap, (int)align_up((size_t)(2 * syms + 4 + 8 + pay_bytes + 16 + 64), 64));   // + T, the 31-bit states, slack, zero pad
             // container bound: the streams together hold every symbol once (<= 16 bits each, whole chunks), plus per stream T | pad, the
             // 64 final states, a table entry (M > 32) and the byte the bit region rounds up to
-            p.max_container = std::max(p.max_container, align_up((size_t)p.img[b].hdr_bytes + (size_t)(2 * all_syms) + (size_t)M * (2 + pay_bytes + 4 + 4) + 64, 16));
+            p.max_container = std::max(p.max_container, align_up((size_t)p.img[b].hdr_bytes + (size_t)(2 * all_syms) + (size_t)Mb * (2 + pay_bytes + 4 + 4) + 64, 16));
+            p.img[b].sbase = p.nstreams;
+            for (int m = 0; m < Mb; ++m) p.sref.push_back(StreamRef{ b, m, Mb, p.nstreams });
+            p.nstreams += Mb;
         }
-        p.rslot_off.assign((size_t)B * M, 0);
-        for (long i = 0; i < (long)B * M; ++i) p.rslot_off[i] = (long)i * p.rslot_cap;
-        slot_pos = (long)B * M * p.rslot_cap;
+        p.rslot_off.assign((size_t)p.nstreams, 0);
+        for (long i = 0; i < (long)p.nstreams; ++i) p.rslot_off[i] = (long)i * p.rslot_cap;
+        slot_pos = (long)p.nstreams * p.rslot_cap;
     }
     p.off_slots = take((size_t)slot_pos);
-    const size_t ns = (size_t)B * std::max(M, 32);
+    const size_t ns = std::max((size_t)p.nstreams, (size_t)B * 32);
     p.off_rinfo = take(ns * 2 * sizeof(int32_t));
     p.off_rstate = take(ns * 64 * Q * sizeof(uint32_t));
     p.off_rpos = take(ns * sizeof(uint32_t));
@@ -308,6 +326,7 @@ static void build_plan(Plan &p, int B, const int *Hs, const int *Ws, const size_
     p.d_slot_cap = dtake(p.slot_cap.size() * sizeof(int32_t));
     p.d_rslot_off = dtake(p.rslot_off.size() * sizeof(long));
     p.d_tiles = dtake(p.tiles.size() * sizeof(TileRef));
+    p.d_sref = dtake(p.sref.size() * sizeof(StreamRef));
     p.d_total = d;
 }
 
@@ -351,15 +370,25 @@ static int check_dims_v(int B, const int *Hs, const int *Ws)
         if (Hs[b] < 32 || Ws[b] < 32 || Hs[b] > 8160 || Ws[b] > 8160) return fail(LLICTI_EINVAL, "bad shape of image %d: H=%d W=%d (need 32<=H,W<=8160)", b, Hs[b], Ws[b]);
     return 0;
 }
-static size_t plan_workspace_bytes_v(int B, const int *Hs, const int *Ws, int mode)
+// modes: one mode (n_modes = 1) or one per image (rANS containers of one lane kind, stream counts may differ)
+static size_t plan_workspace_bytes_vm(int B, const int *Hs, const int *Ws, const int *modes, int n_modes)
 {
-    const int ME = mode_streams(mode);
-    if (check_dims_v(B, Hs, Ws) || ME < 0) return 0;
+    if (check_dims_v(B, Hs, Ws) || !modes || (n_modes != 1 && n_modes != B)) return 0;
+    const int ME = mode_streams(modes[0]);
+    if (ME < 0) return 0;
+    std::vector<int> Ms;
+    if (n_modes == B && B > 1)
+        for (int b = 0; b < B; ++b) {
+            const int MEb = mode_streams(modes[b]);
+            if (MEb < 0 || (MEb >> 8) != (ME >> 8) || ((MEb & 0xFF) == 0) != ((ME & 0xFF) == 0)) return 0;
+            Ms.push_back(MEb & 0xFF);
+        }
     Plan p, q;
-    build_plan(p, B, Hs, Ws, nullptr, ME);
-    build_plan(q, B, Hs, Ws, nullptr, ME, 256, 0, true);      // (llicti_set_tuning("force_ragged"): image blocks at 64-element boundaries)
+    build_plan(p, B, Hs, Ws, nullptr, ME, 256, 0, false, Ms.empty() ? nullptr : Ms.data());
+    build_plan(q, B, Hs, Ws, nullptr, ME, 256, 0, true, Ms.empty() ? nullptr : Ms.data());      // (llicti_set_tuning("force_ragged"): image blocks at 64-element boundaries)
     return std::max(p.total, q.total);
 }
+static size_t plan_workspace_bytes_v(int B, const int *Hs, const int *Ws, int mode) { return plan_workspace_bytes_vm(B, Hs, Ws, &mode, 1); }
 static size_t plan_workspace_bytes(int B, int H, int W, int mode)
 {
     if (check_dims(B, H, W)) return 0;

@@ -47,6 +47,8 @@ struct Geom {
 // One image of a whole-batch call (device table, llicti_hip.hip: Plan).
 struct ImgGeo {
     int H, W, h4, w4, padint, hdr_bytes;      // hdr_bytes = 17 + 3 h4 w4 (LLICTI_nets.py:347-350)
+    int M, sbase;                             // rANS containers: the image's stream count (its header says so: images of one call may differ) and its first stream
+    int byte0, pad_;                          // header byte 0 of its container (AC: the number of scales; rANS: the v3 tag with M)
     long plane;                               // H * W
     long pix_off;                             // first element of the image's [3][H][W] block in planes / fplanes (workspace)
     long rgb_off;                             // first byte of its [3][H][W] block in the caller's RGB buffer
@@ -147,6 +149,7 @@ struct StreamDesc {     // one arithmetic-coded stream of the whole-batch encode
 
 
 struct TileRef { int img, yx; };        // one tile of a mixed-size band-CNN launch: image, tile row << 16 | tile column
+struct StreamRef { int b, m, M, sbase; };   // one rANS stream of a call: image, stream of the image, the image's stream count, the image's first stream
 
 // ------------------------------------------------------------------------------------------------ container format constants
 constexpr int kLiftMaxParts = 65536;        // entries of the partials scratch: B * gridDim.x <= this

@@ -170,6 +170,7 @@ struct DeviceGuard {
 };
 
 extern "C" size_t llicti_workspace_bytes_v(int B, const int *Hs, const int *Ws, int mode) { return plan_workspace_bytes_v(B, Hs, Ws, mode); }
+extern "C" size_t llicti_workspace_bytes_vm(int B, const int *Hs, const int *Ws, const int *modes) { return plan_workspace_bytes_vm(B, Hs, Ws, modes, B); }
 extern "C" size_t llicti_workspace_bytes(int B, int H, int W, int mode) { return plan_workspace_bytes(B, H, W, mode); }
 extern "C" size_t llicti_max_container_bytes(int H, int W) { return plan_max_container_bytes(H, W); }
 extern "C" int llicti_header_dims(const uint8_t *h, int *H, int *W) { return plan_header_dims(h, H, W); }
@@ -604,14 +605,17 @@ static int acquire_block(llicti_ctx *c, size_t need, PlanBlock *out)
 
 // The plan of a batch: cached by (mode, sizes, placement).  A miss builds the tables on the host, copies them into a pinned block and
 // enqueues ONE asynchronous upload on the call's stream -- no device synchronisation, no allocation once the pool is warm.
-static int get_plan(llicti_ctx *c, int B, const int *Hs, const int *Ws, const size_t *rgb_off, int ME, hipStream_t s, PlanDev **out)
+static int get_plan(llicti_ctx *c, int B, const int *Hs, const int *Ws, const size_t *rgb_off, int ME, const int *Ms, hipStream_t s, PlanDev **out)
 {
     std::vector<long> key;
-    key.reserve(3 + 3 * (size_t)B);
+    key.reserve(3 + 4 * (size_t)B);
     key.push_back(ME); key.push_back(B); key.push_back(c->cnn_tile_rows * 2 + (c->force_ragged ? 1 : 0));
     {
         long pos = 0;
-        for (int b = 0; b < B; ++b) { key.push_back(Hs[b]); key.push_back(Ws[b]); key.push_back(rgb_off ? (long)rgb_off[b] : pos); pos += 3L * Hs[b] * Ws[b]; }
+        for (int b = 0; b < B; ++b) {
+            key.push_back(Hs[b]); key.push_back(Ws[b]); key.push_back(rgb_off ? (long)rgb_off[b] : pos); key.push_back((Ms && (ME & 0xFF)) ? Ms[b] : (ME & 0xFF));
+            pos += 3L * Hs[b] * Ws[b];
+        }
     }
     auto it = c->plans.find(key);
     if (it != c->plans.end()) {
@@ -625,10 +629,10 @@ static int get_plan(llicti_ctx *c, int B, const int *Hs, const int *Ws, const si
     std::unique_ptr<PlanDev> pd(new PlanDev());
     Plan &p = pd->p;
     ++c->n_plan_build;
-    build_plan(p, B, Hs, Ws, rgb_off, ME, c->n_cu, c->cnn_tile_rows, c->force_ragged != 0);
+    build_plan(p, B, Hs, Ws, rgb_off, ME, c->n_cu, c->cnn_tile_rows, c->force_ragged != 0, Ms);
     if (p.key != key) return fail(LLICTI_EINVAL, "plan: key mismatch");
-    if (!p.rslot_off.empty() && p.rslot_off.size() != (size_t)B * p.M)
-        return fail(LLICTI_EINVAL, "plan: stream slot table has %zu entries, expected %d x %d", p.rslot_off.size(), B, p.M);
+    if (p.rslot_off.size() != (size_t)p.nstreams || p.sref.size() != (size_t)p.nstreams)
+        return fail(LLICTI_EINVAL, "plan: stream tables have %zu / %zu entries, expected %d", p.rslot_off.size(), p.sref.size(), p.nstreams);
     if (int rc = acquire_block(c, p.d_total, &pd->blk)) return rc;
     uint8_t *h = pd->blk.host;
     auto put = [&](size_t off, const void *src, size_t n) { if (n) memcpy(h + off, src, n); };
@@ -640,6 +644,7 @@ static int get_plan(llicti_ctx *c, int B, const int *Hs, const int *Ws, const si
     put(p.d_slot_cap, p.slot_cap.data(), p.slot_cap.size() * sizeof(int32_t));
     put(p.d_rslot_off, p.rslot_off.data(), p.rslot_off.size() * sizeof(long));
     put(p.d_tiles, p.tiles.data(), p.tiles.size() * sizeof(TileRef));
+    put(p.d_sref, p.sref.data(), p.sref.size() * sizeof(StreamRef));
     bool ok = hipMemcpyAsync(pd->blk.dev, h, p.d_total, hipMemcpyHostToDevice, s) == hipSuccess;
     ok = ok && hipEventRecord(pd->blk.uploaded, s) == hipSuccess;
     ok = ok && hipEventRecord(pd->blk.done, s) == hipSuccess;      // (so that the block is never recycled in front of its own upload)
@@ -700,21 +705,46 @@ struct PlanUse {
     ~PlanUse() { if (pd && hipEventRecord(pd->blk.done, s) == hipSuccess) pd->blk.used = true; }
 };
 
-static int encode_batch(llicti_ctx *c, const uint8_t *d_rgb, const size_t *rgb_off, int B, const int *Hs, const int *Ws, int mode,
+// modes: one container mode for the call (n_modes = 1) or one per image (n_modes = B: rANS containers of ONE lane kind whose stream counts may differ);
+// -> ME of the call (the lane kind, with the first image's count) and, for per-image counts, Ms
+static int resolve_modes(const char *who, const int *modes, int n_modes, int B, int *ME_out, std::vector<int> &Ms)
+{
+    Ms.clear();
+    if (!modes || (n_modes != 1 && n_modes != B)) return fail(LLICTI_EINVAL, "%s: modes must hold one mode or one per image", who);
+    const int ME0 = mode_streams(modes[0]);
+    if (ME0 < 0) return fail(LLICTI_EINVAL, "%s: unknown mode 0x%x", who, modes[0]);
+    *ME_out = ME0;
+    if (n_modes == 1) return 0;
+    bool differ = false;
+    for (int b = 0; b < B; ++b) {
+        const int ME = mode_streams(modes[b]);
+        if (ME < 0) return fail(LLICTI_EINVAL, "%s: unknown mode 0x%x of image %d", who, modes[b], b);
+        if ((ME >> 8) != (ME0 >> 8) || ((ME & 0xFF) == 0) != ((ME0 & 0xFF) == 0))
+            return fail(LLICTI_EINVAL, "%s: the images of one call share a container kind (reference format, or rANS streams of one lane count); image %d differs", who, b);
+        Ms.push_back(ME & 0xFF);
+        differ = differ || ME != ME0;
+    }
+    if (!differ) Ms.clear();
+    return 0;
+}
+
+static int encode_batch(llicti_ctx *c, const uint8_t *d_rgb, const size_t *rgb_off, int B, const int *Hs, const int *Ws, const int *modes, int n_modes,
                         void *d_workspace, size_t workspace_bytes, uint8_t *d_out, size_t out_stride, int32_t *d_seg_len, void *stream)
 {
     if (!c || !d_rgb || !d_workspace || !d_out || !d_seg_len) return fail(LLICTI_EINVAL, "encode_images: null pointer");
     if (check_dims_v(B, Hs, Ws)) return LLICTI_EINVAL;
-    const int ME = mode_streams(mode);
-    if (ME < 0) return fail(LLICTI_EINVAL, "encode_images: unknown mode 0x%x", mode);
-    const int M = ME & 0xFF, Q = 1 << (ME >> 8);
+    int ME = 0;
+    std::vector<int> Ms;
+    if (int rc = resolve_modes("encode_images", modes, n_modes, B, &ME, Ms)) return rc;
+    const int Q = 1 << (ME >> 8);
     for (int b = 0; b < 3; ++b) if (!c->have[b]) return fail(LLICTI_ENOWEIGHTS, "band %d weights not set", b);
     DeviceGuard guard(c);
     hipStream_t s = (hipStream_t)stream;
     PlanDev *pd = nullptr;
-    if (int rc = get_plan(c, B, Hs, Ws, rgb_off, ME, s, &pd)) return rc;
+    if (int rc = get_plan(c, B, Hs, Ws, rgb_off, ME, Ms.empty() ? nullptr : Ms.data(), s, &pd)) return rc;
     PlanUse use{ pd, s };
     const Plan &p = pd->p;
+    const int M = p.M;
     if (!p.uniform && M == 0) return fail(LLICTI_EINVAL, "encode_images: a batch of mixed sizes needs a rANS container (the reference-format container codes equal sizes per call)");
     if (workspace_bytes < p.total) return fail(LLICTI_ENOSPACE, "encode_images: workspace %zu < %zu", workspace_bytes, p.total);
     if (out_stride < p.max_container) return fail(LLICTI_ENOSPACE, "encode_images: out_stride %zu < %zu", out_stride, p.max_container);
@@ -731,15 +761,15 @@ static int encode_batch(llicti_ctx *c, const uint8_t *d_rgb, const size_t *rgb_o
     const StageGeom *d_sg = pd->dev<StageGeom>(p.d_sg);
     const StreamDesc *d_desc = pd->dev<StreamDesc>(p.d_desc);
     const long *d_rslot_off = pd->dev<long>(p.d_rslot_off);
+    const StreamRef *d_sref = pd->dev<StreamRef>(p.d_sref);
     const TileRef *d_tiles = p.uniform ? nullptr : pd->dev<TileRef>(p.d_tiles);
 
     CallScope call(c, s);
-    const int byte0 = M ? rans_byte0(M, Q) : LLICTI_NLEVELS;
     {
         ProfSpan span(c, PROF_MISC, s);
         // (the lift is the call's first kernel and sets no status: it clears the call's status words on the way)
         if (int rc = launch_lift(d_rgb, B, p.max_plane, p.vec_ok, planes, fplanes, mm, (int32_t *)(ws + p.off_lift_part), s, status, kStatusHead + B, d_img)) return rc;
-        header_write_kernel<<<B, 256, 0, s>>>(d_rgb, mm, d_img, byte0, d_out, (long)out_stride, d_seg_len);
+        header_write_kernel<<<B, 256, 0, s>>>(d_rgb, mm, d_img, d_out, (long)out_stride, d_seg_len);
     }
     // The encoder has no dependency between stages: every (level, band) reads only original pixels.  With llicti_set_tuning("enc_side_levels", 1)
     // levels 4..1 (twelve CNN + twelve pairs launches, a quarter of the work) run on a side stream next to level 0's, with their own
@@ -799,10 +829,11 @@ static int encode_batch(llicti_ctx *c, const uint8_t *d_rgb, const size_t *rgb_o
         ProfSpan span(c, PROF_RANS_ENC, s);
         int32_t *rinfo = (int32_t *)(ws + p.off_rinfo);
         const StageGeom *sglv = d_sg + (size_t)(0 * 3 + 2) * B;      // the last stage: an xwide stream's seed symbols are read from its pixels
-        if (Q == 4) rans_encode_kernel<4><<<B * M, 256, 0, s>>>(pairs, d_desc, B, M, slots, d_rslot_off, p.rslot_cap, rinfo, status, sglv, planes, mm);
-        else if (Q == 2) rans_encode_kernel<2><<<B * M, 128, 0, s>>>(pairs, d_desc, B, M, slots, d_rslot_off, p.rslot_cap, rinfo, status, sglv, planes, mm);
-        else rans_encode_kernel<1><<<B * M, 64, 0, s>>>(pairs, d_desc, B, M, slots, d_rslot_off, p.rslot_cap, rinfo, status, sglv, planes, mm);
-        rans_pack_kernel<<<dim3(M, B), 256, 0, s>>>(slots, d_rslot_off, rinfo, M, d_img, d_out, (long)out_stride, d_seg_len, status);
+        const int NS = p.nstreams;                                   // the streams of all images (an image's count is its own: ImgGeo::M)
+        if (Q == 4) rans_encode_kernel<4><<<NS, 256, 0, s>>>(pairs, d_desc, B, d_sref, slots, d_rslot_off, p.rslot_cap, rinfo, status, sglv, planes, mm);
+        else if (Q == 2) rans_encode_kernel<2><<<NS, 128, 0, s>>>(pairs, d_desc, B, d_sref, slots, d_rslot_off, p.rslot_cap, rinfo, status, sglv, planes, mm);
+        else rans_encode_kernel<1><<<NS, 64, 0, s>>>(pairs, d_desc, B, d_sref, slots, d_rslot_off, p.rslot_cap, rinfo, status, sglv, planes, mm);
+        rans_pack_kernel<<<NS, 256, 0, s>>>(slots, d_rslot_off, rinfo, d_sref, d_img, d_out, (long)out_stride, d_seg_len, status);
     }
     latch_status_kernel<<<1, 64, 0, s>>>(status, c->d_status, nullptr, 0);
     HIPCHK(hipGetLastError());
@@ -813,7 +844,14 @@ extern "C" int llicti_encode_images_v(llicti_ctx *c, const uint8_t *d_rgb, const
                                       void *d_workspace, size_t workspace_bytes,
                                       uint8_t *d_out, size_t out_stride, int32_t *d_seg_len, void *stream)
 {
-    return encode_batch(c, d_rgb, rgb_off, B, Hs, Ws, mode, d_workspace, workspace_bytes, d_out, out_stride, d_seg_len, stream);
+    return encode_batch(c, d_rgb, rgb_off, B, Hs, Ws, &mode, 1, d_workspace, workspace_bytes, d_out, out_stride, d_seg_len, stream);
+}
+
+extern "C" int llicti_encode_images_vm(llicti_ctx *c, const uint8_t *d_rgb, const size_t *rgb_off, int B, const int *Hs, const int *Ws, const int *modes,
+                                       void *d_workspace, size_t workspace_bytes,
+                                       uint8_t *d_out, size_t out_stride, int32_t *d_seg_len, void *stream)
+{
+    return encode_batch(c, d_rgb, rgb_off, B, Hs, Ws, modes, B, d_workspace, workspace_bytes, d_out, out_stride, d_seg_len, stream);
 }
 
 extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, int H, int W, int mode,
@@ -822,7 +860,7 @@ extern "C" int llicti_encode_images(llicti_ctx *c, const uint8_t *d_rgb, int B, 
 {
     if (check_dims(B, H, W)) return LLICTI_EINVAL;
     std::vector<int> Hs(B, H), Ws(B, W);
-    return encode_batch(c, d_rgb, nullptr, B, Hs.data(), Ws.data(), mode, d_workspace, workspace_bytes, d_out, out_stride, d_seg_len, stream);
+    return encode_batch(c, d_rgb, nullptr, B, Hs.data(), Ws.data(), &mode, 1, d_workspace, workspace_bytes, d_out, out_stride, d_seg_len, stream);
 }
 
 static int decode_stages(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t in_stride, const int32_t *d_seg_len,
@@ -843,24 +881,25 @@ static int decode_stages(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t
     const Geom *d_geo = pd->dev<Geom>(p.d_geo);
     const StageGeom *d_sg = pd->dev<StageGeom>(p.d_sg);
     const long *d_rslot_off = pd->dev<long>(p.d_rslot_off);
+    const StreamRef *d_sref = pd->dev<StreamRef>(p.d_sref);
+    const int NS = p.nstreams;
     const TileRef *d_tiles = p.uniform ? nullptr : pd->dev<TileRef>(p.d_tiles);
 
     zero_words_kernel<<<(kStatusHead + B + 255) / 256, 256, 0, s>>>(status, kStatusHead + B);
-    const int byte0 = M ? rans_byte0(M, Q) : LLICTI_NLEVELS;
     uint32_t *rstate = (uint32_t *)(ws + p.off_rstate);
     uint32_t *rpos = (uint32_t *)(ws + p.off_rpos);
     uint32_t *rtail = (uint32_t *)(ws + p.off_rtail);
     {
         ProfSpan span(c, PROF_MISC, s);
-        header_read_kernel<<<B, 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, d_img, byte0, planes, fplanes, mm, status);
+        header_read_kernel<<<B, 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, d_img, planes, fplanes, mm, status);
         if (M == 0) {
             unpack_kernel<<<dim3(LLICTI_NSTREAMS, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, B, slots, pd->dev<long>(p.d_slot_off), pd->dev<int32_t>(p.d_slot_cap), slot_len, status);
         } else {
-            rans_unpack_kernel<<<dim3(M, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, M, 2 + Q * RansGeo<1>::kPayBytes,
-                                                          slots, d_rslot_off, p.rslot_cap, rpos, status);
-            if (Q == 4) rans_init_kernel<4><<<B * M, 64, 0, s>>>(slots, d_rslot_off, M, rstate, rpos, rtail, status);
-            else if (Q == 2) rans_init_kernel<2><<<B * M, 64, 0, s>>>(slots, d_rslot_off, M, rstate, rpos, rtail, status);
-            else rans_init_kernel<1><<<B * M, 64, 0, s>>>(slots, d_rslot_off, M, rstate, rpos, rtail, status);
+            rans_unpack_kernel<<<NS, 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, d_sref, 2 + Q * RansGeo<1>::kPayBytes,
+                                                  slots, d_rslot_off, p.rslot_cap, rpos, status);
+            if (Q == 4) rans_init_kernel<4><<<NS, 64, 0, s>>>(slots, d_rslot_off, d_sref, rstate, rpos, rtail, status);
+            else if (Q == 2) rans_init_kernel<2><<<NS, 64, 0, s>>>(slots, d_rslot_off, d_sref, rstate, rpos, rtail, status);
+            else rans_init_kernel<1><<<NS, 64, 0, s>>>(slots, d_rslot_off, d_sref, rstate, rpos, rtail, status);
         }
     }
     // 45 dependent stages (LLICTI_nets.py:440-498): CNN of band b needs bands < b of this level, Co needs Y, Cg needs Y, Co
@@ -875,18 +914,18 @@ static int decode_stages(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t
                 {
                 ProfSpan span(c, PROF_RANS_STAGE, s);
                 if (Q == 4) {
-                    rans_decode_stage_lane_kernel<4><<<B * M, 256, 0, s>>>(params, sgv, M, slots, d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status, c->d_phi_lut);
+                    rans_decode_stage_lane_kernel<4><<<NS, 256, 0, s>>>(params, sgv, d_sref, slots, d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status, c->d_phi_lut);
                 } else if (Q == 2) {
-                    rans_decode_stage_pair_kernel<<<B * M, 64 * kRansWaves, 0, s>>>(params, sgv, M, c->d_phi_lut, slots, d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status);
+                    rans_decode_stage_pair_kernel<<<NS, 64 * kRansWaves, 0, s>>>(params, sgv, d_sref, c->d_phi_lut, slots, d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status);
                 } else {
-                    rans_decode_stage_kernel<<<B * M, 64 * kRansWaves, 0, s>>>(params, sgv, M, c->d_phi_lut, slots, d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status);
+                    rans_decode_stage_kernel<<<NS, 64 * kRansWaves, 0, s>>>(params, sgv, d_sref, c->d_phi_lut, slots, d_rslot_off, p.rslot_cap, rstate, rpos, rtail, planes, fplanes, mm, last, status);
                 }
                 }
                 if (last) {
                     ProfSpan span(c, PROF_RANS_TAIL, s);
-                    if (Q == 4) rans_tail_kernel<4><<<B * M, 64 * (1 + kTailAhead) * kTailChains<4>, 0, s>>>(params, sgv, M, rstate, rpos, rtail, planes, fplanes, mm, status);
-                    else if (Q == 2) rans_tail_kernel<2><<<B * M, 64 * (1 + kTailAhead), 0, s>>>(params, sgv, M, rstate, rpos, rtail, planes, fplanes, mm, status);
-                    else rans_tail_kernel<1><<<B * M, 64 * (1 + kTailAhead), 0, s>>>(params, sgv, M, rstate, rpos, rtail, planes, fplanes, mm, status);
+                    if (Q == 4) rans_tail_kernel<4><<<NS, 64 * (1 + kTailAhead) * kTailChains<4>, 0, s>>>(params, sgv, d_sref, rstate, rpos, rtail, planes, fplanes, mm, status);
+                    else if (Q == 2) rans_tail_kernel<2><<<NS, 64 * (1 + kTailAhead), 0, s>>>(params, sgv, d_sref, rstate, rpos, rtail, planes, fplanes, mm, status);
+                    else rans_tail_kernel<1><<<NS, 64 * (1 + kTailAhead), 0, s>>>(params, sgv, d_sref, rstate, rpos, rtail, planes, fplanes, mm, status);
                 }
             }
             if (M == 0) {
@@ -949,17 +988,18 @@ static int decode_stages(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t
 }
 
 static int decode_batch(llicti_ctx *c, const uint8_t *d_in, size_t in_stride, const int32_t *d_seg_len, int B, const int *Hs, const int *Ws,
-                        int mode, void *d_workspace, size_t workspace_bytes, uint8_t *d_rgb, const size_t *rgb_off, void *stream)
+                        const int *modes, int n_modes, void *d_workspace, size_t workspace_bytes, uint8_t *d_rgb, const size_t *rgb_off, void *stream)
 {
     if (!c || !d_in || !d_seg_len || !d_workspace || !d_rgb) return fail(LLICTI_EINVAL, "decode_images: null pointer");
     if (check_dims_v(B, Hs, Ws)) return LLICTI_EINVAL;
-    const int ME = mode_streams(mode);
-    if (ME < 0) return fail(LLICTI_EINVAL, "decode_images: unknown mode 0x%x", mode);
+    int ME = 0;
+    std::vector<int> Ms;
+    if (int rc = resolve_modes("decode_images", modes, n_modes, B, &ME, Ms)) return rc;
     for (int b = 0; b < 3; ++b) if (!c->have[b]) return fail(LLICTI_ENOWEIGHTS, "band %d weights not set", b);
     DeviceGuard guard(c);
     hipStream_t s = (hipStream_t)stream;
     PlanDev *pd = nullptr;
-    if (int rc = get_plan(c, B, Hs, Ws, rgb_off, ME, s, &pd)) return rc;
+    if (int rc = get_plan(c, B, Hs, Ws, rgb_off, ME, Ms.empty() ? nullptr : Ms.data(), s, &pd)) return rc;
     PlanUse use{ pd, s };
     const Plan &p = pd->p;
     if (!p.uniform && p.M == 0) return fail(LLICTI_EINVAL, "decode_images: a batch of mixed sizes needs a rANS container (the reference-format container codes equal sizes per call)");
@@ -989,7 +1029,14 @@ extern "C" int llicti_decode_images_v(llicti_ctx *c, const uint8_t *d_in, size_t
                                       int B, const int *Hs, const int *Ws, int mode, void *d_workspace, size_t workspace_bytes,
                                       uint8_t *d_rgb, const size_t *rgb_off, void *stream)
 {
-    return decode_batch(c, d_in, in_stride, d_seg_len, B, Hs, Ws, mode, d_workspace, workspace_bytes, d_rgb, rgb_off, stream);
+    return decode_batch(c, d_in, in_stride, d_seg_len, B, Hs, Ws, &mode, 1, d_workspace, workspace_bytes, d_rgb, rgb_off, stream);
+}
+
+extern "C" int llicti_decode_images_vm(llicti_ctx *c, const uint8_t *d_in, size_t in_stride, const int32_t *d_seg_len,
+                                       int B, const int *Hs, const int *Ws, const int *modes, void *d_workspace, size_t workspace_bytes,
+                                       uint8_t *d_rgb, const size_t *rgb_off, void *stream)
+{
+    return decode_batch(c, d_in, in_stride, d_seg_len, B, Hs, Ws, modes, B, d_workspace, workspace_bytes, d_rgb, rgb_off, stream);
 }
 
 extern "C" int llicti_decode_images(llicti_ctx *c, const uint8_t *d_in, size_t in_stride, const int32_t *d_seg_len,
@@ -998,7 +1045,7 @@ extern "C" int llicti_decode_images(llicti_ctx *c, const uint8_t *d_in, size_t i
 {
     if (check_dims(B, H, W)) return LLICTI_EINVAL;
     std::vector<int> Hs(B, H), Ws(B, W);
-    return decode_batch(c, d_in, in_stride, d_seg_len, B, Hs.data(), Ws.data(), mode, d_workspace, workspace_bytes, d_rgb, nullptr, stream);
+    return decode_batch(c, d_in, in_stride, d_seg_len, B, Hs.data(), Ws.data(), &mode, 1, d_workspace, workspace_bytes, d_rgb, nullptr, stream);
 }
 
 extern "C" int llicti_check_status(llicti_ctx *c, void *stream)

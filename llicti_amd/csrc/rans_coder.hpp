@@ -71,7 +71,7 @@ __device__ __forceinline__ void lds_or_bits(uint32_t *buf, int pos, int n, uint3
 // (dword aligned) | 248 Q bytes of final states; rinfo = (2, 2 + nbytes + 248 Q) for rans_pack_kernel.
 template <int Q>
 __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__restrict__ pairs, const StreamDesc *__restrict__ desc,
-                                                         int B, int M, uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
+                                                         int B, const StreamRef *__restrict__ sref, uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
                                                          int rslot_cap, int32_t *__restrict__ rinfo, int32_t *status,
                                                          const StageGeom *__restrict__ sglv, const int16_t *__restrict__ planes, const int32_t *__restrict__ minmax)
 {
@@ -87,7 +87,9 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
     constexpr int kFlush = 64 * Q, kWin = 8 * kFlush;
     __shared__ uint32_t sh_win[kWin];               // staging RING of the bit region: stream dword d at sh_win[d & (kWin - 1)], d in [wbase, wbase + kWin)
     __shared__ __attribute__((aligned(16))) int sh_tot[2][Q][4];       // a round's four bit totals per sub-chunk (ping-pong by round parity)
-    const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M;
+    const int sidx = blockIdx.x;
+    const StreamRef sr_ = sref[sidx];               // the stream's image, its index among the image's streams, the image's stream count (images of a call may differ)
+    const int b = sr_.b, m = sr_.m, M = sr_.M;
     const int tid = threadIdx.x, lane = tid & 63, wq = tid >> 6;      // wavefront wq codes sub-chunk wq (stream lanes 64 wq .. 64 wq + 63)
     const StageGeom sgl = sglv[b];                  // the image's last stage (level 0, band x10): an xwide stream's seed symbols are read from its pixels
     uint8_t *slot = slots + rslot_off[sidx];
@@ -464,7 +466,7 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
 // T and pad (-> bit cursor), the 64 Q states
 template <int Q>
 __global__ __launch_bounds__(64) void rans_init_kernel(const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
-                                                       int M, uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos,
+                                                       const StreamRef *__restrict__ sref, uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos,
                                                        uint32_t *__restrict__ rtail, int32_t *status)
 {
     using GEO = RansGeo<Q>;
@@ -494,7 +496,7 @@ __global__ __launch_bounds__(64) void rans_init_kernel(const uint8_t *__restrict
         rstate[((long)sidx * Q + qq) * 64 + lane] = (1u << 31) | ((uint32_t)(w >> (bpos & 7)) & 0x7FFFFFFFu);
     }
     if (lane == 0) { rpos[sidx] = (uint32_t)cur; rtail[sidx] = (uint32_t)T | ((uint32_t)single << 16); }
-    if (bad && lane == 0) flag_image(status, sidx / M, LLICTI_EFORMAT);
+    if (bad && lane == 0) flag_image(status, sref[sidx].b, LLICTI_EFORMAT);
 }
 
 // One stage (level, band, colour channel) of all images.  One workgroup of 4 wavefronts per stream (one per
@@ -598,7 +600,7 @@ __device__ __forceinline__ int group_cdf_entry_fast(const CompFast &A, const Com
     return (int)__builtin_rintf(dpp_sum5(term_fast(A, pt), term_fast(B, pt)) * scale) + i;
 }
 
-__global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(const float *__restrict__ params, const StageGeom *__restrict__ sgv, int M,
+__global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(const float *__restrict__ params, const StageGeom *__restrict__ sgv, const StreamRef *__restrict__ sref,
                                                                const float2 *__restrict__ phi_lut,
                                                                const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
                                                                int rslot_cap, uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos,
@@ -608,7 +610,9 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
 {
     __shared__ uint32_t sh_res[2][64][2];        // ping-pong by step parity: [0] = c_low, [1] = c_high
     __shared__ float2 sh_lut[kPhiLutN];          // the hint's normal CDF (term_lut)
-    const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M;
+    const int sidx = blockIdx.x;
+    const StreamRef sr_ = sref[sidx];               // the stream's image, its index among the image's streams, the image's stream count (images of a call may differ)
+    const int b = sr_.b, m = sr_.m, M = sr_.M;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const StageGeom sg = sgv[b];                 // the image's own stage geometry (the images of a call may differ in size)
     const int nc = sg.hc * sg.wc;
@@ -840,7 +844,7 @@ __device__ __forceinline__ uint32_t pair_swap_u(uint32_t v)
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
 }
 
-__global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_pair_kernel(const float *__restrict__ params, const StageGeom *__restrict__ sgv, int M,
+__global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_pair_kernel(const float *__restrict__ params, const StageGeom *__restrict__ sgv, const StreamRef *__restrict__ sref,
                                                                const float2 *__restrict__ phi_lut,
                                                                const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
                                                                int rslot_cap, uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos,
@@ -851,7 +855,9 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_pair_kernel
     constexpr int Q = 2, L = 64 * Q;
     __shared__ uint32_t sh_res[2][L][2];         // ping-pong by step parity: [0] = c_low, [1] = c_high
     __shared__ float2 sh_lut[kPhiLutN];          // the hint's normal CDF (term_lut)
-    const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M;
+    const int sidx = blockIdx.x;
+    const StreamRef sr_ = sref[sidx];               // the stream's image, its index among the image's streams, the image's stream count (images of a call may differ)
+    const int b = sr_.b, m = sr_.m, M = sr_.M;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const StageGeom sg = sgv[b];                 // the image's own stage geometry (the images of a call may differ in size)
     const int nc = sg.hc * sg.wc;
@@ -1084,7 +1090,7 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_pair_kernel
 // from which every lane knows where its bits start.  The stream's bits come from an LDS ring of 512 dwords (a step takes at most
 // 128), refilled 128 dwords at a time: requested at the end of a step, stored at the end of the next, used after the barrier that follows.
 template <int Q>
-__global__ __launch_bounds__(64 * Q) void rans_decode_stage_lane_kernel(const float *__restrict__ params, const StageGeom *__restrict__ sgv, int M,
+__global__ __launch_bounds__(64 * Q) void rans_decode_stage_lane_kernel(const float *__restrict__ params, const StageGeom *__restrict__ sgv, const StreamRef *__restrict__ sref,
                                                                const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
                                                                int rslot_cap, uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos,
                                                                const uint32_t *__restrict__ rtail,
@@ -1106,7 +1112,9 @@ __global__ __launch_bounds__(64 * Q) void rans_decode_stage_lane_kernel(const fl
     constexpr int kLutN = kPhiLutN;
     constexpr float kLutZ = (float)kPhiLutZ, kLutS = kLutN / (2.0f * kLutZ);
     __shared__ float2 sh_lut[kLutN];
-    const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M;
+    const int sidx = blockIdx.x;
+    const StreamRef sr_ = sref[sidx];               // the stream's image, its index among the image's streams, the image's stream count (images of a call may differ)
+    const int b = sr_.b, m = sr_.m, M = sr_.M;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;      // tid = lane of the stream
     const StageGeom sg = sgv[b];                 // the image's own stage geometry (the images of a call may differ in size)
     const int nc = sg.hc * sg.wc;
@@ -1313,7 +1321,7 @@ constexpr int kTailAhead = 3;                    // symbols per round = preparin
 template <int Q> constexpr int kTailChains = kSeeded<Q> ? 2 : 1;      // xwide: two chains, each with its own coder + preparing wavefronts
 
 template <int Q>
-__global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_tail_kernel(const float *__restrict__ params, const StageGeom *__restrict__ sgv, int M,
+__global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_tail_kernel(const float *__restrict__ params, const StageGeom *__restrict__ sgv, const StreamRef *__restrict__ sref,
                                                        const uint32_t *__restrict__ rstate, const uint32_t *__restrict__ rpos,
                                                        const uint32_t *__restrict__ rtail,
                                                        int16_t *__restrict__ planes, float *__restrict__ fplanes,
@@ -1326,7 +1334,9 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_t
     __shared__ int sh_e1[NCH][2][kTailAhead][64];       // approximate table entry at anchor 8 l
     __shared__ long sh_off[NCH][2][kTailAhead];         // the symbol's pixel
     __shared__ int sh_cur[2];                           // xwide: where the two chains stopped reading
-    const int sidx = blockIdx.x, b = sidx / M, m = sidx - b * M;
+    const int sidx = blockIdx.x;
+    const StreamRef sr_ = sref[sidx];               // the stream's image, its index among the image's streams, the image's stream count (images of a call may differ)
+    const int b = sr_.b, m = sr_.m, M = sr_.M;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // role 0: the chain's coder.  A workgroup's wavefronts go to the four SIMDs round robin: with two chains the coders are wavefronts 0 and 1 (their
     // own SIMD each, shared with one preparing wavefront), not 0 and 4 (the same SIMD, taking turns at its issue port)
@@ -1563,17 +1573,18 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_t
 }
 
 __global__ __launch_bounds__(256) void rans_pack_kernel(const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
-                                                        const int32_t *__restrict__ rinfo, int M, const ImgGeo *__restrict__ iv,
+                                                        const int32_t *__restrict__ rinfo, const StreamRef *__restrict__ sref, const ImgGeo *__restrict__ iv,
                                                         uint8_t *__restrict__ out, long out_stride, int32_t *__restrict__ seg_len, int32_t *status)
 {
-    const int m = blockIdx.x, b = blockIdx.y;
+    const StreamRef sr_ = sref[blockIdx.x];
+    const int b = sr_.b, m = sr_.m, M = sr_.M, s0 = sr_.sbase;      // (s0 + k: stream k of this image)
     const int hdr_bytes = iv[b].hdr_bytes;
     const int G = rans_group(M), sg = m / G;
     long dst = hdr_bytes + (G > 1 ? 4L * G * (sg + 1) : 0);
-    for (int k = 0; k < m; ++k) dst += rinfo[2 * (b * M + k) + 1];
-    const int n = rinfo[2 * (b * M + m) + 1];
+    for (int k = 0; k < m; ++k) dst += rinfo[2 * (s0 + k) + 1];
+    const int n = rinfo[2 * (s0 + m) + 1];
     if (dst + n > out_stride) { if (threadIdx.x == 0) atomicExch(&status[0], LLICTI_ENOSPACE); return; }
-    const uint8_t *src = slots + rslot_off[b * M + m] + rinfo[2 * (b * M + m)];
+    const uint8_t *src = slots + rslot_off[s0 + m] + rinfo[2 * (s0 + m)];
     uint8_t *o = out + (long)b * out_stride + dst;
     block_copy_bytes(o, src, n);
     if (threadIdx.x == 0) {
@@ -1582,7 +1593,7 @@ __global__ __launch_bounds__(256) void rans_pack_kernel(const uint8_t *__restric
             uint8_t *tab = o - 4 * G;
             int tot = 4 * G;
             for (int k = 0; k < G; ++k) {
-                const int len = rinfo[2 * (b * M + m + k) + 1];
+                const int len = rinfo[2 * (s0 + m + k) + 1];
                 tab[4 * k] = (uint8_t)(len & 0xFF); tab[4 * k + 1] = (uint8_t)((len >> 8) & 0xFF);
                 tab[4 * k + 2] = (uint8_t)((len >> 16) & 0xFF); tab[4 * k + 3] = (uint8_t)((len >> 24) & 0xFF);
                 tot += len;
@@ -1594,10 +1605,11 @@ __global__ __launch_bounds__(256) void rans_pack_kernel(const uint8_t *__restric
 }
 
 __global__ __launch_bounds__(256) void rans_unpack_kernel(const uint8_t *__restrict__ in, long in_stride, const int32_t *__restrict__ seg_len,
-                                                          int M, int min_stream, uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
+                                                          const StreamRef *__restrict__ sref, int min_stream, uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
                                                           int rslot_cap, uint32_t *__restrict__ rpos, int32_t *status)
 {
-    const int m = blockIdx.x, b = blockIdx.y;
+    const StreamRef sr_ = sref[blockIdx.x];
+    const int b = sr_.b, m = sr_.m, M = sr_.M, s0 = sr_.sbase;
     const int G = rans_group(M), sg = m / G;
     const int32_t *sl = seg_len + (long)b * LLICTI_NSEG;
     long src = 0;
@@ -1627,7 +1639,7 @@ __global__ __launch_bounds__(256) void rans_unpack_kernel(const uint8_t *__restr
             src += off;
         }
     }
-    uint8_t *o = slots + rslot_off[b * M + m] + 2;               // the bit region (stream offset 2) lands dword aligned
+    uint8_t *o = slots + rslot_off[s0 + m] + 2;                  // the bit region (stream offset 2) lands dword aligned
     if (bad || n < min_stream || n + 2 + 64 > rslot_cap || src + n > in_stride) {
         if (threadIdx.x == 0) flag_image(status, b, LLICTI_EFORMAT);
         n = min_stream;                                            // a harmless stream: T = 0, no bits, states 2^31
@@ -1638,5 +1650,5 @@ __global__ __launch_bounds__(256) void rans_unpack_kernel(const uint8_t *__restr
     }
     const int padded = min(rslot_cap - 2, n + 64);
     for (int t = n + threadIdx.x; t < padded; t += blockDim.x) o[t] = 0;
-    if (threadIdx.x == 0) rpos[b * M + m] = (uint32_t)n;         // the length rans_init_kernel parses
+    if (threadIdx.x == 0) rpos[s0 + m] = (uint32_t)n;            // the length rans_init_kernel parses
 }

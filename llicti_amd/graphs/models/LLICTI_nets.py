@@ -19,7 +19,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from ...codec import (MODE_AC, MODE_RANS, NSEG, HipCodec, auto_container, bytestream_list_to_container, container_to_bytestream_list,
+from ...codec import (MODE_AC, MODE_RANS, NSEG, HipCodec, auto_container, balanced_modes, bytestream_list_to_container, container_to_bytestream_list,
                       header_dims, mode_of_header, mode_of_name)
 from ...config import check_supported
 
@@ -107,6 +107,8 @@ class LLICTI(nn.Module):
         # (llicti_amd.codec.auto_container: xwide rANS streams, one decoder workgroup per stream and compute unit)
         self.container = str(config["container"]) if "container" in config else "ac"
         self.mode = None if self.container == "auto" else mode_of_name(self.container)
+        # container "auto" on a batch of mixed sizes: a stream count per image (llicti_amd.codec.balanced_modes) unless config.balance_streams = False
+        self.balance_streams = bool(config["balance_streams"]) if "balance_streams" in config else True
         self._stage = {}                # pinned host staging buffers of the batched path, by (tag, slot): [buffer, event behind its last copy]
         self._xfer = {}                 # (upload, download) copy streams of the batched path, by device index
 
@@ -164,7 +166,12 @@ class LLICTI(nn.Module):
         if self.mode is not None:
             return self.mode
         dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-        return mode_of_name(auto_container(B, torch.cuda.get_device_properties(dev).multi_processor_count, sizes=sizes))
+        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+        if self.balance_streams and sizes and len(sizes) == B and len(set(sizes)) > 1:
+            # images of different sizes in one call: a stream count per image, in proportion to its pixels (all streams equally long: a decoder
+            # stage takes as long as its longest stream), each image inside its own byte budget -- llicti_encode_images_vm
+            return balanced_modes(sizes, n_cu)
+        return mode_of_name(auto_container(B, n_cu, sizes=sizes))
 
     def _pinned(self, key, nbytes):
         """Pinned host staging buffer (flat uint8, at least nbytes, grown to the running maximum) of `key` = (tag, slot).  The buffer's last
@@ -296,24 +303,23 @@ class LLICTI(nn.Module):
         failures are reported by codec().check() / image_status().  The images of a call share a container kind; in a rANS container their
         SIZES may differ -- then (or with flat=True) the result is (flat uint8 device tensor, Hs, Ws): the images back to back, [3][H][W] each."""
         codec = self.codec(devc if (devc is not None and torch.device(devc).type == "cuda") else None)
-        Hs, Ws, mode = [], [], None
+        Hs, Ws, modes = [], [], []
         for bl in lists:
             if len(bl) != 6 or any(len(r) != 9 for r in bl):
                 raise ValueError("bytestream_list must be 6 lists of 9 byte strings")
             if len(bl[0][0]) != 3 or len(bl[0][1]) != 12 or len(bl[0][2]) != 2:
                 raise ValueError("malformed header streams")
             hdr = bytes(bl[0][0]) + bytes(bl[0][1]) + bytes(bl[0][2])
-            m = mode_of_header(hdr[0])                  # AC container: hdr[0] == num_scales (LLICTI_nets.py:424)
+            modes.append(mode_of_header(hdr[0]))        # AC container: hdr[0] == num_scales (LLICTI_nets.py:424); rANS: its lane kind and stream count
             H, W = header_dims(hdr)
-            if mode is None:
-                mode = m
-            elif m != mode:
-                raise ValueError("all images of one decompres_batch call must be in the same container")
             Hs.append(H)
             Ws.append(W)
+        if any((m & ~0xFF) != (modes[0] & ~0xFF) for m in modes):
+            raise ValueError("all images of one decompres_batch call must be in the same kind of container (their stream counts may differ)")
+        mode = modes[0] if all(m == modes[0] for m in modes) else modes
         B = len(lists)
-        mixed = any(h != Hs[0] or w != Ws[0] for h, w in zip(Hs, Ws))
-        if mixed and mode == MODE_AC:
+        mixed = any(h != Hs[0] or w != Ws[0] for h, w in zip(Hs, Ws)) or isinstance(mode, list)
+        if mixed and modes[0] == MODE_AC:
             raise ValueError("images of different sizes in the reference-format container decode one size per call")
         stride = max(codec.max_container_bytes(h, w) for h, w in set(zip(Hs, Ws)))
         cont_h = self._pinned(("cont_in", slot), B * stride)[:B * stride].view(B, stride)

@@ -694,11 +694,17 @@ def test_agent_batched_eval_equals_unbatched(torch_mod, tmp_path, caplog, oracle
     a_a = LLICTIAgent(default_config(test_data=imgs, eval_batch=4, container="auto", keep_streams=True))
     res_a = a_a.run()
     assert len(res_a) == 10 and all(r["max_abs_err"] == 0.0 for r in res_a)
+    from llicti_amd.codec import balanced_modes
     for k0 in (0, 4, 8):
-        want = auto_container(len(sizes[k0:k0 + 4]), n_cu, sizes=sizes[k0:k0 + 4])
-        assert want in ("xrans1", "rans1"), want
-        for r in res_a[k0:k0 + 4]:
-            assert mode_of_header(r["bytestream_list"][0][0][0]) == mode_of_name(want)
+        sz = sizes[k0:k0 + 4]
+        want = balanced_modes(sz, n_cu) if len(set(sz)) > 1 else [mode_of_name(auto_container(len(sz), n_cu, sizes=sz))] * len(sz)
+        for r, m in zip(res_a[k0:k0 + 4], want):
+            assert mode_of_header(r["bytestream_list"][0][0][0]) == m      # per image: streams in proportion to its pixels, inside its own budget
+    big = [(224, 301), (150, 131), (160, 352), (96, 128)]                   # one call, four stream counts' worth of sizes
+    a_g = LLICTIAgent(default_config(test_data=[make_image("smooth", h, w, 430 + i) for i, (h, w) in enumerate(big)], eval_batch=4, container="auto", keep_streams=True))
+    res_g = a_g.run()
+    got = [mode_of_header(r["bytestream_list"][0][0][0]) for r in res_g]
+    assert got == balanced_modes(big, n_cu) and len(set(got)) > 1 and all(r["max_abs_err"] == 0.0 for r in res_g)
     assert auto_container(24, n_cu, sizes=[(512, 768)] * 24) == auto_container(24, n_cu) == "xrans10"
     # in-memory data set, default (reference-format) container, batch of 4: a batch closes where the size changes; equals the oracle
     a_m = LLICTIAgent(default_config(test_data=imgs[:4], eval_batch=4, keep_streams=True))
@@ -1831,3 +1837,49 @@ def test_mixed_size_entry_points_reject_misuse(torch_mod, codecs):
     rec = c.decode_v(cont, seg, Hs, Ws, mode)
     c.check()
     assert np.array_equal(rec.cpu().numpy(), _flat(rgbs))
+
+
+def test_mixed_size_batch_stream_count_per_image(torch_mod, codecs, oracle_weights):
+    """llicti_encode_images_vm / llicti_decode_images_vm: one container mode PER IMAGE -- rANS streams of one lane kind whose COUNT differs from image
+    to image (every header carries its own): image b's bytes are those of its own single-image encode in modes[b] and the oracle's; lossless on a
+    poisoned workspace; `balanced_modes` gives counts in proportion to the pixels, each inside the image's budget, at most one stream per compute
+    unit; lane kinds must not be mixed, nor the reference format with rANS."""
+    from llicti_amd import _lib
+    from llicti_amd.codec import MODE_AC, MODE_RANS, balanced_modes, container_to_bytestream_list, streams_in_budget
+    from oracle import oracle as orc
+    torch = torch_mod
+    c = codecs("trainedlike")
+    W_o = oracle_weights("trainedlike")
+    shapes = [(150, 131), (96, 160), (224, 301), (67, 93), (160, 352), (150, 131)]
+    rgbs = [make_image("smooth" if i % 2 else "noise", h, w, 800 + i) for i, (h, w) in enumerate(shapes)]
+    Hs, Ws = [h for h, _ in shapes], [w for _, w in shapes]
+    flat = _dev(torch, _flat(rgbs))
+    for wide, Ms in ((2, [2, 1, 5, 1, 4, 3]), (1, [3, 1, 2, 2, 1, 3]), (0, [4, 8, 1, 2, 32, 3])):
+        modes = [MODE_RANS(m, wide=wide) for m in Ms]
+        cont, seg = c.encode_v(flat, Hs, Ws, modes)
+        c.check()
+        cont_h, seg_h = cont.cpu().numpy(), seg.cpu().numpy()
+        for b, rgb in enumerate(rgbs):
+            c1, s1 = c.encode(_dev(torch, rgb[None]), mode=modes[b])
+            n = int(seg_h[b].sum())
+            assert np.array_equal(seg_h[b], s1[0].cpu().numpy()) and np.array_equal(cont_h[b, :n], c1[0, :n].cpu().numpy()), (wide, b)
+            if b in (0, 2, 4):
+                assert container_to_bytestream_list(cont_h[b], seg_h[b]) == orc.encode_image_rans(rgb, W_o, Ms[b], wide), (wide, b)
+        c.poison_workspace()
+        rec = c.decode_v(cont, seg, Hs, Ws, modes)
+        c.check()
+        assert np.array_equal(rec.cpu().numpy(), _flat(rgbs)), wide
+    with pytest.raises(_lib.LlictiError):
+        c.encode_v(flat, Hs, Ws, [MODE_RANS(2, wide=2)] * 5 + [MODE_RANS(2, wide=1)])
+    with pytest.raises(_lib.LlictiError):
+        c.encode_v(flat, Hs, Ws, [MODE_RANS(2)] * 5 + [MODE_AC])
+    # the balanced assignment on a batch at the reference's eval-set sizes
+    import json
+    import os
+    from conftest import GOLDEN
+    sh = [tuple(s) for s in json.load(open(os.path.join(GOLDEN, "eval_shapes.json")))["shapes"][100:124]]
+    bm = balanced_modes(sh, 256)
+    Mb = [m & 0xFF for m in bm]
+    assert sum(Mb) <= 256 and all(1 <= m <= streams_in_budget(h, w) for m, (h, w) in zip(Mb, sh))
+    per = [h * w / m for m, (h, w) in zip(Mb, sh)]
+    assert max(per) / min(per) < 1.3                                   # equally long streams (one count for all: 2.2)

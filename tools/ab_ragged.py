@@ -2,7 +2,7 @@
 """Where does a mixed-size batch lose against an equal-size one?  (i) the bench batch (24 x 768x512, xrans10) through the equal-size code path and
 through the mixed-size one (`force_ragged`: per-image tables, tile lists, the RAGGED CNN instantiation) -- same work, so the difference is the code
 path; (ii) 24 images at the reference's eval-set sizes (mixed) against 24 images of their MEAN size -- the difference on top is load imbalance
-(a launch waits for its largest image).  Usage: python tools/ab_ragged.py [out.json]"""
+(a launch waits for its largest image); (iii) the same mixed batches with a stream count per image in proportion to its pixels.  Usage: python tools/ab_ragged.py [out.json]"""
 import json
 import os
 import sys
@@ -52,7 +52,7 @@ def run_uniform(B, H, W, ragged):
             "enc_kernel_ms": {k: round(v, 3) for k, v in ce.items() if v > 0}, "dec_kernel_ms": {k: round(v, 3) for k, v in cd.items() if v > 0}}
 
 
-def run_mixed(sh):
+def run_mixed(sh, mode=mode):
     Hs, Ws = [h for h, _ in sh], [w for _, w in sh]
     flat = torch.from_numpy(np.concatenate([np.random.default_rng(i).integers(0, 256, 3 * h * w, dtype=np.uint8) for i, (h, w) in enumerate(sh)])).to(dev)
     cont, seg = codec.encode_v(flat, Hs, Ws, mode)
@@ -80,6 +80,11 @@ for k0 in (100, 300):
     out[f"eval_set_images_{k0}_{k0 + 24}_mixed"]["sizes"] = sorted(set(map(tuple, sh)))
     sh_sorted = sorted(sh, key=lambda s: s[0] * s[1])
     out[f"eval_set_images_{k0}_{k0 + 24}_sorted_by_size"] = run_mixed(sh_sorted)
+    # (iii) a stream count per image, in proportion to its pixels (llicti_encode_images_vm): all streams equally long
+    from llicti_amd.codec import balanced_modes, name_of_mode
+    bm = balanced_modes([tuple(s) for s in sh], 256)
+    out[f"eval_set_images_{k0}_{k0 + 24}_balanced_stream_counts"] = run_mixed(sh, bm)
+    out[f"eval_set_images_{k0}_{k0 + 24}_balanced_stream_counts"]["streams"] = sorted(set(name_of_mode(m) for m in bm))
 print(json.dumps(out, indent=1))
 if len(sys.argv) > 1:
     json.dump(out, open(sys.argv[1], "w"), indent=1)
