@@ -65,12 +65,18 @@ for case in range(N):
     codec.load_state_dict(sd)
     W_o = orc.Weights(pack_state_dict(sd))
     Hs, Ws = [h for h, _ in sizes], [w for _, w in sizes]
-    if ragged or (M != 0 and rng.integers(0, 4) == 0):          # (equal sizes through the _v entry now and then)
+    Mb = [M] * B                                    # streams of image b (round 5: a count per image in one call, llicti_encode_images_vm)
+    if M != 0 and B > 1 and rng.integers(0, 2) == 0:
+        pool = [1, 2, 3, 4, 8, 10, 11, 16, 32] if wide == 0 else [1, 2, 3, 5, 9, 10, 14]
+        Mb = [M] + [int(rng.choice(pool)) for _ in range(B - 1)]
+    modes = [MODE_RANS(m, wide) for m in Mb] if M != 0 else mode
+    per_image = M != 0 and len(set(Mb)) > 1
+    if ragged or per_image or (M != 0 and rng.integers(0, 4) == 0):          # (equal sizes through the _v entry now and then)
         flat = torch.from_numpy(np.concatenate([a.reshape(-1) for a in imgs])).cuda()
-        cont, seg = codec.encode_v(flat, Hs, Ws, mode)
+        cont, seg = codec.encode_v(flat, Hs, Ws, modes)
         codec.check()
         codec.poison_workspace()                   # the decode must not find the encoder's planes in the workspace
-        rec = codec.decode_v(cont, seg, Hs, Ws, mode)
+        rec = codec.decode_v(cont, seg, Hs, Ws, modes)
         codec.check()
         assert torch.equal(rec, flat), "ROUND TRIP " + tag
     else:
@@ -84,9 +90,10 @@ for case in range(N):
         assert torch.equal(rec, x), "ROUND TRIP " + tag
     ch, sh = cont.cpu().numpy(), seg.cpu().numpy()
     for b in range(B):
-        ref = orc.encode_image(imgs[b], W_o) if M == 0 else orc.encode_image_rans(imgs[b], W_o, M, wide)
+        ref = orc.encode_image(imgs[b], W_o) if M == 0 else orc.encode_image_rans(imgs[b], W_o, Mb[b], wide)
         assert container_to_bytestream_list(ch[b], sh[b]) == ref, "BYTES " + tag + f" image {b}"
     if ragged: counts["mixed_size_calls"] += 1
+    if per_image: counts["stream_count_per_image_calls"] += 1
     if big: counts["big_cheap_images"] += 1
     codec.close()
     counts[f"container:{'ac' if M == 0 else ('rans%d', 'wrans%d', 'xrans%d')[wide] % M}"] += 1

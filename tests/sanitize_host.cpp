@@ -18,11 +18,32 @@ static long n_plans = 0, n_checks = 0;
         if (!(c)) { fprintf(stderr, "FAILED %s (%s:%d)\n", #c, __FILE__, __LINE__); exit(1); } \
     } while (0)
 
-static void check_plan(const Plan &p, int B, const int *Hs, const int *Ws, int ME)
+static void check_plan(const Plan &p, int B, const int *Hs, const int *Ws, int ME, const int *Ms = nullptr)
 {
     ++n_plans;
-    const int M = ME & 0xFF, Q = 1 << (ME >> 8);
+    const int Q = 1 << (ME >> 8);
+    int M = ME & 0xFF;
+    if (Ms && M > 0) { M = 0; for (int b = 0; b < B; ++b) M = std::max(M, Ms[b]); }
     REQUIRE(p.B == B && p.M == M && p.Q == Q);
+    // streams: a count per image (its header's tag says it), a per-stream table, one slot per stream
+    if (M > 0) {
+        int ns = 0;
+        for (int b = 0; b < B; ++b) {
+            const int Mb = Ms ? Ms[b] : M;
+            REQUIRE(p.img[b].M == Mb && p.img[b].sbase == ns);
+            REQUIRE(rans_streams_of_byte0(p.img[b].byte0) == (Mb | ((ME >> 8) << 8)));
+            for (int m = 0; m < Mb; ++m) {
+                const StreamRef &r = p.sref[(size_t)ns + m];
+                REQUIRE(r.b == b && r.m == m && r.M == Mb && r.sbase == ns);
+            }
+            ns += Mb;
+        }
+        REQUIRE(p.nstreams == ns && (int)p.sref.size() == ns && (int)p.rslot_off.size() == ns);
+        REQUIRE(p.d_sref + p.sref.size() * sizeof(StreamRef) <= p.d_total);
+    } else {
+        REQUIRE(p.nstreams == 0 && p.sref.empty());
+        for (int b = 0; b < B; ++b) REQUIRE(p.img[b].byte0 == LLICTI_NLEVELS);
+    }
     // workspace regions: ascending, inside [0, total)
     struct R { size_t off, len; };
     long pix = 0;
@@ -40,7 +61,7 @@ static void check_plan(const Plan &p, int B, const int *Hs, const int *Ws, int M
         REQUIRE(ig.H == Hs[b] && ig.W == Ws[b] && ig.plane == (long)Hs[b] * Ws[b]);
         REQUIRE(ig.hdr_bytes == 17 + 3 * ig.h4 * ig.w4 && ig.h4 >= 1 && ig.w4 >= 1 && ig.h4 <= 255 && ig.w4 <= 255);
         if (b) REQUIRE(p.img[b - 1].pix_off + 3 * p.img[b - 1].plane <= ig.pix_off);
-        uint8_t hdr[17] = { (uint8_t)(M ? rans_byte0(M, Q) : 5), (uint8_t)ig.h4, (uint8_t)ig.w4 };
+        uint8_t hdr[17] = { (uint8_t)ig.byte0, (uint8_t)ig.h4, (uint8_t)ig.w4 };
         hdr[15] = (uint8_t)(ig.padint & 0xFF); hdr[16] = (uint8_t)(ig.padint >> 8);
         int H2 = 0, W2 = 0;
         REQUIRE(plan_header_dims(hdr, &H2, &W2) == 0 && H2 == ig.H && W2 == ig.W);     // the header round-trips the size
@@ -70,7 +91,6 @@ static void check_plan(const Plan &p, int B, const int *Hs, const int *Ws, int M
     }
     REQUIRE(p.off_pairs + (size_t)pair_end * 4 <= p.off_slots);
     if (M > 0) {
-        REQUIRE(p.rslot_off.size() == (size_t)B * M);
         REQUIRE(p.off_slots + (size_t)(p.rslot_off.back() + p.rslot_cap) <= p.off_rinfo);
         REQUIRE(p.d_rslot_off + p.rslot_off.size() * sizeof(long) <= p.d_total);
     } else {
@@ -142,6 +162,19 @@ int main()
         build_plan(p, B, Hs.data(), Ws.data(), nullptr, mode_streams(mode), 1 + (int)(rng() % 320), tr[rng() % 5], false);
         check_plan(p, B, Hs.data(), Ws.data(), mode_streams(mode));
         REQUIRE(plan_workspace_bytes_v(B, Hs.data(), Ws.data(), mode) >= p.total);
+        if (it % 2 == 0) {                                      // a stream count per image (llicti_encode_images_vm): any count the lane kind allows
+            const int ME = mode_streams(mode), kind = ME >> 8;
+            std::vector<int> Ms(B), modes(B);
+            for (int b = 0; b < B; ++b) {
+                Ms[b] = kind == 0 ? 1 + (int)(rng() % 32) : 1 + (int)(rng() % 14);
+                modes[b] = (kind == 2 ? 0x500 : kind == 1 ? 0x300 : 0x100) | Ms[b];
+            }
+            Plan q;
+            build_plan(q, B, Hs.data(), Ws.data(), nullptr, ME, 256, 0, false, Ms.data());
+            check_plan(q, B, Hs.data(), Ws.data(), ME, Ms.data());
+            REQUIRE(plan_workspace_bytes_vm(B, Hs.data(), Ws.data(), modes.data(), B) >= q.total);
+            if (B > 1) { modes[B - 1] = 0; REQUIRE(plan_workspace_bytes_vm(B, Hs.data(), Ws.data(), modes.data(), B) == 0); }      // the reference format among rANS modes: refused
+        }
         if (it % 3 == 0) {                                      // caller-chosen RGB placement
             std::vector<size_t> off(B);
             size_t pos = 64;
