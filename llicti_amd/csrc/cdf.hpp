@@ -40,7 +40,7 @@ __device__ __forceinline__ void cdf_pairs_body(const int16_t *__restrict__ plane
     const long n = (long)i * s.wc + j;
     const long off = s.img_off + ((long)(2 * i + s.oi) << s.lvl) * s.W + ((long)(2 * j + s.oj) << s.lvl);
     const int vy = planes[off], vco = planes[off + s.plane], vcg = planes[off + 2 * s.plane];
-    const float yv = (float)vy / 255.0f, cov = (float)vco / 255.0f;
+    const float yv = div255_exact((float)vy), cov = div255_exact((float)vco);      // (integers in [-255, 255]: bit-identical to the division, numerics.hpp)
     const int32_t *mm = minmax + 4 * b;
 #pragma unroll
     for (int clr = 0; clr < 3; ++clr) {

@@ -778,7 +778,7 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
                     sh_res[k & 1][gsym][1] = vhi;
                     const int v = lo - shift;
                     planes[off + (long)clr * sg.plane] = (int16_t)v;
-                    fplanes[off + (long)clr * sg.plane] = (float)v / 255.0f;
+                    fplanes[off + (long)clr * sg.plane] = div255_exact((float)v);
                 }
             }
         }
@@ -1017,7 +1017,7 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_pair_kernel
                 sh_res[k & 1][gsym][1] = vhi;
                 const int v = lo - shift;
                 planes[off + (long)clr * sg.plane] = (int16_t)v;
-                fplanes[off + (long)clr * sg.plane] = (float)v / 255.0f;
+                fplanes[off + (long)clr * sg.plane] = div255_exact((float)v);
             }
         }
         // (the next step's operands are pinned in their registers here, in front of this step's window reload: see rans_decode_stage_lane_kernel)
@@ -1250,7 +1250,7 @@ __global__ __launch_bounds__(64 * Q) void rans_decode_stage_lane_kernel(const fl
             if (!have_lo) vlo = entry_exact(0);
             const int v = lo - shift;
             planes[off_k + (long)clr * sg.plane] = (int16_t)v;
-            fplanes[off_k + (long)clr * sg.plane] = (float)v / 255.0f;
+            fplanes[off_k + (long)clr * sg.plane] = div255_exact((float)v);
         }
         // The next step's CNN outputs were requested ~8,000 cycles ago and are pinned in their registers HERE, in front of the ring's refill
         // load: left alone, the compiler moves them into the loop-carried registers at the bottom of the loop, behind that load and the
@@ -1304,19 +1304,35 @@ __global__ __launch_bounds__(64 * Q) void rans_decode_stage_lane_kernel(const fl
 
 // After the last stage the 64 Q states of a stream ARE its tail stream (31 bits each, the tail coder's final state on top,
 // its leading one the highest set bit).  The T tail symbols -- all of the last stage's Cg channel (level 0, band x10) -- come out
-// of ONE coder state, serially; a lone wavefront spends ~540 instructions on a symbol and is bound by its own issue rate, so the
-// work is split over the four wavefronts of a workgroup (one per SIMD):
-//   * wavefronts 1..3 PREPARE symbols (everything that does not depend on the coder state): the position's CNN outputs, the
-//     component's mean / 1 / sigma / normalised weight exactly as mix_prepare() has them, and the approximate mixture at the 64
-//     anchors 8 l (Lp <= 512).  Round r + 1's three symbols are prepared (into the other half of a ping-pong LDS buffer) while
-//   * wavefront 0 DECODES round r's three: the anchors pick a bucket, 12 x 5 lanes evaluate the 12 exact table entries around it
-//     (lane = 5 e + mc: mixture component mc of window entry e), and a ballot proves the symbol (an exact 13-ary search takes over
-//     when the hint is wrong); state update, bit-granular renormalisation from the payload in LDS.
+// of ONE coder state, serially; a lone wavefront issues one instruction every ~4 cycles whatever it does, so everything that does not
+// depend on the coder state is done by other wavefronts of the workgroup:
+//   * kTailAhead wavefronts per chain PREPARE symbols: the position's CNN outputs, the component's mean / 1 / sigma / normalised
+//     weight exactly as mix_prepare() has them, the approximate mixture at the 64 anchors 8 l (Lp <= 512) -- and, round 5, a
+//     SPECULATED WINDOW: the twelve exact table entries around the mixture's median (where the approximate table crosses 2^15).
+//     Round r + 1's symbols are prepared (into the other half of a ping-pong LDS buffer) while
+//   * wavefront 0 DECODES round r's: if the slot lies inside the speculated window the symbol is proved by one compare, a ballot and
+//     two v_readlane, and the state update runs on the scalar unit (the state is wave-uniform); otherwise the anchors pick a bucket,
+//     12 x 5 lanes evaluate the 12 exact entries around it (lane = 5 e + mc: mixture component mc of window entry e) and a ballot
+//     proves the symbol (an exact 13-ary search takes over when that hint is wrong too).  Either way the symbol is the one an exact
+//     search of the whole row returns: the entries are the same bits wherever they are computed.  The renormalisation's bits come
+//     from two payload dwords requested at the top of the symbol (they depend on the cursor only); the round's pixels are stored
+//     together.
+// What the window buys depends on the source: on uniform noise (12.8 bits per symbol, tails of ~620 symbols) it is not offered (the
+// median's bucket holds a fiftieth of the mass) and nothing changes; on a source as cheap as the reference's trained model (1.7 bits
+// per symbol: tails of ~4,700 symbols, all on one chain) the tail launch of 24 x 10 xwide streams goes from 2.70 to 1.29 ms, 64-lane
+// streams 0.66 -> 0.34 (profiles/r5/tail_speculation.json: coder alone 1.2 ms, preparing wavefronts alone 1.2 ms).
 // One barrier per round.  Checks: the main region was read to its last bit, the tail state ends at its start state (freq << 15 of
-// the symbol the tail encoder began with; 2^31 when T = 0) with no bit left.  Xwide streams (two seeded chains, above): a second set of four
+// the symbol the tail encoder began with; 2^31 when T = 0) with no bit left.  Xwide streams (two seeded chains, above): a second set of
 // wavefronts runs chain B; the start states are seeds -- checked to be below A^n, with zero digits where the stream has no symbol -- the
-// chains' cursors must not have crossed and the payload between them must be zero.
-constexpr int kTailAhead = 3;                    // symbols per round = preparing wavefronts
+// chains' cursors must not have crossed and the payload between them must be zero.  A ONE-chain xwide stream (cheap symbols: the second
+// chain would cost its final state) leaves chain B's wavefronts idle: its preparing wavefronts join chain A's, a round is 2 kTailAhead symbols.
+#ifndef TAIL_AHEAD
+#define TAIL_AHEAD 4                            // (build switch for A/B runs: 2 / 3 / 4 / 5 measured, profiles/r5/tail_speculation.json)
+#endif
+#ifndef TAIL_SPEC
+#define TAIL_SPEC 1                             // the preparing wavefronts offer a speculated window (0: the coder always evaluates its own -- the kernel of rounds 3-4)
+#endif
+constexpr int kTailAhead = TAIL_AHEAD;           // symbols per round = preparing wavefronts
 
 template <int Q> constexpr int kTailChains = kSeeded<Q> ? 2 : 1;      // xwide: two chains, each with its own coder + preparing wavefronts
 
@@ -1330,22 +1346,29 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_t
     using GEO = RansGeo<Q>;
     constexpr int L = 64 * Q, NCH = kTailChains<Q>;
     __shared__ uint32_t sh_pay[64 * Q + 2];
-    __shared__ float sh_cmp[NCH][2][kTailAhead][16];    // [0..4] mu, [5..9] 1 / sigma, [10..14] normalised weight of the five components
-    __shared__ int sh_e1[NCH][2][kTailAhead][64];       // approximate table entry at anchor 8 l
-    __shared__ long sh_off[NCH][2][kTailAhead];         // the symbol's pixel
+    constexpr int NSL = NCH * kTailAhead;               // prepared symbols per round and buffer: slot = chain kTailAhead + i
+    __shared__ float sh_cmp[2][NSL][16];                // [0..4] mu, [5..9] 1 / sigma, [10..14] normalised weight of the five components
+    __shared__ int sh_e1[2][NSL][64];                   // approximate table entry at anchor 8 l
+    __shared__ long sh_off[2][NSL];                     // the symbol's pixel
+    __shared__ int sh_spec[2][NSL][16];                 // [0..11] the exact entries of the speculated window, [12] its first index (-1: none)
     __shared__ int sh_cur[2];                           // xwide: where the two chains stopped reading
     const int sidx = blockIdx.x;
     const StreamRef sr_ = sref[sidx];               // the stream's image, its index among the image's streams, the image's stream count (images of a call may differ)
     const int b = sr_.b, m = sr_.m, M = sr_.M;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (scalar: roles, chains and symbol counts are wave-uniform, their branches scalar)
     // role 0: the chain's coder.  A workgroup's wavefronts go to the four SIMDs round robin: with two chains the coders are wavefronts 0 and 1 (their
     // own SIMD each, shared with one preparing wavefront), not 0 and 4 (the same SIMD, taking turns at its issue port)
-    const int chain = wave % NCH, role = wave / NCH;
+    const int role = wave / NCH;
     const StageGeom sg = sgv[b];                 // the image's own stage geometry (the images of a call may differ in size)
     const int nc = sg.hc * sg.wc;
     const int cnt = rans_stream_count(nc, m, M, L);
     const int rt = (int)(rtail[sidx] & 0xFFFFu);
     const int nch = (kSeeded<Q> && !(rtail[sidx] >> 16)) ? 2 : 1;      // chains this stream's tail was coded with (xwide: its flag says one or two)
+    // A one-chain xwide stream (well-predicted content: the second chain would cost its final state) has twice the symbols on its chain and a
+    // second set of wavefronts with nothing to do: the idle chain's preparing wavefronts join chain 0's, and a round is 2 kTailAhead symbols.
+    const bool pool = NCH == 2 && nch == 1;
+    const int chain = (pool && role != 0) ? 0 : wave % NCH;
+    const int SA = pool ? NSL : kTailAhead;             // symbols of a chain per round = its preparing wavefronts
     bool bad = rpos[sidx] != 0 || rt > cnt;
     const int Tall = min(rt, cnt);                      // the stream's tail symbols: the coded ones, then (xwide) the seeds'
     int minv, maxv, shift;
@@ -1359,7 +1382,7 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_t
     const bool live = chain < nch;                      // (the second set of wavefronts idles through a one-chain stream's rounds)
     const int Tc = max(Tall - NS, 0);                   // coded symbols; the one with index idx (j = nch ns + idx from the stream's end) is on chain idx % nch
     const int T = live ? (Tc + nch - 1 - chain) / nch : 0;      // this chain's
-    const int R = ((Tc + nch - 1) / nch + kTailAhead - 1) / kTailAhead;      // rounds (chain 0 has the most symbols)
+    const int R = ((Tc + nch - 1) / nch + SA - 1) / SA;      // rounds (chain 0 has the most symbols)
     const long img = sg.img_off;
     const int mc = lane % 5, we = lane / 5;
     auto pixel_of = [&](int j) -> long {                 // the stream's j-th symbol from its end
@@ -1370,8 +1393,9 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_t
     };
 
     if (role != 0) {
-        // ---- preparing wavefronts: symbol t = kTailAhead r + (role - 1) of round r (t counts the chain's symbols in decoding order)
-        const int i = role - 1;
+        // ---- preparing wavefronts: symbol t = SA r + i of round r (t counts the chain's symbols in decoding order), prepared into slot sl
+        const int i = pool ? wave - NCH : role - 1;
+        const int sl = chain * kTailAhead + i;
         struct Row { float sg, mu, wk, bb, dd, y, co; long off; };
         auto fetch = [&](int t) -> Row {
             Row r;
@@ -1409,18 +1433,49 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_t
             float sum = 0.0f;
 #pragma unroll
             for (int k = 0; k < 5; ++k) { Comp ck; ck.mu = mu5[k]; ck.rsig = rs5[k]; ck.wn = wk5[k]; sum += term_fast(comp_fast(ck), pt1); }
-            sh_e1[chain][buf][i][lane] = (int)__builtin_rintf(sum * gr.scale) + i1;
-            if (lane < 5) { sh_cmp[chain][buf][i][lane] = mu; sh_cmp[chain][buf][i][5 + lane] = rsig; sh_cmp[chain][buf][i][10 + lane] = wn; }
-            if (lane == 0) sh_off[chain][buf][i] = row.off;
+            const int e1v = (int)__builtin_rintf(sum * gr.scale) + i1;
+            sh_e1[buf][sl][lane] = e1v;
+            if (lane < 5) { sh_cmp[buf][sl][lane] = mu; sh_cmp[buf][sl][5 + lane] = rsig; sh_cmp[buf][sl][10 + lane] = wn; }
+            if (lane == 0) sh_off[buf][sl] = row.off;
+            // The speculated window.  The coder's per-symbol chain is slot -> bucket -> 12 exact entries (an erfc and five cross-lane
+            // moves) -> ballot -> state update, ~2,500 cycles of which the exact entries are most -- and they depend on the coder state
+            // only through WHERE the window lies.  On a well-predicted source (the reference's trained model spends 1.7 bits per symbol of
+            // this channel) that is nearly always around the mixture's median, which is known here: the anchor bucket in which the
+            // approximate table crosses 2^15, refined linearly.  So the window's twelve entries are computed in THIS wavefront, with
+            // entry_at()'s operations in its order, and the coder only has to look: slot inside [entry 0, entry 11) proves the symbol
+            // exactly as its own window would (same entries, same ballot); outside, it falls back to its bucket search.  Not offered when
+            // the median's bucket holds less than an eighth of the mass (noise: the window would miss nine times in ten).
+            const int lst = __builtin_amdgcn_readfirstlane(__builtin_popcountll(ballot64(lane == 0 || (8 * lane <= max_symbol && e1v <= 0x8000))) - 1);
+            const int eL = __builtin_amdgcn_readlane(e1v, lst);
+            const int eH = (lst < 63 && 8 * (lst + 1) <= max_symbol) ? __builtin_amdgcn_readlane(e1v, min(lst + 1, 63)) : 0x10000;
+            int wbs = -1;
+            if (TAIL_SPEC && eH - eL >= 0x2000) {         // (wave-uniform)
+                const float fr = 8.0f * (float)(0x8000 - eL) * __builtin_amdgcn_rcpf((float)(eH - eL));
+                wbs = max(8 * lst + (int)__builtin_amdgcn_fmed3f(fr, 0.0f, 8.0f) - 5, 0);
+                const int idx = wbs + min(we, 11);
+                const float ptx = sample_pt(gr, min(idx, gr.Lp - 1));
+                const float term = wn * (0.5f * erfc_spec_nobranch(kNegRsqrt2 * ((ptx - mu) * rsig)));
+                const int g0 = 4 * 5 * min(we, 11);
+                const float a0 = __int_as_float(__builtin_amdgcn_ds_bpermute(g0, __float_as_int(term)));
+                const float a1 = __int_as_float(__builtin_amdgcn_ds_bpermute(g0 + 4, __float_as_int(term)));
+                const float a2 = __int_as_float(__builtin_amdgcn_ds_bpermute(g0 + 8, __float_as_int(term)));
+                const float a3 = __int_as_float(__builtin_amdgcn_ds_bpermute(g0 + 12, __float_as_int(term)));
+                const float a4 = __int_as_float(__builtin_amdgcn_ds_bpermute(g0 + 16, __float_as_int(term)));
+                const float acc = (((a0 + a1) + a2) + a3) + a4;
+                const float qf = __builtin_rintf(acc * gr.scale);
+                const uint32_t ent = (idx <= max_symbol) ? ((uint32_t)((int)qf + idx) & 0xFFFFu) : 0x10000u;
+                if (mc == 0 && we < 12) sh_spec[buf][sl][we] = (int)ent;
+            }
+            if (lane == 0) sh_spec[buf][sl][12] = wbs;
         };
         Row rowA = fetch(i);
-        Row rowB = fetch(kTailAhead + i);
+        Row rowB = fetch(SA + i);
         prepare(rowA, 0);
         __syncthreads();                                  // (payload assembled by wavefront 0)
         __syncthreads();                                  // round 0 is prepared
         for (int r = 0; r < R; ++r) {
-            const Row rowC = fetch(kTailAhead * (r + 2) + i);            // two rounds ahead: the loads run under a whole round
-            if (kTailAhead * (r + 1) + i < T) prepare(rowB, (r + 1) & 1);
+            const Row rowC = fetch(SA * (r + 2) + i);            // two rounds ahead: the loads run under a whole round
+            if (SA * (r + 1) + i < T) prepare(rowB, (r + 1) & 1);
             rowB = rowC;
             lds_barrier();      // LDS words only cross here: global loads / stores in flight stay in flight (common.hpp)
         }
@@ -1445,7 +1500,7 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_t
     uint32_t xt;
     int tc;                                               // bit cursor: legacy chains and xwide chain B read DOWN to it, xwide chain A reads UP from it
     if constexpr (kSeeded<Q>) {
-        xt = live ? sh_pay[chain ? GEO::kPayDw - 1 : 0] : (1u << 31);        // final states at fixed places
+        xt = live ? (uint32_t)__builtin_amdgcn_readfirstlane((int)sh_pay[chain ? GEO::kPayDw - 1 : 0]) : (1u << 31);        // final states at fixed places (the state is wave-uniform: kept scalar)
         tc = chain ? GEO::kPayBits - (live ? 32 : 0) : 32;
         if (!(xt >> 31)) { bad = true; xt |= 1u << 31; }
     } else {
@@ -1461,78 +1516,102 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_t
         // a malformed stream still gets its T tail pixels written (from whatever state there is): the output of a flagged image
         // must not depend on what the workspace held
         if (top < 31) bad = true;
-        xt = (top >= 31) ? lds_get_bits(sh_pay, top - 31, 32) : (1u << 31);
+        xt = (top >= 31) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_get_bits(sh_pay, top - 31, 32)) : (1u << 31);
         tc = (top >= 31) ? top - 31 : 0;
     }
     __syncthreads();                                      // round 0 is prepared
     for (int r = 0; r < R; ++r) {
         const int buf = r & 1;
-        for (int i = 0; i < kTailAhead && kTailAhead * r + i < T; ++i) {
-            const float mu = sh_cmp[chain][buf][i][mc], rsig = sh_cmp[chain][buf][i][5 + mc], wn = sh_cmp[chain][buf][i][10 + mc];
-            const int e1 = sh_e1[chain][buf][i][lane];
-            const long off = sh_off[chain][buf][i];
+        int vsym = 0;
+        for (int i = 0; i < SA && SA * r + i < T; ++i) {
+            const int sl = chain * kTailAhead + i;
             const uint32_t slot = xt & 0xFFFFu;
-            // exact entry idx (uniform in the lane's group of five): valid in every lane of the group
-            auto entry_at = [&](int idx) -> uint32_t {
-                const float pt = sample_pt(gr, min(idx, gr.Lp - 1));
-                const float term = wn * (0.5f * erfc_spec_nobranch(kNegRsqrt2 * ((pt - mu) * rsig)));
-                const int g0 = 4 * 5 * min(we, 11);
-                const float a0 = __int_as_float(__builtin_amdgcn_ds_bpermute(g0, __float_as_int(term)));
-                const float a1 = __int_as_float(__builtin_amdgcn_ds_bpermute(g0 + 4, __float_as_int(term)));
-                const float a2 = __int_as_float(__builtin_amdgcn_ds_bpermute(g0 + 8, __float_as_int(term)));
-                const float a3 = __int_as_float(__builtin_amdgcn_ds_bpermute(g0 + 12, __float_as_int(term)));
-                const float a4 = __int_as_float(__builtin_amdgcn_ds_bpermute(g0 + 16, __float_as_int(term)));
-                const float acc = (((a0 + a1) + a2) + a3) + a4;
-                const float qf = __builtin_rintf(acc * gr.scale);
-                return (idx <= max_symbol) ? ((uint32_t)((int)qf + idx) & 0xFFFFu) : 0x10000u;      // past the top symbol: c_high = 2^16
+            // 0. the window the preparing wavefront speculated on (around the mixture's median), if it offered one: its twelve exact entries are there
+            //    already -- lane k < 12 reads entry k, lane 12 the window's first index -- and the symbol is the last entry <= slot, proved when its
+            //    successor is in the window too.  Everything from here to the next state is wave-uniform and meant for the scalar unit: ballot,
+            //    count, two v_readlane, the state update.
+            const int wv = sh_spec[buf][sl][min(lane, 12)];
+            // the <= 16 bits the renormalisation will take lie in two dwords that only depend on the cursor: requested here, next to the window, so that
+            // the LDS round trip runs under the search instead of behind the state update
+            const bool up = kSeeded<Q> && chain == 0;            // xwide chain A reads UP from its cursor, everything else DOWN to it
+            const int wpos = min(max(up ? tc : tc - 16, 0), GEO::kPayBits);      // (a corrupt stream's cursor stays inside the payload array)
+            const uint32_t bw0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh_pay[wpos >> 5]);
+            const uint32_t bw1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh_pay[(wpos >> 5) + 1]);
+            auto take_bits = [&](int pos, int n) -> uint32_t {   // bits [pos, pos + n) of the payload, n <= 16, inside the window
+                const uint64_t w = ((uint64_t)bw1 << 32) | bw0;
+                return (uint32_t)(w >> (pos - (wpos & ~31))) & ((1u << n) - 1u);
             };
-            // 1. hint: the bucket of 8 entries the prepared anchors put the slot in
-            const uint64_t p1 = ballot64(lane == 0 || (8 * lane <= max_symbol && e1 <= (int)slot));
-            int wb = max(8 * (__builtin_popcountll(p1) - 1) - 2, 0);
-            // 2. proof: the 12 exact entries wb .. wb + 11; the symbol is the last one <= slot, its successor must be in the window too
-            uint32_t ent = entry_at(wb + we);
-            const uint64_t pw12 = ballot64(mc == 0 && we < 12 && wb + we <= max_symbol && (ent <= slot || wb + we == 0));
-            int np = __builtin_popcountll(pw12);
-            if (np == 0 || np == 12) {
-                // the hint was wrong (only absurd mixtures get here): exact 13-ary search from scratch, then the window at the result
-                int lo = 0, hi = max_symbol + 1;
-                while (hi - lo > 1) {
-                    const int stp = (hi - lo + 12) / 13;
-                    const int pi = min(lo + stp * (min(we, 11) + 1), hi - 1);
-                    const uint32_t e = entry_at(pi);
-                    const uint64_t pb = ballot64(mc == 0 && we < 12 && e <= slot);
-                    const int k = __builtin_popcountll(pb);                        // probes are ordered: the passes form a prefix
-                    const int nlo = (k > 0) ? min(lo + stp * k, hi - 1) : lo;
-                    const int nhi = (k < 12) ? min(lo + stp * (k + 1), hi - 1) : hi;
-                    lo = nlo; hi = nhi;
+            int wb = __builtin_amdgcn_readlane(wv, 12), np = 0;
+            if (wb >= 0) np = __builtin_popcountll(ballot64(lane < 12 && wb + lane <= max_symbol && ((uint32_t)wv <= slot || wb + lane == 0)));
+            uint32_t vlo, vhi;
+            if (np >= 1 && np <= 11) {
+                vlo = (uint32_t)__builtin_amdgcn_readlane(wv, np - 1);
+                vhi = (uint32_t)__builtin_amdgcn_readlane(wv, np);
+            } else {
+                const float mu = sh_cmp[buf][sl][mc], rsig = sh_cmp[buf][sl][5 + mc], wn = sh_cmp[buf][sl][10 + mc];
+                const int e1 = sh_e1[buf][sl][lane];
+                // exact entry idx (uniform in the lane's group of five): valid in every lane of the group
+                auto entry_at = [&](int idx) -> uint32_t {
+                    const float pt = sample_pt(gr, min(idx, gr.Lp - 1));
+                    const float term = wn * (0.5f * erfc_spec_nobranch(kNegRsqrt2 * ((pt - mu) * rsig)));
+                    const int g0 = 4 * 5 * min(we, 11);
+                    const float a0 = __int_as_float(__builtin_amdgcn_ds_bpermute(g0, __float_as_int(term)));
+                    const float a1 = __int_as_float(__builtin_amdgcn_ds_bpermute(g0 + 4, __float_as_int(term)));
+                    const float a2 = __int_as_float(__builtin_amdgcn_ds_bpermute(g0 + 8, __float_as_int(term)));
+                    const float a3 = __int_as_float(__builtin_amdgcn_ds_bpermute(g0 + 12, __float_as_int(term)));
+                    const float a4 = __int_as_float(__builtin_amdgcn_ds_bpermute(g0 + 16, __float_as_int(term)));
+                    const float acc = (((a0 + a1) + a2) + a3) + a4;
+                    const float qf = __builtin_rintf(acc * gr.scale);
+                    return (idx <= max_symbol) ? ((uint32_t)((int)qf + idx) & 0xFFFFu) : 0x10000u;      // past the top symbol: c_high = 2^16
+                };
+                // 1. hint: the bucket of 8 entries the prepared anchors put the slot in
+                const uint64_t p1 = ballot64(lane == 0 || (8 * lane <= max_symbol && e1 <= (int)slot));
+                wb = max(8 * (__builtin_popcountll(p1) - 1) - 2, 0);
+                // 2. proof: the 12 exact entries wb .. wb + 11; the symbol is the last one <= slot, its successor must be in the window too
+                uint32_t ent = entry_at(wb + we);
+                const uint64_t pw12 = ballot64(mc == 0 && we < 12 && wb + we <= max_symbol && (ent <= slot || wb + we == 0));
+                np = __builtin_popcountll(pw12);
+                if (np == 0 || np == 12) {
+                    // the hint was wrong (only absurd mixtures get here): exact 13-ary search from scratch, then the window at the result
+                    int lo = 0, hi = max_symbol + 1;
+                    while (hi - lo > 1) {
+                        const int stp = (hi - lo + 12) / 13;
+                        const int pi = min(lo + stp * (min(we, 11) + 1), hi - 1);
+                        const uint32_t e = entry_at(pi);
+                        const uint64_t pb = ballot64(mc == 0 && we < 12 && e <= slot);
+                        const int k = __builtin_popcountll(pb);                        // probes are ordered: the passes form a prefix
+                        const int nlo = (k > 0) ? min(lo + stp * k, hi - 1) : lo;
+                        const int nhi = (k < 12) ? min(lo + stp * (k + 1), hi - 1) : hi;
+                        lo = nlo; hi = nhi;
+                    }
+                    wb = lo;
+                    ent = entry_at(wb + we);
+                    np = 1;
                 }
-                wb = lo;
-                ent = entry_at(wb + we);
-                np = 1;
+                vlo = (uint32_t)__builtin_amdgcn_readlane((int)ent, 5 * (np - 1));
+                vhi = (uint32_t)__builtin_amdgcn_readlane((int)ent, 5 * np);
             }
-            const uint32_t vlo = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * 5 * (np - 1), (int)ent);
-            const uint32_t vhi = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * 5 * np, (int)ent);
-            const int s = wb + np - 1;
-            if (lane == 0) {
-                const int v = s - shift;
-                planes[off + 2 * sg.plane] = (int16_t)v;
-                fplanes[off + 2 * sg.plane] = (float)v / 255.0f;
-            }
+            vsym = (lane == i) ? wb + np - 1 - shift : vsym;      // the round's pixels are stored together, lane i symbol i (one vector store per round instead of a masked block per symbol)
             xt = (vhi - vlo) * (xt >> 16) + slot - vlo;
             if constexpr (kSeeded<Q>) {
                 int nb = __clz((int)xt);
                 const int avail = chain ? tc - 32 : GEO::kPayBits - (nch == 2 ? 32 : 0) - tc;      // (never into the other chain's state; whether the chains crossed is checked at the end)
-                if (nb > 16 || avail < nb) { bad = true; nb = min(nb, min(avail, 16)); }   // corrupt: keep going on what is there
+                if (nb > 16 || avail < nb) { bad = true; nb = max(min(nb, min(avail, 16)), 0); }   // corrupt: keep going on what is there
                 if (chain) tc -= nb;
-                xt = ((xt << nb) | lds_get_bits(sh_pay, tc, nb)) | (1u << 31);
+                xt = ((xt << nb) | take_bits(tc, nb)) | (1u << 31);
                 if (!chain) tc += nb;
-            } else if (kTailAhead * r + i == T - 1) bad = bad || xt != (vhi - vlo) << 15;      // the encoder's first symbol: absorbing start, no bits
+            } else if (SA * r + i == T - 1) bad = bad || xt != (vhi - vlo) << 15;      // the encoder's first symbol: absorbing start, no bits
             else {
                 int nb = __clz((int)xt);
-                if (nb > 16 || tc < nb) { bad = true; nb = min(nb, min(tc, 16)); }  // corrupt: keep going on what is there
+                if (nb > 16 || tc < nb) { bad = true; nb = max(min(nb, min(tc, 16)), 0); }  // corrupt: keep going on what is there
                 tc -= nb;
-                xt = ((xt << nb) | lds_get_bits(sh_pay, tc, nb)) | (1u << 31);
+                xt = ((xt << nb) | take_bits(tc, nb)) | (1u << 31);
             }
+        }
+        if (lane < SA && SA * r + lane < T) {
+            const long off = sh_off[buf][chain * kTailAhead + lane];
+            planes[off + 2 * sg.plane] = (int16_t)vsym;
+            fplanes[off + 2 * sg.plane] = div255_exact((float)vsym);      // (an integer in [-255, 255]: bit-identical to the division, numerics.hpp)
         }
         lds_barrier();      // LDS words only cross here: global loads / stores in flight stay in flight (common.hpp)
     }
@@ -1550,7 +1629,7 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_t
             const long off = img + ((long)(2 * pi + sg.oi) << sg.lvl) * sg.W + ((long)(2 * pj + sg.oj) << sg.lvl);
             const int pv = dg - shift;
             planes[off + 2 * sg.plane] = (int16_t)pv;
-            fplanes[off + 2 * sg.plane] = (float)pv / 255.0f;
+            fplanes[off + 2 * sg.plane] = div255_exact((float)pv);
         }
         bad = bad || ballot64(live && lane < ns && j >= NS && dg != 0) != 0;      // digits of symbols the stream does not have
         if (lane == 0) sh_cur[chain] = tc;

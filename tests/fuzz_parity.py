@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised HIP-vs-oracle parity hunt (GPU box): random shapes, image kinds, weight perturbations, containers.
 Test infrastructure (it calls the CPU oracle), hence under tests/; not collected by pytest (minutes of GPU time).
-usage: tests/fuzz_parity.py [N_CASES] [SEED] [SUMMARY.json] [xwide]   -- stops at the first mismatch with a reproducer line ("xwide": only the
+usage: tests/fuzz_parity.py [N_CASES] [SEED] [SUMMARY.json] [xwide] [corrupt]   -- stops at the first mismatch with a reproducer line ("xwide": only the
 256-lane containers, whose tail -- two seeded chains, radix-A seeds -- has the most cases: narrow value ranges, streams shorter than the seeds);
 the summary (cases, per-container / per-kind counts, wall time) is what profiles/<round>/fuzz_summary.json holds."""
 import collections, json, os, sys, time
@@ -15,7 +15,8 @@ from helpers import make_image
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-XWIDE_ONLY = len(sys.argv) > 4 and sys.argv[4] == "xwide"
+XWIDE_ONLY = len(sys.argv) > 4 and "xwide" in sys.argv[4:]
+CORRUPT_ALL = len(sys.argv) > 4 and "corrupt" in sys.argv[4:]      # every rANS case also decodes a corrupted copy (default: a third of them)
 gold = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 base = {w: dict(np.load(os.path.join(gold, f"weights_{w}.npz"))) for w in ("rand1337", "trainedlike")}
 t0 = time.time()
@@ -92,6 +93,46 @@ for case in range(N):
     for b in range(B):
         ref = orc.encode_image(imgs[b], W_o) if M == 0 else orc.encode_image_rans(imgs[b], W_o, Mb[b], wide)
         assert container_to_bytestream_list(ch[b], sh[b]) == ref, "BYTES " + tag + f" image {b}"
+    if M != 0 and (CORRUPT_ALL or rng.integers(0, 3) == 0):
+        # round 5, corrupted containers: bytes of ONE image's streams flipped -> the HIP decoder and the oracle agree on whether the image is malformed
+        # (status LLICTI_EFORMAT <=> the oracle's decoder refuses it) and, where neither notices (a flip the integrity checks cannot see), on every pixel;
+        # the other images of the call decode to their originals; nothing hangs or faults.  (The reference-format container has no integrity check.)
+        from llicti_amd._lib import LlictiError
+        bsel = int(rng.integers(0, B))
+        hdr, used = int(sh[bsel][:4].sum()), int(sh[bsel].sum())
+        bad = cont.clone()
+        for p_ in rng.integers(hdr, used, int(rng.choice([1, 1, 2, 8]))):
+            bad[bsel, int(p_)] ^= int(rng.integers(1, 256))
+        codec.poison_workspace(0x3C)
+        if ragged or per_image:
+            recb = codec.decode_v(bad, seg, Hs, Ws, modes)
+            offs = HipCodec.flat_offsets(Hs, Ws)[0]
+            got = [recb[int(offs[b]):int(offs[b]) + 3 * Hs[b] * Ws[b]].view(3, Hs[b], Ws[b]).cpu().numpy() for b in range(B)]
+        else:
+            codec.workspace(B, H, W, mode)
+            recb = codec.decode(bad, seg, H, W, mode=mode)
+            got = [recb[b].cpu().numpy() for b in range(B)]
+        try:
+            codec.check()
+            flagged = False
+        except LlictiError:
+            flagged = True
+        st = codec.image_status(B)
+        assert flagged == bool(st.any()), "STATUS " + tag
+        try:
+            want = orc.decode_image_rans(container_to_bytestream_list(bad[bsel].cpu().numpy(), sh[bsel]), W_o)
+        except RuntimeError:
+            want = None
+        assert (st[bsel] != 0) == (want is None), "CORRUPT VERDICT " + tag + f" image {bsel}: hip status {st[bsel]}, oracle {'refuses' if want is None else 'accepts'}"
+        if want is not None:
+            assert np.array_equal(got[bsel], want), "CORRUPT PIXELS " + tag + f" image {bsel}"
+            counts["corrupt_undetected_same_pixels"] += 1
+        else:
+            counts["corrupt_detected_by_both"] += 1
+        for b in range(B):
+            if b != bsel:
+                assert st[b] == 0 and np.array_equal(got[b], imgs[b]), "CORRUPT NEIGHBOUR " + tag + f" image {b}"
+        counts["corrupted_containers"] += 1
     if ragged: counts["mixed_size_calls"] += 1
     if per_image: counts["stream_count_per_image_calls"] += 1
     if big: counts["big_cheap_images"] += 1
@@ -106,4 +147,4 @@ print("fuzz ok:", N, "cases")
 if len(sys.argv) > 3:
     json.dump({"tool": "tests/fuzz_parity.py", "cases": N, "seed": int(sys.argv[2]), "mismatches": 0, "pixels": pixels,
                "wall_s": round(time.time() - t0, 1), "containers": "xwide only" if XWIDE_ONLY else "all", "checked": "decode(encode(x)) == x on a poisoned workspace; every image's container "
-               "byte-identical to the CPU oracle's", "counts": dict(sorted(counts.items()))}, open(sys.argv[3], "w"), indent=1)
+               "byte-identical to the CPU oracle's; corrupted rANS containers (byte flips in one image's streams): HIP status == the oracle's verdict, equal pixels where neither notices, neighbours intact", "counts": dict(sorted(counts.items()))}, open(sys.argv[3], "w"), indent=1)
