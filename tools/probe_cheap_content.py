@@ -90,6 +90,12 @@ for kind in ("sharp", "single"):
             cat, _ = codec.last_timing_detail()
             codec.set_profiling(False)
             row["decode_kernel_ms"] = {k: round(v, 3) for k, v in cat.items() if v > 0}
+            codec.set_profiling(True)
+            codec.encode(x, mode=mode, out=c, seg_len=s)
+            torch.cuda.synchronize()
+            cat, _ = codec.last_timing_detail()
+            codec.set_profiling(False)
+            row["encode_kernel_ms"] = {k: round(v, 3) for k, v in cat.items() if v > 0}
             t16 = c[0, int(s[0, :4].sum()):int(s[0, :4].sum()) + 2].cpu().numpy()
             tf = int(t16[0]) | (int(t16[1]) << 8)
             row["T_field_stream0"] = (tf & 0x7FF) | ((tf >> 15) << 11) if name.startswith("x") else tf & 0x7FF
