@@ -90,7 +90,7 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
     const int sidx = blockIdx.x;
     const StreamRef sr_ = sref[sidx];               // the stream's image, its index among the image's streams, the image's stream count (images of a call may differ)
     const int b = sr_.b, m = sr_.m, M = sr_.M;
-    const int tid = threadIdx.x, lane = tid & 63, wq = tid >> 6;      // wavefront wq codes sub-chunk wq (stream lanes 64 wq .. 64 wq + 63)
+    const int tid = threadIdx.x, lane = tid & 63, wq = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wavefront wq codes sub-chunk wq (stream lanes 64 wq .. 64 wq + 63); scalar: what depends on it alone branches on the scalar unit
     const StageGeom sgl = sglv[b];                  // the image's last stage (level 0, band x10): an xwide stream's seed symbols are read from its pixels
     uint8_t *slot = slots + rslot_off[sidx];
     uint32_t *out32 = reinterpret_cast<uint32_t *>(slot + 4);
@@ -174,6 +174,7 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
             if (wq < 2) {                               // (an idle chain B records no steps and reports 0 bits)
                 const int nst = min(32, n_own - 32 * blk);
                 if (lane == 0) sh_xs[wq][0] = xc;
+                uint32_t recv = 0, xsv = 0;             // lane t: step t's record and the state behind it -- written to LDS once per block, not once per step
                 for (int t = 0; t < nst; ++t) {
                     const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)raw, t);
                     const uint32_t lo = v & 0xFFFFu;
@@ -182,11 +183,12 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
                     uint32_t freq = hi - lo;
                     if (freq == 0 || hi < lo) { bad = 1; freq = 1; }
                     const int nb = rans_emit_bits(xc, freq);
-                    if (lane == 0) sh_fld[nch * (32 * blk + t) + wq] = (xc & ((1u << nb) - 1u)) | ((uint32_t)nb << 16);
+                    recv = (lane == t) ? ((xc & ((1u << nb) - 1u)) | ((uint32_t)nb << 16)) : recv;
                     used += nb;
                     xc = rans_push(xc >> nb, lo, freq);
-                    if (lane == 0) sh_xs[wq][t + 1] = xc;
+                    xsv = (lane == t) ? xc : xsv;
                 }
+                if (lane < nst) { sh_fld[nch * (32 * blk + lane) + wq] = recv; sh_xs[wq][lane + 1] = xsv; }
                 if (lane == 0) sh_used[blk & 1][wq] = used;
             }
             __syncthreads();
