@@ -1739,6 +1739,33 @@ def test_rans_xwide_long_tail_bitexact(torch_mod, kind):
         c.close()
 
 
+@pytest.mark.parametrize("kind", ["sharp", "single"])
+def test_tail_speculated_window_all_stream_kinds(torch_mod, kind):
+    """Round 5: the tail decoder looks at a window its preparing wavefronts speculated on (around the mixture's median) before it searches.  On
+    cheap, model-drawn content the window is offered for nearly every symbol and most slots fall inside it ("single": all but the rare tail
+    symbol; "sharp": a few per cent miss and take the bucket search behind an offered window) -- every stream kind (64 / 128 / 256 lanes, one
+    tail chain or two, the pooled wavefronts of a one-chain xwide stream) decodes to the original on a poisoned workspace, and the bytes it
+    decodes are the oracle's."""
+    from test_oracle_golden import _cheap_case
+    from llicti_amd.codec import HipCodec, container_to_bytestream_list, mode_of_name
+    from oracle import oracle as orc
+    torch = torch_mod
+    sd, W_o, img = _cheap_case(kind)
+    c = HipCodec("cuda:0")
+    try:
+        c.load_state_dict(sd)
+        x = _dev(torch, np.stack([img, img[:, :, ::-1].copy(), img[:, ::-1].copy()]))
+        for name, M, wide in (("rans1", 1, 0), ("rans4", 4, 0), ("wrans1", 1, 1), ("wrans3", 3, 1), ("xrans1", 1, 2), ("xrans3", 3, 2)):
+            mode = mode_of_name(name)
+            cont, seg = c.encode(x, mode=mode)
+            c.check()
+            assert container_to_bytestream_list(cont[0].cpu().numpy(), seg[0].cpu().numpy()) == orc.encode_image_rans(img, W_o, M, wide), (kind, name)
+            rec = _decode_poisoned(c, cont, seg, img.shape[1], img.shape[2], mode)
+            assert np.array_equal(rec.cpu().numpy(), x.cpu().numpy()), (kind, name)
+    finally:
+        c.close()
+
+
 def test_mixed_size_batch_caller_placed_rgb(torch_mod, codecs):
     """llicti_encode_images_v / llicti_decode_images_v with caller-chosen byte offsets of the images in the RGB buffer (`rgb_off`: gaps between the
     images, unaligned starts, a different order in memory than in the call): the containers are those of the tightly packed call, the decoder
