@@ -24,6 +24,22 @@ MODE_AC = 0                      # the reference's container: 45 torchac-algorit
 MAX_STREAMS_IN_BUDGET = 10       # an xwide v3 stream (seeded tail chains, two where they pay) costs ~2-4 bytes: 10 per 768x512 image are +0.0003 (noise) ... +0.0008 (an image drawn from the model) bpp over the reference-format container
 XWIDE_MIN_TAIL = 2048            # last-stage symbols a 256-lane stream needs for its tail to fill the 7,936-bit payload its initial states carry (the format's cap is 2,047 tail symbols)
 NARROW_MIN_TAIL = 512            # ... and a 64-lane stream for its 1,984 bits
+CHEAP_LAST_STAGE_BITS = 4.0      # bits per symbol of the last stage's Cg stream below which "auto" leaves the xwide streams: their tail's seed symbols are raw (9 bits each
+                                 # where the model would spend < 4) and a tail beyond 4,094 symbols pays a 2-byte escape -- measured on 24 x 768x512 model-drawn images:
+                                 # xrans10 +0.0009 bpp at 3.75 bits, +0.0014 at 1.71 (the reference's trained model on natural images: 1.68), rans10 +0.0008 / +0.0009
+CHEAP_NARROW_MIN_TAIL = 1280     # last-stage symbols a 64-lane stream needs on such a source (1,984 bits at ~1.6 bits per symbol; the format's cap: 2,047)
+
+
+def last_stage_bits(seg_len, H, W):
+    """Bits per symbol the LAST stage's Cg stream (segment 48: level 0, band x10) of a coded image took -- what the encoder's host side knows about the
+    content without looking at a pixel.  seg_len: the image's 49 segment lengths."""
+    return 8.0 * float(seg_len[NSEG - 1]) / max(1, (H // 2) * (W // 2))
+
+
+def narrow_streams_in_budget(H, W, cheap=True):
+    """64-lane streams per image inside +0.001 bpp (same byte rule as streams_in_budget; the payload rule for 1,984 bits)."""
+    nc_last = (H // 2) * (W // 2)
+    return max(0, min(MAX_STREAMS_IN_BUDGET, nc_last // (CHEAP_NARROW_MIN_TAIL if cheap else NARROW_MIN_TAIL), int((H * W / 8000.0 + 25.0) / 7.0)))
 
 
 def streams_in_budget(H, W):
@@ -48,13 +64,20 @@ def auto_streams(B, n_cu=256, sizes=None):
     return m
 
 
-def auto_container(B, n_cu=256, sizes=None):
+def auto_container(B, n_cu=256, sizes=None, cheap=False):
     """Name of the throughput container for B images per call: xwide streams (256 lanes, one decoder lane per symbol -- lanes are nearly
     free in bytes, 0.06 bit each; streams are not, ~2-3.5 bytes each), auto_streams(B) of them per image.  With `sizes` (the (H, W) of the
     images): small images get fewer streams, below ~90x90 pixels one 64-lane stream ("rans1"), below ~45x45 the reference format ("ac";
     a batch of MIXED sizes stays in "rans1", the reference format codes one size per call) -- so that the container stays within +0.001 bpp
     of the reference-format one at every size.  What no size rule can see is the CONTENT: a source cheaper than ~3.9 bits per symbol in the
-    last stage (2,047 tail symbols cannot fill 7,936 bits) wastes part of every xwide stream's payload whatever the size -- DESIGN section 8."""
+    last stage (2,047 tail symbols cannot fill 7,936 bits) wastes part of every xwide stream's payload whatever the size -- DESIGN section 8.
+    `cheap`: the caller has SEEN such content (last_stage_bits() of what it coded so far below CHEAP_LAST_STAGE_BITS): 64-lane streams ("rans<M>",
+    +0.0009 bpp at ten per 768x512 image where xrans10 is at +0.0014; 3-6 % slower)."""
+    if cheap:
+        m = max(1, min(MAX_STREAMS_IN_BUDGET, n_cu // max(1, B)))
+        if sizes:
+            m = min(m, min(narrow_streams_in_budget(h, w) for h, w in sizes))
+        return f"rans{max(m, 1)}"
     m = auto_streams(B, n_cu, sizes)
     if m >= 1:
         return f"xrans{m}"
@@ -64,12 +87,14 @@ def auto_container(B, n_cu=256, sizes=None):
     return "ac"
 
 
-def balanced_modes(sizes, n_cu=256, wide=2):
+def balanced_modes(sizes, n_cu=256, wide=2, cheap=False):
     """Container modes for the images of ONE call of mixed sizes (llicti_encode_images_vm): xwide streams, their number per image in proportion to
     the image's pixels -- so that all streams of the call are equally long (a decoder stage takes as long as its longest stream) -- with at most
     `n_cu` streams in all (one decoder workgroup per stream and compute unit) and every image inside its own byte budget (streams_in_budget).  An
     image too small for an xwide stream makes the whole call fall back to one 64-lane stream per image."""
-    budgets = [streams_in_budget(h, w) for h, w in sizes]
+    if cheap:                                       # content seen to be cheap (auto_container): 64-lane streams, their own budget rule
+        wide = 0
+    budgets = [(narrow_streams_in_budget(h, w) if wide == 0 else streams_in_budget(h, w)) for h, w in sizes]
     if min(budgets) < 1:
         return [MODE_RANS(1)] * len(sizes)
     pix = [h * w for h, w in sizes]

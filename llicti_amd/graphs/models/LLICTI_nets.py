@@ -19,7 +19,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from ...codec import (MODE_AC, MODE_RANS, NSEG, HipCodec, auto_container, balanced_modes, bytestream_list_to_container, container_to_bytestream_list,
+from ...codec import (CHEAP_LAST_STAGE_BITS, MODE_AC, MODE_RANS, NSEG, HipCodec, auto_container, balanced_modes, bytestream_list_to_container, container_to_bytestream_list, last_stage_bits,
                       header_dims, mode_of_header, mode_of_name)
 from ...config import check_supported
 
@@ -109,6 +109,11 @@ class LLICTI(nn.Module):
         self.mode = None if self.container == "auto" else mode_of_name(self.container)
         # container "auto" on a batch of mixed sizes: a stream count per image (llicti_amd.codec.balanced_modes) unless config.balance_streams = False
         self.balance_streams = bool(config["balance_streams"]) if "balance_streams" in config else True
+        # container "auto" and the CONTENT: what the images coded so far spent per symbol of their last stage (a running mean the host keeps from the
+        # segment lengths it downloads anyway); below CHEAP_LAST_STAGE_BITS the next calls use 64-lane streams, which stay inside the bpp budget on
+        # such sources (llicti_amd.codec.auto_container; config.content_aware = False switches it off)
+        self.content_aware = bool(config["content_aware"]) if "content_aware" in config else True
+        self.content_bits = None
         self._stage = {}                # pinned host staging buffers of the batched path, by (tag, slot): [buffer, event behind its last copy]
         self._xfer = {}                 # (upload, download) copy streams of the batched path, by device index
 
@@ -167,11 +172,20 @@ class LLICTI(nn.Module):
             return self.mode
         dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+        cheap = self.content_aware and self.content_bits is not None and self.content_bits < CHEAP_LAST_STAGE_BITS
         if self.balance_streams and sizes and len(sizes) == B and len(set(sizes)) > 1:
             # images of different sizes in one call: a stream count per image, in proportion to its pixels (all streams equally long: a decoder
             # stage takes as long as its longest stream), each image inside its own byte budget -- llicti_encode_images_vm
-            return balanced_modes(sizes, n_cu)
-        return mode_of_name(auto_container(B, n_cu, sizes=sizes))
+            return balanced_modes(sizes, n_cu, cheap=cheap)
+        return mode_of_name(auto_container(B, n_cu, sizes=sizes, cheap=cheap))
+
+    def note_content(self, seg_len, Hs, Ws):
+        """Book what a coded batch spent on its last stage (seg_len: int32 [B, 49] on the host): a running mean over the images seen, the newest batch
+        weighing a quarter -- container "auto" reads it (mode_for_batch)."""
+        bits = [last_stage_bits(seg_len[b], int(h), int(w)) for b, (h, w) in enumerate(zip(Hs, Ws)) if (int(h) // 2) * (int(w) // 2) >= 4096]
+        if bits:
+            m = float(np.mean(bits))
+            self.content_bits = m if self.content_bits is None else 0.75 * self.content_bits + 0.25 * m
 
     def _pinned(self, key, nbytes):
         """Pinned host staging buffer (flat uint8, at least nbytes, grown to the running maximum) of `key` = (tag, slot).  The buffer's last
@@ -266,6 +280,7 @@ class LLICTI(nn.Module):
         cont.record_stream(down)
         seg.record_stream(down)
         enc = EncodedBatch(codec, rgb, cont_h, seg_h, ev, x_ycocg, mode, Hs, Ws)
+        enc.note = self.note_content
         enc.t0 = t0
         return enc
 
@@ -362,6 +377,7 @@ class EncodedBatch:
         self.Hs, self.Ws = Hs, Ws           # per image (a list batch: rgb is the flat device buffer, the images back to back)
         self.t0 = None                      # list batches: timing event on the compute stream behind the wait for the upload
         self._lists = None
+        self.note = None                    # LLICTI.note_content: the model books what the batch's last stage cost (container "auto")
 
     def lists(self, check=True):
         """Wait for the download (NOT for anything enqueued after it) and cut the containers into bytestream_lists (6 lists x 9 `bytes`).
@@ -372,4 +388,6 @@ class EncodedBatch:
                 self.codec.check()
             seg_np, cont_np = self.seg_h.numpy(), self.cont_h.numpy()
             self._lists = [container_to_bytestream_list(cont_np[b], seg_np[b]) for b in range(seg_np.shape[0])]
+            if self.note is not None and self.Hs is not None:
+                self.note(seg_np, self.Hs, self.Ws)
         return self._lists

@@ -715,6 +715,44 @@ def test_agent_batched_eval_equals_unbatched(torch_mod, tmp_path, caplog, oracle
     assert res_m[2]["bytestream_list"] == orc.encode_image(imgs[2], W_o)
 
 
+def test_agent_auto_container_follows_the_content(torch_mod):
+    """Container "auto" and the content (round 5): the agent's model books what every coded batch spent per symbol of its last stage (from the
+    segment lengths the host downloads anyway); on a source as cheap as the reference's trained model the first batches -- content unknown --
+    go out in xwide streams, the later ones in 64-lane streams, which stay inside the bpp budget there (tests/test_oracle_golden.py::
+    test_auto_container_budget_on_cheap_content).  Every image is lossless and the switched batches' bytes are the oracle's."""
+    from test_oracle_golden import _cheap_case
+    from oracle import oracle as orc
+    from llicti_amd.agents.llicti_agent import LLICTIAgent
+    from llicti_amd.codec import CHEAP_LAST_STAGE_BITS, _mode_wide, auto_container, mode_of_header, mode_of_name
+    from llicti_amd.config import default_config
+    from llicti_amd.weights import load_reference_state_dict
+    torch = torch_mod
+    sd, W_c, img0 = _cheap_case("single")
+    H, W = img0.shape[1:]
+    bl0 = orc.encode_image(make_image("smooth", H, W, 11), W_c)
+    imgs = [img0]
+    for seed in (6, 7, 8, 9, 10):                       # five more images drawn from the same model
+        rng = np.random.default_rng(seed)
+        bl = [list(bl0[0])] + [[rng.integers(0, 256, len(x), dtype=np.uint8).tobytes() for x in row] for row in bl0[1:]]
+        imgs.append(orc.decode_image(bl, W_c))
+    a = LLICTIAgent(default_config(test_data=imgs, eval_batch=2, container="auto", keep_streams=True))
+    load_reference_state_dict(a.model, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    res = a.run()
+    assert len(res) == 6 and all(r["max_abs_err"] == 0.0 for r in res)
+    assert a.model.content_bits is not None and a.model.content_bits < CHEAP_LAST_STAGE_BITS
+    modes = [mode_of_header(r["bytestream_list"][0][0][0]) for r in res]
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    assert modes[0] == modes[1] == mode_of_name(auto_container(2, n_cu, sizes=[(H, W)]))                    # content unknown: the size rule's xwide streams
+    want = mode_of_name(auto_container(2, n_cu, sizes=[(H, W)], cheap=True))
+    assert _mode_wide(modes[0]) == 2 and _mode_wide(want) == 0
+    assert modes[4] == modes[5] == want                                                                     # seen to be cheap: 64-lane streams
+    assert res[5]["bytestream_list"] == orc.encode_image_rans(imgs[5], W_c, want & 0xFF, 0)
+    # switched off by the config: the size rule alone
+    b = LLICTIAgent(default_config(test_data=imgs[:4], eval_batch=2, container="auto", keep_streams=True, content_aware=False))
+    load_reference_state_dict(b.model, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    assert all(_mode_wide(mode_of_header(r["bytestream_list"][0][0][0])) == 2 for r in b.run())
+
+
 def test_cli_file_roundtrip(torch_mod, tmp_path, capsys):
     """image file -> .llic -> image file through the command-line front end, both containers."""
     from llicti_amd import cli, fileio
