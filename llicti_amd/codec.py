@@ -31,9 +31,30 @@ CHEAP_NARROW_MIN_TAIL = 1280     # last-stage symbols a 64-lane stream needs on 
 
 
 def last_stage_bits(seg_len, H, W):
-    """Bits per symbol the LAST stage's Cg stream (segment 48: level 0, band x10) of a coded image took -- what the encoder's host side knows about the
-    content without looking at a pixel.  seg_len: the image's 49 segment lengths."""
+    """Bits per symbol the LAST stage's Cg stream (segment 48: level 0, band x10) of an image in the REFERENCE-FORMAT container took -- what the
+    encoder's host side knows about the content without looking at a pixel.  seg_len: the image's 49 segment lengths."""
     return 8.0 * float(seg_len[NSEG - 1]) / max(1, (H // 2) * (W // 2))
+
+
+def content_bits(container, seg_len, mode, H, W):
+    """The same quantity from a coded image in ANY container (container: the image's bytes, uint8; seg_len: its 49 segment lengths), or None where
+    the container does not say.  A rANS v3 stream interleaves all stages, but its TAIL is made of last-stage Cg symbols only, as many as fill the
+    31 bits x lanes its initial states carry -- so the tail count T in the first u16 of the image's first stream prices them: 31 lanes / T bits per
+    symbol (xwide: T's twelfth bit is bit 15, and 4,095 stands for "4,095 or more").  None: no tail (a stream shorter than its payload: small images)
+    or a mode whose segments start with a length table (64 / 128 streams)."""
+    if mode == MODE_AC:
+        return last_stage_bits(seg_len, H, W)
+    wide, M = _mode_wide(mode), mode & 0xFF
+    if M > 32:
+        return None
+    off = int(seg_len[0]) + int(seg_len[1]) + int(seg_len[2]) + int(seg_len[3])
+    if int(seg_len[4]) < 2:
+        return None
+    t16 = int(container[off]) | (int(container[off + 1]) << 8)
+    T = (t16 & 0x7FF) | (((t16 >> 15) << 11) if wide == 2 else 0)
+    if T == 0:
+        return None
+    return 31.0 * (64 << wide) / T
 
 
 def narrow_streams_in_budget(H, W, cheap=True):

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from ...codec import (CHEAP_LAST_STAGE_BITS, MODE_AC, MODE_RANS, NSEG, HipCodec, auto_container, balanced_modes, bytestream_list_to_container, container_to_bytestream_list, last_stage_bits,
+from ...codec import (CHEAP_LAST_STAGE_BITS, MODE_AC, MODE_RANS, NSEG, HipCodec, auto_container, balanced_modes, bytestream_list_to_container, container_to_bytestream_list, content_bits,
                       header_dims, mode_of_header, mode_of_name)
 from ...config import check_supported
 
@@ -179,10 +179,13 @@ class LLICTI(nn.Module):
             return balanced_modes(sizes, n_cu, cheap=cheap)
         return mode_of_name(auto_container(B, n_cu, sizes=sizes, cheap=cheap))
 
-    def note_content(self, seg_len, Hs, Ws):
-        """Book what a coded batch spent on its last stage (seg_len: int32 [B, 49] on the host): a running mean over the images seen, the newest batch
-        weighing a quarter -- container "auto" reads it (mode_for_batch)."""
-        bits = [last_stage_bits(seg_len[b], int(h), int(w)) for b, (h, w) in enumerate(zip(Hs, Ws)) if (int(h) // 2) * (int(w) // 2) >= 4096]
+    def note_content(self, cont, seg_len, mode, Hs, Ws):
+        """Book what a coded batch spent per symbol of its last stage (cont: uint8 [B, stride] and seg_len: int32 [B, 49] on the host; mode: the call's,
+        or one per image; llicti_amd.codec.content_bits): a running mean over the images seen, the newest batch weighing a quarter -- container
+        "auto" reads it (mode_for_batch)."""
+        modes = [int(mode)] * len(Hs) if isinstance(mode, (int, np.integer)) else [int(m) for m in mode]
+        bits = [content_bits(cont[b], seg_len[b], modes[b], int(h), int(w)) for b, (h, w) in enumerate(zip(Hs, Ws))]
+        bits = [v for v in bits if v is not None]
         if bits:
             m = float(np.mean(bits))
             self.content_bits = m if self.content_bits is None else 0.75 * self.content_bits + 0.25 * m
@@ -389,5 +392,5 @@ class EncodedBatch:
             seg_np, cont_np = self.seg_h.numpy(), self.cont_h.numpy()
             self._lists = [container_to_bytestream_list(cont_np[b], seg_np[b]) for b in range(seg_np.shape[0])]
             if self.note is not None and self.Hs is not None:
-                self.note(seg_np, self.Hs, self.Ws)
+                self.note(cont_np, seg_np, self.mode, self.Hs, self.Ws)
         return self._lists

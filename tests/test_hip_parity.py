@@ -747,6 +747,12 @@ def test_agent_auto_container_follows_the_content(torch_mod):
     assert _mode_wide(modes[0]) == 2 and _mode_wide(want) == 0
     assert modes[4] == modes[5] == want                                                                     # seen to be cheap: 64-lane streams
     assert res[5]["bytestream_list"] == orc.encode_image_rans(imgs[5], W_c, want & 0xFF, 0)
+    # content that is not cheap (noise, seed-1337 weights: 12.8 bits per last-stage symbol) never leaves the xwide streams
+    noise = [make_image("noise", H, W, 50 + i) for i in range(6)]
+    n = LLICTIAgent(default_config(test_data=noise, eval_batch=2, container="auto", keep_streams=True))
+    res_n = n.run()
+    assert all(_mode_wide(mode_of_header(r["bytestream_list"][0][0][0])) == 2 and r["max_abs_err"] == 0.0 for r in res_n)
+    assert n.model.content_bits is not None and n.model.content_bits > 8.0, n.model.content_bits
     # switched off by the config: the size rule alone
     b = LLICTIAgent(default_config(test_data=imgs[:4], eval_batch=2, container="auto", keep_streams=True, content_aware=False))
     load_reference_state_dict(b.model, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})

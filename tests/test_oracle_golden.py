@@ -485,7 +485,7 @@ def test_auto_container_budget_on_cheap_content(kind, oracle_weights):
     content -- llicti_amd.codec.last_stage_bits() of the segment lengths -- is below CHEAP_LAST_STAGE_BITS, and the container "auto" picks once it
     has seen that (auto_container(..., cheap=True): 64-lane streams) is inside +0.001 bpp.  Natural-like fixtures stay on the xwide side."""
     from helpers import make_image
-    from llicti_amd.codec import CHEAP_LAST_STAGE_BITS, _mode_wide, auto_container, last_stage_bits, mode_of_name
+    from llicti_amd.codec import CHEAP_LAST_STAGE_BITS, _mode_wide, auto_container, bytestream_list_to_container, content_bits, last_stage_bits, mode_of_name
     sd, W_c, img = _cheap_case(kind)
     H, W = img.shape[1:]
     bl_ac = orc.encode_image(img, W_c)
@@ -500,6 +500,9 @@ def test_auto_container_budget_on_cheap_content(kind, oracle_weights):
         bl = orc.encode_image_rans(img, W_c, mode & 0xFF, _mode_wide(mode))
         assert np.array_equal(orc.decode_image_rans(bl, W_c), img)
         deltas[cheap] = 8.0 * (sum(len(s) for row in bl for s in row) - ac) / (H * W)
+        # ... and what the host reads off a rANS container: the tail count of the image's first stream prices the last stage's symbols
+        cb = content_bits(*bytestream_list_to_container(bl), mode, H, W)
+        assert cb is not None and cb < CHEAP_LAST_STAGE_BITS, (name, cb)
     assert deltas[True] <= 0.001, deltas
     if kind == "single":
         assert deltas[False] > 0.001, deltas                   # the xwide choice of the size rule alone: over the budget on this source
@@ -508,6 +511,12 @@ def test_auto_container_budget_on_cheap_content(kind, oracle_weights):
     bl_n = orc.encode_image(make_image("smooth", H, W, 11), W_t)
     seg_n = [len(s) for s in bl_n[0][:4]] + [len(s) for row in bl_n[1:] for s in row]
     assert last_stage_bits(seg_n, H, W) > CHEAP_LAST_STAGE_BITS
+    for name, wts, kind_n in (("xrans5", W_t, "smooth"), ("rans5", W_t, "smooth"), ("wrans3", W_t, "smooth"), ("xrans5", oracle_weights("rand1337"), "noise")):
+        mode = mode_of_name(name)
+        bl = orc.encode_image_rans(make_image(kind_n, H, W, 11), wts, mode & 0xFF, _mode_wide(mode))
+        cb = content_bits(*bytestream_list_to_container(bl), mode, H, W)
+        assert cb is not None and cb > CHEAP_LAST_STAGE_BITS, (name, kind_n, cb)
+    assert content_bits(*bytestream_list_to_container(bl_n), 0, H, W) == last_stage_bits(seg_n, H, W)      # reference format: the last segment
 
 
 def _fullsize_samples():
