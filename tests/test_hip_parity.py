@@ -759,6 +759,29 @@ def test_agent_auto_container_follows_the_content(torch_mod):
     assert all(_mode_wide(mode_of_header(r["bytestream_list"][0][0][0])) == 2 for r in b.run())
 
 
+def test_native_client_without_torch(torch_mod, tmp_path):
+    """The drop-in boundary is a C library: tools/native_client.cpp -- no Python, no PyTorch in its process, plain hipMalloc buffers -- is
+    compiled against include/llicti_hip.h, linked with the in-tree libllicti_hip.so and run: encode -> decode on an overwritten workspace
+    is lossless in the throughput container and in the reference's format, and a corrupted container is reported (LLICTI_EFORMAT, the
+    image named, its neighbours intact).  (torch_mod only gates the test on a GPU box.)"""
+    import os
+    import shutil
+    import subprocess
+    from llicti_amd import _lib
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("no hipcc on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so_dir = os.path.dirname(_lib.SO_PATH)
+    exe = str(tmp_path / "native_client")
+    subprocess.check_call([hipcc, "-O2", "-std=c++17", "--offload-arch=gfx950", "-I", os.path.join(root, "include"), os.path.join(root, "tools", "native_client.cpp"),
+                           "-L", so_dir, "-lllicti_hip", "-Wl,-rpath," + so_dir, "-o", exe])
+    for args in ([], ["3", "150", "131", "2"], ["2", "256", "384", "10"]):
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "native client ok" in r.stdout, (args, r.stdout[-800:], r.stderr[-800:])
+        assert r.stdout.count("lossless: yes") == 2 and "per-image status names it: yes, other images intact: yes" in r.stdout, r.stdout
+
+
 def test_cli_file_roundtrip(torch_mod, tmp_path, capsys):
     """image file -> .llic -> image file through the command-line front end, both containers."""
     from llicti_amd import cli, fileio
