@@ -24,6 +24,27 @@ def test_library_exports_every_header_symbol():
     assert b"gfx950" in _lib.lib().llicti_version()
 
 
+def test_header_is_plain_c_and_native_client_builds(tmp_path):
+    """include/llicti_hip.h is the boundary a non-Python host binds: it must compile as plain C (gcc, no HIP, no C++) -- plain pointers and sizes,
+    no torch type in any signature -- and tools/native_client.cpp (the C-ABI from a host with no Python in the process; run on the GPU box by
+    tests/test_hip_parity.py::test_native_client_without_torch) must build against it and link with the in-tree library (hipcc cross-compiles)."""
+    import shutil
+    import subprocess
+    from llicti_amd import _lib
+    _lib.build()
+    hdr = os.path.join(ROOT, "include", "llicti_hip.h")
+    csrc = tmp_path / "use_header.c"
+    csrc.write_text('#include "llicti_hip.h"\nint main(void) { llicti_ctx *c = 0; return llicti_workspace_bytes(1, 64, 64, 0) == 0 && c == 0 ? 0 : 1; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-I", os.path.dirname(hdr), str(csrc)])
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("no hipcc here")
+    so_dir = os.path.dirname(_lib.SO_PATH)
+    subprocess.check_call([hipcc, "-O1", "-std=c++17", "--offload-arch=gfx950", "-I", os.path.dirname(hdr), os.path.join(ROOT, "tools", "native_client.cpp"),
+                           "-L", so_dir, "-lllicti_hip", "-Wl,-rpath," + so_dir, "-o", str(tmp_path / "native_client")])
+    assert (tmp_path / "native_client").exists()
+
+
 def test_magic_division_selftest():
     """The stage geometry's division by an invariant width (div_magic / div_by_magic, used by every decoder to turn a symbol
     index into a row and a column) against '/': every divisor 1 .. 8192, boundary and pseudo-random dividends below 2^31."""
