@@ -1544,7 +1544,8 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_t
                 return (uint32_t)(w >> (pos - (wpos & ~31))) & ((1u << n) - 1u);
             };
             int wb = __builtin_amdgcn_readlane(wv, 12), np = 0;
-            if (wb >= 0) np = __builtin_popcountll(ballot64(lane < 12 && wb + lane <= max_symbol && ((uint32_t)wv <= slot || wb + lane == 0)));
+            // (entries past the top symbol are 2^16, never <= slot; entry 0 is the floor of the search: counted whatever it holds)
+            if (wb >= 0) np = __builtin_popcountll((ballot64((uint32_t)wv <= slot) & 0xFFFull) | (wb == 0 ? 1ull : 0ull));
             uint32_t vlo, vhi;
             if (np >= 1 && np <= 11) {
                 vlo = (uint32_t)__builtin_amdgcn_readlane(wv, np - 1);
