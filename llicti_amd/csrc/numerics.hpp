@@ -117,6 +117,25 @@ __device__ __forceinline__ ParRow par_row(const float *params, int b, long npos,
 {
     return ParRow{ params + (long)b * 64 * npos, npos, (int)pos };
 }
+// The same position for code that reads it inside a LOOP (the stage decoders' step loops): ONE scalar base (the image's planes) + a 32-bit
+// per-lane byte offset -- `global_load_dword v, v_off, s[base]`.  63 planes of the largest band grid (4080 x 4080 positions) are 4.2e9 bytes: inside 32
+// bits unsigned.  With ParRow the compiler keeps a 64-bit scalar base PER PLANE across such a loop -- 50 SGPRs it does not have: two v_readlane of a
+// spilled pair, a wait state and a 64-bit add in front of every load (219 + 144 spill moves in the lane decoder's disassembly, 103 + 35 with this form;
+// its stage launches 1.84 -> 1.80 ms).  One-shot readers (the pairs and table kernels: a thread reads its position once) are better off with ParRow:
+// their plane bases are computed once on the scalar unit (cdf_pairs_kernel 0.556 -> 0.566 ms with this form, so it keeps the other).
+struct ParRow32 {
+    const float *img;       // &params[b][0][0]: wave-uniform
+    uint32_t stride4;       // BYTES between channel planes: 4 h w
+    uint32_t pos4;          // the position, in bytes
+    __device__ __forceinline__ float operator[](int ch) const
+    {
+        return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(img) + (uint32_t)(pos4 + (uint32_t)ch * stride4));
+    }
+};
+__device__ __forceinline__ ParRow32 par_row32(const float *params, int b, long npos, long pos)
+{
+    return ParRow32{ params + (long)b * 64 * npos, 4u * (uint32_t)npos, 4u * (uint32_t)pos };
+}
 
 // par: a ParRow, or a plain array of the position's 64 values (same indexing)
 template <class PAR>

@@ -657,7 +657,7 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_kernel(cons
         Raw r;
         const int n = min(64 * (m + k * M) + gsym, nc - 1);          // clamped: the loads are unconditional
         const int i = div_wc(sg, n), j = n - i * sg.wc;          // multiply-shift: a runtime division costs ~25 of the step's ~900 instructions
-        const ParRow par = par_row(params + sg.par_off, 0, (long)sg.h * sg.w, (long)i * sg.w + j);
+        const ParRow32 par = par_row32(params + sg.par_off, 0, (long)sg.h * sg.w, (long)i * sg.w + j);
         r.off = img + ((long)(2 * i + sg.oi) << sg.lvl) * sg.W + ((long)(2 * j + sg.oj) << sg.lvl);
         r.sgA = par[5 * clr + mA]; r.muA = par[16 + 5 * clr + mA]; r.wkA = par[32 + 5 * clr + mA];
         r.sgB = par[5 * clr + 4];  r.muB = par[16 + 5 * clr + 4];  r.wkB = par[32 + 5 * clr + 4];
@@ -902,7 +902,7 @@ __global__ __launch_bounds__(64 * kRansWaves) void rans_decode_stage_pair_kernel
         Raw r;
         const int n = min(L * (m + k * M) + gsym, nc - 1);           // clamped: the loads are unconditional
         const int i = div_wc(sg, n), j = n - i * sg.wc;
-        const ParRow par = par_row(params + sg.par_off, 0, (long)sg.h * sg.w, (long)i * sg.w + j);
+        const ParRow32 par = par_row32(params + sg.par_off, 0, (long)sg.h * sg.w, (long)i * sg.w + j);
         r.off = img + ((long)(2 * i + sg.oi) << sg.lvl) * sg.W + ((long)(2 * j + sg.oj) << sg.lvl);
         r.y = r.co = 0.0f;
 #pragma unroll
@@ -1153,7 +1153,7 @@ __global__ __launch_bounds__(64 * Q) void rans_decode_stage_lane_kernel(const fl
         Raw r;
         const int n = min(L * (m + k * M) + tid, nc - 1);            // clamped: the loads are unconditional
         const int i = div_wc(sg, n), j = n - i * sg.wc;
-        const ParRow prw = par_row(params + sg.par_off, 0, npos, (long)i * sg.w + j);
+        const ParRow32 prw = par_row32(params + sg.par_off, 0, npos, (long)i * sg.w + j);
         r.off = img + ((long)(2 * i + sg.oi) << sg.lvl) * sg.W + ((long)(2 * j + sg.oj) << sg.lvl);
         r.y = r.co = 0.0f;
 #pragma unroll
