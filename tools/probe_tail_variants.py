@@ -3,8 +3,10 @@
   python tools/probe_tail_variants.py gen DIR            -- 24 x 768x512 images drawn from the "single" model of tools/probe_cheap_content.py
                                                              (1.7 bits per last-stage symbol) and a noise batch, encoded in xrans10 / rans10 with the
                                                              default build; containers to DIR
-  LLICTI_HIP_SO=... python tools/probe_tail_variants.py run DIR NAME   -- decode them with that build, print the kernel groups (debug builds decode
-                                                             wrong pixels by construction: only timed)"""
+  LLICTI_HIP_SO=... python tools/probe_tail_variants.py run DIR NAME   -- decode them with that build, print the kernel groups
+Builds: hipcc -D switches of rans_tail_kernel (-DTAIL_SPEC=0: no speculated window; -DTAIL_AHEAD=n: preparing wavefronts per chain), see tools/r5_run8.sh.
+The timing-only switches of profiles/r5/tail_speculation.json (coder alone / preparing wavefronts alone / forced hits: wrong pixels by construction,
+"lossless": false in their rows) were removed from the kernel again after the measurement: history, commit a3bba44's parent series."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
