@@ -247,24 +247,31 @@ class LLICTIAgent:
             d0.record(stream)
             rec, _, _ = self.model.decode_batch_async(lists, self.device, slot=job["slot"], flat=True)
             n = rec.numel()
-            diff = torch.maximum(rec, enc.rgb[:n]) - torch.minimum(rec, enc.rgb[:n])    # |x - x_reco| * 255 in uint8 arithmetic, the images back to back
+            # the lossless check (llicti_agent.py:151-162) on the device, the images back to back: ONE comparison pass says per image whether any sub-pixel
+            # differs -- the answer is "no" for every image of every run that is not broken, so the error's SIZE (the reference prints it) is only
+            # worked out, in report(), for an image that does differ (round 5: maximum - minimum - amax over every batch was four passes over 28 MB)
+            ne = rec != enc.rgb[:n]
             offs, _ = enc.codec.flat_offsets(job["Hs"], job["Ws"])
             if len(set(zip(job["Hs"], job["Ws"]))) == 1:
-                err = diff.view(job["B"], -1).amax(dim=1).to(torch.int16)
+                err = ne.view(job["B"], -1).any(dim=1).to(torch.int16)
             else:
-                err = torch.stack([diff[int(o):int(o) + 3 * h * w].amax() for o, h, w in zip(offs, job["Hs"], job["Ws"])]).to(torch.int16)
+                err = torch.stack([ne[int(o):int(o) + 3 * h * w].any() for o, h, w in zip(offs, job["Hs"], job["Ws"])]).to(torch.int16)
             d1.record(stream)
             err_h = self.model._pinned(("err", job["slot"]), 2 * job["B"])[:2 * job["B"]].view(torch.int16)
             err_h.copy_(err, non_blocking=True)                # read in report() behind its own event: no wait for later batches
             self.model._pinned_mark(("err", job["slot"]), stream)
             ev = torch.cuda.Event()
             ev.record(stream)
-            return {"job": job, "lists": lists, "rates": rates, "err": err_h, "ev": ev, "e_dec": (d0, d1)}
+            return {"job": job, "lists": lists, "rates": rates, "err": err_h, "ev": ev, "e_dec": (d0, d1), "rec": rec, "offs": offs}
 
         def report(fin):
             job = fin["job"]
             fin["ev"].synchronize()                            # this batch's decode and check are done; what was enqueued behind them keeps running
-            err = fin["err"].numpy().astype(np.float64)
+            err = fin["err"].numpy().astype(np.float64)                # 0 / 1 per image: does any sub-pixel differ
+            for b in np.nonzero(err)[0]:                               # (never, unless something is broken) how much: max |x - x_reco| * 255
+                o, n_b = int(fin["offs"][b]), 3 * job["Hs"][b] * job["Ws"][b]
+                a, c = fin["rec"][o:o + n_b].to(torch.int16), job["enc"].rgb[o:o + n_b].to(torch.int16)
+                err[b] = float((a - c).abs().max())
             enc_ms = job["e_enc"][0].elapsed_time(job["e_enc"][1])
             dec_ms = fin["e_dec"][0].elapsed_time(fin["e_dec"][1])
             pix = float(sum(h * w for h, w in zip(job["Hs"], job["Ws"])))

@@ -715,6 +715,35 @@ def test_agent_batched_eval_equals_unbatched(torch_mod, tmp_path, caplog, oracle
     assert res_m[2]["bytestream_list"] == orc.encode_image(imgs[2], W_o)
 
 
+def test_agent_batched_lossless_check_reports_a_difference(torch_mod, caplog):
+    """The batched eval's lossless check (llicti_agent.py:151-162) is one comparison pass per batch; the SIZE of an error is worked out only for an
+    image that differs.  A decoder that returns one wrong sub-pixel (injected here: the decoded buffer of the second batch is altered before the
+    check reads it) must end in the reference's "does NOT match" line for exactly that image, with the right magnitude, and leave the others alone."""
+    import logging
+    from llicti_amd.agents.llicti_agent import LLICTIAgent
+    from llicti_amd.config import default_config
+    torch = torch_mod
+    caplog.set_level(logging.INFO)
+    imgs = [make_image("smooth" if i % 2 else "noise", h, w, 700 + i) for i, (h, w) in enumerate([(96, 128), (67, 93), (96, 128), (128, 96), (96, 128)])]
+    a = LLICTIAgent(default_config(test_data=imgs, eval_batch=2, container="xrans1", keep_streams=True))
+    real = a.model.decode_batch_async
+    calls = {"n": 0}
+
+    def tampered(lists, devc=None, slot=0, flat=False):
+        rec, Hs, Ws = real(lists, devc, slot=slot, flat=flat)
+        calls["n"] += 1
+        if calls["n"] == 2:                                # batch 1 = images 2 and 3: image 3's first sub-pixel is off by 7 grey levels
+            o = 3 * Hs[0] * Ws[0]
+            rec[o] = (rec[o].to(torch.int16) + 7).clamp(0, 255).to(torch.uint8) if int(rec[o]) <= 248 else rec[o] - 7
+        return rec, Hs, Ws
+    a.model.decode_batch_async = tampered
+    res = a.run()
+    assert [r["max_abs_err"] for r in res] == [0.0, 0.0, 0.0, 7.0, 0.0]
+    bad = [r.message for r in caplog.records if "does NOT match" in r.message]
+    assert len(bad) == 1 and bad[0].lstrip().startswith("3 ") and "7.0000" in bad[0], bad
+    assert sum("Check: Decoded img matches original" in r.message for r in caplog.records) == 4
+
+
 def test_agent_auto_container_follows_the_content(torch_mod):
     """Container "auto" and the content (round 5): the agent's model books what every coded batch spent per symbol of its last stage (from the
     segment lengths the host downloads anyway); on a source as cheap as the reference's trained model the first batches -- content unknown --
