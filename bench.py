@@ -24,6 +24,7 @@ One JSON line is printed by rank 0.
   roofline              the dominant kernel (fp32-MFMA interpolator CNN): algorithmic FLOP of the launches of one
                         encode+decode / their summed HIP-event durations (events on the launch stream, extra profiled steps)
   roofline_cdf_table    configs[3]: the full-table CDF kernel on one 3840x2160 image, SURVEY 8(d)'s bytes (2 Lp + 60 per symbol)
+  coder                 SURVEY 8(d): coded symbols per second of the entropy coder's own kernels (profiled encode / decode of the run)
   bpp_delta_vs_reference, m_sweep, ac_container, ac_container_large, single_image, image_4k, natural_like, model_drawn
                         informational legs, N = 1 only, outside the timed region
   cpu_baseline          the CPU oracle in the reference's structure on the host cores, bounded sample; .torch_cpu: the same path
@@ -1125,6 +1126,18 @@ def main(argv=None):
                          "cnn_tflops_per_level": {f"level{l}": round(2.0 * MAC_PER_POSITION * level_positions(H, W, l) * B * 2 / (cnn_level_ms[l] * 1e-3) / 1e12, 2)
                                                   for l in range(5) if cnn_level_ms[l] > 0},
                          "kernel_ms": kernel_ms},
+            # "the coder itself is integer / latency-bound: report symbols/s" -- the step's coded symbols (3 colour channels of every
+            # pixel but the raw DC band) over the entropy coder's own kernels of the profiled encode / decode (HIP events around the launches)
+            "coder": (lambda nsym, e, d: {
+                "symbols_per_step": nsym,
+                "encode_gsym_s": round(nsym / ((e.get("rans_encode", 0.0) + e.get("ac", 0.0)) * 1e-3) / 1e9, 3) if (e.get("rans_encode", 0.0) + e.get("ac", 0.0)) > 0 else None,
+                "decode_gsym_s": round(nsym / ((d.get("rans_stage", 0.0) + d.get("rans_tail", 0.0) + d.get("ac", 0.0)) * 1e-3) / 1e9, 3)
+                                 if (d.get("rans_stage", 0.0) + d.get("rans_tail", 0.0) + d.get("ac", 0.0)) > 0 else None,
+                "encode_with_pairs_gsym_s": round(nsym / ((e.get("rans_encode", 0.0) + e.get("ac", 0.0) + e.get("cdf_pairs", 0.0)) * 1e-3) / 1e9, 3)
+                                            if (e.get("rans_encode", 0.0) + e.get("ac", 0.0) + e.get("cdf_pairs", 0.0)) > 0 else None,
+                "what": "encode: the rANS / range-coder kernel alone (its (c_low, c_high) pairs come from cdf_pairs_kernel: the second figure has both); decode: the "
+                        "stage launches + the tail -- the decoder evaluates the mixture CDF inside its symbol search, so this is search + coder"})(
+                3 * (H * W - (H // 32) * (W // 32)) * B, kernel_ms.get("encode", {}), kernel_ms.get("decode", {})),
         }
         if ac_bytes is not None:
             fx, fx_path = _latest_profile_json("bpp_delta_fixtures.json")

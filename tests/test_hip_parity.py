@@ -1401,6 +1401,7 @@ def test_bench_line_contract(torch_mod):
               "cpu_baseline", "bpp_delta_vs_reference", "meets_north_star", "north_star_check"):
         assert k in d, k
     assert d["meets_north_star"] is False                       # not the north star's 768x512 shape: never claimed on another one
+    assert d["coder"]["symbols_per_step"] > 0 and d["coder"]["decode_gsym_s"] > 0 and d["coder"]["encode_gsym_s"] > 0      # symbols/s of the coder
     assert abs(d["bpp_delta_vs_reference"]["timed_container_minus_reference_format_bpp"]) < 4.0      # 3 tiny images, 9 xwide streams each: mostly the 992-byte state blocks (12 kpixel images)
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
