@@ -183,6 +183,20 @@ def cpu_weights():
     return orc.Weights(pack_state_dict(LLICTI(default_config()).state_dict()))
 
 
+def host_cpu():
+    """(model name of the host CPU from /proc/cpuinfo, logical CPUs the process may use): SURVEY.md 8(d) asks for both beside the CPU baseline."""
+    model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return model, (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+
+
 def cpu_baseline(H, W):
     """Oracle ("port": C + OpenMP restatement in the reference's structure), on a bounded sample of the same workload."""
     import numpy as np
@@ -209,7 +223,7 @@ def cpu_baseline(H, W):
     return {"value": round(n_img * H * W / 1e6 / (t_enc + t_dec), 5), "unit": "MPix/s", "cores": cores, "kind": "port",
             "sample": f"{n_img} images {W}x{H} uniform-noise RGB (seeds 0..{n_img - 1}), encode {t_enc:.2f}s + decode {t_dec:.2f}s, "
                       "C/OpenMP oracle: materialised Lp-entry tables (OpenMP over positions) + single-thread range coder",
-            "enc_s": round(t_enc, 3), "dec_s": round(t_dec, 3)}, bl0
+            "enc_s": round(t_enc, 3), "dec_s": round(t_dec, 3), "cpu_model": host_cpu()[0], "host_logical_cpus": host_cpu()[1]}, bl0
 
 
 def cpu_baseline_torch(H, W):
