@@ -63,7 +63,10 @@ class LLICTIAgent:
     `python -m torch.distributed.run --nproc-per-node G ...` (RANK / LOCAL_RANK / WORLD_SIZE in the environment) the G agents shard the
     test set: image i -> rank i mod G, weights read once by rank 0 and broadcast (RCCL), no collective on the hot path,
     ONE all_gather of the per-image records at the end; rank 0 prints the reference's per-image lines in index order and the rate table
-    -- the log of a 1-GPU run (llicti_amd/shard.py; tests/test_distributed_cpu.py::test_agent_two_ranks_equal_one_rank)."""
+    -- the log of a 1-GPU run (llicti_amd/shard.py; tests/test_distributed_cpu.py::test_agent_two_ranks_equal_one_rank).  One caveat: with
+    container "auto" the KIND of streams a batch gets follows the content the rank has coded so far (LLICTI.note_content: 64-lane streams
+    once the source is seen to be cheap), so on such content an image's bytes -- not its pixels -- can depend on the rank count and on
+    eval_batch; a fixed container (or config.content_aware = False) makes the logged sizes independent of both."""
 
     def __init__(self, config, model=None):
         self.config = config
