@@ -127,7 +127,8 @@ __global__ __launch_bounds__(CnnGeo<TH>::kThreads) void band_params_kernel(const
     // The mixed-size form takes tile -> (image, tile row, tile column) from the list and the image's geometry from the table (wave-uniform:
     // scalar loads), where it is needed -- in the staging and in the epilogue -- and does not keep it across the tile (the kernel is at its
     // SGPR budget).  The equal-size form is, instruction for instruction, what it was before the list existed.
-    auto stage = [&](int tile, float *dst) {
+    // (always_inline: left to the inliner, band 2's 4-row form got a real call -- s_swappc_b64, a 176-byte stack frame -- at each of its five sites)
+    auto stage = [&](int tile, float *dst) __attribute__((always_inline)) {
         int img, ty, tx;
         Geom gl;                                                // (mixed sizes only)
         if constexpr (RAGGED) {
@@ -146,16 +147,17 @@ __global__ __launch_bounds__(CnnGeo<TH>::kThreads) void band_params_kernel(const
         const int i0 = ty * kTileH - 2, j0 = tx * kTileW - 2;
         const float *base = RAGGED ? fplanes + g.pix_off : fplanes + (long)img * 3 * g.plane;
 #if CNN_STAGE_FAST
-        uint32_t lt[3];                                         // mixed sizes: the row pitch is the image's, so the three per-lane offsets are recomputed per
-        if constexpr (RAGGED) {                                 // staged tile (~25 vector operations of a tile's ~10^5 cycles)
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const int thr = 48 - 16 * t;
-                const bool up = lane >= thr;
-                const int cidx = min(up ? lane - thr : lane + 16 * t, kInCols - 1);
-                lt[t] = (uint32_t)((((long)(2 * (t + (up ? 1 : 0))) * g.W + 2 * cidx) << g.lvl) * 4);
-            }
-        }
+        // mixed sizes: the row pitch is the image's, so a piece's per-lane offset is computed where the piece is requested, from its (scalar) phase --
+        // ~8 vector operations per piece, ~70 of a tile's ~10^5 cycles -- instead of being kept for the three phases across the staging: the 16-row
+        // form of band 2 sits at the 128-VGPR cap of a 1024-thread workgroup and spilled eight registers over them
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                            // (opaque per staged tile: left visible, the lane's part of the offsets is hoisted out of the tile loop -- into spilled registers)
+        auto lane_off = [&](int t) __attribute__((always_inline)) -> uint32_t {
+            const int thr = 48 - 16 * t;
+            const bool up = ln >= thr;
+            const int cidx = min(up ? ln - thr : ln + 16 * t, kInCols - 1);
+            return (uint32_t)((((long)(2 * (t + (up ? 1 : 0))) * g.W + 2 * cidx) << g.lvl) * 4);
+        };
         // rows i0 .. i0 + kInRows - 1 and columns j0 .. j0 + kInCols - 1 of the band grid, all strictly inside it and below
         // the last row / column (where lazyDWT's odd-edge pad could apply)
         if (i0 >= 0 && i0 + kInRows - 1 <= g.h - 2 && j0 >= 0 && j0 + kInCols - 1 <= g.w - 2) {
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(CnnGeo<TH>::kThreads) void band_params_kernel(const
                     const int src = pl / 3, ci = pl - 3 * src;
                     const long uoff = ((long)ci * g.plane + (((long)(8 * q4 + src_oi(src)) * g.W + src_oj(src)) << g.lvl)) * 4;
                     uint32_t lo;
-                    if constexpr (RAGGED) lo = (t == 0) ? lt[0] : (t == 1) ? lt[1] : lt[2];
+                    if constexpr (RAGGED) lo = lane_off(t);
                     else lo = (t == 0) ? lane_t[0] : (t == 1) ? lane_t[1] : lane_t[2];
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(origin + uoff + lo),
                                                      (__attribute__((address_space(3))) void *)(dst + u * 64), 4, 0, 0);
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(CnnGeo<TH>::kThreads) void band_params_kernel(const
         // one of its waves stages, the other three keep the matrix pipe busy.  (All 16 waves staging right
         // after the barrier left the pipe idle for ~9 % of the tile.)
         const bool more = tile + (int)gridDim.x < n_tiles;
-        auto stage_next = [&](int site) {
+        auto stage_next = [&](int site) __attribute__((always_inline)) {
             if (more && stage_site == site % CNN_STAGE_SITES) stage(tile + gridDim.x, lds_in + (cur ^ 1) * (NPL * kInPlane));
         };
         // Wave priority falls as the wave advances through its tile (3, 2, 1, 0 by quarter of the MFMA work): the

@@ -358,3 +358,28 @@ def test_host_plan_logic_driver(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "clean" in out.stdout
+
+
+def test_no_scratch_in_mfma_and_stage_kernels():
+    """no kernel of the library may spill a vector register or use a private segment -- the band CNN (18 instantiations: band x
+    tile rows x equal / mixed sizes) and the stage decoders least of all.  Round 5's `band_params_kernel<2,16,true>` (the heaviest kernel of the
+    mixed-size path) carried 8 spilled VGPRs at the 128-register cap of a 1024-thread workgroup, and `<2,4,false>` a 176-byte stack frame: its
+    staging lambda was a real call.  hipcc's own metadata (`-S --cuda-device-only`, no GPU needed) is the witness: tools/kernel_resources.py."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from kernel_resources import kernel_resources
+    finally:
+        sys.path.pop(0)
+    rows = kernel_resources()
+    names = [r["demangled"] for r in rows]
+    cnn = [r for r in rows if "band_params_kernel" in r["name"]]
+    stage = [r for r in rows if "rans_decode_stage" in r["name"] or "rans_tail_kernel" in r["name"] or "rans_encode_kernel" in r["name"]]
+    assert len(cnn) == 18, names                        # 3 bands x {16, 8, 4} tile rows x {equal, mixed} sizes
+    assert len(stage) >= 9, names                       # three stage decoders + encoder / tail per lane kind
+    for r in rows:
+        assert r["vgpr_spill_count"] == 0, (r["demangled"], r)
+        assert r["private_segment_fixed_size"] == 0 and not r["uses_dynamic_stack"], (r["demangled"], r)
+    for r in cnn:                                       # a 1024-thread workgroup has 128 unified registers per lane, a 512-thread one 256
+        cap = 512 * 256 // r["max_flat_workgroup_size"]
+        assert r["vgpr_count"] + r["agpr_count"] <= cap, (r["demangled"], r)

@@ -4,7 +4,7 @@
                                                              (1.7 bits per last-stage symbol) and a noise batch, encoded in xrans10 / rans10 with the
                                                              default build; containers to DIR
   LLICTI_HIP_SO=... python tools/probe_tail_variants.py run DIR NAME   -- decode them with that build, print the kernel groups
-Builds: hipcc -D switches of rans_tail_kernel (-DTAIL_SPEC=0: no speculated window; -DTAIL_AHEAD=n: preparing wavefronts per chain), see tools/r5_run8.sh.
+Builds: hipcc -D switches of rans_tail_kernel (-DTAIL_SPEC=0: no speculated window; -DTAIL_AHEAD=n: preparing wavefronts per chain).
 The timing-only switches of profiles/r5/tail_speculation.json (coder alone / preparing wavefronts alone / forced hits: wrong pixels by construction,
 "lossless": false in their rows) were removed from the kernel again after the measurement: history, commit a3bba44's parent series."""
 import json, os, sys
