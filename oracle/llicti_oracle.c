@@ -784,24 +784,21 @@ typedef struct { long n; uint32_t *clow, *chigh; int16_t *sym; } stage_syms_t;
 #define RANS_STATE_BITS 31                              /* a lane state is 2^31 | 31 bits */
 #define RANS_MAX_PAY_BITS (RANS_MAX_LANES * RANS_STATE_BITS)   /* what the initial states carry (the tail stream): 1984 / 3968 / 7936 bits */
 #define RANS_TAIL_MAX   2047                            /* tail symbols of a 64- / 128-lane stream (the 11-bit T field) */
-#define RANS_TAIL_MAX_X 8191                            /* ... of an xwide stream, whose T field has a 12th bit (bit 15 of the u16): T < 4095 as it is, */
-#define RANS_TAIL_ESC_X 4095                            /* ... T >= 4095 as the escape 4095 in the field + the count itself as a u16 behind the states */
-/* xwide streams (256 lanes) only -- the older kinds keep their bytes.  Their tail is coded by TWO single-state coders ("chains") that share the
- * payload, and neither starts from an empty state:
- *   seeds    with A = the number of symbol values of the image's Cg channel (max - min + 1) and n = the largest count with A^n <= 2^31 (at most
- *            31; three for the full range of 511, five for 53), and counting the stream's symbols from its end (j = 0: the last one), chain A
- *            starts from 2^31 | sum sym(i) A^i over i < n and chain B from the same of sym(n + i) (symbol INDICES, raw, radix A; a stream shorter
- *            than 2 n symbols leaves the missing digits zero): the 31 bits an empty start state wastes carry n symbols that are never coded;
- *   chains   symbol j >= 2 n is pushed on chain A if j is even, on chain B if it is odd, j ascending (the decoder pops j descending), while
- *            used_A + used_B + bits(j) + 64 <= payload bits; T = the first j that does not fit (or the stream's length, or 8191: a payload of
- *            7936 bits is filled by 2047 symbols only if they cost 3.9 bits each -- the trained model on natural images spends 1.7 there,
- *            reference log exp_debug.log.1:2682 -- so an xwide tail may be up to RANS_TAIL_MAX_X symbols long);
- *   payload  bits [0, 32) = A's final state; A's bit fields from bit 32 UPWARDS in the order the decoder reads them (last pushed first); B's
- *            final state in the top 32 bits, B's fields below it, read DOWNWARDS (last pushed on top); what lies between is zero.
- * Two chains because the tail is serial: the decoder runs them on two wavefronts, the encoder too. */
+/* xwide streams (256 lanes) are "v4" (round 6; header: padHW bits 10..15 say so and carry the stream count) -- the 64- and 128-lane kinds keep
+ * their v3 bytes.  What v4 changes (spec: llicti_oracle.h, "xwide v4"):
+ *   arena    the tail coder's output is no longer cut to the 7936 payload bits the initial states carry: the stream's last T symbols are taken in
+ *            blocks of 32 until the output reaches the payload size, and what exceeds it ("spill", < 512 bits) lies at the BOTTOM of the main bit
+ *            region, where the main decoder -- reading DOWN -- leaves it.  No unused payload bits, and T is a multiple of 32: an 8-bit field;
+ *   one chain  starts from the stream's LAST symbol itself, raw (x = its index: 9 bits of state for one symbol, nothing else), and pushes without
+ *            emitting while the state is below the interval: a chain costs ~1 bit (its end marker) instead of the ~31 a start state of 2^31 did;
+ *   two chains  (expensive symbols: v3's integer rule) as in v3 -- seeded with n raw symbols each -- at the two ends of the arena;
+ *   header   9 bits (T / 32 rounded up, the one-chain flag) on TOP of the bit region under an end marker, instead of a u16 in front and an escape. */
+#define RANS_TAIL_MAX_X 8160                            /* = 32 * 255: the cap of an xwide stream's tail (the field is T / 32 rounded up, 8 bits) */
+#define RANS_TAIL_BLOCK 32
+#define RANS_SPILL_MAX  512                             /* bits by which the tail coder's output may exceed the payload: < 32 symbols x 16 bits */
 #define RANS_SEED_LANES 256
 #define RANS_SEED_MAX   31
-static inline int rans_seed_count(int A, uint32_t *pw)          /* n and A^n */
+static inline int rans_seed_count(int A, uint32_t *pw)          /* n and A^n: the largest count with A^n <= 2^31 (at most 31) */
 {
     int n = 0;
     uint64_t p = 1;
@@ -841,18 +838,16 @@ static long rans_stream_count(long nc, int m, int M, int L)
     return L * K - ((last == nchunks - 1 && (nc % L)) ? L - (nc % L) : 0);
 }
 
-/* the xwide tail (see RANS_SEED_LANES above): fills pay (zeroed, 7936 bits), returns T or -1 on an impossible pair */
-static long rans_tail_encode_x(const stage_syms_t *sl, int m, int M, long cnt, int A, uint8_t *pay, int *single)
+/* the xwide v4 tail: fills arena (zeroed, RANS_MAX_PAY_BITS + RANS_SPILL_MAX bits), returns T (or -1 on an impossible pair); *alen = the arena's
+ * length in bits (>= the payload's 7936: what exceeds it is the spill), *single = one chain */
+static long rans_tail_encode_x(const stage_syms_t *sl, int m, int M, long cnt, int A, uint8_t *arena, long *alen, int *single)
 {
     const int L = RANS_SEED_LANES;
     const long P = (long)L * RANS_STATE_BITS;
-    uint32_t x[2] = { 1u << 31, 1u << 31 }, pw;
+    uint32_t pw;
     const int ns = rans_seed_count(A, &pw);
-    /* one chain or two: a second chain costs its 32-bit final state and saves what its ns seed symbols would have cost coded -- worth it (and
-     * the faster decode) when symbols are expensive, not when the model predicts them well.  Integer rule, the same in every implementation,
-     * on the stream's last up to 64 symbols (a mean, so that every stream of a statistically uniform batch decides alike: one single-chain
-     * stream makes the whole tail launch wait for its serial decode): two chains iff the stream has 2 ns symbols and
-     * ns * mean(16 - floor(log2 freq)) >= 32 + ns / 2. */
+    /* one chain or two -- v3's integer rule, on the stream's last up to 64 symbols (a mean, so that the streams of a statistically uniform batch
+     * decide alike): two chains iff the stream has 2 ns symbols and ns * mean(16 - floor(log2 freq)) >= 32 + ns / 2 */
     int nch = 1;
     if (cnt >= 2 * ns) {
         const long k64 = cnt < 64 ? cnt : 64;
@@ -867,41 +862,56 @@ static long rans_tail_encode_x(const stage_syms_t *sl, int m, int M, long cnt, i
         if (2 * wsum * ns >= k64 * (64 + ns)) nch = 2;
     }
     *single = (nch == 1);
+    uint32_t x[2] = { 0, 0 };
     long j = 0;
-    for (int c = 0; c < nch; ++c) {
-        uint32_t mul = 1;
-        for (int i = 0; i < ns && j < cnt; ++i, ++j, mul *= (uint32_t)A) {
-            const long q = cnt - 1 - j;
-            const int sy = sl->sym[(long)L * (m + (q / L) * M) + (q % L)];
-            if (sy < 0 || sy >= A) return -1;
-            x[c] += (uint32_t)sy * mul;
+    if (nch == 2) {
+        for (int c = 0; c < 2; ++c) {                           /* seeds: n raw symbol indices per chain, radix A, on top of 2^31 */
+            uint32_t mul = 1;
+            x[c] = 1u << 31;
+            for (int i = 0; i < ns && j < cnt; ++i, ++j, mul *= (uint32_t)A) {
+                const long q = cnt - 1 - j;
+                const int sy = sl->sym[(long)L * (m + (q / L) * M) + (q % L)];
+                if (sy < 0 || sy >= A) return -1;
+                x[c] += (uint32_t)sy * mul;
+            }
         }
+    } else if (cnt > 0) {                                       /* one chain: its start state IS the last symbol's index */
+        const long q = cnt - 1;
+        const int sy = sl->sym[(long)L * (m + (q / L) * M) + (q % L)];
+        if (sy < 0 || sy >= A) return -1;
+        x[0] = (uint32_t)sy;
+        j = 1;
     }
-    const long j0 = j;                                         /* first coded symbol: nch ns (or the stream's end) */
+    const long j0 = j;                                          /* first coded symbol */
+    const long fixed = nch == 2 ? 64 : 33;                      /* the final states; one chain: + its end marker */
     static __thread uint32_t fld[RANS_TAIL_MAX_X];
     static __thread uint8_t fnb[RANS_TAIL_MAX_X];
     long used[2] = { 0, 0 };
     for (; j < cnt && j < RANS_TAIL_MAX_X; ++j) {
+        if (j % RANS_TAIL_BLOCK == 0 && used[0] + used[1] + fixed >= P) break;      /* the payload is full: T is this multiple of 32 */
         const long q = cnt - 1 - j;
         const long n = (long)L * (m + (q / L) * M) + (q % L);
         const uint32_t lo = sl->clow[n], freq = sl->chigh[n] - lo;
         if (freq == 0 || freq > 0x10000u) return -1;
         const int c = (int)((j - j0) % nch);
-        const int nb = rans_emit_bits(x[c], freq);
-        if (used[0] + used[1] + nb + 32 * nch > P) break;
+        const int nb = rans_emit_bits(x[c], freq);              /* (a state still below 2^31 -- one chain, its first symbols -- emits nothing unless the push would overflow) */
         fld[j] = x[c] & ((1u << nb) - 1u);
         fnb[j] = (uint8_t)nb;
         used[c] += nb;
         x[c] = rans_push(x[c] >> nb, lo, freq);
     }
     const long T = j;
-    put_bits(pay, 0, 32, x[0]);
-    if (nch == 2) put_bits(pay, P - 32, 32, x[1]);
-    long pa = 32, pb = P - 32;
-    for (long t = T - 1; t >= j0; --t) {                       /* the decoder's order */
-        if ((t - j0) % nch) { pb -= fnb[t]; put_bits(pay, pb, fnb[t], fld[t]); }
-        else { put_bits(pay, pa, fnb[t], fld[t]); pa += fnb[t]; }
+    long len = used[0] + used[1] + fixed;
+    if (len < P) len = P;
+    *alen = len;
+    put_bits(arena, 0, 32, x[0]);
+    if (nch == 2) put_bits(arena, len - 32, 32, x[1]);
+    long pa = 32, pb = len - 32;
+    for (long t = T - 1; t >= j0; --t) {                        /* the decoder's order: chain A's fields UP from bit 32, chain B's DOWN from its state */
+        if ((t - j0) % nch) { pb -= fnb[t]; put_bits(arena, pb, fnb[t], fld[t]); }
+        else { put_bits(arena, pa, fnb[t], fld[t]); pa += fnb[t]; }
     }
+    if (nch == 1) put_bits(arena, pa, 1, 1u);                   /* end marker: the arena's highest set bit */
     return T;
 }
 
@@ -909,11 +919,11 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
                            uint8_t *out, long cap, int32_t seg_len[49])
 {
     if (H < 32 || W < 32 || H > 8160 || W > 8160) return -2;
-    const int wide = (M >> 8) & 3;                      /* M | 0x100: wide streams of 128 lanes (M <= 14); M | 0x200: xwide streams of 256 lanes (M <= 14, 32, 64) */
+    const int wide = (M >> 8) & 3;                      /* M | 0x100: wide streams of 128 lanes (M <= 14); M | 0x200: xwide streams of 256 lanes (v4: M <= 32, 64, 128) */
     M &= 0xFF;
     if (wide == 0 && (M < 1 || (M > 32 && M != 64 && M != 128))) return -2;
     if (wide == 1 && (M < 1 || M > 14)) return -2;
-    if (wide == 2 && (M < 1 || (M > 14 && M != 32 && M != 64))) return -2;
+    if (wide == 2 && (M < 1 || (M > 32 && M != 64 && M != 128))) return -2;
     if (wide == 3) return -2;
     const int L = 64 << wide;
     const int PAY_BITS = L * RANS_STATE_BITS;
@@ -928,10 +938,11 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
     const int h4 = h, w4 = w;
     if (cap < 17 + 3L * h4 * w4) { free(planes); return -1; }
     for (int i = 0; i < 49; ++i) seg_len[i] = 0;
-    {   /* byte 0: bit 7 rANS, bit 3 format v3, bit 6 extended, bits 5,4,2,1,0 = v: M = v + 1 (<= 32) streams of 64 lanes; extended: v = 0, 1:
-         * 64 / 128 streams of 64 lanes; 2 .. 15: v - 1 wide streams; 16 .. 29: v - 15 xwide streams; 30, 31: 32 / 64 xwide streams */
+    {   /* byte 0: bit 7 rANS, bit 3 format v3+, bit 6 extended, bits 5,4,2,1,0 = v: M = v + 1 (<= 32) streams of 64 lanes; extended: v = 0, 1:
+         * 64 / 128 streams of 64 lanes; 2 .. 15: v - 1 wide streams; v = 16 (byte 0 = 0xE8): xwide streams, v4 -- their count is in the pad field (below).
+         * (v = 17 .. 31 were the xwide v3 tags of rounds 4-5: retired, rejected.) */
         const int lat = M > 32 || wide;
-        const int v = wide == 2 ? (M == 32 ? 30 : M == 64 ? 31 : M + 15) : wide == 1 ? M + 1 : M > 32 ? (M == 64 ? 0 : 1) : M - 1;
+        const int v = wide == 2 ? 16 : wide == 1 ? M + 1 : M > 32 ? (M == 64 ? 0 : 1) : M - 1;
         out[pos++] = (uint8_t)(0x88 | (lat << 6) | (((v >> 3) & 3) << 4) | (v & 7));
     }
     out[pos++] = (uint8_t)h4; out[pos++] = (uint8_t)w4;
@@ -942,7 +953,10 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
         orc_level_geom(H, W, l, &Hl, &Wl, &h, &w, &padH, &padW);
         padint = 4 * padint + 2 * padH + padW;
     }
-    int16_t padi16 = (int16_t)padint;
+    /* xwide v4: bits 10 .. 15 of the pad field (zero in every other container: the five levels' flags are bits 0 .. 9) = u: M = u for 1 .. 32,
+     * u = 33 / 34: 64 / 128 streams (two / four per segment).  A reader of the older formats finds a pad field that contradicts the size and refuses. */
+    if (wide == 2) padint |= (M <= 32 ? M : M == 64 ? 33 : 34) << 10;
+    int16_t padi16 = (int16_t)(uint16_t)padint;
     memcpy(out + pos, &padi16, 2); pos += 2; seg_len[2] = 2;
     for (int c = 0; c < 3; ++c)
         for (int i = 0; i < h4; ++i)
@@ -976,20 +990,20 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
     }
     free(planes);
     long rc = 0;
-    const long bcap = 2 * total + 64;                    /* <= 16 bits per symbol + sentinel */
+    const long bcap = 2 * total + 256;                   /* <= 16 bits per symbol + (xwide) spill and header field */
     uint8_t *bits = (uint8_t *)malloc(bcap);
     const int S = ORC_NSTREAM - 1;                       /* the last stage: the only one the tail may take symbols from */
     for (int m = 0; m < M && rc >= 0; ++m) {
         /* 1. tail: the stream's last T symbols (decode order), single-state coder, pushed last symbol first; its bits
          *    go UP from bit 0 of the payload, its final state (32 bits, leading one = the payload's highest set bit) on top */
-        uint8_t pay[RANS_MAX_PAY_BITS / 8];
+        uint8_t pay[(RANS_MAX_PAY_BITS + RANS_SPILL_MAX) / 8 + 8];   /* xwide: the arena (payload ++ spill) */
         memset(pay, 0, sizeof pay);
         const long cnt = rans_stream_count(st[S].n, m, M, L);
         uint32_t xt = 1u << 31;
-        long tb = 0, T = 0;
-        int single = 0;                                      /* xwide: one tail chain instead of two (bit 14 of the stream's first u16) */
-        if (L == RANS_SEED_LANES) {                          /* xwide: two seeded chains in one payload */
-            T = rans_tail_encode_x(&st[S], m, M, cnt, minmax[5] - minmax[2] + 1, pay, &single);
+        long tb = 0, T = 0, alen = PAY_BITS;
+        int single = 0;                                      /* xwide: one tail chain instead of two (bit 8 of the stream's header field) */
+        if (L == RANS_SEED_LANES) {                          /* xwide v4 */
+            T = rans_tail_encode_x(&st[S], m, M, cnt, minmax[5] - minmax[2] + 1, pay, &alen, &single);
             if (T < 0) { rc = -5; break; }
         }
         while (L != RANS_SEED_LANES && T < cnt && T < RANS_TAIL_MAX) {
@@ -1010,9 +1024,12 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
         /* 2. the L lanes start from the payload: lane l = 2^31 | payload bits [31 l, 31 l + 31) */
         uint32_t x[RANS_MAX_LANES];
         for (int l = 0; l < L; ++l) x[l] = (1u << 31) | get_bits(pay, (long)RANS_STATE_BITS * l, RANS_STATE_BITS);
-        /* 3. main coder, last decoded symbol first; bits go UP from bit 0 of the stream's bit region */
+        /* 3. main coder, last decoded symbol first; bits go UP from bit 0 of the stream's bit region (xwide v4: from the end of the spill, which is
+         *    what the tail coder's output has beyond the payload -- the main decoder, reading DOWN, stops there and leaves it to the tail decoder) */
         memset(bits, 0, bcap);
-        long bp = 0;
+        long bp = alen - PAY_BITS;
+        for (long e = 0; e < bp; ++e)
+            if ((pay[(PAY_BITS + e) >> 3] >> ((PAY_BITS + e) & 7)) & 1u) bits[e >> 3] |= (uint8_t)(1u << (e & 7));
         for (int s = ORC_NSTREAM - 1; s >= 0 && rc >= 0; --s) {
             const long nchunks = (st[s].n + L - 1) / L;
             if (nchunks <= m) continue;
@@ -1033,10 +1050,17 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
             }
         }
         if (rc < 0) break;
+        long hdr = 0;                                        /* bytes in front of the bit region: the u16 of the 64- / 128-lane kinds */
+        if (L == RANS_SEED_LANES) {
+            /* xwide v4: the header field on TOP of the bit region -- 8 bits T / 32 rounded up (the decoder takes min(32 v, its own count of the
+             * stream's last-stage symbols)), 1 bit "one chain" -- and an end marker bit above it; zero bits up to the byte boundary */
+            const long v = (T + RANS_TAIL_BLOCK - 1) / RANS_TAIL_BLOCK;
+            put_bits(bits, bp, 10, (uint32_t)(v | ((long)single << 8) | (1l << 9)));
+            bp += 10;
+        } else hdr = 2;
         const long nbytes = (bp + 7) / 8;
         const long padb = 8 * nbytes - bp;               /* unused (zero) bits on top of the region's last byte */
-        const int t_esc = (L == RANS_SEED_LANES && T >= RANS_TAIL_ESC_X);   /* xwide, very long tail: T field = 4095, the count itself as a u16 behind the states */
-        const long bytes = 2 + nbytes + PAY_BITS / 8 + (t_esc ? 2 : 0);
+        const long bytes = hdr + nbytes + PAY_BITS / 8;
         if (pos + bytes + 4 * G > cap) { rc = -1; break; }
         if (G > 1) {
             /* M = 64 / 128: segment m / G = G little-endian u32 stream lengths, then its G streams */
@@ -1044,14 +1068,14 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
             uint8_t *tab = out + pos - seg_len[4 + m / G] + 4 * (m % G);
             tab[0] = (uint8_t)(bytes & 0xFF); tab[1] = (uint8_t)((bytes >> 8) & 0xFF); tab[2] = (uint8_t)((bytes >> 16) & 0xFF); tab[3] = (uint8_t)(bytes >> 24);
         }
-        const long Tf = t_esc ? RANS_TAIL_ESC_X : T;         /* 11 bits, or (xwide) 12: the twelfth is bit 15 */
-        const long t16 = (Tf & 0x7FF) | (padb << 11) | ((long)single << 14) | ((Tf >> 11) << 15);
-        out[pos] = (uint8_t)(t16 & 0xFF); out[pos + 1] = (uint8_t)(t16 >> 8);
-        memcpy(out + pos + 2, bits, nbytes);
-        uint8_t *fs = out + pos + 2 + nbytes;
+        if (hdr) {
+            const long t16 = (T & 0x7FF) | (padb << 11);
+            out[pos] = (uint8_t)(t16 & 0xFF); out[pos + 1] = (uint8_t)(t16 >> 8);
+        }
+        memcpy(out + pos + hdr, bits, nbytes);
+        uint8_t *fs = out + pos + hdr + nbytes;
         memset(fs, 0, PAY_BITS / 8);
         for (int l = 0; l < L; ++l) put_bits(fs, (long)RANS_STATE_BITS * l, RANS_STATE_BITS, x[l] & 0x7FFFFFFFu);
-        if (t_esc) { fs[PAY_BITS / 8] = (uint8_t)(T & 0xFF); fs[PAY_BITS / 8 + 1] = (uint8_t)(T >> 8); }
         pos += bytes;
         seg_len[4 + m / G] += (int32_t)bytes;
     }
@@ -1081,7 +1105,11 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
     if ((in[0] & 0x88) != 0x88) return -4;                        /* bit 3 clear: the retired v2 format */
     const int tagv = (((in[0] >> 4) & 3) << 3) | (in[0] & 7);
     const int ext = (in[0] >> 6) & 1, wide = !ext || tagv < 2 ? 0 : tagv < 16 ? 1 : 2;
-    const int M = !ext ? tagv + 1 : tagv == 0 ? 64 : tagv == 1 ? 128 : tagv < 16 ? tagv - 1 : tagv == 30 ? 32 : tagv == 31 ? 64 : tagv - 15;
+    const int padfield = (int)(uint16_t)(in[15] | (in[16] << 8));
+    const int u6 = padfield >> 10;                                /* xwide v4: the stream count; zero in every other container */
+    if (wide == 2 && (tagv != 16 || u6 < 1 || u6 > 34)) return -4; /* (tagv 17 .. 31, or no count: the xwide v3 layout of rounds 4-5, retired) */
+    if (wide != 2 && u6) return -4;
+    const int M = wide == 2 ? (u6 <= 32 ? u6 : u6 == 33 ? 64 : 128) : !ext ? tagv + 1 : tagv == 0 ? 64 : tagv == 1 ? 128 : tagv - 1;
     const int L = 64 << wide;
     const int PAY_BITS = L * RANS_STATE_BITS;
     const int G = M > 32 ? M / 32 : 1;
@@ -1094,7 +1122,14 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
     memcpy(minmax, in + 3, 12);
     const int h4 = in[1], w4 = in[2];
     if (seg_len[3] != 3 * h4 * w4) return -3;
-    /* streams: T | bit region (read DOWN from the sentinel) | L x 31-bit states */
+    /* streams: u16 (T | pad) | bit region (read DOWN from its top) | L x 31-bit states; xwide v4: bit region under its header field | states */
+    long cnt_last[128];                                            /* every stream's share of the LAST stage (level 0, band x10): an xwide tail cannot be longer */
+    {
+        int Hl0, Wl0, h0, w0, padH0, padW0, hc0, wc0;
+        orc_level_geom(H, W, 0, &Hl0, &Wl0, &h0, &w0, &padH0, &padW0);
+        stream_dims(h0, w0, padH0, padW0, 2, &hc0, &wc0);
+        for (int m = 0; m < M; ++m) cnt_last[m] = rans_stream_count((long)hc0 * wc0, m, M, L);
+    }
     uint32_t (*x)[RANS_MAX_LANES] = (uint32_t (*)[RANS_MAX_LANES])malloc(sizeof(uint32_t) * RANS_MAX_LANES * M);
     const uint8_t **bitsp = (const uint8_t **)malloc(sizeof(uint8_t *) * M);
     long *cur = (long *)calloc(M, sizeof(long)), *T = (long *)calloc(M, sizeof(long));
@@ -1119,20 +1154,32 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
             }
             if (len < 2 + PAY_BITS / 8) { free(x); free(bitsp); free(cur); free(T); return -3; }
             const uint8_t *sp = in + pos;
-            const int t16 = sp[0] | (sp[1] << 8);
-            const int padb = (t16 >> 11) & 7;
-            long Tv = (t16 & 0x7FF) | (L == RANS_SEED_LANES ? ((long)(t16 >> 15) << 11) : 0);      /* xwide: bit 15 is the field's twelfth bit */
-            const int t_esc = (L == RANS_SEED_LANES && Tv == RANS_TAIL_ESC_X);                    /* ... and 4095 says: the length follows the states */
-            const long nbytes = len - 2 - PAY_BITS / 8 - (t_esc ? 2 : 0);
-            if (((t16 >> 15) && L != RANS_SEED_LANES) || (((t16 >> 14) & 1) && L != RANS_SEED_LANES) || nbytes < 0 || (nbytes == 0 && padb)) { free(x); free(bitsp); free(cur); free(T); return -3; }
-            if (t_esc) {
-                Tv = (long)sp[len - 2] | ((long)sp[len - 1] << 8);
-                if (Tv < RANS_TAIL_ESC_X || Tv > RANS_TAIL_MAX_X) { free(x); free(bitsp); free(cur); free(T); return -3; }
+            long nbytes, hdr;
+            if (L == RANS_SEED_LANES) {
+                /* xwide v4: bit region | states.  The region's highest set bit is its end marker; the 9 bits below it are the header field (T / 32
+                 * rounded up, bit 8: one tail chain), the main coder's bits lie below that -- read DOWN -- on top of the tail coder's spill. */
+                hdr = 0;
+                nbytes = len - PAY_BITS / 8;
+                const int lastb = sp[nbytes - 1];
+                if (lastb == 0) { free(x); free(bitsp); free(cur); free(T); return -3; }
+                const long top = 8 * (nbytes - 1) + (31 - clz32((uint32_t)lastb));
+                if (top < 9) { free(x); free(bitsp); free(cur); free(T); return -3; }
+                const uint32_t f9 = get_bits(sp, top - 9, 9);
+                long Tv = 32L * (f9 & 0xFF);
+                if (Tv > cnt_last[m]) Tv = cnt_last[m];               /* the stream's whole share of the last stage */
+                T[m] = Tv | ((long)((f9 >> 8) & 1) << 16);            /* bit 16: one chain */
+                cur[m] = top - 9;
+            } else {
+                hdr = 2;
+                const int t16 = sp[0] | (sp[1] << 8);
+                const int padb = (t16 >> 11) & 7;
+                nbytes = len - 2 - PAY_BITS / 8;
+                if ((t16 >> 14) || nbytes < 0 || (nbytes == 0 && padb)) { free(x); free(bitsp); free(cur); free(T); return -3; }
+                T[m] = t16 & 0x7FF;
+                cur[m] = 8 * nbytes - padb;                           /* number of data bits */
             }
-            T[m] = Tv | ((long)((t16 >> 14) & 1) << 16);         /* bit 16: the xwide stream's tail has one chain, not two */
-            bitsp[m] = sp + 2;
-            cur[m] = 8 * nbytes - padb;                               /* number of data bits */
-            const uint8_t *fs = sp + 2 + nbytes;
+            bitsp[m] = sp + hdr;
+            const uint8_t *fs = sp + hdr + nbytes;
             for (int l = 0; l < L; ++l) x[m][l] = (1u << 31) | get_bits(fs, (long)RANS_STATE_BITS * l, RANS_STATE_BITS);
             pos += len;
         }
@@ -1208,23 +1255,40 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
             const int minv = minmax[2], maxv = minmax[5], shift = -minmax[2];
             const int Lp = maxv - minv + 2;
             for (int m = 0; m < M; ++m) {
-                if (cur[m] != 0) bad = 1;                        /* every bit of the main region must have been read */
-                uint8_t pay[RANS_MAX_PAY_BITS / 8 + 4];
+                const long E = (L == RANS_SEED_LANES) ? cur[m] : 0;   /* xwide v4: what the main decoder leaves at the bottom of the region is the tail coder's spill */
+                if (cur[m] != E || E >= RANS_SPILL_MAX) { bad = 1; continue; }      /* (64 / 128 lanes: every bit of the main region must have been read) */
+                uint8_t pay[(RANS_MAX_PAY_BITS + RANS_SPILL_MAX) / 8 + 8];
                 memset(pay, 0, sizeof pay);
                 for (int l = 0; l < L; ++l) put_bits(pay, (long)RANS_STATE_BITS * l, RANS_STATE_BITS, x[m][l] & 0x7FFFFFFFu);
+                for (long e = 0; e < E; ++e)
+                    if ((bitsp[m][e >> 3] >> (e & 7)) & 1u) pay[(PAY_BITS + e) >> 3] |= (uint8_t)(1u << ((PAY_BITS + e) & 7));
                 const long cnt = rans_stream_count(n_sym, m, M, L);
                 const int nch = (T[m] >> 16) ? 1 : 2;            /* (xwide) */
                 const long Tm = T[m] & 0xFFFF;
                 if (Tm > cnt) { bad = 1; continue; }
                 if (L == RANS_SEED_LANES) {
-                    /* xwide: one or two seeded chains (see RANS_SEED_LANES): A reads UP from bit 32, B DOWN from the top state */
+                    /* xwide v4: the arena is the payload ++ the spill.  Two chains: seeded, A's state in bits [0, 32) and its fields UP from bit 32,
+                     * B's state in the arena's top 32 bits and its fields DOWN from there.  One chain: A alone; it started from the stream's last
+                     * symbol (raw) and emitted nothing while its state was below the interval -- so the decoder takes min(clz, bits left) bits, and
+                     * "bits left" ends at the chain's end marker, the arena's highest set bit. */
+                    const long alen = PAY_BITS + E;
                     uint32_t pw;
                     const int ns = rans_seed_count(Lp - 1, &pw);
-                    const long NS = cnt < nch * ns ? cnt : nch * ns;
-                    if (Tm < NS) { bad = 1; continue; }
-                    uint32_t xc[2] = { get_bits(pay, 0, 32), nch == 2 ? get_bits(pay, PAY_BITS - 32, 32) : (1u << 31) };
-                    if (!(xc[0] >> 31) || !(xc[1] >> 31)) { bad = 1; continue; }
-                    long pa = 32, pb = nch == 2 ? PAY_BITS - 32 : PAY_BITS;
+                    const long NS = nch == 2 ? (cnt < 2 * ns ? cnt : 2 * ns) : (cnt < 1 ? cnt : 1);
+                    if (Tm < NS || (nch == 2 && cnt < 2 * ns)) { bad = 1; continue; }
+                    long pa = 32, pb;
+                    uint32_t xc[2] = { get_bits(pay, 0, 32), 0 };
+                    if (nch == 2) {
+                        xc[1] = get_bits(pay, alen - 32, 32);
+                        pb = alen - 32;
+                        if (!(xc[0] >> 31) || !(xc[1] >> 31)) { bad = 1; continue; }
+                    } else {
+                        long top = -1;
+                        for (long b = alen - 1; b >= 32; --b)
+                            if ((pay[b >> 3] >> (b & 7)) & 1u) { top = b; break; }
+                        if (top < 32 || (E > 0 && top != alen - 1)) { bad = 1; continue; }      /* a spill ends with the marker */
+                        pb = top;
+                    }
                     int stop = 0;
                     for (long t = Tm - 1; t >= NS && !stop; --t) {
                         const long q = cnt - 1 - t;
@@ -1240,15 +1304,31 @@ int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const or
                         const int s = rans_find(&mx, slot, Lp, minv, maxv, &c_low, &c_high);
                         xc[c] = (c_high - c_low) * (xc[c] >> 16) + slot - c_low;
                         planes[clr * plane_sz + off] = (int16_t)(s - shift);
-                        const int nb = clz32(xc[c]);
-                        if (nb > 16 || pa + nb > pb) { bad = 1; stop = 1; break; }
+                        int nb = clz32(xc[c]);
+                        if (nch == 1) {
+                            if (nb > pb - pa) nb = (int)(pb - pa);       /* the chain's first pushes emitted nothing: what is left is all there is */
+                            else if (nb > 16) { bad = 1; stop = 1; break; }
+                        } else if (nb > 16 || pa + nb > pb) { bad = 1; stop = 1; break; }
                         if (c) { pb -= nb; xc[c] = (xc[c] << nb) | get_bits(pay, pb, nb); }
-                        else { xc[c] = (xc[c] << nb) | get_bits(pay, pa, nb); pa += nb; }
+                        else { xc[c] = (nb < 32 ? (xc[c] << nb) : 0u) | get_bits(pay, pa, nb); pa += nb; }
                     }
                     if (stop) continue;
+                    if (nch == 1) {
+                        /* the chain is back at its start: every bit read, the state = the stream's last symbol (zero if it has none) */
+                        if (pa != pb) bad = 1;
+                        const uint32_t v = xc[0];
+                        if (v >= (uint32_t)(Lp - 1) || (cnt < 1 && v)) { bad = 1; continue; }
+                        if (cnt >= 1) {
+                            const long q = cnt - 1;
+                            const long n = (long)L * (m + (q / L) * M) + (q % L);
+                            int i2 = (int)(n / wc), j2 = (int)(n % wc);
+                            planes[clr * plane_sz + ((long)(2 * i2 + BAND_OI[src]) << lvl) * W + ((long)(2 * j2 + BAND_OJ[src]) << lvl)] = (int16_t)((int)v - shift);
+                        }
+                        continue;
+                    }
                     for (long bq = pa; bq < pb; ++bq)
-                        if ((pay[bq >> 3] >> (bq & 7)) & 1u) bad = 1;             /* nothing between the two chains (behind the one) */
-                    for (int c = 0; c < nch; ++c) {                               /* the start states: the last nch n symbols, raw */
+                        if ((pay[bq >> 3] >> (bq & 7)) & 1u) bad = 1;             /* nothing between the two chains */
+                    for (int c = 0; c < nch; ++c) {                               /* the start states: the last 2 n symbols, raw */
                         uint32_t v = xc[c] & 0x7FFFFFFFu;
                         if (!(xc[c] >> 31) || v >= pw) bad = 1;
                         for (int i = 0; i < ns; ++i, v /= (uint32_t)(Lp - 1)) {

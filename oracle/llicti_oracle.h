@@ -111,13 +111,16 @@ long orc_stream_pairs(const int16_t *planes, int H, int W, const int16_t minmax[
                       const float *params /* [h*w][60] from orc_band_params */,
                       uint32_t *clow, uint32_t *chigh, int16_t *sym);
 
-/* ---- rANS container ("LLICTI-rANS v3", a NEW format of this build: the reference has only torchac) ----
- * Same header segments except byte 0: bit 7 = rANS, bit 3 = format v3 (v2 had it clear and is rejected), bit 6 = extended, bits
- * 5,4,2,1,0 = v.  Not extended: M = v + 1 streams (1 .. 32) of L = 64 lanes.  Extended, v = 0 / 1: M = 64 / 128 streams of 64 lanes
- * (latency modes: M / 32 streams per segment behind a table of their u32 lengths).  Extended, v = 2 .. 15: M = v - 1 WIDE streams
- * (1 .. 14) of L = 128 lanes.  Extended, v = 16 .. 29: M = v - 15 XWIDE streams (1 .. 14) of L = 256 lanes; v = 30 / 31: 32 / 64 xwide
- * streams (64: two per segment behind the length table).  (Round 3 gave v = 2 .. 31 to 1 .. 30 wide streams; no container with more
- * than 14 wide streams was ever written outside a test.)
+/* ---- rANS containers ("LLICTI-rANS v3", and "v4" for the 256-lane streams; NEW formats of this build: the reference has only torchac) ----
+ * Same header segments except byte 0 and -- v4 -- the high bits of the pad field: byte 0 bit 7 = rANS, bit 3 = format v3 or later (v2 had it clear
+ * and is rejected), bit 6 = extended, bits 5,4,2,1,0 = v.  Not extended: M = v + 1 streams (1 .. 32) of L = 64 lanes.  Extended, v = 0 / 1: M = 64 /
+ * 128 streams of 64 lanes (latency modes: M / 32 streams per segment behind a table of their u32 lengths).  Extended, v = 2 .. 15: M = v - 1 WIDE
+ * streams (1 .. 14) of L = 128 lanes.  Extended, v = 16 (byte 0 = 0xE8): XWIDE streams of L = 256 lanes in the v4 layout; their count is in bits
+ * 10 .. 15 of the int16 pad field (bits 0 .. 9 are the five levels' pad flags; these six bits are zero in every other container): u = 1 .. 32 -> M = u
+ * streams, one per segment; u = 33 / 34 -> 64 / 128 streams, two / four per segment behind the length table.
+ * COMPATIBILITY RULE: a format revision that changes the meaning of stream bytes takes a header value no earlier reader accepts.  v = 17 .. 31 were
+ * the xwide tags of rounds 4-5 (v3 layout: u16 T field in front, seeded chains inside the payload, escape); v4 retires them -- this reader refuses
+ * them with -4 / LLICTI_EFORMAT -- and a round-5 reader refuses a v4 container because its pad field contradicts the image size.
  * Same CDFs, same symbols; the 45 torchac streams are replaced by M independent L-way interleaved rANS streams per image
  * (seg_len[4 .. 4+M-1], the rest 0).  Stage st (decode order) has nc symbols in cropped raster order; symbol n sits in chunk
  * n/L, lane n%L; chunk c belongs to stream c % M and is that stream's step c / M of the stage.
@@ -129,35 +132,43 @@ long orc_stream_pairs(const int16_t *planes, int H, int W, const int16_t minmax[
  *              region DOWNWARDS (the encoder, which runs the steps backwards and the lanes descending, wrote it upwards).
  *   tail       a lane's initial state carries payload instead of nothing: the stream's last T symbols of the LAST stage
  *              (sequence positions cnt-T .. cnt-1 of its cnt symbols there) are coded by a single-state coder of the same kind,
- *              last symbol first, the first pushed symbol starting from x = f << 15 (it codes to 2^31 + c_low without a bit);
- *              its bits go up from bit 0 of a 31 L-bit payload (1984 / 3968 / 7936 bits), its final 32-bit state on top (leading one =
- *              the payload's highest set bit).  T is maximal with 32 + bits <= 31 L (T <= 2047).  Lane l starts from 2^31 | payload
- *              bits [31 l, 31 l + 31).  After the last stage the decoder is left with exactly those states: it reassembles the payload,
- *              finds the tail state by its leading one, decodes the T symbols reading downwards, and must end with the tail
- *              coder's start state and no bit left (and the main region read to its last bit) -- the format's integrity check.
- *   tail, xwide (round 4; the 64- and 128-lane kinds above keep their bytes): ONE OR TWO single-state coders ("chains") share the payload and
- *              none starts from an empty state (described for two; the choice and the one-chain form at the end).  With A = the number of symbol values of the image's Cg channel (max - min + 1), n = the largest
- *              count with A^n <= 2^31 (at most 31) and j counting the stream's symbols from its end (j = 0 the last): chain A starts from
- *              2^31 | sum sym(i) A^i (i < n), chain B from the same of sym(n + i) -- symbol INDICES, raw; missing symbols = zero digits -- so the
- *              ~31 bits an empty start state wastes carry n symbols that are never coded.  Symbol j >= 2 n is pushed on chain A if j is even,
- *              on B if odd, j ascending, while used_A + used_B + bits(j) + 64 <= 7936; T = the first j that does not fit (<= 8191, <= cnt).
- *              Payload: bits [0, 32) A's final state, A's bit fields from bit 32 UP in the decoder's reading order (last pushed first); the
- *              top 32 bits B's final state, B's fields below it, read DOWN; zeros between.  Checks: both states have their leading one, the
- *              cursors do not cross, the bits between them are zero, each chain ends at a seed below A^n whose digits beyond the stream's
- *              length are zero.  (Two chains: the tail is serial, and both sides run them on two wavefronts.)
- *              One chain or two: the second chain costs its 32-bit final state and saves what its n seed symbols would have cost coded, so it
- *              pays when symbols are expensive and not when the model predicts them well.  The encoder decides per stream, on its last up to
- *              64 symbols (k of them): two chains iff the stream has 2 n symbols and n * sum(16 - floor(log2 freq)) / k >= 32 + n / 2 (integer
- *              form: 2 n sum >= k (64 + n)), and says so in bit 14 of the stream's first u16 (1 = ONE chain).  One chain: n seed symbols, every
- *              coded symbol on chain A, stop rule with 32 instead of 64, no state on top; the payload above A's fields is zero.
- *   stream     u16 LE (T | pad << 11 | single << 14: bit 14 only in xwide streams, bit 15 zero -- xwide: T's twelfth bit) | bit region, LSB first, ceil(bits / 8) bytes, pad = unused zero bits on
- *              top of its last byte | L x 31-bit final states (low 31 bits of x_l at bit 31 l; 248 / 496 / 992 bytes) | xwide streams only
- *              (round 5): the T field has a twelfth bit, bit 15 of the u16 (T < 4095 costs nothing), and a tail of 4095 symbols or more is
- *              written as 4095 in the field with the count itself, 4095 .. 8191, as a u16 LE behind the states.  (A source cheaper than
- *              7936 / 2047 = 3.9 bits per last-stage symbol cannot fill a 256-lane payload with 2047 symbols -- the rest of the 992 bytes was
- *              waste; the trained model on natural images spends 1.7 bits there.  The 64- and 128-lane kinds keep T <= 2047, bit 15 zero: their
- *              payloads hold 1984 / 3968 bits.)
- * Cost over the ideal code length: ~6 bytes per stream that has symbols (v2: ~60; wide: ~6.5; xwide: ~2-3.5), an empty stream 250 / 498 / 994.
+ *              last symbol first, and its output is cut into the 31 L bits the lanes start from: lane l = 2^31 | payload bits [31 l, 31 l + 31).
+ *              After the last stage the decoder is left with exactly those states, reassembles the payload and decodes the T symbols.
+ *   tail, 64 / 128 lanes (v3, unchanged): the first pushed symbol starts from x = f << 15 (it codes to 2^31 + c_low without a bit); the bits go up
+ *              from bit 0 of the payload (1984 / 3968 bits), the final 32-bit state on top (leading one = the payload's highest set bit).  T is
+ *              maximal with 32 + bits <= 31 L (T <= 2047).  The decoder finds the tail state by its leading one, reads downwards, and must end
+ *              with the tail coder's start state and no bit left (and the main region read to its last bit) -- the format's integrity check.
+ *              Stream: u16 LE (T | pad << 11, bits 14 and 15 zero) | bit region, LSB first, ceil(bits / 8) bytes, pad = unused zero bits on top
+ *              of its last byte | L x 31-bit final states (low 31 bits of x_l at bit 31 l; 248 / 496 bytes).
+ *   tail, xwide v4 (round 6):
+ *     arena    the tail coder's output is NOT cut to the payload: tail symbols are taken -- counting from the stream's end, j = 0 the last -- until,
+ *              at a multiple of 32, the output has reached the payload's 7936 bits (or the stream's share of the last stage, or 8160 symbols, ends).
+ *              The output ("arena", alen bits) is the payload followed by a SPILL of alen - 7936 < 512 bits, which lies at the bottom of the main
+ *              bit region: the main coder's bits start above it, and the main decoder, reading down, leaves it -- its cursor ends AT the spill's
+ *              length, which is how the tail decoder knows alen.  No unused payload bits where the tail has symbols to take; T is a multiple of
+ *              32 (or the stream's whole share), so its field is T / 32 rounded up: 8 bits.
+ *     chains   ONE OR TWO single-state coders.  With A = the number of symbol values of the image's Cg channel (max - min + 1) and n = the
+ *              largest count with A^n <= 2^31 (at most 31): TWO chains iff the stream has 2 n symbols and, over its last up to 64 symbols (k of
+ *              them), 2 n sum(16 - floor(log2 freq)) >= k (64 + n) -- symbols expensive enough that n raw ones are worth a 32-bit state.
+ *              Two: chain A starts from 2^31 | sum sym(i) A^i (i < n), chain B from the same of sym(n + i) (symbol INDICES, raw); symbol
+ *              j >= 2 n is pushed on A if j is even, on B if odd.  Arena: bits [0, 32) A's final state, A's bit fields from bit 32 UP in the
+ *              decoder's reading order (last pushed first); the top 32 bits B's final state, B's fields below it, read DOWN; zeros between
+ *              (only a tail that ran out of symbols leaves any: alen = 7936 then).  Checks: both states have their leading one, the cursors do
+ *              not cross, the bits between them are zero, each chain ends at a seed below A^n.
+ *              One: the chain starts from x = sym(0) -- the stream's last symbol itself, its index, nothing added -- and symbol j >= 1 is pushed
+ *              with the same rule (n minimal with (x >> n) < f << 16), which emits NOTHING while the state is still small: the first few pushes
+ *              only grow it (x < f: x + c_low).  So a chain costs what its symbols cost (v3's start state of 2^31 cost ~31 bits minus the raw
+ *              seeds).  Arena: bits [0, 32) the final state (flat: it may be below 2^31 if the tail is a handful of symbols), the fields from
+ *              bit 32 up in the decoder's reading order, then ONE end-marker bit -- the arena's highest set bit (a spill ends with it).  The
+ *              decoder takes min(clz(x), bits left below the marker) bits after each symbol: once the bits are used up it is in the encoder's
+ *              silent start and the state stays small.  Checks: clz <= 16 wherever bits were left, every bit read, the final state = sym(0) < A.
+ *     stream   bit region, LSB first | L x 31-bit final states (992 bytes).  Bit region, bottom up: the spill | the main coder's bits | 8 bits
+ *              ceil(T / 32) | 1 bit "one chain" | 1 end-marker bit | zeros to the byte boundary: the decoder finds the marker as the highest set
+ *              bit of the region's last byte (which is never zero), takes the 9 bits below it and reads the main bits down from there.
+ *              T = min(32 field, the stream's share of the last stage).
+ * Cost over the ideal code length, measured on 768x512 images (tools/sim_v4.py, tests): 64 lanes ~6 bytes per stream that has symbols, 128 lanes
+ * ~6.5, xwide v4 2.3-2.8 (noise) / 4.1 (natural-like, model-drawn) / 5.1 (a 1.5-bit source) of which 1.8 are the 256 lanes' 0.057 bit each (v3:
+ * 3.5-4.1 / 5.1-6.6 / 9.8); an empty stream costs 250 / 498 / 994 bytes.
  * M: streams per image, | 0x100 for wide streams, | 0x200 for xwide streams.  Returns total bytes or <0. */
 long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *wts, int M,
                            uint8_t *out, long cap, int32_t seg_len[49]);
