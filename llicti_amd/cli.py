@@ -39,7 +39,7 @@ def main(argv=None):
         bl = fileio.read_llic(a.src)
         H, W = header_dims(bl[0][0] + bl[0][1] + bl[0][2])
         n = sum(len(s) for r in bl for s in r)
-        mode = mode_of_header(bl[0][0][0])
+        mode = mode_of_header(bl)
         print(f"{a.src}: {W}x{H} RGB, container {name_of_mode(mode)}, {n} bytes, {8.0 * n / (H * W):.4f} bpp")
         return 0
     if a.cmd == "encode":

@@ -131,9 +131,9 @@ def balanced_modes(sizes, n_cu=256, wide=2, cheap=False):
 
 
 def MODE_RANS(M=8, wide=False):
-    """"LLICTI-rANS v3" container: M independent interleaved rANS streams per image.  wide = 0 / False: 64 lanes per stream, M in
-    1 .. 32, 64, 128; wide = 1 / True: 128 lanes (two 64-symbol chunks per coder step), M in 1 .. 14; wide = 2 ("xwide"): 256 lanes,
-    one decoder lane per symbol, M in 1 .. 14, 32, 64 (include/llicti_hip.h)."""
+    """rANS container: M independent interleaved rANS streams per image.  wide = 0 / False: 64 lanes per stream, M in 1 .. 32, 64, 128 (v3);
+    wide = 1 / True: 128 lanes (two 64-symbol chunks per coder step), M in 1 .. 14 (v3); wide = 2 ("xwide"): 256 lanes, one decoder lane per
+    symbol, the v4 stream layout, M in 1 .. 32, 64, 128 (include/llicti_hip.h)."""
     return (0x100 + 0x200 * int(wide)) | int(M)
 
 
@@ -142,11 +142,11 @@ def _mode_wide(mode: int) -> int:
 
 
 def rans_tag(M, wide=False):
-    """Header byte 0 of a rANS v3 container with M streams per image."""
+    """Header byte 0 of a rANS container with M streams per image (xwide v4: 0xE8 whatever M -- the count is in the pad field, rans_pad_hi)."""
     wide = int(wide)
     ext = 1 if (M > 32 or wide) else 0
     if wide == 2:
-        v = {32: 30, 64: 31}.get(M, M + 15)
+        v = 16
     elif wide == 1:
         v = M + 1
     else:
@@ -154,20 +154,44 @@ def rans_tag(M, wide=False):
     return 0x88 | (ext << 6) | (((v >> 3) & 3) << 4) | (v & 7)
 
 
-def mode_of_header(byte0: int) -> int:
+def rans_pad_hi(M, wide=False):
+    """Bits 10 .. 15 of the header's int16 pad field: the stream count of an xwide v4 container (1 .. 32 as they are, 33 / 34 = 64 / 128 streams),
+    zero in every other container."""
+    return (M if M <= 32 else {64: 33, 128: 34}[M]) if int(wide) == 2 else 0
+
+
+def mode_of_header(hdr, pad=None) -> int:
+    """Container mode of a header: `hdr` = its 17 bytes (bytes 0 .. 2, the 12 min / max bytes, the int16 pad field), or a bytestream_list, or
+    byte 0 alone with the pad field in `pad` (only an xwide v4 container needs it: its stream count lives in the field's bits 10 .. 15)."""
+    if isinstance(hdr, (list, tuple)):
+        hdr = bytes(hdr[0][0]) + bytes(hdr[0][1]) + bytes(hdr[0][2])
+    if isinstance(hdr, (bytes, bytearray, np.ndarray)):
+        byte0 = int(hdr[0])
+        if len(hdr) >= 17:
+            pad = int(hdr[15]) | (int(hdr[16]) << 8)
+    else:
+        byte0 = int(hdr)
+    u = 0 if pad is None else (int(pad) >> 10) & 0x3F
     if byte0 == 5:
         return MODE_AC
-    if (byte0 & 0x88) == 0x88:          # rANS v3: bits 5,4,2,1,0 = v; bit 6 clear: M = v + 1; set: v = 0, 1 -> 64, 128 streams, 2 .. 15 -> v - 1 wide streams,
-        v = (((byte0 >> 4) & 3) << 3) | (byte0 & 7)       # 16 .. 29 -> v - 15 xwide streams, 30 / 31 -> 32 / 64 xwide streams
+    if (byte0 & 0x88) == 0x88:          # rANS: bits 5,4,2,1,0 = v; bit 6 clear: M = v + 1; set: v = 0, 1 -> 64, 128 streams, 2 .. 15 -> v - 1 wide streams,
+        v = (((byte0 >> 4) & 3) << 3) | (byte0 & 7)       # 16 -> xwide streams in the v4 layout, their count in the pad field's high bits
         if (byte0 >> 6) & 1:
+            if v >= 16:
+                if v != 16 or not (1 <= u <= 34):
+                    raise ValueError(f"container tag 0x{byte0:02x} with pad field high bits {u}: an xwide container of the retired v3 layout (rounds 4-5), "
+                                     "or an xwide v4 tag without its pad field -- this build reads and writes xwide v4")
+                return MODE_RANS(u if u <= 32 else {33: 64, 34: 128}[u], wide=2)
+            if u:
+                raise ValueError("pad field high bits set in a container that is not xwide v4")
             if v <= 1:
                 return MODE_RANS(64 << v)
-            if v < 16:
-                return MODE_RANS(v - 1, wide=1)
-            return MODE_RANS({30: 32, 31: 64}.get(v, v - 15), wide=2)
+            return MODE_RANS(v - 1, wide=1)
+        if u:
+            raise ValueError("pad field high bits set in a container that is not xwide v4")
         return MODE_RANS(v + 1)
     if (byte0 & 0x88) == 0x80:
-        raise ValueError(f"container tag 0x{byte0:02x} is the retired LLICTI-rANS v2 format; this build reads and writes v3 only")
+        raise ValueError(f"container tag 0x{byte0:02x} is the retired LLICTI-rANS v2 format; this build reads and writes v3 / v4 only")
     raise ValueError(f"unknown container tag 0x{byte0:02x}")
 
 

@@ -77,7 +77,7 @@ __global__ void header_read_kernel(const uint8_t *__restrict__ in, long in_strid
         if (tot > in_stride) segs_ok = false;
         ok = segs_ok && (sl[0] == 3 && sl[1] == 12 && sl[2] == 2 && sl[3] == 3 * h4 * w4);
         if (ok) {
-            const int pad = (int)(int16_t)(p[15] | (p[16] << 8));
+            const int pad = (int)(uint16_t)(p[15] | (p[16] << 8));      // (xwide v4 containers carry their stream count in bits 10 .. 15: ig.padint has them)
             ok = (p[0] == byte0 && p[1] == h4 && p[2] == w4 && pad == padint);           // LLICTI_nets.py:423-428
         }
         if (!ok) flag_image(status, b, LLICTI_EFORMAT);

@@ -132,6 +132,7 @@ static TileForm choose_tile_form(int n_cu, int tile_rows, int band, COUNT &&coun
 // Hs, Ws: B sizes; rgb_off: B byte offsets of the images in the caller's RGB buffer, or nullptr = tightly packed in call order.
 // n_cu, tile_rows: the band CNN's tile forms of a mixed-size plan are chosen (and its tile lists written) here.
 static int rans_byte0(int M, int Q);
+static int rans_pad_hi(int M, int Q);
 
 // Ms: B stream counts (rANS containers: the images of a call may have different ones -- every header carries its own -- so that larger images
 // get more streams and a stage launch does not wait for its largest image), or nullptr = ME's count for every image.
@@ -149,6 +150,7 @@ static void build_plan(Plan &p, int B, const int *Hs, const int *Ws, const size_
         for (int b = 0; b < B; ++b) { if (rgb_off && (long)rgb_off[b] != pos) p.uniform = false; pos += 3L * Hs[b] * Ws[b]; }      // (the division form of the kernels assumes tightly packed images)
     }
     p.vec_ok = true;
+    p.rgb_bytes = 0;
     p.key.clear();
     p.key.reserve(3 + 4 * (size_t)B);
     p.key.push_back(ME); p.key.push_back(B); p.key.push_back(tile_rows * 2 + (force_ragged ? 1 : 0));
@@ -162,7 +164,7 @@ static void build_plan(Plan &p, int B, const int *Hs, const int *Ws, const size_
         ImgGeo &ig = p.img[b];
         ig.H = Hs[b]; ig.W = Ws[b];
         const Geom g4 = make_geom(1, ig.H, ig.W, 4);
-        ig.h4 = g4.h; ig.w4 = g4.w; ig.padint = pad_int(ig.H, ig.W); ig.hdr_bytes = 17 + 3 * g4.h * g4.w;
+        ig.h4 = g4.h; ig.w4 = g4.w; ig.hdr_bytes = 17 + 3 * g4.h * g4.w;
         ig.plane = (long)ig.H * ig.W;
         ig.pix_off = pix;
         pix += p.uniform ? 3 * ig.plane : (long)align_up((size_t)(3 * ig.plane), 64);
@@ -173,6 +175,7 @@ static void build_plan(Plan &p, int B, const int *Hs, const int *Ws, const size_
         p.max_plane = std::max(p.max_plane, ig.plane);
         ig.M = m_of(b);
         ig.byte0 = ig.M ? rans_byte0(ig.M, Q) : LLICTI_NLEVELS;
+        ig.padint = pad_int(ig.H, ig.W) | ((ig.M ? rans_pad_hi(ig.M, Q) : 0) << 10);      // the header's int16 pad field (xwide v4: its high bits carry the stream count)
         p.key.push_back(ig.H); p.key.push_back(ig.W); p.key.push_back(ig.rgb_off); p.key.push_back(ig.M);
     }
     size_t o = 0;
@@ -257,10 +260,10 @@ static void build_plan(Plan &p, int B, const int *Hs, const int *Ws, const size_
                 syms += (nchunks + Mb - 1) / Mb * L;
                 all_syms += (n + 63) / 64 * 64;
             }
-            p.rslot_cap = std::max(p.rslot_cap, (int)align_up((size_t)(2 * syms + 4 + 8 + pay_bytes + 16 + 64), 64));   // + T, the 31-bit states, slack, zero pad
+            p.rslot_cap = std::max(p.rslot_cap, (int)align_up((size_t)(2 * syms + 4 + 8 + pay_bytes + 16 + 64 + (Q == 4 ? kRansSpillMax / 8 + 8 : 0)), 64));   // + T, the 31-bit states, slack, zero pad (xwide v4: + the tail's spill and the header field)
             // container bound: the streams together hold every symbol once (<= 16 bits each, whole chunks), plus per stream T | pad, the
             // 64 final states, a table entry (M > 32) and the byte the bit region rounds up to
-            p.max_container = std::max(p.max_container, align_up((size_t)p.img[b].hdr_bytes + (size_t)(2 * all_syms) + (size_t)Mb * (2 + pay_bytes + 4 + 4) + 64, 16));
+            p.max_container = std::max(p.max_container, align_up((size_t)p.img[b].hdr_bytes + (size_t)(2 * all_syms) + (size_t)Mb * (2 + pay_bytes + 4 + 4 + (Q == 4 ? kRansSpillMax / 8 : 0)) + 64, 16));
             p.img[b].sbase = p.nstreams;
             for (int m = 0; m < Mb; ++m) p.sref.push_back(StreamRef{ b, m, Mb, p.nstreams });
             p.nstreams += Mb;
@@ -336,31 +339,39 @@ static int mode_streams(int mode)      // -> M, | 0x100 for wide streams (LLICTI
 {
     if (mode == 0) return 0;
     const int M = mode & 0xFF;
-    if ((mode & ~0xFF) == 0x500) return ((M >= 1 && M <= 14) || M == 32 || M == 64) ? (M | 0x200) : -1;
+    if ((mode & ~0xFF) == 0x500) return ((M >= 1 && M <= 32) || M == 64 || M == 128) ? (M | 0x200) : -1;
     if ((mode & ~0xFF) == 0x300) return (M >= 1 && M <= 14) ? (M | 0x100) : -1;
     if ((mode & ~0xFF) != 0x100) return -1;
     if (M < 1 || (M > 32 && M != 64 && M != 128)) return -1;
     return M;
 }
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
-// Header byte 0 of the rANS v3 container (the AC container stores the number of scales, 5, there): bit 7 = rANS, bit 3 = format v3 (the
+// Header byte 0 of a rANS container (the AC container stores the number of scales, 5, there): bit 7 = rANS, bit 3 = format v3 or later (the
 // retired v2 had it clear), bit 6 = extended, bits 5,4,2,1,0 = a 5-bit value v:  M = v + 1 (1 .. 32 streams of 64 lanes, one per segment);
-// extended: v = 0, 1: 64 / 128 streams of 64 lanes (M / 32 per segment); v = 2 .. 15: v - 1 wide streams (128 lanes); v = 16 .. 29: v - 15
-// xwide streams (256 lanes); v = 30, 31: 32 / 64 xwide streams (64: two per segment).
+// extended: v = 0, 1: 64 / 128 streams of 64 lanes (M / 32 per segment); v = 2 .. 15: v - 1 wide streams (128 lanes); v = 16: xwide streams
+// (256 lanes) in the v4 layout, whose COUNT is in bits 10 .. 15 of the int16 pad field (rans_pad_hi(); those bits are zero in every other
+// container, so a reader of the older formats finds a pad field that contradicts the size and refuses).  v = 17 .. 31 were the xwide tags of
+// the v3 layout (rounds 4-5): retired, refused.
 static int rans_byte0(int M, int Q)
 {
     const int ext = (M > 32 || Q > 1) ? 1 : 0;
-    const int v = Q == 4 ? (M == 32 ? 30 : M == 64 ? 31 : M + 15) : Q == 2 ? M + 1 : M > 32 ? (M == 64 ? 0 : 1) : M - 1;
+    const int v = Q == 4 ? 16 : Q == 2 ? M + 1 : M > 32 ? (M == 64 ? 0 : 1) : M - 1;
     return 0x88 | (ext << 6) | (((v >> 3) & 3) << 4) | (v & 7);
 }
-static int rans_streams_of_byte0(int b0)      // -> M (| 0x100 for wide, | 0x200 for xwide streams); 0: not a v3 tag
+static int rans_pad_hi(int M, int Q) { return Q == 4 ? (M <= 32 ? M : M == 64 ? 33 : 34) : 0; }      // bits 10 .. 15 of the pad field
+// -> M (| 0x100 for wide, | 0x200 for xwide streams) of a header's byte 0 and pad field; 0: not a rANS container this build reads
+static int rans_streams_of_header(int b0, int padfield)
 {
     if ((b0 & 0x88) != 0x88) return 0;
-    const int v = (((b0 >> 4) & 3) << 3) | (b0 & 7);
+    const int v = (((b0 >> 4) & 3) << 3) | (b0 & 7), u = (padfield >> 10) & 0x3F;
+    if (((b0 >> 6) & 1) && v >= 16) {
+        if (v != 16 || u < 1 || u > 34) return 0;             // (v3's xwide tags, or no count)
+        return (u <= 32 ? u : u == 33 ? 64 : 128) | 0x200;
+    }
+    if (u) return 0;
     if (!((b0 >> 6) & 1)) return v + 1;
     if (v <= 1) return 64 << v;
-    if (v < 16) return (v - 1) | 0x100;
-    return (v == 30 ? 32 : v == 31 ? 64 : v - 15) | 0x200;
+    return (v - 1) | 0x100;
 }
 
 static int check_dims_v(int B, const int *Hs, const int *Ws)
@@ -404,7 +415,7 @@ static size_t plan_max_container_bytes(int H, int W)
     Plan a, w, x;
     build_plan(a, 1, &H, &W, nullptr, 0);
     build_plan(w, 1, &H, &W, nullptr, 14 | 0x100);          // ... and wide ...
-    build_plan(x, 1, &H, &W, nullptr, 64 | 0x200);          // ... and xwide streams (larger state blocks)
+    build_plan(x, 1, &H, &W, nullptr, 128 | 0x200);         // ... and xwide streams (larger state blocks)
     return std::max(std::max(std::max(p.max_container, q.max_container), std::max(w.max_container, x.max_container)), a.max_container);
 }
 
@@ -413,8 +424,9 @@ static int plan_header_dims(const uint8_t *h, int *H, int *W)
     if (!h || !H || !W) return fail(LLICTI_EINVAL, "header_dims: null pointer");
     if ((h[0] & 0x88) == 0x80)
         return fail(LLICTI_EFORMAT, "header: byte 0 = 0x%02x is the retired LLICTI-rANS v2 container; this build reads and writes v3 only", h[0]);
-    if (h[0] != LLICTI_NLEVELS && rans_streams_of_byte0(h[0]) == 0)
-        return fail(LLICTI_EFORMAT, "header: byte 0 = 0x%02x is neither %d scales (AC container) nor a rANS v3 container tag", h[0], LLICTI_NLEVELS);
+    if (h[0] != LLICTI_NLEVELS && rans_streams_of_header(h[0], (int)(uint16_t)(h[15] | (h[16] << 8))) == 0)
+        return fail(LLICTI_EFORMAT, "header: byte 0 = 0x%02x (pad field 0x%04x) is neither %d scales (AC container) nor a rANS container tag of this build "
+                    "(the xwide v3 layout of rounds 4-5 is retired)", h[0], (unsigned)(h[15] | (h[16] << 8)), LLICTI_NLEVELS);
     int Hc = h[1], Wc = h[2];
     int pad = (int)(int16_t)(h[15] | (h[16] << 8));
     for (int l = LLICTI_NLEVELS - 1; l >= 0; --l) {     // _get_padHW_lev_list, LLICTI_nets.py:533-542

@@ -158,8 +158,9 @@ constexpr int kAnchorRow = 208;
 
 constexpr int kRansStateBits = 31;
 constexpr int kRansTailMax = 2047;          // tail symbols of a 64- / 128-lane stream (the 11-bit T field)
-constexpr int kRansTailMaxX = 8191;         // ... of an xwide stream (round 5): its T field has a twelfth bit (bit 15 of the stream's first u16), and
-constexpr int kRansTailEscX = 4095;         // ... T >= 4,095 is written as 4,095 in the field + the count itself as a u16 behind the states
+constexpr int kRansTailBlock = 32;          // xwide v4: a tail is a multiple of 32 symbols (or the stream's whole share of the last stage): its field is T / 32 rounded up, 8 bits
+constexpr int kRansTailMaxX = 255 * kRansTailBlock;      // 8,160: ... of an xwide stream
+constexpr int kRansSpillMax = 512;          // xwide v4: bits by which the tail coder's output may exceed the payload (< 32 symbols x 16 bits); they lie at the bottom of the main bit region
 // A stream has 64 Q lanes: Q = 1, Q = 2 ("wide" streams: two 64-symbol sub-chunks per step, decoded two lanes per symbol by
 // rans_decode_stage_pair_kernel, at the price of a tail twice as long) or Q = 4 ("xwide": 256 lanes, decoded ONE lane per symbol by
 // rans_decode_stage_lane_kernel, four wavefronts per stream).  Symbol n of a stage sits in chunk n / 64Q.
@@ -168,23 +169,21 @@ template <int Q> struct RansGeo {
     static constexpr int kPayBits = kLanes * kRansStateBits;      // 1984 / 3968 / 7936: what the initial states carry (the tail stream)
     static constexpr int kPayBytes = kPayBits / 8;                // 248 / 496 / 992
     static constexpr int kPayDw = (kPayBits + 31) / 32;           // 62 / 124 / 248
-    static constexpr int kMinStream = 2 + kPayBytes;              // T | pad, (empty bit region), states
+    static constexpr int kMinStream = 2 + kPayBytes;              // T | pad (xwide v4: the header field under its end marker -- ten bits of the bit region), states
 };
 constexpr int kRansPayBytesMax = RansGeo<4>::kPayBytes;
 constexpr int kPhiLutN = 2048;                   // the lane decoder's hint table (llicti_ctx::d_phi_lut)
 constexpr double kPhiLutZ = 6.0;
-// xwide streams (Q = 4) only -- the older stream kinds keep their bytes.  A rANS chain ends in a 32-bit state of which only what the symbols put
-// in is information: a coder that starts from an empty state wastes ~31 bits.  And the tail is serial.  So an xwide stream's tail is coded by up to
-// TWO single-state coders ("chains") sharing the payload, none starting empty (spec: oracle/llicti_oracle.c, RANS_SEED_LANES; two chains where
-// symbols are expensive, one where the model predicts them well and a second final state would cost more than its seed saves: the encoder's
-// integer rule on the stream's last 64 symbols, bit 14 of the stream's first u16 = one chain):
-//   seeds    A = number of symbol values of the image's Cg channel, n = rans_seed_count(A) = the largest count with A^n <= 2^31 (<= 31); counting
-//            the stream's symbols from its end (j = 0 the last), chain A starts from 2^31 | sum sym(i) A^i (i < n), chain B from that of sym(n + i):
-//            2 n symbols that are never coded (three each for the full range of 511: ~3 bytes a stream; ten 256-lane streams an image cost what
-//            five cost before);
-//   chains   symbol j >= 2 n goes to chain A if j is even, B if odd, j ascending, while used_A + used_B + bits(j) + 64 <= payload bits;
-//   payload  [0, 32) A's final state, A's fields from bit 32 up in the decoder's reading order; the top 32 bits B's final state, B's fields below
-//            it read downwards; zeros between.  The states sit at fixed places: no search for the payload's highest set bit.
+// xwide streams (Q = 4) only, "v4" since round 6 -- the older stream kinds keep their v3 bytes (spec: oracle/llicti_oracle.h, "tail, xwide v4").
+//   arena    the tail coder's output is not cut to the payload: tail symbols are taken (j = 0: the stream's last) until, at a multiple of 32, the
+//            output has reached the payload's 7,936 bits; what exceeds them (the "spill", < 512 bits) lies at the bottom of the main bit region,
+//            where the main decoder -- reading down -- leaves it: its final cursor IS the spill's length;
+//   chains   one or two (the encoder's integer rule on the stream's last 64 symbols; bit 8 of the header field = one).  Two: seeded as in v3 --
+//            A = number of symbol values of the image's Cg channel, n = rans_seed_count(A), chain A starts from 2^31 | sum sym(i) A^i (i < n),
+//            chain B from that of sym(n + i), symbol j >= 2 n on A if j is even -- states in the arena's lowest and highest 32 bits, fields
+//            towards each other.  One: the chain starts from x = sym(0), raw, and emits nothing while its state is below the interval; fields
+//            up from bit 32, one end-marker bit above the last -- the arena's highest set bit;
+//   header   on top of the bit region: 8 bits ceil(T / 32), 1 bit "one chain", 1 end-marker bit, zeros to the byte boundary.
 template <int Q> constexpr bool kSeeded = (Q == 4);
 constexpr int kSeedMax = 31;
 LLICTI_HD int rans_seed_count(int A, uint32_t &pw)      // n and A^n

@@ -895,11 +895,12 @@ static int decode_stages(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t
         if (M == 0) {
             unpack_kernel<<<dim3(LLICTI_NSTREAMS, B), 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, B, slots, pd->dev<long>(p.d_slot_off), pd->dev<int32_t>(p.d_slot_cap), slot_len, status);
         } else {
+            const StageGeom *sglv = d_sg + (size_t)(0 * 3 + 2) * B;      // the last stage: an xwide v4 tail is at most the stream's share of it
             rans_unpack_kernel<<<NS, 256, 0, s>>>(d_in, (long)in_stride, d_seg_len, d_sref, 2 + Q * RansGeo<1>::kPayBytes,
-                                                  slots, d_rslot_off, p.rslot_cap, rpos, status);
-            if (Q == 4) rans_init_kernel<4><<<NS, 64, 0, s>>>(slots, d_rslot_off, d_sref, rstate, rpos, rtail, status);
-            else if (Q == 2) rans_init_kernel<2><<<NS, 64, 0, s>>>(slots, d_rslot_off, d_sref, rstate, rpos, rtail, status);
-            else rans_init_kernel<1><<<NS, 64, 0, s>>>(slots, d_rslot_off, d_sref, rstate, rpos, rtail, status);
+                                                  slots, d_rslot_off, p.rslot_cap, rpos, status, Q == 4 ? 4 : 2);
+            if (Q == 4) rans_init_kernel<4><<<NS, 64, 0, s>>>(slots, d_rslot_off, d_sref, rstate, rpos, rtail, status, sglv);
+            else if (Q == 2) rans_init_kernel<2><<<NS, 64, 0, s>>>(slots, d_rslot_off, d_sref, rstate, rpos, rtail, status, sglv);
+            else rans_init_kernel<1><<<NS, 64, 0, s>>>(slots, d_rslot_off, d_sref, rstate, rpos, rtail, status, sglv);
         }
     }
     // 45 dependent stages (LLICTI_nets.py:440-498): CNN of band b needs bands < b of this level, Co needs Y, Cg needs Y, Co
@@ -923,9 +924,9 @@ static int decode_stages(llicti_ctx *c, PlanDev *pd, const uint8_t *d_in, size_t
                 }
                 if (last) {
                     ProfSpan span(c, PROF_RANS_TAIL, s);
-                    if (Q == 4) rans_tail_kernel<4><<<NS, 64 * (1 + kTailAhead) * kTailChains<4>, 0, s>>>(params, sgv, d_sref, rstate, rpos, rtail, planes, fplanes, mm, status);
-                    else if (Q == 2) rans_tail_kernel<2><<<NS, 64 * (1 + kTailAhead), 0, s>>>(params, sgv, d_sref, rstate, rpos, rtail, planes, fplanes, mm, status);
-                    else rans_tail_kernel<1><<<NS, 64 * (1 + kTailAhead), 0, s>>>(params, sgv, d_sref, rstate, rpos, rtail, planes, fplanes, mm, status);
+                    if (Q == 4) rans_tail_kernel<4><<<NS, 64 * (1 + kTailAhead) * kTailChains<4>, 0, s>>>(params, sgv, d_sref, rstate, rpos, rtail, planes, fplanes, mm, status, slots, d_rslot_off);
+                    else if (Q == 2) rans_tail_kernel<2><<<NS, 64 * (1 + kTailAhead), 0, s>>>(params, sgv, d_sref, rstate, rpos, rtail, planes, fplanes, mm, status, slots, d_rslot_off);
+                    else rans_tail_kernel<1><<<NS, 64 * (1 + kTailAhead), 0, s>>>(params, sgv, d_sref, rstate, rpos, rtail, planes, fplanes, mm, status, slots, d_rslot_off);
                 }
             }
             if (M == 0) {

@@ -42,6 +42,13 @@ __device__ __forceinline__ int rans_emit_bits(uint32_t x, uint32_t freq)
     const int n0 = __clz((int)freq) - 16;                 // 32 - bit length of (freq << 16)
     return n0 + (((x >> n0) >= (freq << 16)) ? 1 : 0);
 }
+// the same for ANY state 0 <= x < 2^32 (the one-chain tail of an xwide v4 stream starts from a small state: nothing to emit until it has grown)
+__device__ __forceinline__ int rans_emit_bits_any(uint32_t x, uint32_t freq)
+{
+    if (freq >= 0x10000u) return 0;
+    const int n0 = max(__clz((int)freq) - 16 - __clz((int)x), 0);
+    return n0 + (((x >> n0) >= (freq << 16)) ? 1 : 0);
+}
 // C(s, x) = (x / freq) << 16 + x % freq + lo for x < freq << 16: the quotient fits 16 bits, so a float reciprocal estimate
 // is off by at most one and one signed remainder test repairs it (8 operations instead of a 32-bit division)
 __device__ __forceinline__ uint32_t rans_push(uint32_t x, uint32_t lo, uint32_t freq)
@@ -77,7 +84,7 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
 {
     using GEO = RansGeo<Q>;
     constexpr int L = GEO::kLanes;
-    __shared__ uint32_t sh_pay[64 * Q];             // the tail stream / the final states (62 Q dwords used, the rest slack)
+    __shared__ uint32_t sh_pay[64 * Q + kRansSpillMax / 32 + 8];      // the tail coder's output (xwide v4: payload ++ spill) / the final states (62 Q dwords used, the rest slack)
     // dwords: one flush = one dword per thread; a step adds at most kFlush / 2, a round of four steps 2 kFlush.  Ring of 8 flush units: when a
     // round's barrier opens, up to 3 kFlush dwords are waiting (a leftover below one unit + the previous round's), the round's own ORs reach
     // 2 kFlush + 1 further -- below wbase + 5 kFlush + 2 -- while slower wavefronts may still be reading / zeroing [wbase, wbase + 2 kFlush):
@@ -97,6 +104,7 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
     const int cap_dw = (rslot_cap - 4 - GEO::kPayBytes - 8) >> 2;      // dwords the bit region may take
     int bad = 0;
     sh_pay[tid] = 0;
+    if (tid < kRansSpillMax / 32 + 8) sh_pay[64 * Q + tid] = 0;
 #pragma unroll
     for (int t = 0; t < kWin; t += kFlush) sh_win[t + tid] = 0;
     __syncthreads();
@@ -110,15 +118,19 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
     const StreamDesc dl = desc[(long)(LLICTI_NSTREAMS - 1) * B + b];
     const int cnt = rans_stream_count(dl.n, m, M, L);
     int T = 0;
-    int tail_single = 0;                            // xwide: the tail has one chain, not two (bit 14 of the stream's first u16)
+    int tail_single = 0;                            // xwide: the tail has one chain, not two (bit 8 of the stream's header field)
+    int alen = GEO::kPayBits;                       // xwide v4: bits of the tail coder's output; what exceeds the payload starts the main bit region
     if constexpr (kSeeded<Q>) {
-        // xwide: two seeded chains (above), chain c on wavefront c.  The chains are independent but for the stop rule, which looks at both:
-        // they run in blocks of 32 steps, record (field, bits) of every step in symbol order and their states of the last block, and meet at a
-        // barrier after each block; the first block that overshoots the payload ends the recursion, and where exactly the sequential rule stops
-        // -- T -- and where each field goes are prefix sums over the records, done by all 256 threads.
-        __shared__ uint32_t sh_fld[kRansTailMaxX + 1];  // (field, bits) of every tail step, in symbol order: up to 8,191 of them (round 5: a tail of 2,047 symbols
+        // xwide v4 (host_types.hpp, oracle/llicti_oracle.h): ONE chain that starts from the stream's last symbol itself (raw) and emits nothing while
+        // its state is small, or TWO seeded chains where symbols are expensive -- chain c on wavefront c.  The chains are independent but for the
+        // stop rule, which looks at both: they run in blocks of 32 steps, record (field, bits) of every step in symbol order and their states of the
+        // last two blocks, and meet at a barrier after each block.  The output ("arena") is not cut to the payload: symbols are taken until, at a
+        // multiple of 32 counted from the stream's end, it has reached the payload's 7,936 bits -- so the recursion runs one block past the block that
+        // got there -- and what exceeds the payload (< 512 bits, the spill) is handed to the main coder as the bottom of its bit region.  Where
+        // exactly the rule stops -- T -- and where each field goes are prefix sums over the records, done by all 256 threads.
+        __shared__ uint32_t sh_fld[kRansTailMaxX + 1];  // (field, bits) of every tail step, in symbol order: up to 8,160 of them (a tail of 2,047 symbols
                                                         // fills the 7,936-bit payload only at 3.9 bits per symbol; the trained model's last stage costs 1.7)
-        __shared__ uint32_t sh_xs[2][34];
+        __shared__ uint32_t sh_xs[2][2][34];            // [block parity][chain]: the state at the block's start, then behind each of its steps
         __shared__ int sh_used[2][2], sh_scan[2][4], sh_cut[3];
         const uint32_t *pl = pairs + dl.pair_off;
         int minv, maxv, shift;
@@ -142,15 +154,17 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
             if (2 * wsum * ns >= k64 * (64 + ns)) nch = 2;
         }
         tail_single = (nch == 1);
-        const int NS = min(nch * ns, cnt);
-        const int ncod = max(min(cnt, kRansTailMaxX) - nch * ns, 0);       // candidates j = nch ns + idx, idx < ncod; chain c takes idx = nch i + c
+        const int sn = (nch == 2) ? ns : 1;                                // raw symbols in a chain's start state
+        const int fixed = (nch == 2) ? 64 : 33;                            // the final states; one chain: + its end marker
+        const int NS = min(nch * sn, cnt);
+        const int ncod = max(min(cnt, kRansTailMaxX) - nch * sn, 0);       // candidates j = nch sn + idx, idx < ncod; chain c takes idx = nch i + c
         const int n_own = (wq < nch) ? (ncod + nch - 1 - wq) / nch : 0;
         const int nblk = ((ncod + nch - 1) / nch + 31) >> 5;               // chain A's steps, in blocks
-        uint32_t xc = 1u << 31;
+        uint32_t xc = (nch == 2) ? (1u << 31) : 0u;
         if (wq < nch) {
-            const int j = wq * ns + lane;
+            const int j = wq * sn + lane;
             int term = 0;
-            if (lane < ns && j < cnt) {
+            if (lane < sn && j < cnt) {
                 const int q = cnt - 1 - j;
                 const int n = L * (m + (q / L) * M) + (q % L);
                 const int pi = div_wc(sgl, n), pj = n - pi * sgl.wc;
@@ -164,16 +178,18 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
         }
         auto fetch_blk = [&](int blk) -> uint32_t {     // lane t < 32: step 32 blk + t of the wavefront's chain
             const int i = 32 * blk + (lane & 31);
-            const int q = cnt - 1 - (nch * ns + nch * i + wq);
+            const int q = cnt - 1 - (nch * sn + nch * i + wq);
             return (i < n_own) ? pl[L * (m + (q / L) * M) + (q % L)] : 0u;
         };
-        int used = 0, blk = 0;
+        int used = 0, blk = 0, prev_tot = 0;
         uint32_t raw = fetch_blk(0);
+        if (wq < 2 && lane == 0) { sh_xs[0][wq][0] = xc; sh_used[0][wq] = 0; }      // (a stream with nothing to code: the start states are the final ones)
+        if (nblk > 0)
         for (;; ++blk) {                                // workgroup-uniform
             const uint32_t rawn = fetch_blk(blk + 1);
             if (wq < 2) {                               // (an idle chain B records no steps and reports 0 bits)
                 const int nst = min(32, n_own - 32 * blk);
-                if (lane == 0) sh_xs[wq][0] = xc;
+                if (lane == 0) sh_xs[blk & 1][wq][0] = xc;
                 uint32_t recv = 0, xsv = 0;             // lane t: step t's record and the state behind it -- written to LDS once per block, not once per step
                 for (int t = 0; t < nst; ++t) {
                     const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)raw, t);
@@ -182,23 +198,25 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
                     if (hi == 0) hi = 0x10000u;
                     uint32_t freq = hi - lo;
                     if (freq == 0 || hi < lo) { bad = 1; freq = 1; }
-                    const int nb = rans_emit_bits(xc, freq);
+                    const int nb = rans_emit_bits_any(xc, freq);
                     recv = (lane == t) ? ((xc & ((1u << nb) - 1u)) | ((uint32_t)nb << 16)) : recv;
                     used += nb;
                     xc = rans_push(xc >> nb, lo, freq);
                     xsv = (lane == t) ? xc : xsv;
                 }
-                if (lane < nst) { sh_fld[nch * (32 * blk + lane) + wq] = recv; sh_xs[wq][lane + 1] = xsv; }
+                if (lane < nst) { sh_fld[nch * (32 * blk + lane) + wq] = recv; sh_xs[blk & 1][wq][lane + 1] = xsv; }
                 if (lane == 0) sh_used[blk & 1][wq] = used;
             }
             __syncthreads();
             raw = rawn;
-            if (sh_used[blk & 1][0] + sh_used[blk & 1][1] + 32 * nch > GEO::kPayBits || blk + 1 >= nblk) break;
+            const bool full_before = blk > 0 && prev_tot + fixed >= GEO::kPayBits;      // the payload was full a block ago: the stopping multiple of 32 lies in this block or the one before
+            prev_tot = sh_used[blk & 1][0] + sh_used[blk & 1][1];
+            if (full_before || blk + 1 >= nblk) break;
         }
-        const int nrun = min(32 * nch * (blk + 1), ncod);     // records there are
-        // Where the sequential rule stops (tcod) and where each field goes are prefix sums over the records: thread tid takes records
-        // 2048 q + 8 tid .. + 7 of quarter q (one quarter covers the 2,047 symbols every tail had before round 5; a long tail of a cheap source has up to
-        // four), the chains' bit counts before a quarter carried over from the quarters in front of it.
+        const int nrun = (nblk > 0) ? min(32 * nch * (blk + 1), ncod) : 0;     // records there are
+        // Where the rule stops (tcod) and where each field goes are prefix sums over the records: thread tid takes records
+        // 2048 q + 8 tid .. + 7 of quarter q (a long tail of a cheap source has up to four), the chains' bit counts before a quarter carried
+        // over from the quarters in front of it.
         auto onb = [&](int e) -> bool { return nch == 2 && (e & 1); };      // record 2048 q + 8 tid + e belongs to chain B (2048 and 8 are even)
         const int nq = (nrun + 2047) >> 11;
         int nbv[8];
@@ -227,20 +245,21 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
         };
         if (tid == 0) sh_cut[0] = nrun;
         __syncthreads();
-        for (int q = 0; q < nq; ++q) {                  // 1. the first record that does not fit
+        for (int q = 0; q < nq; ++q) {                  // 1. the first record at a multiple of 32 symbols (from the stream's end) in front of which the arena has reached the payload
             int ea, eb, ta, tb2;
             scan_quarter(q, ea, eb, ta, tb2);
             int ca = ea, cb = eb, first = 0x7FFFFFFF;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                if (ca + cb + nbv[e] + 32 * nch > GEO::kPayBits && first == 0x7FFFFFFF) first = 2048 * q + 8 * tid + e;
+                const int idx = 2048 * q + 8 * tid + e;
+                if (((NS + idx) & (kRansTailBlock - 1)) == 0 && ca + cb + fixed >= GEO::kPayBits && idx < nrun && first == 0x7FFFFFFF) first = idx;
                 if (onb(e)) cb += nbv[e]; else ca += nbv[e];
             }
             if (first != 0x7FFFFFFF) atomicMin(&sh_cut[0], first);
             base_a += ta; base_b += tb2;
         }
         __syncthreads();
-        const int tcod = sh_cut[0];                     // coded symbols: the sequential rule's stop
+        const int tcod = sh_cut[0];                     // coded symbols
         base_a = 0; base_b = 0;
         if (tid == 0 && tcod == nrun) { sh_cut[1] = -1; sh_cut[2] = -1; }
         for (int q = 0; q < nq; ++q) {                  // 2. the chains' bits up to there
@@ -255,9 +274,10 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
             base_a += ta; base_b += tb2;
         }
         __syncthreads();
-        if (tid == 0 && sh_cut[1] < 0) { sh_cut[1] = base_a; sh_cut[2] = base_b; }      // every record fits: the totals
+        if (tid == 0 && (sh_cut[1] < 0 || nq == 0)) { sh_cut[1] = base_a; sh_cut[2] = base_b; }      // every record is coded: the totals
         __syncthreads();
         const int used_a = sh_cut[1], used_b = sh_cut[2];
+        alen = max(GEO::kPayBits, fixed + used_a + used_b);     // the arena: payload ++ spill
         base_a = 0; base_b = 0;
         for (int q = 0; q < nq; ++q) {                  // 3. the fields to their places: chain A's upwards from bit 32 in the decoder's reading order, chain B's below its state
             int ea, eb, ta, tb2;
@@ -266,7 +286,7 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 if (2048 * q + 8 * tid + e < tcod) {
-                    const int pos = onb(e) ? GEO::kPayBits - 32 - used_b + cb : 32 + used_a - ca - nbv[e];
+                    const int pos = onb(e) ? alen - 32 - used_b + cb : 32 + used_a - ca - nbv[e];
                     lds_or_bits(sh_pay, pos, nbv[e], fv[e]);
                 }
                 if (onb(e)) cb += nbv[e]; else ca += nbv[e];
@@ -274,13 +294,22 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
             base_a += ta; base_b += tb2;
         }
         if (tid == 0) {
-            sh_pay[0] = sh_xs[0][(tcod + nch - 1) / nch - 32 * blk];
-            if (nch == 2) sh_pay[GEO::kPayDw - 1] = sh_xs[1][(tcod >> 1) - 32 * blk];
+            // the chains' states behind their last coded step: s steps in, i.e. entry s - 32 b of block b = min(s / 32, the last block run)
+            auto state_of = [&](int c, int steps) -> uint32_t { const int bb = min(steps >> 5, blk); return sh_xs[bb & 1][c][steps - 32 * bb]; };
+            sh_pay[0] = state_of(0, (tcod + nch - 1) / nch);
+            if (nch == 2) {
+                const uint32_t xb = state_of(1, tcod >> 1);
+                lds_or_bits(sh_pay, alen - 32, 16, xb & 0xFFFFu);
+                lds_or_bits(sh_pay, alen - 16, 16, xb >> 16);
+            } else lds_or_bits(sh_pay, 32 + used_a, 1, 1u);      // one chain: the end marker behind its last field -- the arena's highest set bit
         }
         T = NS + tcod;
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < kWin; t += kFlush) sh_win[t + tid] = 0;
+        __syncthreads();
+        // the spill -- arena bits [7936, alen): whole dwords of sh_pay, the payload being 248 of them -- is the bottom of the main bit region
+        if (tid < kRansSpillMax / 32 + 1) sh_win[tid] = sh_pay[GEO::kPayDw + tid];
         __syncthreads();
     } else {
         const uint32_t *pl = pairs + dl.pair_off;
@@ -329,7 +358,7 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
     const int tail_from = cnt - T;                  // sequence position (L k + stream lane) of the first tail symbol
 
     // 3. main coder, last decoded symbol first; bits go UP from bit 0 of the bit region
-    int bp = 0, wbase = 0;                          // bit cursor; first dword of the staging window (workgroup-uniform)
+    int bp = alen - GEO::kPayBits, wbase = 0;       // bit cursor (xwide v4: above the tail's spill); first dword of the staging window (workgroup-uniform)
     int par = 0;                                    // parity of the coded steps (sh_tot)
     // A stage's steps of this stream: K of them (0: the stage has no chunk for stream m), its pairs, the first tail position
     struct Stg { const uint32_t *pp; int n, K, lim; };
@@ -434,8 +463,20 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
         a0 = n0; a1 = n1; a2 = n2; a3 = n3; b0 = n4; b1 = n5; b2 = n6; b3 = n7;
         sg_cur = sg_nxt;
     }
-    // 4. the rest of the ring, the 64 Q final states (31 bits each), T | pad
+    // 4. the rest of the ring, the 64 Q final states (31 bits each), T | pad (xwide v4: the header field on top of the bit region instead)
     __syncthreads();
+    if constexpr (kSeeded<Q>) {
+        // 8 bits T / 32 rounded up, 1 bit "one chain", 1 end-marker bit -- ORed into the ring above the main coder's last bit (every wavefront's
+        // ORs of the last round are behind the barrier; the ring holds at least 3 flush units beyond the cursor)
+        if (tid == 0) {
+            const uint32_t f10 = (uint32_t)((T + kRansTailBlock - 1) / kRansTailBlock) | ((uint32_t)tail_single << 8) | (1u << 9);
+            const int sh = bp & 31;
+            atomicOr(&sh_win[(bp >> 5) & (kWin - 1)], f10 << sh);
+            atomicOr(&sh_win[((bp >> 5) + 1) & (kWin - 1)], (uint32_t)(((uint64_t)f10 << sh) >> 32));
+        }
+        bp += 10;
+        __syncthreads();
+    }
     const int nbytes = (bp + 7) >> 3;
     sh_pay[tid] = 0;
     __syncthreads();
@@ -451,43 +492,58 @@ __global__ __launch_bounds__(64 * Q) void rans_encode_kernel(const uint32_t *__r
         uint8_t *fs = slot + 4 + nbytes;
         for (int t = tid; t < GEO::kPayBytes; t += 64 * Q) fs[t] = (uint8_t)(sh_pay[t >> 2] >> (8 * (t & 3)));
     }
-    // xwide streams: the T field has a twelfth bit (bit 15), and a tail of 4,095 symbols or more is written as 4,095 with the count itself as a u16
-    // behind the states (oracle/llicti_oracle.h, "stream")
-    const bool t_esc = kSeeded<Q> && T >= kRansTailEscX;
     if (tid == 0) {
-        const int Tf = t_esc ? kRansTailEscX : T;
-        const int t16 = (Tf & 0x7FF) | ((8 * nbytes - bp) << 11) | (tail_single << 14) | ((Tf >> 11) << 15);      // pad: unused (zero) bits on top of the region's last byte
-        slot[2] = (uint8_t)(t16 & 0xFF); slot[3] = (uint8_t)(t16 >> 8);
-        if (t_esc && !over) { uint8_t *te = slot + 4 + nbytes + GEO::kPayBytes; te[0] = (uint8_t)(T & 0xFF); te[1] = (uint8_t)(T >> 8); }
-        rinfo[2 * sidx] = 2; rinfo[2 * sidx + 1] = (bad == 2) ? 0 : 2 + nbytes + GEO::kPayBytes + (t_esc ? 2 : 0);      // overflowed slot (never with the plan's sizing): nothing to pack, ENOSPACE is latched
+        if constexpr (kSeeded<Q>) {
+            // the stream is bit region | states: it starts at the region (slot + 4)
+            rinfo[2 * sidx] = 4; rinfo[2 * sidx + 1] = (bad == 2) ? 0 : nbytes + GEO::kPayBytes;
+        } else {
+            const int t16 = (T & 0x7FF) | ((8 * nbytes - bp) << 11);      // pad: unused (zero) bits on top of the region's last byte
+            slot[2] = (uint8_t)(t16 & 0xFF); slot[3] = (uint8_t)(t16 >> 8);
+            rinfo[2 * sidx] = 2; rinfo[2 * sidx + 1] = (bad == 2) ? 0 : 2 + nbytes + GEO::kPayBytes;      // overflowed slot (never with the plan's sizing): nothing to pack, ENOSPACE is latched
+        }
     }
     if (bad) atomicExch(&status[0], bad == 1 ? LLICTI_EFORMAT : LLICTI_ENOSPACE);
 }
 
-// decode: parse a stream (copied to slot + 2 by rans_unpack_kernel, which also left its validated length in rpos):
-// T and pad (-> bit cursor), the 64 Q states
+// decode: parse a stream (copied by rans_unpack_kernel so that its bit region starts at slot + 4, dword aligned; its validated length is in rpos):
+// T and the bit cursor, the 64 Q states.  64 / 128 lanes: u16 (T | pad << 11) | bit region | states.  xwide v4: bit region | states, the
+// region's highest set bit its end marker, the 9 bits below it the header field (T / 32 rounded up -- T = min(32 field, the stream's share of
+// the last stage) -- and the one-chain flag), the main coder's bits below that.
 template <int Q>
 __global__ __launch_bounds__(64) void rans_init_kernel(const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
                                                        const StreamRef *__restrict__ sref, uint32_t *__restrict__ rstate, uint32_t *__restrict__ rpos,
-                                                       uint32_t *__restrict__ rtail, int32_t *status)
+                                                       uint32_t *__restrict__ rtail, int32_t *status, const StageGeom *__restrict__ sglv)
 {
     using GEO = RansGeo<Q>;
     const int sidx = blockIdx.x, lane = threadIdx.x;
     const uint8_t *slot = slots + rslot_off[sidx];
     const int n = (int)rpos[sidx];                                 // >= GEO::kMinStream
-    const int t16 = slot[2] | (slot[3] << 8);
-    int T = (t16 & 0x7FF) | (kSeeded<Q> ? (t16 >> 15) << 11 : 0);  // xwide: bit 15 is the field's twelfth bit ...
-    const bool t_esc = kSeeded<Q> && T == kRansTailEscX;           // ... and 4,095 says: the count follows the states as a u16
-    int nbytes = n - 2 - GEO::kPayBytes - (t_esc ? 2 : 0);
-    const int pad = (t16 >> 11) & 7;
     bool bad = false;
-    const int single = kSeeded<Q> ? (t16 >> 14) & 1 : 0;           // xwide: one tail chain instead of two
-    if ((!kSeeded<Q> && (t16 >> 14)) || nbytes < 0 || (nbytes == 0 && pad)) { bad = true; T = 0; nbytes = max(nbytes, 0); }
-    if (t_esc && !bad) {
-        T = slot[2 + n - 2] | (slot[2 + n - 1] << 8);               // (the stream sits at slot + 2)
-        if (T < kRansTailEscX || T > kRansTailMaxX) { bad = true; T = 0; }
+    int T = 0, single = 0, cur = 0, nbytes;
+    if constexpr (kSeeded<Q>) {
+        nbytes = n - GEO::kPayBytes;                               // >= 2
+        const uint8_t *reg = slot + 4;
+        const int lastb = reg[nbytes - 1];
+        const int top = 8 * (nbytes - 1) + 31 - __clz(lastb | 1);      // the end marker
+        if (lastb == 0 || top < 9) bad = true;
+        else {
+            const int p0 = top - 9;
+            const uint32_t w = (uint32_t)reg[p0 >> 3] | ((uint32_t)reg[(p0 >> 3) + 1] << 8) | ((uint32_t)reg[min((p0 >> 3) + 2, nbytes - 1)] << 16);
+            const uint32_t f9 = (w >> (p0 & 7)) & 0x1FFu;
+            const StreamRef sr_ = sref[sidx];
+            const StageGeom sgl = sglv[sr_.b];                     // the image's last stage: a tail is at most the stream's share of it
+            T = min(kRansTailBlock * (int)(f9 & 0xFFu), rans_stream_count(sgl.hc * sgl.wc, sr_.m, sr_.M, GEO::kLanes));
+            single = (int)(f9 >> 8);
+            cur = p0;
+        }
+    } else {
+        const int t16 = slot[2] | (slot[3] << 8);
+        T = t16 & 0x7FF;
+        nbytes = n - 2 - GEO::kPayBytes;
+        const int pad = (t16 >> 11) & 7;
+        if ((t16 >> 14) || nbytes < 0 || (nbytes == 0 && pad)) { bad = true; T = 0; nbytes = max(nbytes, 0); }
+        cur = bad ? 0 : 8 * nbytes - pad;
     }
-    const int cur = bad ? 0 : 8 * nbytes - pad;
     const uint8_t *fs = slot + 4 + nbytes;
 #pragma unroll
     for (int qq = 0; qq < Q; ++qq) {
@@ -1343,11 +1399,13 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_t
                                                        const uint32_t *__restrict__ rstate, const uint32_t *__restrict__ rpos,
                                                        const uint32_t *__restrict__ rtail,
                                                        int16_t *__restrict__ planes, float *__restrict__ fplanes,
-                                                       const int32_t *__restrict__ minmax, int32_t *status)
+                                                       const int32_t *__restrict__ minmax, int32_t *status,
+                                                       const uint8_t *__restrict__ slots, const long *__restrict__ rslot_off)
 {
     using GEO = RansGeo<Q>;
     constexpr int L = 64 * Q, NCH = kTailChains<Q>;
-    __shared__ uint32_t sh_pay[64 * Q + 2];
+    constexpr int kSpillDw = kSeeded<Q> ? kRansSpillMax / 32 + 1 : 0;      // xwide v4: the arena is the payload ++ the spill the main decoder left at the bottom of its region
+    __shared__ uint32_t sh_pay[64 * Q + 2 + kSpillDw];
     constexpr int NSL = NCH * kTailAhead;               // prepared symbols per round and buffer: slot = chain kTailAhead + i
     __shared__ float sh_cmp[2][NSL][16];                // [0..4] mu, [5..9] 1 / sigma, [10..14] normalised weight of the five components
     __shared__ int sh_e1[2][NSL][64];                   // approximate table entry at anchor 8 l
@@ -1371,7 +1429,10 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_t
     const bool pool = NCH == 2 && nch == 1;
     const int chain = (pool && role != 0) ? 0 : wave % NCH;
     const int SA = pool ? NSL : kTailAhead;             // symbols of a chain per round = its preparing wavefronts
-    bool bad = rpos[sidx] != 0 || rt > cnt;
+    // 64 / 128 lanes: the main region must have been read to its last bit.  xwide v4: what is left of it IS the tail coder's spill (its length the cursor)
+    const int E = kSeeded<Q> ? (int)rpos[sidx] : 0;
+    bool bad = (kSeeded<Q> ? E >= kRansSpillMax : rpos[sidx] != 0) || rt > cnt;
+    const int alen = GEO::kPayBits + (bad ? 0 : E);     // the arena
     const int Tall = min(rt, cnt);                      // the stream's tail symbols: the coded ones, then (xwide) the seeds'
     int minv, maxv, shift;
     clr_range(minmax + 4 * b, 2, minv, maxv, shift);
@@ -1379,8 +1440,9 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_t
     const int max_symbol = gr.Lp - 2;
     uint32_t pw = 1;
     const int ns = kSeeded<Q> ? rans_seed_count(max_symbol + 1, pw) : 0;
-    const int NS = min(nch * ns, cnt);                  // seed symbols (0 for the older stream kinds)
-    bad = bad || Tall < NS;
+    const int sn = kSeeded<Q> ? (nch == 2 ? ns : 1) : 0;     // raw symbols in a chain's start state (xwide v4: n per chain of two, the stream's last symbol for one chain)
+    const int NS = min(nch * sn, cnt);                  // seed symbols (0 for the older stream kinds)
+    bad = bad || Tall < NS || (nch == 2 && cnt < 2 * ns);
     const bool live = chain < nch;                      // (the second set of wavefronts idles through a one-chain stream's rounds)
     const int Tc = max(Tall - NS, 0);                   // coded symbols; the one with index idx (j = nch ns + idx from the stream's end) is on chain idx % nch
     const int T = live ? (Tc + nch - 1 - chain) / nch : 0;      // this chain's
@@ -1401,7 +1463,7 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_t
         struct Row { float sg, mu, wk, bb, dd, y, co; long off; };
         auto fetch = [&](int t) -> Row {
             Row r;
-            const long pp = pixel_of(nch * ns + chain + nch * (T - 1 - t));
+            const long pp = pixel_of(nch * sn + chain + nch * (T - 1 - t));
             const int pi = (int)(pp >> 32), pj = (int)(uint32_t)pp;
             const ParRow src = par_row(params + sg.par_off, 0, (long)sg.h * sg.w, (long)pi * sg.w + pj);
             r.off = img + ((long)(2 * pi + sg.oi) << sg.lvl) * sg.W + ((long)(2 * pj + sg.oj) << sg.lvl);
@@ -1497,14 +1559,39 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_t
             lds_or_bits(sh_pay, kRansStateBits * (64 * qq + lane), 16, xl & 0xFFFFu);
             lds_or_bits(sh_pay, kRansStateBits * (64 * qq + lane) + 16, kRansStateBits - 16, xl >> 16);
         }
+        if constexpr (kSeeded<Q>) {
+            // the spill: bits [0, E) of the stream's bit region (slot + 4), behind the payload's 248 dwords; what lies above it in the region is not the tail's
+            if (lane < kSpillDw) {
+                const uint32_t w = reinterpret_cast<const uint32_t *>(slots + rslot_off[sidx] + 4)[lane];
+                const int nb = min(max(alen - GEO::kPayBits - 32 * lane, 0), 32);
+                sh_pay[GEO::kPayDw + lane] = nb >= 32 ? w : (w & ((1u << nb) - 1u));
+            }
+        }
     }
     __syncthreads();
     uint32_t xt;
     int tc;                                               // bit cursor: legacy chains and xwide chain B read DOWN to it, xwide chain A reads UP from it
+    int a_end = alen;                                     // xwide, one chain: its end marker (the bits it may read end there)
     if constexpr (kSeeded<Q>) {
-        xt = live ? (uint32_t)__builtin_amdgcn_readfirstlane((int)sh_pay[chain ? GEO::kPayDw - 1 : 0]) : (1u << 31);        // final states at fixed places (the state is wave-uniform: kept scalar)
-        tc = chain ? GEO::kPayBits - (live ? 32 : 0) : 32;
-        if (!(xt >> 31)) { bad = true; xt |= 1u << 31; }
+        // final states at fixed places: chain A's in bits [0, 32), chain B's in the arena's top 32 bits (the state is wave-uniform: kept scalar)
+        xt = !live ? (1u << 31) : (uint32_t)__builtin_amdgcn_readfirstlane((int)(chain ? lds_get_bits(sh_pay, alen - 32, 32) : sh_pay[0]));
+        tc = chain ? alen - (live ? 32 : 0) : 32;
+        if (nch == 2) { if (!(xt >> 31)) { bad = true; xt |= 1u << 31; } }
+        else {
+            // one chain: the arena's highest set bit above the state is the chain's end marker (a spill ends with it)
+            int top = -1;
+            for (int d0 = 64 * ((GEO::kPayDw + kSpillDw - 1) / 64); d0 >= 0 && top < 0; d0 -= 64) {
+                const int d = d0 + lane;
+                const uint32_t w = (d >= 1 && d < GEO::kPayDw + kSpillDw) ? sh_pay[d] : 0u;
+                const uint64_t nz = ballot64(w != 0);
+                if (nz) {
+                    const int hl = 63 - __clzll((long long)nz);
+                    top = 32 * (d0 + hl) + 31 - __clz((int)__builtin_amdgcn_readlane((int)w, hl));
+                }
+            }
+            if (top < 32 || (alen > GEO::kPayBits && top != alen - 1)) { bad = true; top = 32; }
+            a_end = top;
+        }
     } else {
         int top = -1;                                                          // the payload's highest set bit
 #pragma unroll
@@ -1536,7 +1623,7 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_t
             // the <= 16 bits the renormalisation will take lie in two dwords that only depend on the cursor: requested here, next to the window, so that
             // the LDS round trip runs under the search instead of behind the state update
             const bool up = kSeeded<Q> && chain == 0;            // xwide chain A reads UP from its cursor, everything else DOWN to it
-            const int wpos = min(max(up ? tc : tc - 16, 0), GEO::kPayBits);      // (a corrupt stream's cursor stays inside the payload array)
+            const int wpos = min(max(up ? tc : tc - 16, 0), alen);               // (a corrupt stream's cursor stays inside the arena's array)
             const uint32_t bw0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh_pay[wpos >> 5]);
             const uint32_t bw1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh_pay[(wpos >> 5) + 1]);
             auto take_bits = [&](int pos, int n) -> uint32_t {   // bits [pos, pos + n) of the payload, n <= 16, inside the window
@@ -1598,11 +1685,22 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_t
             xt = (vhi - vlo) * (xt >> 16) + slot - vlo;
             if constexpr (kSeeded<Q>) {
                 int nb = __clz((int)xt);
-                const int avail = chain ? tc - 32 : GEO::kPayBits - (nch == 2 ? 32 : 0) - tc;      // (never into the other chain's state; whether the chains crossed is checked at the end)
-                if (nb > 16 || avail < nb) { bad = true; nb = max(min(nb, min(avail, 16)), 0); }   // corrupt: keep going on what is there
-                if (chain) tc -= nb;
-                xt = ((xt << nb) | take_bits(tc, nb)) | (1u << 31);
-                if (!chain) tc += nb;
+                if (nch == 2) {
+                    const int avail = chain ? tc - 32 : alen - 32 - tc;      // (never into the other chain's state; whether the chains crossed is checked at the end)
+                    if (nb > 16 || avail < nb) { bad = true; nb = max(min(nb, min(avail, 16)), 0); }   // corrupt: keep going on what is there
+                    if (chain) tc -= nb;
+                    xt = ((xt << nb) | take_bits(tc, nb)) | (1u << 31);
+                    if (!chain) tc += nb;
+                } else {
+                    // one chain: it started small and emitted nothing until its state had grown -- so once the bits below the end marker are used
+                    // up the decoder is in that silent start: it takes what is left (the encoder's first emission: < 16 bits) and then nothing
+                    const int avail = a_end - tc;
+                    if (nb > avail) nb = max(avail, 0);
+                    else if (nb > 16) bad = true;                     // bits were left, so the encoder's state was in [2^31, 2^32): corrupt
+                    if (nb > 16) { bad = true; nb = 16; }
+                    xt = (xt << nb) | take_bits(tc, nb);
+                    tc += nb;
+                }
             } else if (SA * r + i == T - 1) bad = bad || xt != (vhi - vlo) << 15;      // the encoder's first symbol: absorbing start, no bits
             else {
                 int nb = __clz((int)xt);
@@ -1619,14 +1717,15 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_t
         lds_barrier();      // LDS words only cross here: global loads / stores in flight stay in flight (common.hpp)
     }
     if constexpr (kSeeded<Q>) {
-        // the chain is back at its start state: 2^31 | its ns seed symbols in radix A (lane i: digit i = the stream's (chain ns + i)-th symbol from the end)
-        const uint32_t A = (uint32_t)(max_symbol + 1), v = xt & 0x7FFFFFFFu;
-        bad = bad || (live && v >= pw);
+        // the chain is back at its start state.  Two chains: 2^31 | its n seed symbols in radix A (lane i: digit i = the stream's (chain n + i)-th symbol
+        // from the end).  One chain: the stream's last symbol itself (zero if the stream has none), every bit below the end marker read.
+        const uint32_t A = (uint32_t)(max_symbol + 1), v = (nch == 2) ? (xt & 0x7FFFFFFFu) : xt;
+        bad = bad || (live && (nch == 2 ? v >= pw : (v >= A || tc != a_end)));
         uint32_t div = 1;
-        for (int e = 0; e < min(lane, ns); ++e) div *= A;
-        const int dg = (lane < ns) ? (int)((v / div) % A) : 0;
-        const int j = chain * ns + lane;
-        if (live && lane < ns && j < NS) {
+        for (int e = 0; e < min(lane, sn); ++e) div *= A;
+        const int dg = (lane < sn) ? (int)((v / div) % A) : 0;
+        const int j = chain * sn + lane;
+        if (live && lane < sn && j < NS) {
             const long pp = pixel_of(j);
             const int pi = (int)(pp >> 32), pj = (int)(uint32_t)pp;
             const long off = img + ((long)(2 * pi + sg.oi) << sg.lvl) * sg.W + ((long)(2 * pj + sg.oj) << sg.lvl);
@@ -1634,14 +1733,14 @@ __global__ __launch_bounds__(64 * (1 + kTailAhead) * kTailChains<Q>) void rans_t
             planes[off + 2 * sg.plane] = (int16_t)pv;
             fplanes[off + 2 * sg.plane] = div255_exact((float)pv);
         }
-        bad = bad || ballot64(live && lane < ns && j >= NS && dg != 0) != 0;      // digits of symbols the stream does not have
+        bad = bad || ballot64(live && lane < sn && j >= NS && dg != 0) != 0;      // digits of symbols the stream does not have
         if (lane == 0) sh_cur[chain] = tc;
         lds_barrier();
-        if (chain == 0) {
+        if (chain == 0 && nch == 2) {
             // the chains must not have crossed, and what lies between them is zero
             const int ca = sh_cur[0], cb = sh_cur[1];
             uint32_t nz = 0;
-            for (int d = lane; d < GEO::kPayDw; d += 64) {
+            for (int d = lane; d < GEO::kPayDw + kSpillDw; d += 64) {
                 const int lo = max(ca, 32 * d), hi = min(cb, 32 * d + 32);
                 if (lo < hi) nz |= sh_pay[d] & ((hi - lo == 32) ? 0xFFFFFFFFu : (((1u << (hi - lo)) - 1u) << (lo - 32 * d)));
             }
@@ -1688,7 +1787,7 @@ __global__ __launch_bounds__(256) void rans_pack_kernel(const uint8_t *__restric
 
 __global__ __launch_bounds__(256) void rans_unpack_kernel(const uint8_t *__restrict__ in, long in_stride, const int32_t *__restrict__ seg_len,
                                                           const StreamRef *__restrict__ sref, int min_stream, uint8_t *__restrict__ slots, const long *__restrict__ rslot_off,
-                                                          int rslot_cap, uint32_t *__restrict__ rpos, int32_t *status)
+                                                          int rslot_cap, uint32_t *__restrict__ rpos, int32_t *status, int stream_off)
 {
     const StreamRef sr_ = sref[blockIdx.x];
     const int b = sr_.b, m = sr_.m, M = sr_.M, s0 = sr_.sbase;
@@ -1721,8 +1820,8 @@ __global__ __launch_bounds__(256) void rans_unpack_kernel(const uint8_t *__restr
             src += off;
         }
     }
-    uint8_t *o = slots + rslot_off[s0 + m] + 2;                  // the bit region (stream offset 2) lands dword aligned
-    if (bad || n < min_stream || n + 2 + 64 > rslot_cap || src + n > in_stride) {
+    uint8_t *o = slots + rslot_off[s0 + m] + stream_off;         // the bit region lands dword aligned at slot + 4: stream offset 2 behind the u16 of a 64- / 128-lane stream, 0 in an xwide v4 stream
+    if (bad || n < min_stream || n + 4 + 64 > rslot_cap || src + n > in_stride) {
         if (threadIdx.x == 0) flag_image(status, b, LLICTI_EFORMAT);
         n = min_stream;                                            // a harmless stream: T = 0, no bits, states 2^31
         for (int t = threadIdx.x; t < n; t += blockDim.x) o[t] = 0;
@@ -1730,7 +1829,7 @@ __global__ __launch_bounds__(256) void rans_unpack_kernel(const uint8_t *__restr
         const uint8_t *p = in + (long)b * in_stride + src;
         block_copy_bytes(o, p, n);
     }
-    const int padded = min(rslot_cap - 2, n + 64);
+    const int padded = min(rslot_cap - stream_off, n + 64);
     for (int t = n + threadIdx.x; t < padded; t += blockDim.x) o[t] = 0;
     if (threadIdx.x == 0) rpos[s0 + m] = (uint32_t)n;            // the length rans_init_kernel parses
 }

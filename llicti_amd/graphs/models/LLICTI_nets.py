@@ -328,7 +328,7 @@ class LLICTI(nn.Module):
             if len(bl[0][0]) != 3 or len(bl[0][1]) != 12 or len(bl[0][2]) != 2:
                 raise ValueError("malformed header streams")
             hdr = bytes(bl[0][0]) + bytes(bl[0][1]) + bytes(bl[0][2])
-            modes.append(mode_of_header(hdr[0]))        # AC container: hdr[0] == num_scales (LLICTI_nets.py:424); rANS: its lane kind and stream count
+            modes.append(mode_of_header(hdr))           # AC container: hdr[0] == num_scales (LLICTI_nets.py:424); rANS: its lane kind and stream count
             H, W = header_dims(hdr)
             Hs.append(H)
             Ws.append(W)
