@@ -46,20 +46,21 @@ sys.path.insert(0, ROOT)
 MAC_PER_POSITION = 193248            # 84,480 layer-0 + 92,928 mid + 15,840 out
 PEAK_FP32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_HBM_GBS = 8000.0
-DEFAULT_CONTAINER = "auto"           # rANS v3, xwide streams (256 lanes), default_streams(batch) of them per image, see below
-MAX_STREAMS_IN_BUDGET = 10           # = llicti_amd.codec.MAX_STREAMS_IN_BUDGET: an xwide v3 stream (seeded tail chains, two where they pay) costs ~2-4 bytes: 10 per 768x512 image are +0.0003 (noise) ... +0.0008 (an image drawn from the model) bpp over the reference-format container (m_sweep)
+DEFAULT_CONTAINER = "auto"           # rANS xwide streams (256 lanes, v4 layout), their number per image a function of the image's SIZE alone: default_container(H, W)
 
 
-def default_streams(B, n_cu=256):
-    """Streams per image of the timed container (llicti_amd.codec.auto_streams: what LLICTI(config.container = "auto") and the batched
-    LLICTIAgent.eval_model use too): one decoder workgroup per stream on its own compute unit, at most MAX_STREAMS_IN_BUDGET."""
-    from llicti_amd.codec import auto_streams
-    return auto_streams(B, n_cu)
-
-
-def default_container(B, n_cu=256):
+def default_container(H, W):
+    """The timed container: llicti_amd.codec.auto_container -- what LLICTI(config.container = "auto") and LLICTIAgent.eval_model use too.  It depends on
+    the image size only (768x512: xrans16), not on the batch, the device or the rank count: the N = 8 run times the SAME container as N = 1."""
     from llicti_amd.codec import auto_container
-    return auto_container(B, n_cu)
+    return auto_container(H, W)
+
+
+def default_streams(H, W):
+    from llicti_amd.codec import image_streams
+    return image_streams(H, W)
+
+
 NORTH_STAR_MPIX_S = 200.0            # BASELINE.json north_star: >= 200 MPix/s encode+decode on 768x512 at 1 MI355X ...
 NORTH_STAR_DBPP = 0.001              # ... with bpp within 0.001 of the reference
 MAC_PER_BAND = (352 * 48 + 30976 + 5280, 352 * 72 + 30976 + 5280, 352 * 120 + 30976 + 5280)   # layer 0 (K = 48 / 72 / 120) + 4 x 88 x 88 + 4 x 15 x 88
@@ -76,7 +77,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default: 24; 32 at --gpus 8 = BASELINE.json configs[4])")
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=768)
-    ap.add_argument("--container", default=DEFAULT_CONTAINER, help="auto (rANS v3, xwide streams, their number per image from the batch size: default_streams()), rans<M> / wrans<M> / xrans<M> (M streams of 64 / 128 / 256 lanes per image) or ac (torchac-compatible)")
+    ap.add_argument("--container", default=DEFAULT_CONTAINER, help="auto (rANS xwide v4 streams, their number per image from the image size: default_container()), rans<M> / wrans<M> / xrans<M> (M streams of 64 / 128 / 256 lanes per image) or ac (torchac-compatible)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-torch-cpu", action="store_true", help="skip the PyTorch-CPU run of one image inside cpu_baseline (10-25 s)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed informational legs (profiling runs)")
@@ -780,7 +781,7 @@ def main(argv=None):
             tag = "; BASELINE.json configs[4] (256 images sharded 32 per GPU)" if (world == 8 and B == 32 and (H, W) == (512, 768)) else ""
             print(json.dumps({"metric": "dry_run", "value": None, "n_gpus": world, "ranks_seen": dist.get_world_size() if world > 1 else 1,
                               "batch_per_gpu": B, "pixels": agg["pixels"], "bytes": agg["bytes"], "elapsed_max_s": agg["elapsed_s"],
-                              "container": default_container(B) if args.container == "auto" else args.container,
+                              "container": default_container(H, W) if args.container == "auto" else args.container,
                               "config": {"workload": f"{B}x{W}x{H} per GPU" + tag},
                               "per_rank": rows, "straggler_ratio": straggler,
                               "distinct_devices": shard.distinct_devices([int(p[2]) for p in per])}), flush=True)
@@ -817,7 +818,7 @@ def main(argv=None):
 
     from llicti_amd.codec import mode_of_name as mode_of
     if args.container == "auto":
-        args.container = default_container(B, torch.cuda.get_device_properties(dev).multi_processor_count)
+        args.container = default_container(H, W)
     mode = mode_of(args.container)
     torch.manual_seed(1337)
     sd = LLICTI(default_config()).state_dict()                # seed-1337 default init, identical on every rank
@@ -997,8 +998,8 @@ def main(argv=None):
         #      by for a like-for-like scaling efficiency (the driver's N = 1 point is the batch of 24)
         try:
             b32 = torch.from_numpy(make_batch(32, H, W, seed0=0)).to(dev)
-            r32 = legs.run(b32, mode_of(default_container(32, torch.cuda.get_device_properties(dev).multi_processor_count)), reps=3)
-            r32["container"] = default_container(32, torch.cuda.get_device_properties(dev).multi_processor_count)
+            r32 = legs.run(b32, mode_of(default_container(H, W)), reps=3)
+            r32["container"] = default_container(H, W)
             r32["workload"] = f"32x{W}x{H} on ONE GPU: the per-GPU batch of bench.py --gpus 8 (BASELINE.json configs[4]); N = 8 efficiency like for like = value(N = 8) / (8 x this)"
             legs_out["batch32_single_gpu"] = r32
             del b32

@@ -63,10 +63,15 @@ class LLICTIAgent:
     `python -m torch.distributed.run --nproc-per-node G ...` (RANK / LOCAL_RANK / WORLD_SIZE in the environment) the G agents shard the
     test set: image i -> rank i mod G, weights read once by rank 0 and broadcast (RCCL), no collective on the hot path,
     ONE all_gather of the per-image records at the end; rank 0 prints the reference's per-image lines in index order and the rate table
-    -- the log of a 1-GPU run (llicti_amd/shard.py; tests/test_distributed_cpu.py::test_agent_two_ranks_equal_one_rank).  One caveat: with
-    container "auto" the KIND of streams a batch gets follows the content the rank has coded so far (LLICTI.note_content: 64-lane streams
-    once the source is seen to be cheap), so on such content an image's bytes -- not its pixels -- can depend on the rank count and on
-    eval_batch; a fixed container (or config.content_aware = False) makes the logged sizes independent of both."""
+    -- the log of a 1-GPU run (llicti_amd/shard.py; tests/test_distributed_cpu.py::test_agent_two_ranks_equal_one_rank): container "auto" gives an
+    image a container that depends on its size alone (llicti_amd.codec.image_streams), so its bytes -- and with them every logged rate -- are the same
+    whatever the rank count, eval_batch or the coding order.
+
+    Defaults: a config WITHOUT `container` / `eval_batch` keys -- the reference's own configs/llicti_A.json -- runs eval_model in
+    container "auto" with eval_batch 24, and says so in one log line; `"container": "ac"` is the opt-in for reference-format bytes (one image at a
+    time unless eval_batch says otherwise)."""
+
+    DEFAULT_EVAL_BATCH = 24
 
     def __init__(self, config, model=None):
         self.config = config
@@ -307,7 +312,18 @@ class LLICTIAgent:
 
     @torch.no_grad()
     def eval_model(self):
-        eval_batch = int(self.config["eval_batch"]) if "eval_batch" in self.config else 1
+        # the reference's own config has neither key: the throughput path is the default, the reference-format loop the opt-in
+        defaulted = getattr(self.model, "container_defaulted", False) and "container" not in self.config
+        if defaulted and hasattr(self.model, "set_container") and self.model.container != "auto":
+            self.model.set_container("auto")
+        if "eval_batch" in self.config:
+            eval_batch = int(self.config["eval_batch"])
+        else:
+            eval_batch = self.DEFAULT_EVAL_BATCH if (defaulted or getattr(self.model, "container", "ac") != "ac") else 1
+        if defaulted or "eval_batch" not in self.config:
+            self.logger.info('eval_model: container "%s", eval_batch %d (defaults of the MI355X path: rANS streams per image by its size, batched and pipelined; '
+                             '"container": "ac" + "eval_batch": 1 in the config give the reference-format one-image loop)',
+                             getattr(self.model, "container", "?"), eval_batch)
         if eval_batch > 1:
             return self.eval_model_batched(eval_batch)
         self.model.eval()

@@ -21,113 +21,73 @@ NSEG = 49
 MODE_AC = 0                      # the reference's container: 45 torchac-algorithm streams per image
 
 
-MAX_STREAMS_IN_BUDGET = 10       # an xwide v3 stream (seeded tail chains, two where they pay) costs ~2-4 bytes: 10 per 768x512 image are +0.0003 (noise) ... +0.0008 (an image drawn from the model) bpp over the reference-format container
-XWIDE_MIN_TAIL = 2048            # last-stage symbols a 256-lane stream needs for its tail to fill the 7,936-bit payload its initial states carry (the format's cap is 2,047 tail symbols)
-NARROW_MIN_TAIL = 512            # ... and a 64-lane stream for its 1,984 bits
-CHEAP_LAST_STAGE_BITS = 4.0      # bits per symbol of the last stage's Cg stream below which "auto" leaves the xwide streams: their tail's seed symbols are raw (9 bits each
-                                 # where the model would spend < 4) and a tail beyond 4,094 symbols pays a 2-byte escape -- measured on 24 x 768x512 model-drawn images:
-                                 # xrans10 +0.0009 bpp at 3.75 bits, +0.0014 at 1.71 (the reference's trained model on natural images: 1.68), rans10 +0.0008 / +0.0009
-CHEAP_NARROW_MIN_TAIL = 1280     # last-stage symbols a 64-lane stream needs on such a source (1,984 bits at ~1.6 bits per symbol; the format's cap: 2,047)
+# ---- container "auto": a PURE FUNCTION OF THE IMAGE'S SIZE (round 6).  Round 5's rule also looked at the batch size, the compute-unit count and -- through a
+# running mean the model kept -- at what had been coded before, so an image's bytes depended on eval_batch, on the coding order and on the rank count
+# (ADVICE r5): a sharded run's log differed from the one-rank run's on exactly the content the reference exists for.  Now an image
+# of H x W always gets the same container whatever it is coded with, next to or after.
+STREAM_BYTES_BUDGETED = 4.7      # what an xwide v4 stream is budgeted at: measured with the oracle on natural-like and model-drawn images of 321x481 ... 768x512, a container
+                                 # of M streams is -16 ... -24 + (4.0 ... 4.9) M bytes larger than the reference-format one (2.3-2.8 per stream on noise, 5.1 on a 1.5-bit
+                                 # source; tests/sim_v4.py; 1.8 of them are the 256 lanes' 0.057 bit each)
+AC_TERMINATION_BYTES = 22.5      # ... the offset: what the reference format spends on its 45 range-coder terminations, less the 1.5 bytes the tables differ by
+XWIDE_MIN_SHARE = 6144           # last-stage symbols per stream: the tail fills the 7,936-bit payload the initial states carry from 1.3 bits per symbol up (the reference's
+                                 # trained model on natural images: 1.68, exp_debug.log.1:2682; a source cheaper than that leaves payload unused: ~1 byte per missing 8 bits)
+NARROW_MIN_TAIL = 512            # ... and a 64-lane stream its 1,984 bits
+LENGTH_TABLE_BYTES = 4.0         # a stream of a 64- / 128-stream container pays a u32 in its segment's length table
 
 
 def last_stage_bits(seg_len, H, W):
-    """Bits per symbol the LAST stage's Cg stream (segment 48: level 0, band x10) of an image in the REFERENCE-FORMAT container took -- what the
-    encoder's host side knows about the content without looking at a pixel.  seg_len: the image's 49 segment lengths."""
+    """Bits per symbol the LAST stage's Cg stream (segment 48: level 0, band x10) of an image in the REFERENCE-FORMAT container took
+    (bench.py reports it for its content classes).  seg_len: the image's 49 segment lengths."""
     return 8.0 * float(seg_len[NSEG - 1]) / max(1, (H // 2) * (W // 2))
 
 
-def content_bits(container, seg_len, mode, H, W):
-    """The same quantity from a coded image in ANY container (container: the image's bytes, uint8; seg_len: its 49 segment lengths), or None where
-    the container does not say.  A rANS v3 stream interleaves all stages, but its TAIL is made of last-stage Cg symbols only, as many as fill the
-    31 bits x lanes its initial states carry -- so the tail count T in the first u16 of the image's first stream prices them: 31 lanes / T bits per
-    symbol (xwide: T's twelfth bit is bit 15, and 4,095 stands for "4,095 or more").  None: no tail (a stream shorter than its payload: small images)
-    or a mode whose segments start with a length table (64 / 128 streams)."""
-    if mode == MODE_AC:
-        return last_stage_bits(seg_len, H, W)
-    wide, M = _mode_wide(mode), mode & 0xFF
-    if M > 32:
-        return None
-    off = int(seg_len[0]) + int(seg_len[1]) + int(seg_len[2]) + int(seg_len[3])
-    if int(seg_len[4]) < 2:
-        return None
-    t16 = int(container[off]) | (int(container[off + 1]) << 8)
-    T = (t16 & 0x7FF) | (((t16 >> 15) << 11) if wide == 2 else 0)
-    if T == 0:
-        return None
-    return 31.0 * (64 << wide) / T
-
-
-def narrow_streams_in_budget(H, W, cheap=True):
-    """64-lane streams per image inside +0.001 bpp (same byte rule as streams_in_budget; the payload rule for 1,984 bits)."""
-    nc_last = (H // 2) * (W // 2)
-    return max(0, min(MAX_STREAMS_IN_BUDGET, nc_last // (CHEAP_NARROW_MIN_TAIL if cheap else NARROW_MIN_TAIL), int((H * W / 8000.0 + 25.0) / 7.0)))
-
-
-def streams_in_budget(H, W):
-    """xwide streams per image that keep the container within +0.001 bpp of the reference-format one for an H x W image (measured with the
-    CPU oracle over sizes 32x32 ... 768x512, smooth / model-drawn / noise content: tests/test_oracle_golden.py::test_auto_container_budget_by_size).
-    Two limits.  BYTES: the M streams of an image cost about 7 M - 25 bytes more than the reference format's 45 range-coder terminations,
-    and 0.001 bpp are H W / 8000 bytes.  PAYLOAD: a stream's 256 initial states carry 992 bytes that only the stream's own share of the LAST
-    stage's symbols can fill (its tail): with fewer than ~2,048 of them per stream what is left is pure waste -- a 96x128 image in ten xwide
-    streams is 25 % larger than in the reference format.  0: no xwide stream fits (use a 64-lane stream or the reference format)."""
+def image_streams(H, W):
+    """xwide v4 streams of an H x W image in container "auto" -- a function of the size alone.  Two limits.  BYTES: M streams cost about
+    STREAM_BYTES_BUDGETED M over the ideal code length, the reference format's terminations AC_TERMINATION_BYTES, and the north star's 0.001 bpp
+    are H W / 8000 bytes (tests/test_oracle_golden.py::test_auto_container_budget_by_size holds the oracle's sizes against it).  PAYLOAD: a
+    stream's 256 initial states carry 992 bytes that only its own share of the LAST stage's symbols can fill.  768x512: 15; 0: no xwide stream
+    fits (auto_container falls back to one 64-lane stream or the reference format).  More than 32 streams come as 64 or 128 (two / four per
+    container segment behind a table of their lengths)."""
     nc_last = (H // 2) * (W // 2)                 # coded positions of level 0, band x10
-    return max(0, min(14, nc_last // XWIDE_MIN_TAIL, int((H * W / 8000.0 + 25.0) / 7.0)))      # (14: the most xwide streams a container tag can say, one per segment)
+    budget = H * W / 8000.0 + AC_TERMINATION_BYTES
+    m = min(int(budget / STREAM_BYTES_BUDGETED), nc_last // XWIDE_MIN_SHARE)
+    if m > 32:
+        for big in (128, 64):
+            if big * (STREAM_BYTES_BUDGETED + LENGTH_TABLE_BYTES) <= budget and nc_last // XWIDE_MIN_SHARE >= big:
+                return big
+        m = 32
+    return max(0, m)
 
 
-def auto_streams(B, n_cu=256, sizes=None):
-    """Streams per image of the throughput container for a batch of B images: as many as keep ONE decoder workgroup per stream on its
-    own compute unit (B * M <= CUs: a second workgroup on a CU slows both by 1.4x, so more streams than that buy nothing) and stay
-    inside the north star's 0.001 bpp -- at most 10 per 768x512 image, fewer for smaller ones (streams_in_budget; `sizes`: the (H, W) of the
-    batch's images, the smallest one decides; balanced_modes() gives every image of a mixed batch its own count instead).  24 images of 768x512 on a 256-CU MI355X: 10; 32 images (configs[4] per GPU): 8."""
-    m = max(1, min(MAX_STREAMS_IN_BUDGET, n_cu // max(1, B)))
-    if sizes:
-        m = min(m, min(streams_in_budget(h, w) for h, w in sizes))
-    return m
-
-
-def auto_container(B, n_cu=256, sizes=None, cheap=False):
-    """Name of the throughput container for B images per call: xwide streams (256 lanes, one decoder lane per symbol -- lanes are nearly
-    free in bytes, 0.06 bit each; streams are not, ~2-3.5 bytes each), auto_streams(B) of them per image.  With `sizes` (the (H, W) of the
-    images): small images get fewer streams, below ~90x90 pixels one 64-lane stream ("rans1"), below ~45x45 the reference format ("ac";
-    a batch of MIXED sizes stays in "rans1", the reference format codes one size per call) -- so that the container stays within +0.001 bpp
-    of the reference-format one at every size.  What no size rule can see is the CONTENT: a source cheaper than ~3.9 bits per symbol in the
-    last stage (2,047 tail symbols cannot fill 7,936 bits) wastes part of every xwide stream's payload whatever the size -- DESIGN section 8.
-    `cheap`: the caller has SEEN such content (last_stage_bits() of what it coded so far below CHEAP_LAST_STAGE_BITS): 64-lane streams ("rans<M>",
-    +0.0009 bpp at ten per 768x512 image where xrans10 is at +0.0014; 3-6 % slower)."""
-    if cheap:
-        m = max(1, min(MAX_STREAMS_IN_BUDGET, n_cu // max(1, B)))
-        if sizes:
-            m = min(m, min(narrow_streams_in_budget(h, w) for h, w in sizes))
-        return f"rans{max(m, 1)}"
-    m = auto_streams(B, n_cu, sizes)
+def image_mode(H, W, mixed=False):
+    """Container mode of ONE image in container "auto": image_streams() xwide v4 streams; an image too small for one gets a 64-lane stream (from
+    ~45x45 pixels) or -- only where the call holds images of one size (`mixed` False) -- the reference format."""
+    m = image_streams(H, W)
     if m >= 1:
-        return f"xrans{m}"
-    nc_last = min((h // 2) * (w // 2) for h, w in sizes)
-    if nc_last >= NARROW_MIN_TAIL or len(set(sizes)) > 1:
-        return "rans1"
-    return "ac"
+        return MODE_RANS(m, wide=2)
+    if (H // 2) * (W // 2) >= NARROW_MIN_TAIL or mixed:
+        return MODE_RANS(1)
+    return MODE_AC
 
 
-def balanced_modes(sizes, n_cu=256, wide=2, cheap=False):
-    """Container modes for the images of ONE call of mixed sizes (llicti_encode_images_vm): xwide streams, their number per image in proportion to
-    the image's pixels -- so that all streams of the call are equally long (a decoder stage takes as long as its longest stream) -- with at most
-    `n_cu` streams in all (one decoder workgroup per stream and compute unit) and every image inside its own byte budget (streams_in_budget).  An
-    image too small for an xwide stream makes the whole call fall back to one 64-lane stream per image."""
-    if cheap:                                       # content seen to be cheap (auto_container): 64-lane streams, their own budget rule
-        wide = 0
-    budgets = [(narrow_streams_in_budget(h, w) if wide == 0 else streams_in_budget(h, w)) for h, w in sizes]
-    if min(budgets) < 1:
-        return [MODE_RANS(1)] * len(sizes)
-    pix = [h * w for h, w in sizes]
-    total = min(n_cu, sum(budgets))
-    Ms = [max(1, min(b, int(total * p / sum(pix)))) for b, p in zip(budgets, pix)]
-    while sum(Ms) < total:                          # what the rounding left over: to the image whose streams are longest
-        cand = [i for i in range(len(Ms)) if Ms[i] < budgets[i]]
-        if not cand:
-            break
-        i = max(cand, key=lambda k: pix[k] / Ms[k])
-        Ms[i] += 1
-    return [MODE_RANS(m, wide=wide) for m in Ms]
+def auto_container(H, W):
+    """Name of the "auto" container of an H x W image (image_mode)."""
+    return name_of_mode(image_mode(H, W))
+
+
+def auto_modes(sizes):
+    """Container modes of the images of ONE call ([(H, W), ...]) in container "auto": each image's own (image_mode) -- xwide streams, their number per image
+    a function of its size -- unless one of them is too small for an xwide stream: the images of a call share a lane kind, so then every image of the
+    call gets one 64-lane stream (the reference format, where all are that small and of one size).  What an image of a call of EQUAL sizes gets depends
+    on its size alone; in a call of mixed sizes a tiny neighbour (below ~90x90 pixels) can push an image to the 64-lane kind -- the reference's test set
+    has no such image (tests/golden/eval_shapes.json: 321x481 is its smallest)."""
+    mixed = len(set(sizes)) > 1
+    modes = [image_mode(h, w, mixed) for h, w in sizes]
+    if all(_mode_wide(m) == 2 for m in modes if m != MODE_AC) and MODE_AC not in modes:
+        return modes
+    if all(m == MODE_AC for m in modes):
+        return modes
+    return [MODE_RANS(1)] * len(sizes)
 
 
 def MODE_RANS(M=8, wide=False):

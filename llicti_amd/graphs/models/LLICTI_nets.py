@@ -19,8 +19,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from ...codec import (CHEAP_LAST_STAGE_BITS, MODE_AC, MODE_RANS, NSEG, HipCodec, auto_container, balanced_modes, bytestream_list_to_container, container_to_bytestream_list, content_bits,
-                      header_dims, mode_of_header, mode_of_name)
+from ...codec import (MODE_AC, MODE_RANS, NSEG, HipCodec, auto_modes, bytestream_list_to_container, container_to_bytestream_list, header_dims, mode_of_header, mode_of_name)
 from ...config import check_supported
 
 
@@ -102,20 +101,21 @@ class LLICTI(nn.Module):
         self.entropymodel = LLICTIEntropyLayer(config)
         self._codec = None
         self._weights_version = None
-        # container written by compress(): the reference's (torchac-compatible) one unless the config asks for a throughput container,
-        # e.g. config.container = "xrans9", or "auto": the fastest one inside the north star's 0.001 bpp for the batch size of the call
-        # (llicti_amd.codec.auto_container: xwide rANS streams, one decoder workgroup per stream and compute unit)
-        self.container = str(config["container"]) if "container" in config else "ac"
-        self.mode = None if self.container == "auto" else mode_of_name(self.container)
-        # container "auto" on a batch of mixed sizes: a stream count per image (llicti_amd.codec.balanced_modes) unless config.balance_streams = False
-        self.balance_streams = bool(config["balance_streams"]) if "balance_streams" in config else True
-        # container "auto" and the CONTENT: what the images coded so far spent per symbol of their last stage (a running mean the host keeps from the
-        # segment lengths it downloads anyway); below CHEAP_LAST_STAGE_BITS the next calls use 64-lane streams, which stay inside the bpp budget on
-        # such sources (llicti_amd.codec.auto_container; config.content_aware = False switches it off)
-        self.content_aware = bool(config["content_aware"]) if "content_aware" in config else True
-        self.content_bits = None
+        # container written by compress().  config.container: "ac" = the reference's (torchac-compatible) format -- what compress() returns when the
+        # config does not say; "xrans<M>" / "wrans<M>" / "rans<M>" = a rANS container with M streams per image; "auto" = xwide rANS streams (v4), their
+        # number a function of the IMAGE'S SIZE alone (llicti_amd.codec.image_streams: 16 for 768x512 -- inside the north star's 0.001 bpp of the
+        # reference format), so that an image's bytes do not depend on what it is coded with, next to or after.  LLICTIAgent.eval_model switches a
+        # model whose config has NO container key -- the reference's own llicti_A.json -- to "auto" (set_container): there the north star's
+        # "torchac replaced by a HIP rANS coder" is the default and the reference's byte format the opt-in.
+        self.container_defaulted = "container" not in config
+        self.set_container(str(config["container"]) if "container" in config else "ac")
         self._stage = {}                # pinned host staging buffers of the batched path, by (tag, slot): [buffer, event behind its last copy]
         self._xfer = {}                 # (upload, download) copy streams of the batched path, by device index
+
+    def set_container(self, name):
+        """Container of the following compress() / encode_batch_async() calls: "ac", "rans<M>", "wrans<M>", "xrans<M>" or "auto"."""
+        self.container = str(name)
+        self.mode = None if self.container == "auto" else mode_of_name(self.container)
 
     # ------------------------------------------------------------------ plumbing
     def _weights_key(self):
@@ -166,29 +166,16 @@ class LLICTI(nn.Module):
         return lists[0], x_ycocg
 
     def mode_for_batch(self, B, device=None, sizes=None):
-        """Container mode of a call with B images (of `sizes` [(H, W), ...] where known): the configured one, or for "auto" the throughput
-        container for that batch -- streams per image limited by the compute units AND by the smallest image's byte budget."""
+        """Container mode(s) of a call with B images of `sizes` [(H, W), ...] (one entry: all alike): the configured one, or for "auto" each image's
+        own -- a function of its size (llicti_amd.codec.auto_modes), not of the batch, the device or anything coded before.  One int where all images
+        get the same mode, else one per image (llicti_encode_images_vm)."""
         if self.mode is not None:
             return self.mode
-        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
-        cheap = self.content_aware and self.content_bits is not None and self.content_bits < CHEAP_LAST_STAGE_BITS
-        if self.balance_streams and sizes and len(sizes) == B and len(set(sizes)) > 1:
-            # images of different sizes in one call: a stream count per image, in proportion to its pixels (all streams equally long: a decoder
-            # stage takes as long as its longest stream), each image inside its own byte budget -- llicti_encode_images_vm
-            return balanced_modes(sizes, n_cu, cheap=cheap)
-        return mode_of_name(auto_container(B, n_cu, sizes=sizes, cheap=cheap))
-
-    def note_content(self, cont, seg_len, mode, Hs, Ws):
-        """Book what a coded batch spent per symbol of its last stage (cont: uint8 [B, stride] and seg_len: int32 [B, 49] on the host; mode: the call's,
-        or one per image; llicti_amd.codec.content_bits): a running mean over the images seen, the newest batch weighing a quarter -- container
-        "auto" reads it (mode_for_batch)."""
-        modes = [int(mode)] * len(Hs) if isinstance(mode, (int, np.integer)) else [int(m) for m in mode]
-        bits = [content_bits(cont[b], seg_len[b], modes[b], int(h), int(w)) for b, (h, w) in enumerate(zip(Hs, Ws))]
-        bits = [v for v in bits if v is not None]
-        if bits:
-            m = float(np.mean(bits))
-            self.content_bits = m if self.content_bits is None else 0.75 * self.content_bits + 0.25 * m
+        if not sizes:
+            raise ValueError('container "auto" needs the image sizes')
+        sz = list(sizes) if len(sizes) == B else [sizes[0]] * B
+        modes = auto_modes(sz)
+        return modes[0] if all(m == modes[0] for m in modes) else modes
 
     def _pinned(self, key, nbytes):
         """Pinned host staging buffer (flat uint8, at least nbytes, grown to the running maximum) of `key` = (tag, slot).  The buffer's last
@@ -283,7 +270,6 @@ class LLICTI(nn.Module):
         cont.record_stream(down)
         seg.record_stream(down)
         enc = EncodedBatch(codec, rgb, cont_h, seg_h, ev, x_ycocg, mode, Hs, Ws)
-        enc.note = self.note_content
         enc.t0 = t0
         return enc
 
@@ -311,9 +297,15 @@ class LLICTI(nn.Module):
 
     @torch.no_grad()
     def decompres_batch(self, lists, devc=None):
-        rgb = self.decode_batch_async(lists, devc)
+        """bytestream_lists of B images -> float32 [B,3,H,W] (equal sizes), or -- images of different sizes, rANS containers -- a LIST of B tensors
+        [1,3,H_b,W_b], each what decompres() returns for that image."""
+        res = self.decode_batch_async(lists, devc)
         self.codec().check()
-        return rgb.to(torch.float32) / 255           # LLICTI_nets.py:87
+        if isinstance(res, tuple):
+            flat, Hs, Ws = res
+            offs, _ = self.codec().flat_offsets(Hs, Ws)
+            return [flat[int(o):int(o) + 3 * h * w].view(1, 3, h, w).to(torch.float32) / 255 for o, h, w in zip(offs, Hs, Ws)]
+        return res.to(torch.float32) / 255           # LLICTI_nets.py:87
 
     @torch.no_grad()
     def decode_batch_async(self, lists, devc=None, slot=0, flat=False):
@@ -380,7 +372,6 @@ class EncodedBatch:
         self.Hs, self.Ws = Hs, Ws           # per image (a list batch: rgb is the flat device buffer, the images back to back)
         self.t0 = None                      # list batches: timing event on the compute stream behind the wait for the upload
         self._lists = None
-        self.note = None                    # LLICTI.note_content: the model books what the batch's last stage cost (container "auto")
 
     def lists(self, check=True):
         """Wait for the download (NOT for anything enqueued after it) and cut the containers into bytestream_lists (6 lists x 9 `bytes`).
@@ -391,6 +382,4 @@ class EncodedBatch:
                 self.codec.check()
             seg_np, cont_np = self.seg_h.numpy(), self.cont_h.numpy()
             self._lists = [container_to_bytestream_list(cont_np[b], seg_np[b]) for b in range(seg_np.shape[0])]
-            if self.note is not None and self.Hs is not None:
-                self.note(cont_np, seg_np, self.mode, self.Hs, self.Ws)
         return self._lists

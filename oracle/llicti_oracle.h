@@ -166,7 +166,7 @@ long orc_stream_pairs(const int16_t *planes, int H, int W, const int16_t minmax[
  *              ceil(T / 32) | 1 bit "one chain" | 1 end-marker bit | zeros to the byte boundary: the decoder finds the marker as the highest set
  *              bit of the region's last byte (which is never zero), takes the 9 bits below it and reads the main bits down from there.
  *              T = min(32 field, the stream's share of the last stage).
- * Cost over the ideal code length, measured on 768x512 images (tools/sim_v4.py, tests): 64 lanes ~6 bytes per stream that has symbols, 128 lanes
+ * Cost over the ideal code length, measured on 768x512 images (tests/sim_v4.py, tests): 64 lanes ~6 bytes per stream that has symbols, 128 lanes
  * ~6.5, xwide v4 2.3-2.8 (noise) / 4.1 (natural-like, model-drawn) / 5.1 (a 1.5-bit source) of which 1.8 are the 256 lanes' 0.057 bit each (v3:
  * 3.5-4.1 / 5.1-6.6 / 9.8); an empty stream costs 250 / 498 / 994 bytes.
  * M: streams per image, | 0x100 for wide streams, | 0x200 for xwide streams.  Returns total bytes or <0. */

@@ -37,3 +37,14 @@ def make_sampled_image(H, W, seed):
     rng = np.random.default_rng(seed)
     bl = [list(bl[0])] + [[rng.integers(0, 256, len(s), dtype=np.uint8).tobytes() for s in row] for row in bl[1:]]
     return orc.decode_image(bl, W_o)
+
+
+def xwide_stream_header(stream: bytes):
+    """(T field = ceil(T / 32), one-chain flag, bits of the main region below the header field) of an xwide v4 stream (oracle/llicti_oracle.h, "stream"):
+    bit region | 992 bytes of states; the region's highest set bit is its end marker, the 9 bits below it the header field."""
+    nbytes = len(stream) - 992
+    assert nbytes >= 2 and stream[nbytes - 1] != 0
+    top = 8 * (nbytes - 1) + stream[nbytes - 1].bit_length() - 1
+    v = int.from_bytes(stream[:nbytes], "little")
+    f9 = (v >> (top - 9)) & 0x1FF
+    return f9 & 0xFF, f9 >> 8, top - 9

@@ -31,7 +31,7 @@ static void check_plan(const Plan &p, int B, const int *Hs, const int *Ws, int M
         for (int b = 0; b < B; ++b) {
             const int Mb = Ms ? Ms[b] : M;
             REQUIRE(p.img[b].M == Mb && p.img[b].sbase == ns);
-            REQUIRE(rans_streams_of_byte0(p.img[b].byte0) == (Mb | ((ME >> 8) << 8)));
+            REQUIRE(rans_streams_of_header(p.img[b].byte0, p.img[b].padint) == (Mb | ((ME >> 8) << 8)));
             for (int m = 0; m < Mb; ++m) {
                 const StreamRef &r = p.sref[(size_t)ns + m];
                 REQUIRE(r.b == b && r.m == m && r.M == Mb && r.sbase == ns);
@@ -118,7 +118,7 @@ static void check_plan(const Plan &p, int B, const int *Hs, const int *Ws, int M
 }
 
 static const int kModes[] = { 0, 0x100 | 1, 0x100 | 8, 0x100 | 32, 0x100 | 64, 0x100 | 128, 0x300 | 1, 0x300 | 10, 0x300 | 14,
-                              0x500 | 1, 0x500 | 3, 0x500 | 10, 0x500 | 14, 0x500 | 32, 0x500 | 64 };
+                              0x500 | 1, 0x500 | 3, 0x500 | 10, 0x500 | 16, 0x500 | 21, 0x500 | 32, 0x500 | 64, 0x500 | 128 };
 
 int main()
 {
@@ -128,10 +128,20 @@ int main()
     for (int mode : kModes) {
         const int ME = mode_streams(mode);
         REQUIRE(ME >= 0);
-        if (ME) REQUIRE(rans_streams_of_byte0(rans_byte0(ME & 0xFF, 1 << (ME >> 8))) == ME);
+        if (ME) REQUIRE(rans_streams_of_header(rans_byte0(ME & 0xFF, 1 << (ME >> 8)), rans_pad_hi(ME & 0xFF, 1 << (ME >> 8)) << 10) == ME);
     }
-    for (int mode : { -1, 1, 0x100, 0x100 | 33, 0x100 | 127, 0x300 | 15, 0x500 | 15, 0x500 | 33, 0x700 | 1, 0x10000 }) REQUIRE(mode_streams(mode) < 0);
-    for (int b0 = 0; b0 < 256; ++b0) { const int v = rans_streams_of_byte0(b0); REQUIRE(v == 0 || mode_streams(((v >> 8) == 2 ? 0x500 : (v >> 8) == 1 ? 0x300 : 0x100) | (v & 0xFF)) == v); }
+    for (int mode : { -1, 1, 0x100, 0x100 | 33, 0x100 | 127, 0x300 | 15, 0x500, 0x500 | 33, 0x500 | 96, 0x700 | 1, 0x10000 }) REQUIRE(mode_streams(mode) < 0);
+    // every (byte 0, pad field high bits) pair: either not a container of this build, or a mode that round-trips; the xwide v3 tags of rounds 4-5
+    // (v = 17 .. 31) and an xwide v4 tag without its count are refused, and so are high bits in a container that is not xwide
+    for (int b0 = 0; b0 < 256; ++b0)
+        for (int u = 0; u < 64; ++u) {
+            const int v = rans_streams_of_header(b0, (u << 10) | 0x155);
+            REQUIRE(v == 0 || mode_streams(((v >> 8) == 2 ? 0x500 : (v >> 8) == 1 ? 0x300 : 0x100) | (v & 0xFF)) == v);
+            const int tagv = (((b0 >> 4) & 3) << 3) | (b0 & 7);
+            if ((b0 & 0xC8) == 0xC8 && tagv >= 17) REQUIRE(v == 0);
+            if ((b0 & 0xC8) == 0xC8 && tagv == 16) REQUIRE((v != 0) == (u >= 1 && u <= 34));
+            if (!((b0 & 0xC8) == 0xC8 && tagv >= 16) && u) REQUIRE(v == 0);
+        }
     // equal-size plans: every shape of the suite, the fuzzer's range and bench.py, the format's limits, in every mode family
     const int shapes[][2] = { { 32, 32 }, { 33, 64 }, { 67, 93 }, { 64, 48 }, { 96, 160 }, { 150, 131 }, { 97, 351 }, { 256, 256 }, { 512, 768 }, { 768, 512 },
                               { 577, 768 }, { 2160, 3840 }, { 8160, 32 }, { 32, 8160 }, { 8160, 8160 }, { 4097, 4099 } };

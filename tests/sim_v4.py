@@ -3,7 +3,7 @@
 What a stream costs beyond the ideal code length of its symbols is, besides 0.057 bit per lane, its FRAMING: the header field, the
 byte alignment, and what the tail coder wastes of the 7,936-bit payload the 256 initial states carry (payload bits minus the ideal
 bits of the T tail symbols).  This script prices that for the v3 layout and for the v4 candidates on one 768x512 image per content
-class (noise / natural-like / model-drawn / 1.7-bit "cheap"), M streams per image: `python tools/sim_v4.py [M ...]`.
+class (noise / natural-like / model-drawn / 1.7-bit "cheap"), M streams per image: `python tests/sim_v4.py [M ...]`.
 Test infrastructure (uses the CPU oracle); results quoted in DESIGN.md section 5 (rANS v4).
 """
 from __future__ import annotations
@@ -16,7 +16,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from oracle import oracle as orc                      # noqa: E402
 from llicti_amd.weights import pack_state_dict       # noqa: E402
 from helpers import make_image, make_sampled_image   # noqa: E402

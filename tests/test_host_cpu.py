@@ -104,10 +104,11 @@ def test_workspace_and_container_bounds():
     assert L.llicti_workspace_bytes(24, 512, 768, 0x300 | 10) > L.llicti_workspace_bytes(24, 512, 768, 0x100 | 10)
     assert L.llicti_workspace_bytes(1, 512, 768, 0x300 | 14) > 0
     assert L.llicti_workspace_bytes(1, 512, 768, 0x300 | 15) == 0 and L.llicti_workspace_bytes(1, 512, 768, 0x300) == 0
-    # xwide streams (256 lanes): 1 .. 14, 32, 64
+    # xwide streams (256 lanes, v4): 1 .. 32, 64, 128
     assert L.llicti_workspace_bytes(24, 512, 768, 0x500 | 9) > L.llicti_workspace_bytes(24, 512, 768, 0x300 | 9)
     assert L.llicti_workspace_bytes(1, 512, 768, 0x500 | 64) > 0 and L.llicti_workspace_bytes(1, 512, 768, 0x500 | 32) > 0
-    assert L.llicti_workspace_bytes(1, 512, 768, 0x500 | 15) == 0 and L.llicti_workspace_bytes(1, 512, 768, 0x500 | 128) == 0 and L.llicti_workspace_bytes(1, 512, 768, 0x700 | 4) == 0
+    assert L.llicti_workspace_bytes(1, 512, 768, 0x500 | 15) > 0 and L.llicti_workspace_bytes(1, 512, 768, 0x500 | 128) > 0
+    assert L.llicti_workspace_bytes(1, 512, 768, 0x500 | 33) == 0 and L.llicti_workspace_bytes(1, 512, 768, 0x500) == 0 and L.llicti_workspace_bytes(1, 512, 768, 0x700 | 4) == 0
     assert L.llicti_workspace_bytes(1, 512, 768, 0x200 | 4) == 0
 
 

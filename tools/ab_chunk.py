@@ -15,7 +15,7 @@ dev = torch.device("cuda", 0)
 torch.manual_seed(1337)
 codec = HipCodec(dev)
 codec.load_state_dict(LLICTI(default_config()).state_dict())
-mode = mode_of_name(bench.default_container(B))
+mode = mode_of_name(bench.default_container(H, W))
 rgb = torch.from_numpy(bench.make_batch(B, H, W, 0)).to(dev)
 cont, seg = codec.encode(rgb, mode=mode)
 ref = cont.clone()

@@ -16,7 +16,7 @@ codec = HipCodec(dev)
 codec.load_state_dict(LLICTI(default_config()).state_dict())
 out = {}
 for B, H, W in ((24, 512, 768), (32, 512, 768), (1, 512, 768), (1, 2160, 3840)):
-    mode = mode_of_name(bench.default_container(B))
+    mode = mode_of_name(bench.default_container(H, W))
     rgb = torch.from_numpy(bench.make_batch(B, H, W, 0)).to(dev)
     cont, seg = codec.encode(rgb, mode=mode)
     ref = cont.clone()

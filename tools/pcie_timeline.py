@@ -35,7 +35,7 @@ def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     B, H, W = a.batch, 512, 768
-    name = bench.default_container(B, torch.cuda.get_device_properties(dev).multi_processor_count)
+    name = bench.default_container(H, W)
     mode = mode_of_name(name)
     torch.manual_seed(1337)
     codec = HipCodec(dev)
