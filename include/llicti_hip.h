@@ -156,29 +156,36 @@ int llicti_ac_decode_u16cdf(llicti_ctx *ctx, const uint16_t *d_cdf, int Lp, int 
  * container is read, and no read leaves [d_in + b*in_stride, d_in + (b+1)*in_stride). */
 
 /* mode: LLICTI_MODE_AC = the reference's container (45 torchac-algorithm streams per image, bit-exact
- * to the oracle / reference format); LLICTI_MODE_RANS(M) = "LLICTI-rANS v3", a NEW container of this
- * build (BASELINE.json north_star: "torchac replaced by a HIP rANS coder"): header byte 0 = bit 7 (rANS) | bit 3 (format v3; the
+ * to the oracle / reference format); LLICTI_MODE_RANS*(M) = the rANS containers, NEW formats of this
+ * build (BASELINE.json north_star: "torchac replaced by a HIP rANS coder"): header byte 0 = bit 7 (rANS) | bit 3 (format v3 or later; the
  * retired v2 tag has it clear and is rejected with LLICTI_EFORMAT) | bit 6 (extended) | v in bits 5,4,2,1,0 with M = v + 1; extended:
- * v = 0 / 1 = 64 / 128 streams (latency modes), v = 2 .. 15 = v - 1 wide streams (LLICTI_MODE_RANS_WIDE), v = 16 .. 31 = xwide streams
- * (LLICTI_MODE_RANS_X; round 3 had v = 16 .. 31 mean 15 .. 30 WIDE streams -- no container outside a test ever used them; one that did now reads
- * as xwide and fails with LLICTI_EFORMAT, its streams being shorter than an xwide state block); then M independent
+ * v = 0 / 1 = 64 / 128 streams (latency modes), v = 2 .. 15 = v - 1 wide streams (LLICTI_MODE_RANS_WIDE), v = 16 (byte 0 = 0xE8) = xwide streams
+ * in the v4 layout (LLICTI_MODE_RANS_X), their COUNT in bits 10 .. 15 of the header's int16 pad field (1 .. 32 as they are, 33 / 34 = 64 / 128
+ * streams; zero in every other container).  v = 17 .. 31 were the xwide tags of the v3 layout (rounds 4-5): retired, LLICTI_EFORMAT; a reader of
+ * the older formats refuses a v4 container because its pad field contradicts the image size.  Then M independent
  * L-way interleaved rANS streams per image (L = 64 lanes, 128 for wide, 256 for xwide streams; segments 4 .. 4+M-1, the other stream segments
  * empty), same CDFs and symbols, decodable L*M symbols at a time.  States live in [2^31, 2^32) and renormalise bit by bit (the coder loses
- * ~2^-16 of a symbol's length, like the range coder); a stream = u16 (T | pad << 11) | bit region | L x 31-bit final
- * states, and the L INITIAL states carry the last T symbols of the stream's last stage, coded by a single-state tail
- * coder (xwide streams: by one or two such coders sharing the payload -- two where symbols are expensive, the stream says which -- each started
- * from a seed of raw symbols instead of an empty state).
- * Cost over the ideal code length: about 6 bytes per stream that has symbols (xwide: 2 - 3.5) -- M = 8 is within 0.0005 bpp of the AC
- * container on 768x512 images (whose 45 stream terminations cost about 25 bytes).  Format: oracle/llicti_oracle.h,
- * DESIGN.md section 5. */
+ * ~2^-16 of a symbol's length, like the range coder); the L INITIAL states of a stream carry the last T symbols of the stream's last stage,
+ * coded by a single-state tail coder.  64 / 128 lanes (v3): stream = u16 (T | pad << 11) | bit region | L x 31-bit final states.  xwide (v4):
+ * stream = bit region | 256 x 31-bit final states; the tail coder's output is not cut to the 7,936 payload bits -- T is a multiple of 32 and
+ * what exceeds the payload lies at the bottom of the bit region --; the tail is one chain that starts from the stream's last symbol itself, or
+ * two seeded chains where symbols are expensive; the header field (T / 32, the one-chain flag) sits on top of the bit region under an end marker.
+ * Cost over the ideal code length: about 6 bytes per 64-lane stream that has symbols, 2.5 - 5 per xwide v4 stream (the reference format's 45
+ * stream terminations cost about 25 bytes per image).  Format: oracle/llicti_oracle.h, DESIGN.md section 5. */
 #define LLICTI_MODE_AC        0
 #define LLICTI_MODE_RANS(M)  (0x100 | (M))      /* M in 1 .. 32: one stream per segment; {64, 128}: latency modes for single / large
                                                   images, M / 32 streams per segment behind a table of their u32 lengths (+6 bytes per stream) */
 #define LLICTI_MODE_RANS_WIDE(M) (0x300 | (M))  /* M in 1 .. 14 WIDE streams: 128 lanes per stream (two 64-symbol chunks per coder step, 128 x
                                                   31-bit states, about twice the tail symbols), header byte 0 = bit 6 set with v = M + 1; two decoder lanes per symbol */
-#define LLICTI_MODE_RANS_X(M) (0x500 | (M))     /* M in 1 .. 14, 32, 64 XWIDE streams: 256 lanes per stream, header byte 0 = bit 6 set with v = M + 15 (32 / 64: v = 30 / 31;
-                                                  64: two streams per segment); ONE decoder lane per symbol, four wavefronts per stream: the fewest vector instructions
-                                                  per symbol of the three (2 - 3.5 bytes per stream: 10 per 768x512 image are +0.0003 ... +0.0007 bpp over the reference format) */
+#define LLICTI_MODE_RANS_X(M) (0x500 | (M))     /* M in 1 .. 32, 64, 128 XWIDE streams (v4 layout): 256 lanes per stream, header byte 0 = 0xE8, the count in the pad field's
+                                                  bits 10 .. 15 (64 / 128: two / four streams per segment); ONE decoder lane per symbol, four wavefronts per stream: the fewest
+                                                  vector instructions per symbol of the three (15 per 768x512 image are inside +0.001 bpp of the reference format on natural-like content) */
+#define LLICTI_MODE_RANS_X_AUTO(M) (0x10500 | (M))  /* ENCODE ONLY.  xwide v4 streams whose count the ENCODER picks per image, on the device, from the image itself: M (1 .. 32) is the
+                                                  count the image's size gives (llicti_amd.codec.image_streams); an image whose last stage's symbols are expensive (sum of
+                                                  16 - floor(log2 freq) >= 11 per symbol: an xwide stream costs ~2.5 bytes there) gets M + ceil(M / 3) streams (at most 32), one
+                                                  whose last stage cannot fill M payloads of 7,936 bits gets ceil(M / 2), every other M.  A pure function of the image: its
+                                                  container does not depend on the batch, the device or anything coded before.  The container is an ordinary
+                                                  LLICTI_MODE_RANS_X(count) container -- its header says which (llicti_header_mode) -- and is decoded as such. */
 
 /* Bytes of device workspace the calls below need for B images of H x W in `mode` (_v: of Hs[b] x Ws[b]). */
 size_t llicti_workspace_bytes(int B, int H, int W, int mode);
@@ -208,8 +215,8 @@ int llicti_encode_images_v(llicti_ctx *ctx, const uint8_t *d_rgb, const size_t *
                            uint8_t *d_out, size_t out_stride, int32_t *d_seg_len, void *stream);
 /* ... with a container mode PER IMAGE (host array of B modes): rANS containers of one lane kind whose STREAM COUNTS may differ -- every image's header
  * carries its own count.  What it is for: a stage of the decoder takes as long as its longest stream, and in a batch of mixed sizes that is a
- * stream of the largest image; with counts in proportion to the images' sizes (llicti_amd.codec.balanced_modes) all streams are equally long,
- * and every image stays inside its own byte budget (a 768x768 image affords 14 streams, a 352x768 one 8).  Image b's bytes are those of
+ * stream of the largest image; with each image's count given by its own size (llicti_amd.codec.auto_modes) the streams are about equally long,
+ * and every image stays inside its own byte budget (a 768x768 image affords 20 xwide v4 streams, a 321x481 one 6).  Image b's bytes are those of
  * llicti_encode_images(B = 1) on it in modes[b]. */
 int llicti_encode_images_vm(llicti_ctx *ctx, const uint8_t *d_rgb, const size_t *rgb_off, int B, const int *Hs, const int *Ws, const int *modes,
                             void *d_workspace, size_t workspace_bytes,
@@ -242,6 +249,9 @@ int llicti_selftest(void);
 
 /* Image size from a container's first 17 header bytes (host memory). */
 int llicti_header_dims(const uint8_t *h_hdr17, int *H, int *W);
+/* The mode a container's first 17 header bytes name -- LLICTI_MODE_AC or LLICTI_MODE_RANS*(count) -- i.e. what to hand to llicti_decode_images*
+ * (LLICTI_EFORMAT for a header this build does not read: the retired v2 and xwide-v3 layouts). */
+int llicti_header_mode(const uint8_t *h_hdr17, int *mode);
 
 /* Device-resident timing of the last llicti_encode_images / llicti_decode_images call, measured with
  * HIP events on `stream`: ms[0] = whole call, ms[1] = sum of the band-CNN kernel launches,

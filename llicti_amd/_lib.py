@@ -69,6 +69,7 @@ _SIGS = {
     "llicti_decode_images": (_i, [_vp, _vp, _sz, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
     "llicti_check_status": (_i, [_vp, _vp]),
     "llicti_header_dims": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "llicti_header_mode": (_i, [_vp, C.POINTER(_i)]),
     "llicti_image_status": (_i, [_vp, _vp, _i, _vp]),
     "llicti_selftest": (_i, []),
     "llicti_last_timing": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(_i)]),

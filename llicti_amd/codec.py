@@ -60,18 +60,21 @@ def image_streams(H, W):
 
 
 def image_mode(H, W, mixed=False):
-    """Container mode of ONE image in container "auto": image_streams() xwide v4 streams; an image too small for one gets a 64-lane stream (from
-    ~45x45 pixels) or -- only where the call holds images of one size (`mixed` False) -- the reference format."""
+    """ENCODER mode of ONE image in container "auto": MODE_RANS_AUTO(image_streams(H, W)) -- xwide v4 streams, their count picked by the encoder from
+    the image itself: what its size gives, a third more where the last stage's symbols are expensive (an xwide stream costs ~2.5 bytes there instead
+    of ~4.5), half where the last stage is too cheap to fill the streams' payloads; an image too small for one xwide stream gets a 64-lane stream
+    (from ~45x45 pixels) or -- only where the call holds images of one size (`mixed` False) -- the reference format."""
     m = image_streams(H, W)
     if m >= 1:
-        return MODE_RANS(m, wide=2)
+        return MODE_RANS_AUTO(m)
     if (H // 2) * (W // 2) >= NARROW_MIN_TAIL or mixed:
         return MODE_RANS(1)
     return MODE_AC
 
 
 def auto_container(H, W):
-    """Name of the "auto" container of an H x W image (image_mode)."""
+    """Name of the "auto" ENCODER mode of an H x W image (image_mode): "xauto15" for 768x512 -- the container that comes out is xrans8, xrans15 or
+    xrans20, by the image's content."""
     return name_of_mode(image_mode(H, W))
 
 
@@ -97,8 +100,24 @@ def MODE_RANS(M=8, wide=False):
     return (0x100 + 0x200 * int(wide)) | int(M)
 
 
+def MODE_RANS_AUTO(M):
+    """ENCODE ONLY: xwide v4 streams whose count the encoder picks per image, on the device, from the image itself (include/llicti_hip.h,
+    LLICTI_MODE_RANS_X_AUTO): M = the count the image's size gives (image_streams); expensive last-stage symbols -> M + ceil(M / 3), a last stage
+    too cheap to fill M payloads -> ceil(M / 2).  The container is an ordinary MODE_RANS(count, wide=2) one: its header says which (mode_of_header)."""
+    return 0x10500 | int(M)
+
+
+def _mode_auto(mode: int) -> bool:
+    return bool(mode & 0x10000)
+
+
+def auto_counts(M):
+    """The stream counts an "auto" encode of size-rule count M may pick: (cheap, default, expensive) = (ceil(M / 2), M, min(32, M + ceil(M / 3)))."""
+    return (M + 1) // 2, M, min(32, M + (M + 2) // 3)
+
+
 def _mode_wide(mode: int) -> int:
-    return ((mode & ~0xFF) - 0x100) // 0x200
+    return ((mode & 0xF00) - 0x100) // 0x200
 
 
 def rans_tag(M, wide=False):
@@ -160,16 +179,20 @@ def mode_of_name(name: str) -> int:
     name = str(name).lower()
     if name == "ac":
         return MODE_AC
+    if name.startswith("xauto"):
+        return MODE_RANS_AUTO(int(name[5:]))
     if name.startswith("xrans"):
         return MODE_RANS(int(name[5:]), wide=2)
     if name.startswith("wrans"):
         return MODE_RANS(int(name[5:]), wide=1)
     if name.startswith("rans"):
         return MODE_RANS(int(name[4:] or 8))
-    raise ValueError(f"unknown container {name!r}: ac, rans<M>, wrans<M> or xrans<M> (or \"auto\" where a batch size is known)")
+    raise ValueError(f"unknown container {name!r}: ac, rans<M>, wrans<M>, xrans<M>, xauto<M> (or \"auto\" where the image sizes are known)")
 
 
 def name_of_mode(mode: int) -> str:
+    if _mode_auto(mode):
+        return "xauto%d" % (mode & 0xFF)
     return "ac" if mode == MODE_AC else ("rans%d", "wrans%d", "xrans%d")[_mode_wide(mode)] % (mode & 0xFF)
 
 
@@ -450,6 +473,12 @@ class HipCodec:
             _lib.check(self.L.llicti_decode_images_vm(self.ctx, _ptr(containers), containers.shape[1], _ptr(seg_len), B, _ptr(Hs), _ptr(Ws), _ptr(per),
                                                       _ptr(ws), ws.numel(), _ptr(out), None, _stream_ptr(self.device)))
         return out
+
+    def container_modes(self, containers):
+        """The modes the headers of device containers [B, stride] name (a small download: 17 bytes per image; synchronises the current stream) --
+        what decode() / decode_v() take for containers that came out of an "auto" encode (MODE_RANS_AUTO: the encoder picked the stream counts)."""
+        hdr = containers[:, :17].contiguous().cpu().numpy()
+        return [mode_of_header(hdr[b]) for b in range(hdr.shape[0])]
 
     def check(self):
         _lib.check(self.L.llicti_check_status(self.ctx, _stream_ptr(self.device)))

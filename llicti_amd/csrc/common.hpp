@@ -10,7 +10,7 @@
     } while (0)
 
 extern "C" const char *llicti_last_error(void) { return g_err.c_str(); }
-extern "C" const char *llicti_version(void) { return "llicti_hip 0.6 (gfx950, numerics spec v1, rANS container v3; xwide streams with seeded tail chains of up to 8,191 symbols; batches of mixed sizes)"; }
+extern "C" const char *llicti_version(void) { return "llicti_hip 0.7 (gfx950, numerics spec v1, rANS containers: v3 for 64 / 128 lanes, v4 for xwide streams -- tail arena with spill, zero-start chain, stream count in the header's pad field, picked per image by the encoder in the auto mode; batches of mixed sizes)"; }
 
 extern "C" int llicti_level_geom(int H, int W, int lvl, int band, int *Hl, int *Wl, int *h, int *w,
                                  int *padH, int *padW, int *hc, int *wc)

@@ -139,9 +139,11 @@ static int rans_pad_hi(int M, int Q);
 static void build_plan(Plan &p, int B, const int *Hs, const int *Ws, const size_t *rgb_off, int ME, int n_cu = 256, int tile_rows = 0, bool force_ragged = false,
                        const int *Ms = nullptr)
 {
-    const int Q = 1 << (ME >> 8);
+    const int Q = 1 << ((ME >> 8) & 3);
+    const bool autoM = (ME & 0x1000) != 0;      // LLICTI_MODE_RANS_X_AUTO: the counts are the size rule's (Mlo); the encoder picks per image in [rans_auto_min, rans_auto_hi]
     int M = ME & 0xFF;
     if (Ms && M > 0) { M = 0; for (int b = 0; b < B; ++b) M = std::max(M, Ms[b]); }
+    if (autoM) M = rans_auto_hi(M);
     p.B = B; p.ME = ME; p.M = M; p.Q = Q;
     p.uniform = !force_ragged;
     for (int b = 1; b < B; ++b) if (Hs[b] != Hs[0] || Ws[b] != Ws[0]) p.uniform = false;
@@ -173,10 +175,11 @@ static void build_plan(Plan &p, int B, const int *Hs, const int *Ws, const size_
         if ((ig.plane & 3) || (ig.rgb_off & 3)) p.vec_ok = false;
         p.rgb_bytes = std::max(p.rgb_bytes, (size_t)(ig.rgb_off + 3 * ig.plane));
         p.max_plane = std::max(p.max_plane, ig.plane);
-        ig.M = m_of(b);
+        ig.Mlo = autoM ? m_of(b) : 0;
+        ig.M = autoM ? rans_auto_hi(ig.Mlo) : m_of(b);
         ig.byte0 = ig.M ? rans_byte0(ig.M, Q) : LLICTI_NLEVELS;
-        ig.padint = pad_int(ig.H, ig.W) | ((ig.M ? rans_pad_hi(ig.M, Q) : 0) << 10);      // the header's int16 pad field (xwide v4: its high bits carry the stream count)
-        p.key.push_back(ig.H); p.key.push_back(ig.W); p.key.push_back(ig.rgb_off); p.key.push_back(ig.M);
+        ig.padint = pad_int(ig.H, ig.W) | ((ig.M ? rans_pad_hi(ig.M, Q) : 0) << 10);      // the header's int16 pad field (xwide v4: its high bits carry the stream count; an "auto" encode writes the count it picked)
+        p.key.push_back(ig.H); p.key.push_back(ig.W); p.key.push_back(ig.rgb_off); p.key.push_back(m_of(b));
     }
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
@@ -253,11 +256,12 @@ static void build_plan(Plan &p, int B, const int *Hs, const int *Ws, const size_
         p.rslot_cap = 0;
         for (int b = 0; b < B; ++b) {
             const int Mb = p.img[b].M;
+            const int Mfew = p.img[b].Mlo ? rans_auto_min(p.img[b].Mlo) : Mb;      // the fewest streams the image may end up with: the longest ones
             long syms = 0, all_syms = 0;
             for (int st = 0; st < LLICTI_NSTREAMS; ++st) {
                 const long n = p.desc[(size_t)st * B + b].n;
                 const long nchunks = (n + L - 1) / L;
-                syms += (nchunks + Mb - 1) / Mb * L;
+                syms += (nchunks + Mfew - 1) / Mfew * L;
                 all_syms += (n + 63) / 64 * 64;
             }
             p.rslot_cap = std::max(p.rslot_cap, (int)align_up((size_t)(2 * syms + 4 + 8 + pay_bytes + 16 + 64 + (Q == 4 ? kRansSpillMax / 8 + 8 : 0)), 64));   // + T, the 31-bit states, slack, zero pad (xwide v4: + the tail's spill and the header field)
@@ -340,6 +344,7 @@ static int mode_streams(int mode)      // -> M, | 0x100 for wide streams (LLICTI
     if (mode == 0) return 0;
     const int M = mode & 0xFF;
     if ((mode & ~0xFF) == 0x500) return ((M >= 1 && M <= 32) || M == 64 || M == 128) ? (M | 0x200) : -1;
+    if ((mode & ~0xFF) == (0x500 | 0x10000)) return (M >= 1 && M <= 32) ? (M | 0x200 | 0x1000) : -1;      // LLICTI_MODE_RANS_X_AUTO(M): encode only
     if ((mode & ~0xFF) == 0x300) return (M >= 1 && M <= 14) ? (M | 0x100) : -1;
     if ((mode & ~0xFF) != 0x100) return -1;
     if (M < 1 || (M > 32 && M != 64 && M != 128)) return -1;
@@ -391,7 +396,7 @@ static size_t plan_workspace_bytes_vm(int B, const int *Hs, const int *Ws, const
     if (n_modes == B && B > 1)
         for (int b = 0; b < B; ++b) {
             const int MEb = mode_streams(modes[b]);
-            if (MEb < 0 || (MEb >> 8) != (ME >> 8) || ((MEb & 0xFF) == 0) != ((ME & 0xFF) == 0)) return 0;
+            if (MEb < 0 || (MEb >> 8) != (ME >> 8) || ((MEb & 0xFF) == 0) != ((ME & 0xFF) == 0)) return 0;      // (one lane kind per call -- and all "auto" or none)
             Ms.push_back(MEb & 0xFF);
         }
     Plan p, q;

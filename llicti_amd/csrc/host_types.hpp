@@ -48,7 +48,10 @@ struct Geom {
 struct ImgGeo {
     int H, W, h4, w4, padint, hdr_bytes;      // hdr_bytes = 17 + 3 h4 w4 (LLICTI_nets.py:347-350)
     int M, sbase;                             // rANS containers: the image's stream count (its header says so: images of one call may differ) and its first stream
-    int byte0, pad_;                          // header byte 0 of its container (AC: the number of scales; rANS: the v3 tag with M)
+    int byte0;                                // header byte 0 of its container (AC: the number of scales; rANS: the tag)
+    int Mlo;                                  // "auto" xwide encodes (LLICTI_MODE_RANS_X_AUTO): the count the image's size gives; M is then the LARGEST the encoder may
+                                              // pick -- it picks per image, on the device, from what the image's last stage costs (rans_auto_hi / rans_auto_min,
+                                              // choose_streams_kernel) -- and the table holds M streams for it.  0: the count is M, fixed by the caller
     long plane;                               // H * W
     long pix_off;                             // first element of the image's [3][H][W] block in planes / fplanes (workspace)
     long rgb_off;                             // first byte of its [3][H][W] block in the caller's RGB buffer
@@ -209,4 +212,22 @@ LLICTI_HD int rans_stream_count(int nc, int m, int M, int L)
 // M <= 32: stream m is segment 4 + m of the container.  M = 64 / 128 (latency modes for single / large images; the reference's list
 // has 45 stream slots): G = M / 32 streams share segment 4 + m / G = G little-endian u32 stream lengths, then the G streams.
 LLICTI_HD int rans_group(int M) { return M > 32 ? M / 32 : 1; }
+
+// "auto" xwide encodes: the stream count of an image is chosen by the ENCODER, per image, from the image itself -- its size (Mlo, the caller's
+// rule: llicti_amd.codec.image_streams) and what the symbols of its LAST stage cost, S = sum over its n symbols of (16 - floor(log2 freq)):
+//   expensive symbols (S >= 11 n: uniform noise under the sigma-floor weights, ~12 bits each): an xwide v4 stream costs ~2.5 bytes there (two
+//     seeded tail chains carry six raw symbols), so a third more streams fit the same byte budget: rans_auto_hi(Mlo);
+//   a last stage too cheap to fill Mlo payloads of 7,936 bits with a tenth to spare (2 S - n < 2 * 8,704 Mlo; S overstates the ideal bits by
+//     about half a bit per symbol): half the streams, rans_auto_min(Mlo) -- every unfilled payload bit is a wasted bit;
+//   otherwise Mlo.
+// A pure function of the image: the same image gets the same container whatever it is coded with, next to or after (oracle: orc_auto_streams).
+LLICTI_HD int rans_auto_hi(int Mlo) { const int h = Mlo + (Mlo + 2) / 3; return h > 32 ? 32 : h; }
+LLICTI_HD int rans_auto_min(int Mlo) { return (Mlo + 1) / 2; }
+LLICTI_HD int rans_auto_pick(int Mlo, long long S, long long n)
+{
+    if (n <= 0) return Mlo;
+    if (S >= 11 * n) return rans_auto_hi(Mlo);
+    if (2 * S - n < 2LL * 8704 * Mlo) return rans_auto_min(Mlo);
+    return Mlo;
+}
 

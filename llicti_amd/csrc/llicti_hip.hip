@@ -174,6 +174,16 @@ extern "C" size_t llicti_workspace_bytes_vm(int B, const int *Hs, const int *Ws,
 extern "C" size_t llicti_workspace_bytes(int B, int H, int W, int mode) { return plan_workspace_bytes(B, H, W, mode); }
 extern "C" size_t llicti_max_container_bytes(int H, int W) { return plan_max_container_bytes(H, W); }
 extern "C" int llicti_header_dims(const uint8_t *h, int *H, int *W) { return plan_header_dims(h, H, W); }
+extern "C" int llicti_header_mode(const uint8_t *h, int *mode)
+{
+    if (!h || !mode) return fail(LLICTI_EINVAL, "header_mode: null pointer");
+    int H = 0, W = 0;
+    if (int rc = plan_header_dims(h, &H, &W)) return rc;          // (rejects what this build does not read, with the reason)
+    if (h[0] == LLICTI_NLEVELS) { *mode = 0; return LLICTI_OK; }
+    const int v = rans_streams_of_header(h[0], (int)(uint16_t)(h[15] | (h[16] << 8)));
+    *mode = ((v >> 8) == 2 ? 0x500 : (v >> 8) == 1 ? 0x300 : 0x100) | (v & 0xFF);
+    return LLICTI_OK;
+}
 
 extern "C" int llicti_create(llicti_ctx **out, int device)
 {
@@ -736,7 +746,8 @@ static int encode_batch(llicti_ctx *c, const uint8_t *d_rgb, const size_t *rgb_o
     int ME = 0;
     std::vector<int> Ms;
     if (int rc = resolve_modes("encode_images", modes, n_modes, B, &ME, Ms)) return rc;
-    const int Q = 1 << (ME >> 8);
+    const int Q = 1 << ((ME >> 8) & 3);
+    const bool autoM = (ME & 0x1000) != 0;
     for (int b = 0; b < 3; ++b) if (!c->have[b]) return fail(LLICTI_ENOWEIGHTS, "band %d weights not set", b);
     DeviceGuard guard(c);
     hipStream_t s = (hipStream_t)stream;
@@ -830,10 +841,14 @@ static int encode_batch(llicti_ctx *c, const uint8_t *d_rgb, const size_t *rgb_o
         int32_t *rinfo = (int32_t *)(ws + p.off_rinfo);
         const StageGeom *sglv = d_sg + (size_t)(0 * 3 + 2) * B;      // the last stage: an xwide stream's seed symbols are read from its pixels
         const int NS = p.nstreams;                                   // the streams of all images (an image's count is its own: ImgGeo::M)
-        if (Q == 4) rans_encode_kernel<4><<<NS, 256, 0, s>>>(pairs, d_desc, B, d_sref, slots, d_rslot_off, p.rslot_cap, rinfo, status, sglv, planes, mm);
-        else if (Q == 2) rans_encode_kernel<2><<<NS, 128, 0, s>>>(pairs, d_desc, B, d_sref, slots, d_rslot_off, p.rslot_cap, rinfo, status, sglv, planes, mm);
-        else rans_encode_kernel<1><<<NS, 64, 0, s>>>(pairs, d_desc, B, d_sref, slots, d_rslot_off, p.rslot_cap, rinfo, status, sglv, planes, mm);
-        rans_pack_kernel<<<NS, 256, 0, s>>>(slots, d_rslot_off, rinfo, d_sref, d_img, d_out, (long)out_stride, d_seg_len, status);
+        // LLICTI_MODE_RANS_X_AUTO: each image's stream count is picked here, on the device, from what its last stage costs (a pure function of
+        // the image); the table holds the most it may get, the streams it does not get are empty segments
+        int32_t *mused = autoM ? (int32_t *)(ws + p.off_rpos) : nullptr;      // (the decoder's cursor array: unused by an encode)
+        if (autoM) choose_streams_kernel<<<B, 256, 0, s>>>(pairs, d_desc, B, d_img, mused);
+        if (Q == 4) rans_encode_kernel<4><<<NS, 256, 0, s>>>(pairs, d_desc, B, d_sref, slots, d_rslot_off, p.rslot_cap, rinfo, status, sglv, planes, mm, mused);
+        else if (Q == 2) rans_encode_kernel<2><<<NS, 128, 0, s>>>(pairs, d_desc, B, d_sref, slots, d_rslot_off, p.rslot_cap, rinfo, status, sglv, planes, mm, mused);
+        else rans_encode_kernel<1><<<NS, 64, 0, s>>>(pairs, d_desc, B, d_sref, slots, d_rslot_off, p.rslot_cap, rinfo, status, sglv, planes, mm, mused);
+        rans_pack_kernel<<<NS, 256, 0, s>>>(slots, d_rslot_off, rinfo, d_sref, d_img, d_out, (long)out_stride, d_seg_len, status, mused);
     }
     latch_status_kernel<<<1, 64, 0, s>>>(status, c->d_status, nullptr, 0);
     HIPCHK(hipGetLastError());
@@ -996,6 +1011,7 @@ static int decode_batch(llicti_ctx *c, const uint8_t *d_in, size_t in_stride, co
     int ME = 0;
     std::vector<int> Ms;
     if (int rc = resolve_modes("decode_images", modes, n_modes, B, &ME, Ms)) return rc;
+    if (ME & 0x1000) return fail(LLICTI_EINVAL, "decode_images: LLICTI_MODE_RANS_X_AUTO is an encoder's mode -- a container says how many streams it has (header: llicti_header_mode)");
     for (int b = 0; b < 3; ++b) if (!c->have[b]) return fail(LLICTI_ENOWEIGHTS, "band %d weights not set", b);
     DeviceGuard guard(c);
     hipStream_t s = (hipStream_t)stream;

@@ -915,12 +915,31 @@ static long rans_tail_encode_x(const stage_syms_t *sl, int m, int M, long cnt, i
     return T;
 }
 
+/* "auto" xwide encodes: the stream count of an image from the image itself -- Mlo, what its size gives, and S = the sum over the n symbols of its
+ * LAST stage of (16 - floor(log2 freq)): expensive symbols (S >= 11 n) -> Mlo + ceil(Mlo / 3) (at most 32); a last stage that cannot fill Mlo
+ * payloads of 7,936 bits with a tenth to spare (2 S - n < 2 * 8704 Mlo) -> ceil(Mlo / 2); otherwise Mlo.  (llicti_amd/csrc/host_types.hpp: rans_auto_pick) */
+int orc_auto_streams(int Mlo, const uint32_t *clow, const uint32_t *chigh, long n)
+{
+    long long S = 0;
+    for (long i = 0; i < n; ++i) {
+        uint32_t f = chigh[i] - clow[i];
+        if (f == 0 || f > 0x10000u) f = 1;
+        S += clz32(f) - 15;
+    }
+    if (n <= 0) return Mlo;
+    if (S >= 11 * (long long)n) { const int h = Mlo + (Mlo + 2) / 3; return h > 32 ? 32 : h; }
+    if (2 * S - n < 2LL * 8704 * Mlo) return (Mlo + 1) / 2;
+    return Mlo;
+}
+
 long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *wts, int M,
                            uint8_t *out, long cap, int32_t seg_len[49])
 {
     if (H < 32 || W < 32 || H > 8160 || W > 8160) return -2;
     const int wide = (M >> 8) & 3;                      /* M | 0x100: wide streams of 128 lanes (M <= 14); M | 0x200: xwide streams of 256 lanes (v4: M <= 32, 64, 128) */
+    const int autoM = (M >> 12) & 1;                    /* M | 0x200 | 0x1000: the count is the size rule's; the encoder picks the image's own from its last stage (orc_auto_streams) */
     M &= 0xFF;
+    if (autoM && (wide != 2 || M < 1 || M > 32)) return -2;
     if (wide == 0 && (M < 1 || (M > 32 && M != 64 && M != 128))) return -2;
     if (wide == 1 && (M < 1 || M > 14)) return -2;
     if (wide == 2 && (M < 1 || (M > 32 && M != 64 && M != 128))) return -2;
@@ -989,6 +1008,12 @@ long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *
         free(params); free(sym);
     }
     free(planes);
+    if (autoM) {
+        /* the image's own count (host_types.hpp: rans_auto_pick), from what the symbols of its last stage cost; the pad field says which */
+        M = orc_auto_streams(M, st[ORC_NSTREAM - 1].clow, st[ORC_NSTREAM - 1].chigh, st[ORC_NSTREAM - 1].n);
+        const int pf = (padint & 0x3FF) | (M << 10);
+        out[15] = (uint8_t)(pf & 0xFF); out[16] = (uint8_t)((pf >> 8) & 0xFF);
+    }
     long rc = 0;
     const long bcap = 2 * total + 256;                   /* <= 16 bits per symbol + (xwide) spill and header field */
     uint8_t *bits = (uint8_t *)malloc(bcap);

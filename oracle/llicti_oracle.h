@@ -169,7 +169,10 @@ long orc_stream_pairs(const int16_t *planes, int H, int W, const int16_t minmax[
  * Cost over the ideal code length, measured on 768x512 images (tests/sim_v4.py, tests): 64 lanes ~6 bytes per stream that has symbols, 128 lanes
  * ~6.5, xwide v4 2.3-2.8 (noise) / 4.1 (natural-like, model-drawn) / 5.1 (a 1.5-bit source) of which 1.8 are the 256 lanes' 0.057 bit each (v3:
  * 3.5-4.1 / 5.1-6.6 / 9.8); an empty stream costs 250 / 498 / 994 bytes.
- * M: streams per image, | 0x100 for wide streams, | 0x200 for xwide streams.  Returns total bytes or <0. */
+ * M: streams per image, | 0x100 for wide streams, | 0x200 for xwide streams; | 0x1200: xwide streams whose count the ENCODER picks from the image
+ * (orc_auto_streams: M is what the image's size gives; expensive last-stage symbols -> M + ceil(M / 3), a last stage too cheap to fill M
+ * payloads -> ceil(M / 2)) and writes into the header -- the container is an ordinary xwide v4 container of that count.  Returns total bytes or <0. */
+int orc_auto_streams(int Mlo, const uint32_t *clow, const uint32_t *chigh, long n);
 long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *wts, int M,
                            uint8_t *out, long cap, int32_t seg_len[49]);
 int orc_decode_image_rans(const uint8_t *in, const int32_t seg_len[49], const orc_weights *wts,

@@ -233,14 +233,15 @@ def _list_to_segments(bl):
     return np.frombuffer(b"".join(segs), dtype=np.uint8).copy(), seg_len
 
 
-def encode_image_rans(rgb, weights: "Weights", M=8, wide=False):
-    """uint8 [3,H,W] -> bytestream_list holding the rANS v3 container (M streams; wide = 1 / True: 128 lanes per stream instead of 64; wide = 2: 256 lanes, "xwide")."""
+def encode_image_rans(rgb, weights: "Weights", M=8, wide=False, auto=False):
+    """uint8 [3,H,W] -> bytestream_list holding the rANS container (M streams; wide = 1 / True: 128 lanes per stream instead of 64; wide = 2: 256 lanes,
+    "xwide", v4 layout; auto (xwide only): M is the size rule's count and the encoder picks the image's own from its last stage, orc_auto_streams)."""
     rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
     _, H, W = rgb.shape
-    cap = 8 * H * W + 4096 + 1024 * M
+    cap = 8 * H * W + 4096 + 1024 * (2 * M if auto else M)
     out = np.empty(cap, np.uint8)
     seg = np.zeros(49, np.int32)
-    n = lib().orc_encode_image_rans(_p(rgb), H, W, C.byref(weights.c), int(M) | (int(wide) << 8), _p(out), C.c_long(cap), _p(seg))
+    n = lib().orc_encode_image_rans(_p(rgb), H, W, C.byref(weights.c), int(M) | (int(wide) << 8) | (0x1000 if auto else 0), _p(out), C.c_long(cap), _p(seg))
     if n < 0:
         raise RuntimeError(f"orc_encode_image_rans failed: {n}")
     return _segments_to_list(out[:n], seg)
