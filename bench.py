@@ -64,8 +64,8 @@ def default_streams(H, W):
 NORTH_STAR_MPIX_S = 200.0            # BASELINE.json north_star: >= 200 MPix/s encode+decode on 768x512 at 1 MI355X ...
 NORTH_STAR_DBPP = 0.001              # ... with bpp within 0.001 of the reference
 MAC_PER_BAND = (352 * 48 + 30976 + 5280, 352 * 72 + 30976 + 5280, 352 * 120 + 30976 + 5280)   # layer 0 (K = 48 / 72 / 120) + 4 x 88 x 88 + 4 x 15 x 88
-IMAGE_4K_MODES = ("xrans64", "xrans32", "rans128", "rans64", "rans32", "wrans14", "xrans14")   # configs[3] leg: every mode gets its Delta bpp; the headline is the fastest within 0.001 bpp
-IMAGE_4K_HEADLINE = "xrans64"        # ... which tests/test_hip_parity.py::test_4k_image_oracle_parity checks against the oracle (the leg says if another mode won)
+IMAGE_4K_MODES = ("xrans128", "xrans64", "xrans32", "rans128", "rans64", "rans32", "wrans14", "xrans14")   # configs[3] leg: every mode gets its Delta bpp; the headline is the fastest within 0.001 bpp
+IMAGE_4K_HEADLINE = "xrans128"       # ... which tests/test_hip_parity.py::test_4k_image_oracle_parity checks against the oracle (the leg says if another mode won)
 LARGE_AC_BATCH = 512                 # the batch at which the reference-format container is also measured (untimed leg): >= 1536 streams in flight
 
 
@@ -268,8 +268,13 @@ class Legs:
         B, _, H, W = rgb.shape
         cont, seg = codec.encode(rgb, mode=mode)
         codec.check()
+        dmode = mode
+        if mode & 0x10000:                      # "auto": the encoder picked the counts; the decoder takes them from the headers (one per call here)
+            dm = sorted(set(codec.container_modes(cont)))
+            assert len(dm) == 1, dm
+            dmode = dm[0]
         codec.poison_workspace()
-        rec = codec.decode(cont, seg, H, W, mode=mode)
+        rec = codec.decode(cont, seg, H, W, mode=dmode)
         codec.check()
         assert torch.equal(rec, rgb), "decode(encode(x)) != x"
 
@@ -281,11 +286,14 @@ class Legs:
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) / reps
         te = timed(lambda: codec.encode(rgb, mode=mode, out=cont, seg_len=seg))
-        td = timed(lambda: codec.decode(cont, seg, H, W, mode=mode, out=rec))
+        td = timed(lambda: codec.decode(cont, seg, H, W, mode=dmode, out=rec))
         mp = B * H * W / 1e6
         nbytes = int(seg.sum().item())
         r = {"batch": B, "enc_mpix_s": round(mp / te, 2), "dec_mpix_s": round(mp / td, 2), "encdec_mpix_s": round(mp / (te + td), 2),
              "enc_ms": round(te * 1e3, 3), "dec_ms": round(td * 1e3, 3), "bpp": round(8.0 * nbytes / (B * H * W), 5), "bytes": nbytes}
+        if mode & 0x10000:
+            from llicti_amd.codec import name_of_mode
+            r["container_out"] = name_of_mode(dmode)
         if keep:
             return r, cont, seg
         return r
@@ -542,10 +550,10 @@ def model_drawn_leg(torch, dev, B, H, W, mode):
     exists in the reference tree, so the images are DRAWN FROM A MODEL: the trained-like weights of tests/golden with one live mixture component
     of sigma 0.6 grey levels, and the reference-format decoder on this GPU fed random bytes behind the headers of a noise batch emits symbols
     with exactly the model's probabilities (tools/probe_cheap_content.py).  What cheap symbols change: a stream's serial tail is ~4,700 symbols
-    instead of ~620.  Reported: the timed container and the 64-lane container `container: "auto"` switches to on such content (inside the bpp
-    budget there), with bytes against the reference-format container of the same batch and the decode's stage / tail kernel groups."""
+    instead of ~620.  Reported: the timed encoder mode, xrans10 and rans10, with bytes against the reference-format container of the same batch and
+    the decode's stage / tail kernel groups."""
     import numpy as np
-    from llicti_amd.codec import CHEAP_LAST_STAGE_BITS, MODE_AC, MODE_RANS, HipCodec, last_stage_bits, name_of_mode
+    from llicti_amd.codec import MODE_AC, MODE_RANS, HipCodec, last_stage_bits, name_of_mode
     wfile = os.path.join(ROOT, "tests", "golden", "weights_trainedlike.npz")
     if not os.path.exists(wfile):
         return None
@@ -579,14 +587,16 @@ def model_drawn_leg(torch, dev, B, H, W, mode):
     bits = float(np.mean([last_stage_bits(row, H, W) for row in seg_ac.cpu().numpy()]))
     out = {"workload": f"{B}x{W}x{H} images drawn from a one-component model of sigma 0.6 grey levels (trained-like weights otherwise)",
            "bits_per_last_stage_symbol": round(bits, 3), "reference_trained_model_bits_per_last_stage_symbol": 1.68,
-           "auto_switches_below_bits": CHEAP_LAST_STAGE_BITS, "reference_format": {k: r_ac[k] for k in ("encdec_mpix_s", "bpp", "bytes")}}
-    M = mode & 0xFF
-    for m in (mode, MODE_RANS(M)):
+           "reference_format": {k: r_ac[k] for k in ("encdec_mpix_s", "bpp", "bytes")}}
+    # `mode`: the timed ENCODER mode ("auto": the encoder picks the count from the image -- on this content it halves the size rule's count where the
+    # last stage cannot fill the payloads); beside it xrans10 -- round 5's timed container, +0.0014 bpp there in its v3 layout -- and rans10 (64 lanes)
+    for m in dict.fromkeys((mode, MODE_RANS(10, wide=2), MODE_RANS(10))):
         r = legs.run(x, m, reps=3)
         r["bpp_delta_vs_ac_container"] = round(8.0 * (r["bytes"] - r_ac["bytes"]) / (B * H * W), 6)
         cont, seg = codec.encode(x, mode=m)
+        dm = sorted(set(codec.container_modes(cont)))[0] if (m & 0x10000) else m
         codec.set_profiling(True)
-        codec.decode(cont, seg, H, W, mode=m)
+        codec.decode(cont, seg, H, W, mode=dm)
         torch.cuda.synchronize()
         cat, _ = codec.last_timing_detail()
         codec.set_profiling(False)
@@ -816,7 +826,7 @@ def main(argv=None):
     from llicti_amd.graphs.models.LLICTI_nets import LLICTI
     from llicti_amd import shard
 
-    from llicti_amd.codec import mode_of_name as mode_of
+    from llicti_amd.codec import mode_of_name as mode_of, name_of_mode
     if args.container == "auto":
         args.container = default_container(H, W)
     mode = mode_of(args.container)
@@ -836,8 +846,13 @@ def main(argv=None):
     def enc():
         return codec.encode(rgb, mode=mode, out=cont, seg_len=seg)
 
+    # Container "auto" is an ENCODER mode: the stream count of an image is picked by the encoder, on the device, from the image itself (its size
+    # and what its last stage costs; llicti_amd.codec.MODE_RANS_AUTO) and written into the container's header.  A decoder reads the header -- here
+    # once, outside the timed region (a real decoder gets its containers from the host and has the header before it has anything else).
+    dmode = [mode]
+
     def dec():
-        return codec.decode(cont, seg, H, W, mode=mode, out=rec)
+        return codec.decode(cont, seg, H, W, mode=dmode[0], out=rec)
 
     def step():
         enc()
@@ -846,6 +861,13 @@ def main(argv=None):
     # correctness outside the timed region: lossless with the workspace poisoned between encode and decode
     enc()
     codec.check()
+    if mode & 0x10000:
+        got_modes = sorted(set(codec.container_modes(cont)))
+        if len(got_modes) != 1:
+            raise SystemExit(f"the encoder picked different stream counts for the images of the timed batch ({[name_of_mode(m) for m in got_modes]}): "
+                             "the timed decode takes one mode per call -- name a container (--container xrans<M>)")
+        dmode[0] = got_modes[0]
+    container_out = name_of_mode(dmode[0])
     codec.poison_workspace()
     rec.zero_()
     dec()
@@ -910,7 +932,7 @@ def main(argv=None):
         assert np.array_equal(rec_pin.numpy(), rgb_h)
 
         # The same four transfers per step, OVERLAPPED with compute (PciePipeline above)
-        pipe = PciePipeline(torch, codec, dev, mode, rgb, cont, seg, rec, rgb_pin, cont_pin, seg_pin, rec_pin)
+        pipe = PciePipeline(torch, codec, dev, dmode[0], rgb, cont, seg, rec, rgb_pin, cont_pin, seg_pin, rec_pin)      # (the container the timed encode writes on this batch, by name)
         pcie_pipeline = pipe.run
         pcie_pipeline(2)                                   # warm-up: second buffers, streams
         # steady state: the difference of a long and a short pipelined run (both pay the same fill and drain)
@@ -987,7 +1009,7 @@ def main(argv=None):
             r = legs.run(rgb, MODE_RANS(M), reps=2)
             sweep.append({"M": M, "lanes": 64, "encdec_mpix_s": r["encdec_mpix_s"], "enc_mpix_s": r["enc_mpix_s"], "dec_mpix_s": r["dec_mpix_s"],
                           "bpp_delta_vs_ac_container": round(8.0 * (r["bytes"] - ac_bytes) / (B * H * W), 5)})
-        for wide, Ms in ((1, (4, 6, 8, 10)), (2, (4, 6, 8, 9, 10, 12))):      # wide streams: 128 lanes, two lanes per symbol; xwide: 256 lanes, one lane per symbol
+        for wide, Ms in ((1, (4, 6, 8, 10)), (2, (8, 10, 12, 15, 16, 18, 20, 21, 24))):      # wide streams: 128 lanes, two lanes per symbol; xwide (v4): 256 lanes, one lane per symbol
             for M in Ms:
                 r = legs.run(rgb, MODE_RANS(M, wide=wide), reps=2)
                 sweep.append({"M": M, "lanes": 64 << wide, "encdec_mpix_s": r["encdec_mpix_s"], "enc_mpix_s": r["enc_mpix_s"], "dec_mpix_s": r["dec_mpix_s"],
@@ -1011,7 +1033,10 @@ def main(argv=None):
         legs_out["single_image"] = {"workload": f"1x{W}x{H} (BASELINE.json configs[1])",
                                     "rans128": legs.run(one, MODE_RANS(128), reps=5), "rans64": legs.run(one, MODE_RANS(64), reps=5), "rans32": legs.run(one, MODE_RANS(32), reps=5),
                                     "rans16": legs.run(one, MODE_RANS(16), reps=5), "xrans64": legs.run(one, MODE_RANS(64, wide=2), reps=5),
-                                    "xrans32": legs.run(one, MODE_RANS(32, wide=2), reps=5), "xrans10": legs.run(one, MODE_RANS(10, wide=2), reps=5),
+                                    "xrans32": legs.run(one, MODE_RANS(32, wide=2), reps=5), "xrans24": legs.run(one, MODE_RANS(24, wide=2), reps=5),
+                                    "xrans20": legs.run(one, MODE_RANS(20, wide=2), reps=5), "xrans15": legs.run(one, MODE_RANS(15, wide=2), reps=5),
+                                    "xrans10": legs.run(one, MODE_RANS(10, wide=2), reps=5),
+                                    default_container(H, W): legs.run(one, mode_of(default_container(H, W)), reps=5),      # what container "auto" gives this image
                                     "ac": legs.run(one, MODE_AC, reps=1)}
         for nm, r in legs_out["single_image"].items():
             if isinstance(r, dict) and nm != "ac":
@@ -1060,7 +1085,7 @@ def main(argv=None):
         # (informational legs must not cost the line its timed value: a failure in one of them is recorded, not raised)
         for leg_name, leg_fn in (("api_path", lambda: api_path_leg(torch, dev, B, H, W)),
                                  ("api_path_mixed", lambda: api_path_mixed_leg(torch, dev, B)),
-                                 ("overlapped_streams", lambda: overlap_leg(torch, dev, sd, rgb, mode)),
+                                 ("overlapped_streams", lambda: overlap_leg(torch, dev, sd, rgb, dmode[0])),
                                  ("natural_like", lambda: natural_like_leg(torch, dev, B, H, W, mode)),
                                  ("model_drawn", lambda: model_drawn_leg(torch, dev, B, H, W, mode))):
             try:
@@ -1108,8 +1133,11 @@ def main(argv=None):
             "metric": "MPix/s encode+decode", "value": round(value, 3), "unit": "MPix/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{B}x{W}x{H} uniform-noise RGB per GPU, container {args.container}, seed-1337 weights" + tag,
-                       "batch_per_gpu": B, "height": H, "width": W, "container": args.container,
+            "config": {"workload": f"{B}x{W}x{H} uniform-noise RGB per GPU, container {args.container} -> {container_out}, seed-1337 weights" + tag,
+                       "batch_per_gpu": B, "height": H, "width": W, "container": args.container, "container_written": container_out,
+                       "container_is": ("encoder mode xauto<M>: xwide rANS v4 streams, M = what the image's size gives; the encoder picks the image's own count on the device "
+                                        "from what its last stage costs -- a pure function of the image (llicti_amd.codec.MODE_RANS_AUTO); container_written = what came out, "
+                                        "read from the headers once outside the timed region and handed to the decoder" if (mode & 0x10000) else "as named"),
                        "sharding": f"images/{world}gpu", "backend": args.backend if world > 1 else None},
             "rccl_ranks": rccl_ranks, "ranks": world, "backend": (args.backend if world > 1 else None),
             "distinct_devices": n_distinct, "shared_gpu": bool(shared_gpu),
@@ -1204,7 +1232,7 @@ def main(argv=None):
             if mode != MODE_AC:
                 # ... and so must image 0 of the TIMED container (the oracle's restatement of the rANS v3 format)
                 from oracle import oracle as orc
-                ref_r = orc.encode_image_rans(rgb_h[0], cpu_weights(), mode & 0xFF, ((mode & ~0xFF) - 0x100) // 0x200)
+                ref_r = orc.encode_image_rans(rgb_h[0], cpu_weights(), mode & 0xFF, ((mode & 0xF00) - 0x100) // 0x200, auto=bool(mode & 0x10000))
                 got_r = container_to_bytestream_list(cont[0].cpu().numpy(), seg_h[0])
                 cb["timed_container_bitexact_vs_hip"] = bool(got_r == ref_r)
                 if not cb["timed_container_bitexact_vs_hip"]:

@@ -65,6 +65,8 @@ def image_mode(H, W, mixed=False):
     of ~4.5), half where the last stage is too cheap to fill the streams' payloads; an image too small for one xwide stream gets a 64-lane stream
     (from ~45x45 pixels) or -- only where the call holds images of one size (`mixed` False) -- the reference format."""
     m = image_streams(H, W)
+    if m > 32:
+        return MODE_RANS(m, wide=2)             # (64 / 128 streams: very large images; the count is the size rule's)
     if m >= 1:
         return MODE_RANS_AUTO(m)
     if (H // 2) * (W // 2) >= NARROW_MIN_TAIL or mixed:

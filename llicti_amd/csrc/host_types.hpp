@@ -216,7 +216,7 @@ LLICTI_HD int rans_group(int M) { return M > 32 ? M / 32 : 1; }
 // "auto" xwide encodes: the stream count of an image is chosen by the ENCODER, per image, from the image itself -- its size (Mlo, the caller's
 // rule: llicti_amd.codec.image_streams) and what the symbols of its LAST stage cost, S = sum over its n symbols of (16 - floor(log2 freq)):
 //   expensive symbols (S >= 11 n: uniform noise under the sigma-floor weights, ~12 bits each): an xwide v4 stream costs ~2.5 bytes there (two
-//     seeded tail chains carry six raw symbols), so a third more streams fit the same byte budget: rans_auto_hi(Mlo);
+//     seeded tail chains carry six raw symbols), so a third more streams fit the same byte budget: rans_auto_hi(Mlo) -- where the last stage can fill that many payloads;
 //   a last stage too cheap to fill Mlo payloads of 7,936 bits with a tenth to spare (2 S - n < 2 * 8,704 Mlo; S overstates the ideal bits by
 //     about half a bit per symbol): half the streams, rans_auto_min(Mlo) -- every unfilled payload bit is a wasted bit;
 //   otherwise Mlo.
@@ -226,7 +226,7 @@ LLICTI_HD int rans_auto_min(int Mlo) { return (Mlo + 1) / 2; }
 LLICTI_HD int rans_auto_pick(int Mlo, long long S, long long n)
 {
     if (n <= 0) return Mlo;
-    if (S >= 11 * n) return rans_auto_hi(Mlo);
+    if (S >= 11 * n && 2 * S - n >= 2LL * 8704 * rans_auto_hi(Mlo)) return rans_auto_hi(Mlo);      // (... and enough of them to fill that many payloads)
     if (2 * S - n < 2LL * 8704 * Mlo) return rans_auto_min(Mlo);
     return Mlo;
 }

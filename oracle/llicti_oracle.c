@@ -916,7 +916,7 @@ static long rans_tail_encode_x(const stage_syms_t *sl, int m, int M, long cnt, i
 }
 
 /* "auto" xwide encodes: the stream count of an image from the image itself -- Mlo, what its size gives, and S = the sum over the n symbols of its
- * LAST stage of (16 - floor(log2 freq)): expensive symbols (S >= 11 n) -> Mlo + ceil(Mlo / 3) (at most 32); a last stage that cannot fill Mlo
+ * LAST stage of (16 - floor(log2 freq)): expensive symbols (S >= 11 n), enough to fill that many payloads -> Mlo + ceil(Mlo / 3) (at most 32); a last stage that cannot fill Mlo
  * payloads of 7,936 bits with a tenth to spare (2 S - n < 2 * 8704 Mlo) -> ceil(Mlo / 2); otherwise Mlo.  (llicti_amd/csrc/host_types.hpp: rans_auto_pick) */
 int orc_auto_streams(int Mlo, const uint32_t *clow, const uint32_t *chigh, long n)
 {
@@ -927,7 +927,8 @@ int orc_auto_streams(int Mlo, const uint32_t *clow, const uint32_t *chigh, long 
         S += clz32(f) - 15;
     }
     if (n <= 0) return Mlo;
-    if (S >= 11 * (long long)n) { const int h = Mlo + (Mlo + 2) / 3; return h > 32 ? 32 : h; }
+    const int hi = (Mlo + (Mlo + 2) / 3) > 32 ? 32 : Mlo + (Mlo + 2) / 3;
+    if (S >= 11 * (long long)n && 2 * S - n >= 2LL * 8704 * hi) return hi;
     if (2 * S - n < 2LL * 8704 * Mlo) return (Mlo + 1) / 2;
     return Mlo;
 }

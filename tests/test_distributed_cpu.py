@@ -111,8 +111,8 @@ def test_bench_defaults_match_baseline_configs():
     a = bench.parse_args([])
     assert a.gpus == 1 and a.batch == 0 and a.container == "auto"
     # the timed container is a function of the image SIZE alone (llicti_amd.codec.image_streams): the same for every batch size and rank count
-    assert bench.default_container(512, 768) == "xrans15" and bench.default_streams(512, 768) == 15
-    assert bench.default_container(2160, 3840) == "xrans64" and bench.default_container(256, 256) == "xrans2" and bench.default_container(64, 64) == "rans1"
+    assert bench.default_container(512, 768) == "xauto15" and bench.default_streams(512, 768) == 15
+    assert bench.default_container(2160, 3840) == "xrans64" and bench.default_container(256, 256) == "xauto2" and bench.default_container(64, 64) == "rans1"
     # a launcher that started the wrong number of ranks is an error, not a silent single-rank run
     env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     import subprocess
@@ -131,7 +131,7 @@ def test_bench_eight_rank_dry_run_configs4():
                        env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
-    assert out["n_gpus"] == 8 and out["ranks_seen"] == 8 and out["batch_per_gpu"] == 32 and out["container"] == "xrans15"
+    assert out["n_gpus"] == 8 and out["ranks_seen"] == 8 and out["batch_per_gpu"] == 32 and out["container"] == "xauto15"
     assert "configs[4]" in out["config"]["workload"]
     assert out["pixels"] == 256 * 512 * 768 and out["elapsed_max_s"] == 8.0 and out["bytes"] == 1000.0 * 36
     assert [r["rank"] for r in out["per_rank"]] == list(range(8)) and out["distinct_devices"] == 8

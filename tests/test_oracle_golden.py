@@ -417,17 +417,20 @@ def test_bpp_delta_vs_reference_tables_report(golden_index, oracle_weights):
                 from helpers import xwide_stream_header
                 from llicti_amd.codec import auto_container, mode_of_name
                 mode = mode_of_name(auto_container(H, Wd))
-                bl_r = orc.encode_image_rans(rgb, W, mode & 0xFF, ((mode & ~0xFF) - 0x100) // 0x200)
-                assert [xwide_stream_header(x)[1] for rw in bl_r[1:] for x in rw if len(x)] == [0] * (mode & 0xFF)
+                bl_r, got_mode = _encode_in_mode(rgb, W, mode)
+                assert (got_mode & 0xFF) == 20                     # expensive symbols: the size rule's 15 and a third
+                assert [xwide_stream_header(x)[1] for rw in bl_r[1:] for x in rw if len(x)] == [0] * 20
         else:
             # the WHOLE budget on natural-like content at full size -- (build's tables - reference's tables) + (timed container -
             # reference-format container), the second term from the oracle's two containers of this very image (HIP == oracle bytes, -m gpu)
             from helpers import xwide_stream_header
             from llicti_amd.codec import auto_container, mode_of_name
-            cname = auto_container(H, Wd)                # the container bench.py times for BASELINE's batch -- and every other call gives an image of this size
-            mode = mode_of_name(cname)
+            from llicti_amd.codec import name_of_mode
+            mode = mode_of_name(auto_container(H, Wd))   # the encoder mode bench.py times for BASELINE's batch -- and every other call gives an image of this size
             n_ac = sum(len(x) for rw in orc.encode_image(rgb, W) for x in rw)
-            bl_r = orc.encode_image_rans(rgb, W, mode & 0xFF, ((mode & ~0xFF) - 0x100) // 0x200)
+            bl_r, got_mode = _encode_in_mode(rgb, W, mode)
+            cname = name_of_mode(got_mode)               # natural-like and model-drawn content: the size rule's count (xrans15)
+            assert cname == "xrans15", cname
             n_rans = sum(len(x) for rw in bl_r for x in rw)
             cont = 8.0 * (n_rans - n_ac) / (H * Wd)
             # xwide streams choose one tail chain or two by what their symbols cost (bit 8 of a stream's header field): the model-drawn image's are cheap
@@ -482,45 +485,63 @@ def test_torch_cpu_path_roundtrip(case, wname, oracle_weights):
     assert abs(n_t - n_o) <= max(8, n_o // 1000)
 
 
+def _encode_in_mode(img, W_o, mode):
+    """(bytestream_list, mode the container's header names) of the oracle's encode in a codec mode (fixed count or the encoder's "auto")"""
+    from llicti_amd.codec import _mode_auto, _mode_wide, mode_of_header
+    bl = orc.encode_image_rans(img, W_o, mode & 0xFF, _mode_wide(mode), auto=_mode_auto(mode))
+    return bl, mode_of_header(bl)
+
+
 @pytest.mark.parametrize("size", [(32, 32), (48, 64), (64, 96), (96, 128), (128, 192), (192, 256), (321, 481), (512, 768)])
 def test_auto_container_budget_by_size(size, oracle_weights):
-    """`container = "auto"` (llicti_amd.codec.auto_container: a function of the image SIZE alone since round 6) must stay inside the north star's
-    budget at EVERY size, not only at 768x512: a 256-lane stream whose share of the last stage cannot fill its 992-byte payload wastes what is
-    left (a 96x128 image in ten xwide streams is 25 % larger than in the reference format).  For natural-like and model-drawn content the
-    container the rule picks is at most 0.001 bpp LARGER than the reference-format container of the same image (it may be smaller: no 45
-    range-coder terminations)."""
+    """`container = "auto"` (llicti_amd.codec.image_mode: since round 6 a function of the IMAGE alone -- its size gives a stream count, the encoder
+    adjusts it by what the image's last stage costs) must stay inside the north star's budget at EVERY size, not only at 768x512: a 256-lane
+    stream whose share of the last stage cannot fill its 992-byte payload wastes what is left (a 96x128 image in ten xwide streams is 25 % larger
+    than in the reference format).  For natural-like, model-drawn AND noise content the container that comes out is at most 0.001 bpp LARGER than
+    the reference-format container of the same image (it may be smaller: no 45 range-coder terminations)."""
     from helpers import make_image, make_sampled_image
-    from llicti_amd.codec import MODE_AC, MODE_RANS, _mode_wide, auto_container, auto_modes, image_mode, image_streams, mode_of_name
+    from llicti_amd.codec import MODE_AC, MODE_RANS, MODE_RANS_AUTO, auto_container, auto_counts, auto_modes, image_mode, image_streams, mode_of_name
     H, W = size
     W_o = oracle_weights("trainedlike")
     name = auto_container(H, W)
     assert MODE_AC not in auto_modes([size, (512, 768)])            # the reference format codes one size per call
-    assert image_streams(512, 768) == 15 and auto_container(512, 768) == "xrans15" and auto_container(2160, 3840) == "xrans64"
-    # an image's container does not depend on the call it is in: the same mode alone, in a batch of its like and next to other sizes
+    assert image_streams(512, 768) == 15 and auto_container(512, 768) == "xauto15" and auto_container(2160, 3840) == "xrans64"
+    assert auto_counts(15) == (8, 15, 20) and mode_of_name("xauto15") == MODE_RANS_AUTO(15)
+    # an image's mode does not depend on the call it is in: the same alone, in a batch of its like and next to other sizes
     if image_streams(H, W) >= 1:
         assert auto_modes([size]) == [image_mode(H, W)] and auto_modes([size] * 24)[7] == image_mode(H, W)
         assert auto_modes([(768, 768), size, (321, 481)])[1] == image_mode(H, W)
     else:
         assert auto_modes([(768, 768), size]) == [MODE_RANS(1)] * 2      # (one lane kind per call: a tiny neighbour pushes the call to 64-lane streams)
-    for img in (make_image("smooth", H, W, 11), make_sampled_image(H, W, 3)):
-        ac = sum(len(s) for row in orc.encode_image(img, W_o) for s in row)
-        if name == "ac":
-            continue
-        mode = mode_of_name(name)
-        bl = orc.encode_image_rans(img, W_o, mode & 0xFF, _mode_wide(mode))
-        assert np.array_equal(orc.decode_image_rans(bl, W_o), img)
+    if name == "ac":
+        return
+    mode = mode_of_name(name)
+    lo, mid, hi = auto_counts(mode & 0xFF)
+    for img, wts, want in ((make_image("smooth", H, W, 11), W_o, mid), (make_sampled_image(H, W, 3), W_o, mid),
+                           (make_image("noise", H, W, 5), oracle_weights("rand1337"), None)):
+        ac = sum(len(s) for row in orc.encode_image(img, wts) for s in row)
+        bl, got_mode = _encode_in_mode(img, wts, mode)
+        assert np.array_equal(orc.decode_image_rans(bl, wts), img)
+        if name.startswith("xauto"):
+            assert (got_mode & 0xFF) in (lo, mid, hi) and got_mode == MODE_RANS(got_mode & 0xFF, wide=2)
+            if want is not None and H * W >= 128 * 192:
+                assert (got_mode & 0xFF) == want, (name, got_mode & 0xFF)        # natural-like content: the size rule's count
+            if want is None and H * W >= 192 * 256:
+                assert (got_mode & 0xFF) == hi, (name, got_mode & 0xFF)          # the sigma-floor noise: expensive symbols, a third more streams
+            # the container IS the fixed-count container of the count that was picked
+            assert bl == orc.encode_image_rans(img, wts, got_mode & 0xFF, 2)
         got = sum(len(s) for row in bl for s in row)
-        assert 8.0 * (got - ac) / (H * W) <= 0.001, (name, got, ac)
+        assert 8.0 * (got - ac) / (H * W) <= 0.001, (name, got_mode & 0xFF, got, ac)
 
 
 @pytest.mark.parametrize("kind", ["sharp", "single"])
 def test_auto_container_on_cheap_content(kind, oracle_weights):
     """Container "auto" and the CONTENT.  Round 5's xwide v3 stream cost ~10 bytes on a source cheaper than ~4 bits per last-stage symbol -- the
     class the reference's trained model on natural images belongs to (1.7) -- so "auto" switched to 64-lane streams once a running mean of what had
-    been coded said "cheap": an image's bytes depended on the coding order, on eval_batch and on the rank count.  The v4 stream
-    costs ~5 bytes there (no raw seeds beyond one symbol, no escape, no unused payload bits), so the size rule alone stays inside +0.001 bpp on both
-    cheap sources and "auto" looks at nothing but the size."""
-    from llicti_amd.codec import _mode_wide, auto_container, last_stage_bits, mode_of_name
+    been coded said "cheap": an image's bytes depended on the coding order, on eval_batch and on the rank count.  Now the
+    encoder looks at THE IMAGE: the v4 stream costs ~5 bytes there, and where the image's own last stage cannot fill the payloads of the count its
+    size gives ("single": 1.4 bits per symbol) the encoder halves the count -- inside +0.001 bpp on both cheap sources, whatever was coded before."""
+    from llicti_amd.codec import MODE_RANS, auto_container, auto_counts, last_stage_bits, mode_of_name
     sd, W_c, img = _cheap_case(kind)
     H, W = img.shape[1:]
     bl_ac = orc.encode_image(img, W_c)
@@ -528,12 +549,16 @@ def test_auto_container_on_cheap_content(kind, oracle_weights):
     seg = [len(s) for s in bl_ac[0][:4]] + [len(s) for row in bl_ac[1:] for s in row]
     assert len(seg) == 49 and last_stage_bits(seg, H, W) < 4.0, last_stage_bits(seg, H, W)
     name = auto_container(H, W)
-    assert name.startswith("xrans"), name
-    mode = mode_of_name(name)
-    bl = orc.encode_image_rans(img, W_c, mode & 0xFF, _mode_wide(mode))
+    assert name == "xauto4", name
+    bl, got_mode = _encode_in_mode(img, W_c, mode_of_name(name))
+    assert got_mode == MODE_RANS(auto_counts(4)[0 if kind == "single" else 1], wide=2), got_mode
     assert np.array_equal(orc.decode_image_rans(bl, W_c), img)
     delta = 8.0 * (sum(len(s) for row in bl for s in row) - ac) / (H * W)
     assert delta <= 0.001, (name, delta)
+    # what the halving is for: twice the streams on the 1.4-bit source leave payload unfilled (~250 bytes a stream at this size)
+    if kind == "single":
+        n8 = sum(len(s) for row in orc.encode_image_rans(img, W_c, 8, 2) for s in row)
+        assert n8 > sum(len(s) for row in bl for s in row) + 500, n8
 
 
 def _fullsize_samples():
