@@ -234,6 +234,13 @@ int llicti_decode_images_v(llicti_ctx *ctx, const uint8_t *d_in, size_t in_strid
  * reference's compress() returns beside the streams (LLICTI_nets.py:143-144, :159), so a caller that wants it reads it from the workspace
  * behind the encode instead of lifting the image a second time.  Valid until the next whole-batch call on that workspace. */
 int llicti_workspace_planes(llicti_ctx *ctx, int B, int H, int W, int mode, size_t *off_planes, size_t *off_fplanes);
+/* Where a whole-batch call on B images of Hs[b] x Ws[b] in modes[b] (llicti_encode_images_vm / llicti_decode_images_vm; the same placement as the
+ * _v entry points with one mode) leaves the CNN outputs of its LAST launch -- level 0, band x10 -- of image `image`: byte offset of its
+ * float32 [64][npos] block (channel planes, LLICTI_PARAM_STRIDE; position (i, j) of the h x w band grid at i * w + j) inside the caller's
+ * workspace, and npos = h * w.  What it is for: holding the mixed-size form of the band CNN (tile lists, per-image geometry, the odd-edge
+ * staging path) against the reference's own get_params outputs on a full-size odd shape (tests: ..._ragged_vs_reference).  Valid until the
+ * next whole-batch call on that workspace. */
+int llicti_workspace_params_v(llicti_ctx *ctx, int B, const int *Hs, const int *Ws, const int *modes, int image, size_t *off_params, long *npos);
 
 /* Synchronises `stream` and returns the latched device-side status of the calls issued since the
  * last check (LLICTI_OK, LLICTI_EFORMAT, LLICTI_ENOSPACE). */

@@ -78,6 +78,7 @@ _SIGS = {
     "llicti_set_profiling": (_i, [_vp, _i]),
     "llicti_get_counter": (_i, [_vp, C.c_char_p, C.POINTER(_l)]),
     "llicti_workspace_planes": (_i, [_vp, _i, _i, _i, _i, C.POINTER(_sz), C.POINTER(_sz)]),
+    "llicti_workspace_params_v": (_i, [_vp, _i, _vp, _vp, _vp, _i, C.POINTER(_sz), C.POINTER(_l)]),
     "llicti_set_tuning": (_i, [_vp, C.c_char_p, _i]),
 }
 EXPORTS = sorted(_SIGS)

@@ -85,6 +85,9 @@ class LLICTIAgent:
             gpu = config.gpu_device if local < 0 else local % n_dev      # under the launcher: one rank per GPU
             torch.cuda.set_device(gpu)
             self.device = torch.device("cuda", gpu)
+            # several ranks on one host (the launcher): this rank's host threads -- and with them its pinned staging buffers, placed by first touch --
+            # go to the NUMA node its GPU hangs off (llicti_amd.shard.bind_to_gpu_numa); a lone process keeps the affinity it was given
+            self.numa = shard.bind_to_gpu_numa(self.device) if (local >= 0 and int(os.environ.get("WORLD_SIZE", "1")) > 1) else None
         else:
             self.device = torch.device("cpu")          # an injected model (tests: the multi-rank plumbing without a GPU)
         self.rank, self.world = shard.init_from_env(self.device)
@@ -313,19 +316,29 @@ class LLICTIAgent:
     @torch.no_grad()
     def eval_model(self):
         # the reference's own config has neither key: the throughput path is the default, the reference-format loop the opt-in
-        defaulted = getattr(self.model, "container_defaulted", False) and "container" not in self.config
-        if defaulted and hasattr(self.model, "set_container") and self.model.container != "auto":
-            self.model.set_container("auto")
-        if "eval_batch" in self.config:
-            eval_batch = int(self.config["eval_batch"])
-        else:
-            eval_batch = self.DEFAULT_EVAL_BATCH if (defaulted or getattr(self.model, "container", "ac") != "ac") else 1
-        if defaulted or "eval_batch" not in self.config:
-            self.logger.info('eval_model: container "%s", eval_batch %d (defaults of the MI355X path: rANS streams per image by its size, batched and pipelined; '
-                             '"container": "ac" + "eval_batch": 1 in the config give the reference-format one-image loop)',
-                             getattr(self.model, "container", "?"), eval_batch)
-        if eval_batch > 1:
-            return self.eval_model_batched(eval_batch)
+        defaulted = getattr(self.model, "container_defaulted", False) and "container" not in self.config and hasattr(self.model, "set_container")
+        prev = self.model.container if defaulted else None
+        if defaulted:
+            self.model.set_container("auto")          # for this run only: compress() on the model keeps returning the reference format unless the config says otherwise
+        try:
+            if "eval_batch" in self.config:
+                eval_batch = int(self.config["eval_batch"])
+            else:
+                eval_batch = self.DEFAULT_EVAL_BATCH if getattr(self.model, "container", "ac") != "ac" else 1
+            if defaulted or "eval_batch" not in self.config:
+                self.logger.info('eval_model: container "%s", eval_batch %d (defaults of the MI355X path: rANS streams per image, their number from the image itself, '
+                                 'batched and pipelined; "container": "ac" + "eval_batch": 1 in the config give the reference-format one-image loop)',
+                                 getattr(self.model, "container", "?"), eval_batch)
+            if eval_batch > 1:
+                return self.eval_model_batched(eval_batch)
+            return self._eval_model_one_by_one()
+        finally:
+            if defaulted:
+                self.model.set_container(prev)
+
+    @torch.no_grad()
+    def _eval_model_one_by_one(self):
+        """The reference's loop as it is (llicti_agent.py:122-164): one image per compress() / decompres() call."""
         self.model.eval()
         self.results, self._records = [], []
         keep = bool(self.config["keep_streams"]) if "keep_streams" in self.config else False

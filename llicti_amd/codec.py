@@ -503,6 +503,18 @@ class HipCodec:
         n = B * 3 * H * W * 4
         return self._ws[o32.value:o32.value + n].view(torch.float32).view(B, 3, H, W).clone()
 
+    def last_params_v(self, Hs, Ws, mode, image):
+        """float32 [64, h*w] CNN outputs of level 0, band x10 -- the LAST band-CNN launch -- of image `image` of the last encode_v() / decode_v() on
+        images of these sizes in `mode` (one, or one per image), copied out of the workspace (llicti_workspace_params_v); params60() of its [1, 64, h, w]
+        view gives the reference's 60 channels."""
+        Hs, Ws = np.ascontiguousarray(Hs, dtype=np.int32), np.ascontiguousarray(Ws, dtype=np.int32)
+        one, per = self._modes_arg(mode, len(Hs))
+        modes = np.full(len(Hs), one, dtype=np.int32) if per is None else per
+        off, npos = C.c_size_t(), C.c_long()
+        _lib.check(self.L.llicti_workspace_params_v(self.ctx, len(Hs), _ptr(Hs), _ptr(Ws), _ptr(modes), int(image), C.byref(off), C.byref(npos)))
+        n = 64 * npos.value * 4
+        return self._ws[off.value:off.value + n].view(torch.float32).view(64, npos.value).clone()
+
     def counter(self, name):
         """llicti_get_counter: "device_syncs", "device_allocs", "plan_builds", "plan_hits", "block_waits", "plans_cached", "blocks_pooled"."""
         v = C.c_long()

@@ -102,8 +102,14 @@ __global__ __launch_bounds__(64 * kTabWaves) void cdf_table_kernel(const int16_t
     const long img = (long)b * 3 * s.plane;
     const int mi = min(lane, 4);                         // lanes 0..4 prepare one mixture component each
 
-    // rows [n0, n0 + cnt) of every image -> tables[b][cap_rows][row_stride] (row n at index n - n0)
-    for (int n = n0 + wave0; n < min(nc, n0 + cnt); n += nwaves) {
+    // rows [n0, n0 + cnt) of every image -> tables[b][cap_rows][row_stride] (row n at index n - n0).  A wavefront takes kTabRun CONSECUTIVE rows at a
+    // time: with the channel-planar params a row's 15 - 25 parameters are single floats of as many planes, and eight consecutive rows share each of
+    // their 32-byte sectors -- dealt out one row per wavefront (round 5) the eight rows went to eight workgroups on eight XCDs, whose L2s each fetched
+    // the sector from HBM: FETCH_SIZE 3 - 12x the 60 - 100 bytes a row needs (profiles/r6/pmc_table_kernel_summary.csv).
+    constexpr int kTabRun = 8;
+    const int n_end = min(nc, n0 + cnt);
+    for (int nb = n0 + kTabRun * wave0; nb < n_end; nb += kTabRun * nwaves)
+    for (int n = nb; n < min(nb + kTabRun, n_end); ++n) {
         const int i = n / s.wc, j = n - i * s.wc;
         const ParRow par = par_row(params, b, (long)s.h * s.w, (long)i * s.w + j);
         const long off = img + ((long)(2 * i + s.oi) << s.lvl) * s.W + ((long)(2 * j + s.oj) << s.lvl);

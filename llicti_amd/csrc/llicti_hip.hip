@@ -738,6 +738,22 @@ static int resolve_modes(const char *who, const int *modes, int n_modes, int B, 
     return 0;
 }
 
+extern "C" int llicti_workspace_params_v(llicti_ctx *c, int B, const int *Hs, const int *Ws, const int *modes, int image, size_t *off_params, long *npos)
+{
+    if (!c || !off_params || !npos || !modes) return fail(LLICTI_EINVAL, "workspace_params_v: null argument");
+    if (check_dims_v(B, Hs, Ws)) return LLICTI_EINVAL;
+    if (image < 0 || image >= B) return fail(LLICTI_EINVAL, "workspace_params_v: image %d of %d", image, B);
+    int ME = 0;
+    std::vector<int> Ms;
+    if (int rc = resolve_modes("workspace_params_v", modes, B, B, &ME, Ms)) return rc;
+    Plan p;
+    build_plan(p, B, Hs, Ws, nullptr, ME, c->n_cu, c->cnn_tile_rows, c->force_ragged != 0, Ms.empty() ? nullptr : Ms.data());
+    const Geom &g = p.geo[(size_t)0 * B + image];            // level 0: the last level both passes launch
+    *off_params = p.off_params + (size_t)g.par_off * sizeof(float);
+    *npos = (long)g.h * g.w;
+    return LLICTI_OK;
+}
+
 static int encode_batch(llicti_ctx *c, const uint8_t *d_rgb, const size_t *rgb_off, int B, const int *Hs, const int *Ws, const int *modes, int n_modes,
                         void *d_workspace, size_t workspace_bytes, uint8_t *d_out, size_t out_stride, int32_t *d_seg_len, void *stream)
 {

@@ -70,19 +70,81 @@ def device_identity(torch_device):
         return -1
 
 
+def _parse_cpulist(text):
+    """"0-15,128-143" -> [0, ..., 15, 128, ..., 143] (the kernel's cpulist format)."""
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.extend(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def numa_of_pci(identity, sysfs_root="/sys"):
+    """(NUMA node, its CPUs) of the PCI device `identity` (device_identity(): domain << 16 | bus << 8 | device), read from sysfs:
+    <root>/bus/pci/devices/DDDD:BB:DD.0/numa_node and <root>/devices/system/node/node<N>/cpulist.  (None, []) where the platform does not say
+    (a single-node host reports -1; containers may hide sysfs)."""
+    import os
+    if identity is None or int(identity) < 0:
+        return None, []
+    ident = int(identity)
+    name = "%04x:%02x:%02x.0" % (ident >> 16, (ident >> 8) & 0xFF, ident & 0xFF)
+    try:
+        with open(os.path.join(sysfs_root, "bus", "pci", "devices", name, "numa_node")) as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return None, []
+        with open(os.path.join(sysfs_root, "devices", "system", "node", f"node{node}", "cpulist")) as f:
+            return node, _parse_cpulist(f.read())
+    except (OSError, ValueError):
+        return None, []
+
+
+def bind_to_gpu_numa(torch_device=None, identity=None, sysfs_root="/sys", setaffinity=None):
+    """One process per GPU on an 8-GPU node: run this rank's host threads on the CPUs of the NUMA node its GPU hangs off, BEFORE the pinned staging
+    buffers are allocated -- pinned pages are placed by first touch, so they then lie on the GPU's own node and the uint8 RGB / container copies of
+    the PCIe-inclusive and agent paths do not cross the socket interconnect (MI355X nodes: two sockets, four GPUs each).  Returns
+    {"numa_node", "cpus_bound", "cpus"}; leaves the affinity alone (cpus_bound 0) where sysfs does not say or the node's CPUs are not in the
+    process's allowed set.  `identity` / `sysfs_root` / `setaffinity` are for tests."""
+    import os
+    ident = device_identity(torch_device) if identity is None else identity
+    node, cpus = numa_of_pci(ident, sysfs_root)
+    out = {"numa_node": node, "cpus_bound": 0, "cpus": None}
+    if node is None or not cpus:
+        return out
+    try:
+        allowed = set(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return out
+    mine = sorted(set(cpus) & allowed)
+    if not mine:
+        return out
+    try:
+        (setaffinity or os.sched_setaffinity)(0, mine)
+    except OSError:
+        return out
+    out.update({"cpus_bound": len(mine), "cpus": "%d-%d" % (mine[0], mine[-1]) if mine == list(range(mine[0], mine[-1] + 1)) else ",".join(map(str, mine[:8])) + ("..." if len(mine) > 8 else "")})
+    return out
+
+
 def distinct_devices(identities):
     """Number of distinct physical devices among the ranks' identities (unknown identities, -1, count as distinct)."""
     known = [int(i) for i in identities if int(i) >= 0]
     return len(set(known)) + sum(1 for i in identities if int(i) < 0)
 
 
-def per_rank_report(elapsed_s, pcie_elapsed_s, pixels_per_step, steps, identities, devices):
-    """[{rank, device, mpix_s, pcie_inclusive_mpix_s}] and the straggler ratio (slowest / fastest rank's time of the timed steps)."""
+def per_rank_report(elapsed_s, pcie_elapsed_s, pixels_per_step, steps, identities, devices, numa=None):
+    """[{rank, device, mpix_s, pcie_inclusive_mpix_s, numa_node, cpus_bound}] and the straggler ratio (slowest / fastest rank's time of the timed
+    steps).  numa: per rank (node or -1, CPUs the rank bound itself to) from bind_to_gpu_numa()."""
     rows = []
     for r, (t, tp) in enumerate(zip(elapsed_s, pcie_elapsed_s)):
         rows.append({"rank": r, "device": int(devices[r]), "pci": (None if identities[r] < 0 else "%04x:%02x:%02x" % (int(identities[r]) >> 16, (int(identities[r]) >> 8) & 0xFF, int(identities[r]) & 0xFF)),
                      "mpix_s": round(pixels_per_step * steps / t / 1e6, 3) if t > 0 else None,
                      "pcie_inclusive_mpix_s": round(pixels_per_step / tp / 1e6, 3) if tp > 0 else None})
+        if numa is not None:
+            rows[-1]["numa_node"] = (None if int(numa[r][0]) < 0 else int(numa[r][0]))
+            rows[-1]["cpus_bound"] = int(numa[r][1])
     ts = [t for t in elapsed_s if t > 0]
     return rows, (round(max(ts) / min(ts), 4) if ts else None)
 

@@ -8,7 +8,7 @@ import collections, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, torch
-from llicti_amd.codec import HipCodec, MODE_AC, MODE_RANS, container_to_bytestream_list
+from llicti_amd.codec import HipCodec, MODE_AC, MODE_RANS, MODE_RANS_AUTO, container_to_bytestream_list
 from llicti_amd.weights import pack_state_dict
 from oracle import oracle as orc
 from helpers import make_image
@@ -52,8 +52,8 @@ for case in range(N):
         else:
             imgs.append(np.random.default_rng(seed).choice(np.array([0, 255], np.uint8), size=(3, H, W)))
     H, W = sizes[0]
-    M = int(rng.choice([0, 1, 2, 3, 4, 8, 10, 11, 16, 32, 64, 128, -1, -5, -10, -14, -1001, -1003, -1009, -1014, -1032, -1064]))     # negative: |M| wide streams, |M| - 1000 xwide streams
-    if XWIDE_ONLY or big: M = int(rng.choice([-1001, -1002, -1003, -1005, -1009, -1010, -1014, -1032, -1064] if not big else [-1001, -1002, -1003]))
+    M = int(rng.choice([0, 1, 2, 3, 4, 8, 10, 11, 16, 32, 64, 128, -1, -5, -10, -14, -1001, -1003, -1009, -1015, -1021, -1032, -1064, -1128]))     # negative: |M| wide streams, |M| - 1000 xwide streams
+    if XWIDE_ONLY or big: M = int(rng.choice([-1001, -1002, -1003, -1005, -1009, -1010, -1014, -1016, -1020, -1021, -1027, -1032, -1064, -1128] if not big else [-1001, -1002, -1003]))
     wide = 0 if M >= 0 else (2 if M <= -1000 else 1)
     M = abs(M) % 1000
     mode = MODE_AC if M == 0 else MODE_RANS(M, wide)
@@ -68,14 +68,22 @@ for case in range(N):
     Hs, Ws = [h for h, _ in sizes], [w for _, w in sizes]
     Mb = [M] * B                                    # streams of image b (round 5: a count per image in one call, llicti_encode_images_vm)
     if M != 0 and B > 1 and rng.integers(0, 2) == 0:
-        pool = [1, 2, 3, 4, 8, 10, 11, 16, 32] if wide == 0 else [1, 2, 3, 5, 9, 10, 14]
+        pool = [1, 2, 3, 4, 8, 10, 11, 16, 32] if wide == 0 else [1, 2, 3, 5, 9, 10, 14] if wide == 1 else [1, 2, 3, 5, 9, 10, 14, 16, 20, 21, 32]
         Mb = [M] + [int(rng.choice(pool)) for _ in range(B - 1)]
-    modes = [MODE_RANS(m, wide) for m in Mb] if M != 0 else mode
-    per_image = M != 0 and len(set(Mb)) > 1
+    # round 6: the xwide "auto" ENCODER mode now and then -- the encoder picks each image's count on the device from what its last stage costs; the
+    # decoder takes the count from the container's header; the oracle applies the same rule (orc_auto_streams)
+    auto = wide == 2 and all(m <= 32 for m in Mb) and rng.integers(0, 3) == 0
+    modes = [(MODE_RANS_AUTO(m) if auto else MODE_RANS(m, wide)) for m in Mb] if M != 0 else mode
+    if auto:
+        mode = modes[0]
+        tag += " auto"
+    per_image = M != 0 and (len(set(Mb)) > 1 or (auto and B > 1))
     if ragged or per_image or (M != 0 and rng.integers(0, 4) == 0):          # (equal sizes through the _v entry now and then)
         flat = torch.from_numpy(np.concatenate([a.reshape(-1) for a in imgs])).cuda()
         cont, seg = codec.encode_v(flat, Hs, Ws, modes)
         codec.check()
+        if auto:
+            modes = codec.container_modes(cont)    # what the encoder picked, from the headers
         codec.poison_workspace()                   # the decode must not find the encoder's planes in the workspace
         rec = codec.decode_v(cont, seg, Hs, Ws, modes)
         codec.check()
@@ -84,6 +92,9 @@ for case in range(N):
         x = torch.from_numpy(np.stack(imgs)).cuda()
         cont, seg = codec.encode(x, mode=mode)
         codec.check()
+        if auto:                                   # (B == 1 here: one mode per call)
+            mode = codec.container_modes(cont)[0]
+            modes = [mode]
         codec.workspace(B, H, W, mode)
         codec.poison_workspace()
         rec = codec.decode(cont, seg, H, W, mode=mode)
@@ -91,7 +102,7 @@ for case in range(N):
         assert torch.equal(rec, x), "ROUND TRIP " + tag
     ch, sh = cont.cpu().numpy(), seg.cpu().numpy()
     for b in range(B):
-        ref = orc.encode_image(imgs[b], W_o) if M == 0 else orc.encode_image_rans(imgs[b], W_o, Mb[b], wide)
+        ref = orc.encode_image(imgs[b], W_o) if M == 0 else orc.encode_image_rans(imgs[b], W_o, Mb[b], wide, auto=auto)
         assert container_to_bytestream_list(ch[b], sh[b]) == ref, "BYTES " + tag + f" image {b}"
     if M != 0 and (CORRUPT_ALL or rng.integers(0, 3) == 0):
         # round 5, corrupted containers: bytes of ONE image's streams flipped -> the HIP decoder and the oracle agree on whether the image is malformed

@@ -51,7 +51,16 @@ class Recorder:
         self.pairs.append(pair)
 
 
+IMAGES = (("noise0_rand1337", "noise", 0, "rand1337", 512, 768), ("smooth11_trainedlike", "smooth", 11, "trainedlike", 512, 768))
+# Round 6: an ODD shape of the reference's eval set -- 577x768: every level's height is odd (577, 289, 145, 73, 37), so lazyDWT pads the
+# bottom row at every level (LLICTI_nets.py:226-240), bands x11 / x10 code one row less than the band grid (:396-397) and the decoder re-pads
+# (:511-530).  Its samples go to their own file (fullsize_samples_ragged.npz; `python make_fixture_fullsize_samples.py ragged`): positions on the FULL
+# band grid -- the padded last row among them -- with the parameters everywhere and symbols / table entries where the position is coded.
+IMAGES_RAGGED = (("smooth13_trainedlike_577x768", "smooth", 13, "trainedlike", 577, 768),)
+
+
 def main():
+    ragged = len(sys.argv) > 1 and sys.argv[1] == "ragged"
     rec = Recorder()
     mf._install_standins(rec)
     sys.path.insert(0, mf.REF)
@@ -69,12 +78,11 @@ def main():
     ref_nets.LLICTIEntropyModel4.get_params = get_params_rec
     out = {}
     meta = {}
-    for name, kind, seed, wname in (("noise0_rand1337", "noise", 0, "rand1337"), ("smooth11_trainedlike", "smooth", 11, "trainedlike")):
+    for name, kind, seed, wname, H, W in (IMAGES_RAGGED if ragged else IMAGES):
         torch.manual_seed(1337)
         model = ref_nets.LLICTI(cfg).eval()
         if wname == "trainedlike":
             mf.trained_like_(model)
-        H, W = 512, 768
         rgb = mf.make_image(kind, H, W, seed)
         x = torch.from_numpy(rgb.astype(np.float32) / np.float32(255.0)).unsqueeze(0)
         rec.pairs.clear()
@@ -96,24 +104,33 @@ def main():
                     cdf, sym = rec.pairs[(4 - lvl) * 9 + band * 3 + clr]
                     cdf = cdf[0, 0].view(np.uint16)              # [h', w', Lp]
                     sym = sym[0, 0]
-                    assert cdf.shape[:2] == (h, w), (cdf.shape, h, w)      # 768x512: no odd edge, the coded crop is the band grid
+                    hc, wc = cdf.shape[:2]
+                    if not ragged:
+                        assert (hc, wc) == (h, w), (cdf.shape, h, w)      # 768x512: no odd edge, the coded crop is the band grid
+                    assert hc in (h, h - 1) and wc in (w, w - 1)
                     Lp = cdf.shape[2]
                     idx = np.zeros((len(pos), N_ENT), dtype=np.int16)
                     val = np.zeros((len(pos), N_ENT), dtype=np.uint16)
+                    inside = (pos[:, 0] < hc) & (pos[:, 1] < wc)           # (an odd edge: the band grid's last row / column is not coded in bands x11 / x10, x11 / x01)
+                    symv = np.full(len(pos), -1, dtype=np.int16)
                     for k, (i, j) in enumerate(pos):
+                        if not inside[k]:
+                            continue
+                        symv[k] = sym[i, j]
                         s = int(sym[i, j])
                         want = [s, min(s + 1, Lp - 1), max(s - 1, 0), 0, 1, Lp - 2, Lp - 1]
                         want += [int(v) for v in np.linspace(2, Lp - 3, N_ENT - len(want))]
                         idx[k] = want[:N_ENT]
                         val[k] = cdf[i, j, idx[k]]
-                    out[f"{tag}_c{clr}_sym"] = sym[pos[:, 0], pos[:, 1]].astype(np.int16)
+                    out[f"{tag}_c{clr}_sym"] = symv                        # (-1: the position is not coded)
+                    meta[f"{tag}_c{clr}_crop"] = [int(hc), int(wc)]
                     out[f"{tag}_c{clr}_idx"] = idx
                     out[f"{tag}_c{clr}_val"] = val
                     meta[f"{tag}_c{clr}_Lp"] = int(Lp)
         meta[name] = {"kind": kind, "seed": seed, "weights": wname, "H": H, "W": W}
         print(name, "done")
     out["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
-    dst = os.path.join(HERE, "fullsize_samples.npz")
+    dst = os.path.join(HERE, "fullsize_samples_ragged.npz" if ragged else "fullsize_samples.npz")
     np.savez_compressed(dst, **out)
     print(dst, os.path.getsize(dst))
 

@@ -133,6 +133,9 @@ def test_bench_eight_rank_dry_run_configs4():
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
     assert out["n_gpus"] == 8 and out["ranks_seen"] == 8 and out["batch_per_gpu"] == 32 and out["container"] == "xauto15"
     assert "configs[4]" in out["config"]["workload"]
+    # the like-for-like efficiency (against rank 0's solo run of the SAME per-GPU batch and container) and the ranks' NUMA placement are in the line
+    assert out["n1_companion"]["batch"] == 32 and abs(out["efficiency_like_for_like"] - out["pixels"] / out["elapsed_max_s"] / 1e6 / (8 * out["n1_companion"]["value"])) < 1e-3
+    assert [r["numa_node"] for r in out["per_rank"]] == [0, 0, 0, 0, 1, 1, 1, 1] and all(r["cpus_bound"] == 16 for r in out["per_rank"])
     assert out["pixels"] == 256 * 512 * 768 and out["elapsed_max_s"] == 8.0 and out["bytes"] == 1000.0 * 36
     assert [r["rank"] for r in out["per_rank"]] == list(range(8)) and out["distinct_devices"] == 8
     # rank r reported (1 + r) s for one step of 32 images: its own rate, and slowest / fastest = 8
@@ -253,3 +256,33 @@ def test_agent_two_ranks_equal_one_rank():
     assert "bpsp=" not in log_r1 and "Rate Loss|" not in log_r1
     assert [int(v) for v in allr[:, 0]] == list(range(7))
     assert np.allclose(allr[:, 3], [r["bpsp"] for r in res1])
+
+
+def test_numa_binding_from_pci_locality(tmp_path):
+    """One process per GPU: a rank binds its host threads to the CPUs of the NUMA node its GPU hangs off before it allocates pinned staging
+    buffers (llicti_amd.shard.bind_to_gpu_numa; bench.py at N > 1 and LLICTIAgent under the launcher).  Against a made-up sysfs tree: the PCI
+    identity finds the node, the node its cpulist, the affinity is the intersection with what the process may use -- and nothing is touched
+    where sysfs does not say."""
+    from llicti_amd import shard
+    ident = (0 << 16) | (0x43 << 8) | 0x00
+    dev = tmp_path / "bus" / "pci" / "devices" / "0000:43:00.0"
+    dev.mkdir(parents=True)
+    (dev / "numa_node").write_text("1\n")
+    node = tmp_path / "devices" / "system" / "node" / "node1"
+    node.mkdir(parents=True)
+    allowed = sorted(os.sched_getaffinity(0))
+    lo, hi = allowed[0], allowed[min(len(allowed) - 1, 3)]
+    (node / "cpulist").write_text(f"{lo}-{hi},4000-4003\n")
+    assert shard._parse_cpulist("0-3,8,10-11") == [0, 1, 2, 3, 8, 10, 11]
+    assert shard.numa_of_pci(ident, str(tmp_path)) == (1, list(range(lo, hi + 1)) + [4000, 4001, 4002, 4003])
+    calls = []
+    out = shard.bind_to_gpu_numa(identity=ident, sysfs_root=str(tmp_path), setaffinity=lambda pid, cpus: calls.append((pid, list(cpus))))
+    want = [c for c in range(lo, hi + 1) if c in allowed]
+    assert calls == [(0, want)] and out["numa_node"] == 1 and out["cpus_bound"] == len(want)
+    # no sysfs entry, an unknown identity, a single-node host (-1): the affinity is left alone
+    for ident2, root in ((ident + 1, str(tmp_path)), (-1, str(tmp_path)), (ident, str(tmp_path / "nowhere"))):
+        calls.clear()
+        o = shard.bind_to_gpu_numa(identity=ident2, sysfs_root=root, setaffinity=lambda pid, cpus: calls.append(1))
+        assert o["numa_node"] is None and o["cpus_bound"] == 0 and not calls
+    (dev / "numa_node").write_text("-1\n")
+    assert shard.bind_to_gpu_numa(identity=ident, sysfs_root=str(tmp_path), setaffinity=lambda pid, cpus: calls.append(1))["cpus_bound"] == 0 and not calls

@@ -573,6 +573,81 @@ def _fullsize_samples():
 _ALL_LB = tuple((l, b) for l in (1, 0) for b in range(3))
 
 
+def _ragged_samples():
+    import json
+    import os
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "fullsize_samples_ragged.npz"))
+    return z, json.loads(bytes(z["meta_json"]).decode())
+
+
+def check_samples_against(z, meta, name, levels, planes, mm, params_of, row_of, ent_tol=1):
+    """Shared by the CPU (oracle) and GPU (HIP kernels) tests of the full-size reference samples: parameters within 1e-5, symbols exact, table entries
+    within ent_tol counts -- at the positions of the band grid the fixture holds; a position outside the band's coded crop (odd edge: sym = -1) has
+    parameters only.  params_of(lvl, band) -> [h, w, 60]; row_of(lvl, band, clr, i, j) -> the uint16 table row of a CODED position."""
+    for lvl, band in levels:
+        tag = f"{name}_l{lvl}_b{band}"
+        pos = z[tag + "_pos"].astype(np.int64)
+        params = params_of(lvl, band)
+        got = params[pos[:, 0], pos[:, 1]]
+        assert np.abs(got - z[tag + "_params"]).max() < 1e-5, (tag, np.abs(got - z[tag + "_params"]).max())
+        oi, oj = [(1, 1), (0, 1), (1, 0)][band]
+        for clr in range(3):
+            minv = -127 if clr == 0 else int(mm[clr])
+            shift = 127 if clr == 0 else -minv
+            syms = z[f"{tag}_c{clr}_sym"].astype(np.int64)
+            n_out = 0
+            for k, (i, j) in enumerate(pos):
+                if syms[k] < 0:
+                    n_out += 1
+                    continue
+                R, Cc = (2 * i + oi) << lvl, (2 * j + oj) << lvl
+                assert int(planes[clr, R, Cc]) + shift == int(syms[k])
+                row = row_of(lvl, band, clr, int(i), int(j))
+                Lp = meta[f"{tag}_c{clr}_Lp"]
+                idx = z[f"{tag}_c{clr}_idx"][k].astype(np.int64)
+                keep = idx < Lp - 1
+                d = np.abs(np.asarray(row, dtype=np.int64)[idx[keep]] - z[f"{tag}_c{clr}_val"][k][keep].astype(np.int64))
+                assert d.max() <= ent_tol, (tag, clr, k, d.max())
+            crop = meta.get(f"{tag}_c{clr}_crop")
+            if crop is not None:
+                assert n_out == int(np.sum((pos[:, 0] >= crop[0]) | (pos[:, 1] >= crop[1])))
+
+
+def test_full_size_ragged_samples_vs_reference(oracle_weights):
+    """the reference's own numbers on a full-size ODD shape of its eval set -- 577x768: lazyDWT pads the bottom row at every level
+    (LLICTI_nets.py:226-240), bands x11 / x10 code one row less than the band grid (:396-397) -- at ~160 positions per (level <= 1, band), the padded
+    last row and the image's corners among them (tests/golden/fullsize_samples_ragged.npz, from the reference-owned code by
+    make_fixture_fullsize_samples.py ragged): the oracle's parameters within 1e-5, table entries within +-1, symbols exact.  (-m gpu holds the HIP
+    kernels' mixed-size form to the same samples: test_hip_parity.py::test_full_size_ragged_vs_reference.)"""
+    from helpers import make_image
+    z, meta = _ragged_samples()
+    name = "smooth13_trainedlike_577x768"
+    m = meta[name]
+    assert (m["H"], m["W"]) == (577, 768)
+    W = oracle_weights(m["weights"])
+    rgb = make_image(m["kind"], m["H"], m["W"], m["seed"])
+    planes, mm = orc.lift(rgb)
+    cache = {}
+
+    def params_of(lvl, band):
+        if (lvl, band) not in cache:
+            cache[(lvl, band)] = orc.band_params(planes, lvl, band, W)
+        return cache[(lvl, band)]
+
+    def row_of(lvl, band, clr, i, j):
+        oi, oj = [(1, 1), (0, 1), (1, 0)][band]
+        R, Cc = (2 * i + oi) << lvl, (2 * j + oj) << lvl
+        minv = -127 if clr == 0 else int(mm[clr])
+        maxv = 128 if clr == 0 else int(mm[3 + clr])
+        return orc.cdf_row(params_of(lvl, band)[i, j], clr, np.float32(planes[0, R, Cc]) / np.float32(255), np.float32(planes[1, R, Cc]) / np.float32(255), minv, maxv)
+    for lvl, band in _ALL_LB:                                    # odd heights: bands x11 (0) and x10 (2) do not code the band grid's last row
+        crop = meta[f"{name}_l{lvl}_b{band}_c0_crop"]
+        h = params_of(lvl, band).shape[0]
+        assert crop[0] == (h - 1 if band in (0, 2) else h), (lvl, band, crop, h)
+    check_samples_against(z, meta, name, _ALL_LB, planes, mm, params_of, row_of, ent_tol=1)
+
+
 @pytest.mark.parametrize("name,levels", [("smooth11_trainedlike", _ALL_LB), ("noise0_rand1337", _ALL_LB)])
 def test_full_size_samples_vs_reference(name, levels, oracle_weights):
     """the reference's own get_params outputs and int16 table entries at ~160 positions per (level, band) of FULL-SIZE 768x512
