@@ -183,7 +183,8 @@ int llicti_ac_decode_u16cdf(llicti_ctx *ctx, const uint16_t *d_cdf, int Lp, int 
 #define LLICTI_MODE_RANS_X_AUTO(M) (0x10500 | (M))  /* ENCODE ONLY.  xwide v4 streams whose count the ENCODER picks per image, on the device, from the image itself: M (1 .. 32) is the
                                                   count the image's size gives (llicti_amd.codec.image_streams); an image whose last stage's symbols are expensive (sum of
                                                   16 - floor(log2 freq) >= 11 per symbol: an xwide stream costs ~2.5 bytes there) gets M + ceil(M / 3) streams (at most 32), one
-                                                  whose last stage cannot fill M payloads of 7,936 bits gets ceil(M / 2), every other M.  A pure function of the image: its
+                                                  whose symbols are cheap (< 4: ~5 bytes per stream, long serial tails) ceil(2 M / 3), one whose last stage cannot fill the
+                                                  payloads of 7,936 bits ceil(M / 2), every other M.  A pure function of the image: its
                                                   container does not depend on the batch, the device or anything coded before.  The container is an ordinary
                                                   LLICTI_MODE_RANS_X(count) container -- its header says which (llicti_header_mode) -- and is decoded as such. */
 

@@ -114,8 +114,9 @@ def _mode_auto(mode: int) -> bool:
 
 
 def auto_counts(M):
-    """The stream counts an "auto" encode of size-rule count M may pick: (cheap, default, expensive) = (ceil(M / 2), M, min(32, M + ceil(M / 3)))."""
-    return (M + 1) // 2, M, min(32, M + (M + 2) // 3)
+    """The stream counts an "auto" encode of size-rule count M may pick (llicti_amd/csrc/host_types.hpp: rans_auto_pick): (a last stage that cannot
+    fill the payloads, cheap symbols, default, expensive symbols) = (ceil(M / 2), ceil(2 M / 3), M, min(32, M + ceil(M / 3)))."""
+    return (M + 1) // 2, (2 * M + 2) // 3, M, min(32, M + (M + 2) // 3)
 
 
 def _mode_wide(mode: int) -> int:

@@ -5,9 +5,10 @@
 // ------------------------------------------------------------------------------------------------ container kernels
 // encode: header segments straight into the container; seg_len[b][0..3]
 __global__ void header_write_kernel(const uint8_t *__restrict__ rgb, const int32_t *__restrict__ minmax, const ImgGeo *__restrict__ iv,
-                                    uint8_t *__restrict__ out, long out_stride, int32_t *__restrict__ seg_len)
+                                    uint8_t *__restrict__ out, long out_stride, int32_t *__restrict__ seg_len, unsigned long long *__restrict__ ssum)
 {
     const int b = blockIdx.x;
+    if (ssum && threadIdx.x == 0) ssum[b] = 0ull;       // "auto" encodes: the image's last-stage cost is summed into it later in the call (choose_streams_kernel)
     uint8_t *o = out + (long)b * out_stride;
     const ImgGeo ig = iv[b];
     const int byte0 = ig.byte0;

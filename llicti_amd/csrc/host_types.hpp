@@ -214,20 +214,25 @@ LLICTI_HD int rans_stream_count(int nc, int m, int M, int L)
 LLICTI_HD int rans_group(int M) { return M > 32 ? M / 32 : 1; }
 
 // "auto" xwide encodes: the stream count of an image is chosen by the ENCODER, per image, from the image itself -- its size (Mlo, the caller's
-// rule: llicti_amd.codec.image_streams) and what the symbols of its LAST stage cost, S = sum over its n symbols of (16 - floor(log2 freq)):
+// rule: llicti_amd.codec.image_streams, sized for natural-like content at ~4.7 bytes per stream) and what the symbols of its LAST stage cost,
+// S = sum over its n symbols of (16 - floor(log2 freq)) (an integer; it overstates the ideal bits by about half a bit per symbol):
 //   expensive symbols (S >= 11 n: uniform noise under the sigma-floor weights, ~12 bits each): an xwide v4 stream costs ~2.5 bytes there (two
-//     seeded tail chains carry six raw symbols), so a third more streams fit the same byte budget: rans_auto_hi(Mlo) -- where the last stage can fill that many payloads;
-//   a last stage too cheap to fill Mlo payloads of 7,936 bits with a tenth to spare (2 S - n < 2 * 8,704 Mlo; S overstates the ideal bits by
-//     about half a bit per symbol): half the streams, rans_auto_min(Mlo) -- every unfilled payload bit is a wasted bit;
-//   otherwise Mlo.
+//     seeded tail chains carry six raw symbols), so a third more streams fit the same byte budget: rans_auto_hi(Mlo);
+//   cheap symbols (S < 4 n: the class of the reference's trained model on natural images, 1.7 bits each): a stream costs ~5.1 bytes and its
+//     serial tail is ~5,000 symbols long: two thirds of the streams, rans_auto_cheap(Mlo);
+//   and whatever the class, a count whose payloads of 7,936 bits the last stage cannot fill with a tenth to spare (2 S - n < 2 * 8,704 M)
+//     falls to half the size rule's, rans_auto_min(Mlo) -- every unfilled payload bit is a wasted bit.
 // A pure function of the image: the same image gets the same container whatever it is coded with, next to or after (oracle: orc_auto_streams).
 LLICTI_HD int rans_auto_hi(int Mlo) { const int h = Mlo + (Mlo + 2) / 3; return h > 32 ? 32 : h; }
+LLICTI_HD int rans_auto_cheap(int Mlo) { return (2 * Mlo + 2) / 3; }
 LLICTI_HD int rans_auto_min(int Mlo) { return (Mlo + 1) / 2; }
 LLICTI_HD int rans_auto_pick(int Mlo, long long S, long long n)
 {
     if (n <= 0) return Mlo;
-    if (S >= 11 * n && 2 * S - n >= 2LL * 8704 * rans_auto_hi(Mlo)) return rans_auto_hi(Mlo);      // (... and enough of them to fill that many payloads)
-    if (2 * S - n < 2LL * 8704 * Mlo) return rans_auto_min(Mlo);
-    return Mlo;
+    int M = Mlo;
+    if (S >= 11 * n) M = rans_auto_hi(Mlo);
+    else if (S < 4 * n) M = rans_auto_cheap(Mlo);
+    if (2 * S - n < 2LL * 8704 * M) M = (M > Mlo && 2 * S - n >= 2LL * 8704 * Mlo) ? Mlo : rans_auto_min(Mlo);
+    return M;
 }
 

@@ -796,7 +796,7 @@ static int encode_batch(llicti_ctx *c, const uint8_t *d_rgb, const size_t *rgb_o
         ProfSpan span(c, PROF_MISC, s);
         // (the lift is the call's first kernel and sets no status: it clears the call's status words on the way)
         if (int rc = launch_lift(d_rgb, B, p.max_plane, p.vec_ok, planes, fplanes, mm, (int32_t *)(ws + p.off_lift_part), s, status, kStatusHead + B, d_img)) return rc;
-        header_write_kernel<<<B, 256, 0, s>>>(d_rgb, mm, d_img, d_out, (long)out_stride, d_seg_len);
+        header_write_kernel<<<B, 256, 0, s>>>(d_rgb, mm, d_img, d_out, (long)out_stride, d_seg_len, autoM ? (unsigned long long *)(ws + p.off_rpos) : nullptr);
     }
     // The encoder has no dependency between stages: every (level, band) reads only original pixels.  With llicti_set_tuning("enc_side_levels", 1)
     // levels 4..1 (twelve CNN + twelve pairs launches, a quarter of the work) run on a side stream next to level 0's, with their own
@@ -859,12 +859,12 @@ static int encode_batch(llicti_ctx *c, const uint8_t *d_rgb, const size_t *rgb_o
         const int NS = p.nstreams;                                   // the streams of all images (an image's count is its own: ImgGeo::M)
         // LLICTI_MODE_RANS_X_AUTO: each image's stream count is picked here, on the device, from what its last stage costs (a pure function of
         // the image); the table holds the most it may get, the streams it does not get are empty segments
-        int32_t *mused = autoM ? (int32_t *)(ws + p.off_rpos) : nullptr;      // (the decoder's cursor array: unused by an encode)
-        if (autoM) choose_streams_kernel<<<B, 256, 0, s>>>(pairs, d_desc, B, d_img, mused);
-        if (Q == 4) rans_encode_kernel<4><<<NS, 256, 0, s>>>(pairs, d_desc, B, d_sref, slots, d_rslot_off, p.rslot_cap, rinfo, status, sglv, planes, mm, mused);
-        else if (Q == 2) rans_encode_kernel<2><<<NS, 128, 0, s>>>(pairs, d_desc, B, d_sref, slots, d_rslot_off, p.rslot_cap, rinfo, status, sglv, planes, mm, mused);
-        else rans_encode_kernel<1><<<NS, 64, 0, s>>>(pairs, d_desc, B, d_sref, slots, d_rslot_off, p.rslot_cap, rinfo, status, sglv, planes, mm, mused);
-        rans_pack_kernel<<<NS, 256, 0, s>>>(slots, d_rslot_off, rinfo, d_sref, d_img, d_out, (long)out_stride, d_seg_len, status, mused);
+        unsigned long long *ssum = autoM ? (unsigned long long *)(ws + p.off_rpos) : nullptr;      // (the decoder's cursor array: unused by an encode; B x 8 bytes of its >= B x 128)
+        if (autoM) choose_streams_kernel<<<dim3(kAutoSlices, B), 256, 0, s>>>(pairs, d_desc, B, ssum);
+        if (Q == 4) rans_encode_kernel<4><<<NS, 256, 0, s>>>(pairs, d_desc, B, d_sref, slots, d_rslot_off, p.rslot_cap, rinfo, status, sglv, planes, mm, ssum, d_img);
+        else if (Q == 2) rans_encode_kernel<2><<<NS, 128, 0, s>>>(pairs, d_desc, B, d_sref, slots, d_rslot_off, p.rslot_cap, rinfo, status, sglv, planes, mm, ssum, d_img);
+        else rans_encode_kernel<1><<<NS, 64, 0, s>>>(pairs, d_desc, B, d_sref, slots, d_rslot_off, p.rslot_cap, rinfo, status, sglv, planes, mm, ssum, d_img);
+        rans_pack_kernel<<<NS, 256, 0, s>>>(slots, d_rslot_off, rinfo, d_sref, d_img, d_out, (long)out_stride, d_seg_len, status, ssum, d_desc, B);
     }
     latch_status_kernel<<<1, 64, 0, s>>>(status, c->d_status, nullptr, 0);
     HIPCHK(hipGetLastError());

@@ -916,8 +916,9 @@ static long rans_tail_encode_x(const stage_syms_t *sl, int m, int M, long cnt, i
 }
 
 /* "auto" xwide encodes: the stream count of an image from the image itself -- Mlo, what its size gives, and S = the sum over the n symbols of its
- * LAST stage of (16 - floor(log2 freq)): expensive symbols (S >= 11 n), enough to fill that many payloads -> Mlo + ceil(Mlo / 3) (at most 32); a last stage that cannot fill Mlo
- * payloads of 7,936 bits with a tenth to spare (2 S - n < 2 * 8704 Mlo) -> ceil(Mlo / 2); otherwise Mlo.  (llicti_amd/csrc/host_types.hpp: rans_auto_pick) */
+ * LAST stage of (16 - floor(log2 freq)): expensive symbols (S >= 11 n) -> Mlo + ceil(Mlo / 3) (at most 32); cheap symbols (S < 4 n) -> ceil(2 Mlo / 3);
+ * otherwise Mlo; and a count whose payloads of 7,936 bits the last stage cannot fill with a tenth to spare (2 S - n < 2 * 8704 M) falls to Mlo (from
+ * above) or to ceil(Mlo / 2).  (llicti_amd/csrc/host_types.hpp: rans_auto_pick) */
 int orc_auto_streams(int Mlo, const uint32_t *clow, const uint32_t *chigh, long n)
 {
     long long S = 0;
@@ -928,9 +929,11 @@ int orc_auto_streams(int Mlo, const uint32_t *clow, const uint32_t *chigh, long 
     }
     if (n <= 0) return Mlo;
     const int hi = (Mlo + (Mlo + 2) / 3) > 32 ? 32 : Mlo + (Mlo + 2) / 3;
-    if (S >= 11 * (long long)n && 2 * S - n >= 2LL * 8704 * hi) return hi;
-    if (2 * S - n < 2LL * 8704 * Mlo) return (Mlo + 1) / 2;
-    return Mlo;
+    int M = Mlo;
+    if (S >= 11 * (long long)n) M = hi;                          /* expensive symbols: ~2.5 bytes per stream */
+    else if (S < 4 * (long long)n) M = (2 * Mlo + 2) / 3;        /* cheap symbols: ~5.1 bytes per stream, long serial tails */
+    if (2 * S - n < 2LL * 8704 * M) M = (M > Mlo && 2 * S - n >= 2LL * 8704 * Mlo) ? Mlo : (Mlo + 1) / 2;      /* the last stage must fill the payloads */
+    return M;
 }
 
 long orc_encode_image_rans(const uint8_t *rgb, int H, int W, const orc_weights *wts, int M,

@@ -760,33 +760,32 @@ def test_agent_batched_lossless_check_reports_a_difference(torch_mod, caplog):
 def test_agent_auto_container_is_a_function_of_the_image(torch_mod, caplog):
     """Container "auto" (VERDICT r5 #1 / weak #1): an image's container is a function of THE IMAGE -- its size gives a stream count, the encoder
     adjusts it on the device by what the image's own last stage costs -- not of what was coded before it, next to it, or of eval_batch.  A data
-    set that mixes the three content classes (a source as cheap as the reference's trained model, natural-like images, sigma-floor noise) coded
+    set that mixes three content classes (flat images, whose last stage cannot fill the payloads; natural-like images; uniform noise) coded
     with eval_batch 1, 2, 3, 6 and in reverse order gives every image the same bytes every time, each equal to the oracle's "auto" encode of that
     image alone; the cheap images get fewer streams than the natural-like ones, the noise images more.  A config WITHOUT container / eval_batch
     keys (the reference's own llicti_A.json) runs exactly this path, and says so."""
     import logging
-    from test_oracle_golden import _cheap_case
     from oracle import oracle as orc
     from llicti_amd.agents.llicti_agent import LLICTIAgent
     from llicti_amd.codec import MODE_RANS, auto_counts, image_streams, mode_of_header
     from llicti_amd.config import default_config
-    from llicti_amd.weights import load_reference_state_dict
+    from llicti_amd.weights import load_reference_state_dict, pack_state_dict
     torch = torch_mod
     caplog.set_level(logging.INFO)
-    sd, W_c, img0 = _cheap_case("single")
-    H, W = img0.shape[1:]
-    bl0 = orc.encode_image(make_image("smooth", H, W, 11), W_c)
-    cheap = [img0]
-    rng = np.random.default_rng(6)
-    bl = [list(bl0[0])] + [[rng.integers(0, 256, len(x), dtype=np.uint8).tobytes() for x in row] for row in bl0[1:]]
-    cheap.append(orc.decode_image(bl, W_c))
+    from conftest import load_state_dict
+    sd = load_state_dict("trainedlike")
+    W_c = orc.Weights(pack_state_dict(sd))
+    H, W = 256, 384
+    # three content classes under ONE set of weights: flat images (a last stage that costs next to nothing: it cannot fill the payloads of the size
+    # rule's count), natural-like ones, uniform noise (expensive symbols)
+    cheap = [np.full((3, H, W), 77, np.uint8), np.full((3, H, W), 180, np.uint8)]      # (grey: Co = Cg = 0, where these weights' mixtures sit)
     imgs = [cheap[0], make_image("smooth", H, W, 21), make_image("noise", H, W, 22), cheap[1], make_image("noise", H, W, 23), make_image("smooth", H, W, 24)]
 
     def run(data, **cfg):
         a = LLICTIAgent(default_config(test_data=data, keep_streams=True, **cfg))
         load_reference_state_dict(a.model, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
         res = a.run()
-        assert all(r["max_abs_err"] == 0.0 for r in res)
+        assert all(r["max_abs_err"] < 1e-3 for r in res)            # (0.0 in the batched path; the one-image loop compares float32 uint8 / 255 of host and device)
         return [r["bytestream_list"] for r in res]
     base = run(imgs, container="auto", eval_batch=6)
     for eb in (1, 2, 3):
@@ -797,7 +796,7 @@ def test_agent_auto_container_is_a_function_of_the_image(torch_mod, caplog):
     said = [r.message for r in caplog.records if "eval_model: container" in r.message][n_info:]
     assert len(said) == 1 and '"auto"' in said[0] and "eval_batch 24" in said[0], said      # ... and one line saying so
     M = image_streams(H, W)
-    lo, mid, hi = auto_counts(M)
+    lo, _, mid, hi = auto_counts(M)
     counts = [mode_of_header(b) & 0xFF for b in base]
     assert counts == [lo, mid, hi, lo, hi, mid], (counts, (lo, mid, hi))
     for i, b in enumerate(base):
@@ -2055,7 +2054,7 @@ def test_mixed_size_entry_points_reject_misuse(torch_mod, codecs):
         return c.L.llicti_encode_images_v(c.ctx, _ptr(flat), None, B, _ptr(hs) if hs is not None else None, _ptr(wsz) if wsz is not None else None, m,
                                           _ptr(ws), need if wbytes is None else wbytes, _ptr(cont), ostride, _ptr(seg), st)
     assert enc(wbytes=need - 256) == _lib.ENOSPACE
-    assert enc(ostride=c.max_container_bytes(67, 93)) == _lib.ENOSPACE          # fits the smallest image only
+    assert enc(ostride=4096) == _lib.ENOSPACE                                   # smaller than any image's container
     assert enc(B=0) == _lib.EINVAL and enc(hs=None) == _lib.EINVAL and enc(m=0x700 | 3) == _lib.EINVAL
     bad = Hs.copy()
     bad[1] = 9000
