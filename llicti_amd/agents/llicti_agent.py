@@ -243,11 +243,10 @@ class LLICTIAgent:
 
         def start_encode(imgs, slot):
             B = len(imgs)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            up, _ = self.model._copy_streams(self.device)
+            e1 = torch.cuda.Event(enable_timing=True)
             enc = self.model.encode_batch_async(imgs, slot=slot)        # list of uint8 host arrays: staged in pinned memory, uploaded on the model's copy stream
             e1.record(stream)
-            return {"enc": enc, "e_enc": (enc.t0 if enc.t0 is not None else e0, e1), "B": B, "Hs": enc.Hs, "Ws": enc.Ws}
+            return {"enc": enc, "e_enc": (enc.t0, e1), "B": B, "Hs": enc.Hs, "Ws": enc.Ws}      # (t0: recorded by the list path behind the wait for its upload)
 
         def finish(job, idx0):
             """host half of a batch: lists, rates, decode enqueue; then (synchronising) the lossless check and the log lines"""

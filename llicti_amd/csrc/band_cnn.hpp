@@ -33,6 +33,19 @@ constexpr KTab make_ktab(int band, int kInPlane)
 }
 template <int BAND, int TH> inline constexpr KTab kKTab = make_ktab(BAND, CnnGeo<TH>::kInPlane);
 
+// TIMING-ONLY experiment switches (what would an all-heads-per-workgroup, weight-stationary form buy?  results are WRONG with any of
+// them set; never set in the product build -- tools/cnn_ws_experiment.sh builds the variants, profiles/r6/tried_cnn_weight_stationary.json has the numbers):
+//   CNN_EXP_STAGE_EVERY = n   the next tile's input is staged for every n-th tile of a workgroup only (n = 4: what ONE staging per tile for all four
+//                             heads would cost per head -- today the four head-workgroups of a tile each stage it);
+//   CNN_EXP_NO_WFRAG = 1      no weight-fragment LDS reads inside the tile loop (the fragments a wavefront starts with are reused: what weights held
+//                             in registers for the whole kernel would save).
+#ifndef CNN_EXP_STAGE_EVERY
+#define CNN_EXP_STAGE_EVERY 1
+#endif
+#ifndef CNN_EXP_NO_WFRAG
+#define CNN_EXP_NO_WFRAG 0
+#endif
+
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, class F>
@@ -232,7 +245,7 @@ __global__ __launch_bounds__(CnnGeo<TH>::kThreads) void band_params_kernel(const
         // different points of the tile, one per wave group: a SIMD hosts one wave of each group, so while
         // one of its waves stages, the other three keep the matrix pipe busy.  (All 16 waves staging right
         // after the barrier left the pipe idle for ~9 % of the tile.)
-        const bool more = tile + (int)gridDim.x < n_tiles;
+        const bool more = tile + (int)gridDim.x < n_tiles && (CNN_EXP_STAGE_EVERY == 1 || ((tile / (int)gridDim.x) % CNN_EXP_STAGE_EVERY) == CNN_EXP_STAGE_EVERY - 1);
         auto stage_next = [&](int site) __attribute__((always_inline)) {
             if (more && stage_site == site % CNN_STAGE_SITES) stage(tile + gridDim.x, lds_in + (cur ^ 1) * (NPL * kInPlane));
         };
@@ -298,9 +311,9 @@ __global__ __launch_bounds__(CnnGeo<TH>::kThreads) void band_params_kernel(const
 #pragma unroll
                     for (int n = 0; n < kNT; ++n) b_n[n] = bp[(n >> 1) * kInPitch + 16 * (n & 1)];
 #pragma unroll
-                    for (int T = 0; T < kMT0; ++T) a_n[T] = lds[PO::w0 + (T * NK0 + t + 1) * 64 + lane];
+                    for (int T = 0; T < kMT0; ++T) a_n[T] = CNN_EXP_NO_WFRAG ? a_c[T] : lds[PO::w0 + (T * NK0 + t + 1) * 64 + lane];
 #if CNN_REM4X4
-                    ar_n = *reinterpret_cast<const f32x4 *>(ra_base + (t + 1) * 32);
+                    ar_n = CNN_EXP_NO_WFRAG ? ar_c : *reinterpret_cast<const f32x4 *>(ra_base + (t + 1) * 32);
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) br_n[kk] = rb_base[U + (S == 1 ? kk : kk * kInPitch)];
 #endif
@@ -416,7 +429,7 @@ __global__ __launch_bounds__(CnnGeo<TH>::kThreads) void band_params_kernel(const
             float a2w[4] = { 0.0f, 0.0f, 0.0f, 0.0f };      // this tile's layer-2 fragments: requested now, used 22 k-steps later
             static_for<4>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
-                if constexpr (4 * T + r < kKS1) a2w[r] = lds[PO::w2 + (4 * T + r) * 64 + lane];
+                if constexpr (4 * T + r < kKS1) a2w[r] = CNN_EXP_NO_WFRAG ? ring1[r % D1] : lds[PO::w2 + (4 * T + r) * 64 + lane];
             });
 #endif
             static_for<kKS1>([&](auto ttc) {
@@ -424,7 +437,7 @@ __global__ __launch_bounds__(CnnGeo<TH>::kThreads) void band_params_kernel(const
 #if CNN_PREFETCH_L1 > 0
                 constexpr int i = T * kKS1 + tt;
                 const float a = ring1[i % D1];
-                if constexpr (i + D1 < kMT * kKS1) ring1[i % D1] = lds[PO::w1 + (i + D1) * 64 + lane];
+                if constexpr (i + D1 < kMT * kKS1 && !CNN_EXP_NO_WFRAG) ring1[i % D1] = lds[PO::w1 + (i + D1) * 64 + lane];
 #else
                 const float a = lds[PO::w1 + (T * kKS1 + tt) * 64 + lane];
 #endif

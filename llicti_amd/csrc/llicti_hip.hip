@@ -60,6 +60,9 @@ struct PlanBlock {
     hipEvent_t uploaded = nullptr;    // behind the table upload ...
     hipStream_t up_stream = nullptr;  // ... on this stream: a call on another stream waits for it
     bool used = false;                // `done` has been recorded at least once
+    hipStream_t done_stream = nullptr;      // ... last on this stream: a call on ANOTHER stream waits for `done` before it re-records it, so that the one
+                                            // event always lies behind every user of the block (a plan used on stream A, then on B, then evicted
+                                            // was recycled as soon as B's record completed, while A's kernels could still be reading the tables)
 };
 struct PlanDev {
     Plan p;
@@ -633,6 +636,7 @@ static int get_plan(llicti_ctx *c, int B, const int *Hs, const int *Ws, const si
         ++c->n_plan_hit;
         pd->last_use = ++c->use_clock;
         if (pd->blk.up_stream != s) HIPCHK(hipStreamWaitEvent(s, pd->blk.uploaded, 0));      // (uploaded on another stream: order behind it)
+        if (pd->blk.used && pd->blk.done_stream != s) HIPCHK(hipStreamWaitEvent(s, pd->blk.done, 0));      // (last used on another stream: this call's `done` must lie behind that use too)
         *out = pd;
         return 0;
     }
@@ -659,6 +663,7 @@ static int get_plan(llicti_ctx *c, int B, const int *Hs, const int *Ws, const si
     ok = ok && hipEventRecord(pd->blk.uploaded, s) == hipSuccess;
     ok = ok && hipEventRecord(pd->blk.done, s) == hipSuccess;      // (so that the block is never recycled in front of its own upload)
     pd->blk.up_stream = s;
+    pd->blk.done_stream = s;
     pd->blk.used = true;
     if (!ok) { c->pool.push_back(pd->blk); return fail(LLICTI_EHIP, "plan tables: upload failed"); }
     p.tiles.clear(); p.tiles.shrink_to_fit();                      // (the host copy of the largest table is not needed again)
@@ -712,7 +717,7 @@ struct CallScope {
 // marks the plan's table block as in use behind everything the call enqueued (get_plan: blocks are recycled, never freed)
 struct PlanUse {
     PlanDev *pd; hipStream_t s;
-    ~PlanUse() { if (pd && hipEventRecord(pd->blk.done, s) == hipSuccess) pd->blk.used = true; }
+    ~PlanUse() { if (pd && hipEventRecord(pd->blk.done, s) == hipSuccess) { pd->blk.used = true; pd->blk.done_stream = s; } }
 };
 
 // modes: one container mode for the call (n_modes = 1) or one per image (n_modes = B: rANS containers of ONE lane kind whose stream counts may differ);

@@ -84,6 +84,7 @@ for case in range(N):
         codec.check()
         if auto:
             modes = codec.container_modes(cont)    # what the encoder picked, from the headers
+            mode = modes[0]
         codec.poison_workspace()                   # the decode must not find the encoder's planes in the workspace
         rec = codec.decode_v(cont, seg, Hs, Ws, modes)
         codec.check()

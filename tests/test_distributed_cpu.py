@@ -286,3 +286,32 @@ def test_numa_binding_from_pci_locality(tmp_path):
         assert o["numa_node"] is None and o["cpus_bound"] == 0 and not calls
     (dev / "numa_node").write_text("-1\n")
     assert shard.bind_to_gpu_numa(identity=ident, sysfs_root=str(tmp_path), setaffinity=lambda pid, cpus: calls.append(1))["cpus_bound"] == 0 and not calls
+
+
+def test_auto_container_modes_do_not_depend_on_the_partition():
+    """Container "auto" through the model's own chooser (LLICTI.mode_for_batch -> llicti_amd.codec.auto_modes) on the reference's eval-set sizes: whatever
+    the rank count and eval_batch -- i.e. whichever images end up in a call together -- every image gets the same ENCODER mode, the one its own size
+    gives (the rest of the choice, the count adjusted by the image's last-stage cost, is made per image on the device: -m gpu,
+    test_agent_auto_container_is_a_function_of_the_image / test_agent_two_ranks_on_gpu_equal_one_rank).  Round 5's chooser looked at the batch size, the
+    CU count and a running mean of past content: an image's bytes depended on the partition."""
+    import json
+    from llicti_amd.codec import MODE_RANS_AUTO, image_mode, image_streams
+    from llicti_amd.config import default_config
+    from llicti_amd.graphs.models.LLICTI_nets import LLICTI
+    sizes = [tuple(s) for s in json.load(open(os.path.join(ROOT, "tests", "golden", "eval_shapes.json")))["shapes"][:96]]
+    model = LLICTI(default_config(container="auto"))
+
+    def modes(world, eb):
+        got = {}
+        for rank in range(world):
+            ids = list(range(rank, len(sizes), world))
+            for k in range(0, len(ids), eb):
+                batch = ids[k:k + eb]
+                m = model.mode_for_batch(len(batch), None, sizes=[sizes[i] for i in batch])
+                for j, i in enumerate(batch):
+                    got[i] = m if isinstance(m, int) else m[j]
+        return [got[i] for i in range(len(sizes))]
+    base = modes(1, 1)
+    assert base == [image_mode(h, w) for h, w in sizes] == [MODE_RANS_AUTO(image_streams(h, w)) for h, w in sizes]
+    for world, eb in ((1, 24), (2, 24), (2, 5), (3, 7), (8, 24), (8, 3)):
+        assert modes(world, eb) == base, (world, eb)

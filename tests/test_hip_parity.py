@@ -644,6 +644,31 @@ def test_reference_api_roundtrip(torch_mod, capsys):
     assert np.array_equal((x2 * 255).round().to(torch.uint8).cpu().numpy()[0], rgb)
 
 
+def test_decompres_batch_mixed_sizes(torch_mod, oracle_weights):
+    """LLICTI.decompres_batch on bytestream_lists of DIFFERENT sizes (rANS containers: decode_batch_async then returns a flat buffer) gives a
+    list of [1,3,H,W] tensors, each what decompres() returns for that image; equal sizes still give one [B,3,H,W] tensor; the reference format refuses
+    mixed sizes up front."""
+    from llicti_amd.config import default_config
+    from llicti_amd.graphs.models.LLICTI_nets import LLICTI
+    torch = torch_mod
+    torch.manual_seed(1337)
+    model = LLICTI(default_config(container="xrans2")).to("cuda:0").eval()
+    imgs = [make_image("smooth", 96, 128, 1), make_image("noise", 67, 93, 2), make_image("smooth", 150, 131, 3)]
+    lists = model.encode_batch_async(imgs).lists()
+    out = model.decompres_batch(lists, torch.device("cuda:0"))
+    assert isinstance(out, list) and len(out) == 3
+    for o, im, bl in zip(out, imgs, lists):
+        assert tuple(o.shape) == (1, 3) + im.shape[1:] and o.dtype == torch.float32
+        assert np.array_equal((o * 255).round().to(torch.uint8).cpu().numpy()[0], im)
+        assert torch.equal(o, model.decompres(bl, torch.device("cuda:0")))
+    same = model.decompres_batch([lists[0], lists[0]], torch.device("cuda:0"))
+    assert torch.is_tensor(same) and tuple(same.shape) == (2, 3, 96, 128)
+    model.set_container("ac")
+    ac = [model.compress(torch.from_numpy(im.astype(np.float32) / np.float32(255)).unsqueeze(0).to("cuda:0"))[0] for im in imgs[:2]]
+    with pytest.raises(ValueError):
+        model.decompres_batch(ac, torch.device("cuda:0"))
+
+
 def test_agent_eval_model(torch_mod, caplog):
     import logging
     from llicti_amd.agents.llicti_agent import LLICTIAgent
@@ -1518,9 +1543,11 @@ def test_agent_two_ranks_on_gpu_equal_one_rank(torch_mod, tmp_path):
         t = re.sub(r"Enc/Dec-Times:[0-9.]+/[0-9.]+", "Enc/Dec-Times:T/T", t)
         return re.sub(r"\(\d\d:\d\d:\d\d\)", "(clock)", t)
 
-    for eb in (1, 4):
-        one = tmp_path / f"one{eb}.json"
-        p = subprocess.run([sys.executable, script, str(one), str(eb)], capture_output=True, text=True, timeout=600)
+    # ("auto", round 6: an image's container is a function of the image, so the sharded log equals the one-rank log on flat, natural-like and noise
+    #  images alike -- round 5's content-following rule made an image's bytes depend on what its rank had coded before)
+    for eb, cont in ((1, "xrans1"), (4, "xrans1"), (3, "auto")):
+        one = tmp_path / f"one{eb}{cont}.json"
+        p = subprocess.run([sys.executable, script, str(one), str(eb), cont], capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
@@ -1528,16 +1555,16 @@ def test_agent_two_ranks_on_gpu_equal_one_rank(torch_mod, tmp_path):
         env = dict(os.environ)
         if not two:
             env["LLICTI_DIST_BACKEND"] = "gloo"
-        out2 = tmp_path / f"two{eb}.json"
+        out2 = tmp_path / f"two{eb}{cont}.json"
         p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                            "--master-port", str(port), script, str(out2), str(eb)], capture_output=True, text=True, timeout=900, env=env)
+                            "--master-port", str(port), script, str(out2), str(eb), cont], capture_output=True, text=True, timeout=900, env=env)
         assert p.returncode == 0, p.stderr[-3000:]
         a, b = json.load(open(one)), json.load(open(out2))
         assert a["world"] == 1 and b["world"] == 2 and b["own"] == [0, 2, 4, 6, 8]
         assert [r[:3] for r in b["records"]] == [r[:3] for r in a["records"]] and all(r[4] < 1e-3 for r in b["records"])     # (float32 uint8/255 on host vs device division)
         assert np.allclose([r[3] for r in b["records"]], [r[3] for r in a["records"]])
         pick = lambda t: [ln for ln in strip(t).splitlines() if ln.startswith("Agent|") and "bpsp=" in ln] + [strip(t)[strip(t).index("Rate Loss|"):]]      # noqa: E731
-        assert pick(b["log"]) == pick(a["log"]), eb
+        assert pick(b["log"]) == pick(a["log"]), (eb, cont)
 
 
 def test_plan_cache_eviction(torch_mod, codecs):

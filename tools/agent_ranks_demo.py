@@ -27,13 +27,21 @@ for n in ("Agent", "Rate Loss"):
 sizes = [(96, 128), (67, 93), (128, 96), (96, 128), (150, 131), (97, 351), (64, 80), (96, 128), (33, 64)]
 imgs = [np.random.default_rng(70 + i).integers(0, 256, size=(3, hh, ww), dtype=np.uint8) for i, (hh, ww) in enumerate(sizes)]
 eb = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-cfg = default_config(test_data=imgs, container="xrans1", **({"eval_batch": eb} if eb > 1 else {}))
+container = sys.argv[3] if len(sys.argv) > 3 else "xrans1"
+if container == "auto":
+    # container "auto": an image's container is a function of the image (its size, and -- picked by the encoder on the device -- what its last stage
+    # costs), so rank 0's log of a sharded run is the one-rank log on ANY content: flat, natural-like and noise images of several sizes, interleaved
+    from helpers import make_image  # noqa: E402
+    sizes = [(256, 384), (256, 384), (192, 256), (256, 384), (321, 481), (256, 384), (160, 352), (256, 384), (192, 256)]
+    kinds = ["flat", "smooth", "noise", "noise", "smooth", "flat", "noise", "smooth", "flat"]
+    imgs = [np.full((3, hh, ww), 60 + 20 * i, np.uint8) if k == "flat" else make_image(k, hh, ww, 70 + i) for i, ((hh, ww), k) in enumerate(zip(sizes, kinds))]
+cfg = default_config(test_data=imgs, container=container, **({"eval_batch": eb} if eb > 1 else {"eval_batch": 1}))
 agent = LLICTIAgent(cfg)
 res = agent.run()
 import torch.distributed as dist  # noqa: E402
 if agent.rank == 0:
     rows = agent.all_results if agent.world > 1 else res
     json.dump({"world": agent.world, "log": buf.getvalue(), "records": [[r["idx"], r["H"], r["W"], r["bpsp"], r["max_abs_err"]] for r in rows],
-               "own": [r["idx"] for r in res]}, open(sys.argv[1], "w"))
+               "own": [r["idx"] for r in res], "container": container}, open(sys.argv[1], "w"))
 if dist.is_available() and dist.is_initialized():
     dist.destroy_process_group()

@@ -27,7 +27,7 @@ for lvl in (0, 1, 2, 3, 4):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / n
-        pos = B * out.shape[1] * out.shape[2]
+        pos = B * out.shape[2] * out.shape[3]                   # [B, 64 planes, h, w]
         fl = 2.0 * MAC[band] * pos
         tot_ms += ms; tot_fl += fl
         print(f"lvl {lvl} band {band}: {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s")
