@@ -614,8 +614,9 @@ def api_path_leg(torch, dev, B, H, W, n_images=240):
     LLICTIAgent.eval_model with config.eval_batch = B and config.container = "auto": per batch H2D of the uint8 RGB, encode, D2H of the
     containers, container -> the reference's bytestream_list (6 lists x 9 `bytes` per image), rate bookkeeping, bytestream_list -> container,
     H2D, decode, the lossless check and the per-image log line -- everything eval_model does (agents/llicti_agent.py:122-164) inside one
-    wall clock, the host half of batch k overlapped with the GPU half of batch k + 1.  Beside it the one-image loop in the default
-    (reference-format) container on a few images: what a caller gets who changes nothing but the import."""
+    wall clock, the host half of batch k overlapped with the GPU half of batch k + 1.  Beside it the same images through an agent whose config
+    has NEITHER key (what a caller gets who changes nothing but the import: the agent's defaults are that very path) and the opt-in
+    reference-format one-image loop on a few images."""
     import logging
     import numpy as np
     from llicti_amd.agents.llicti_agent import LLICTIAgent
@@ -638,7 +639,23 @@ def api_path_leg(torch, dev, B, H, W, n_images=240):
                       "gpu_enc_ms_per_image": round(float(np.mean([r["enc_s"] for r in res])) * 1e3, 3),
                       "gpu_dec_ms_per_image": round(float(np.mean([r["dec_s"] for r in res])) * 1e3, 3)}
     del agent
-    a1 = LLICTIAgent(default_config(test_data=imgs[:1]))
+    # (a) what a caller gets who changes nothing but the import: the reference's own config has neither `container` nor `eval_batch` -- the agent then
+    #     runs container "auto" with eval_batch 24 (the throughput path is the default, the reference format the opt-in) --,
+    # (b) the opt-in: "container": "ac", "eval_batch": 1 = the reference's byte format in its one-image loop
+    a0 = LLICTIAgent(default_config(test_data=imgs[:2 * B]))
+    a0.run()
+    a0.config["test_data"] = imgs
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r0 = a0.run()
+    torch.cuda.synchronize()
+    dt0 = time.perf_counter() - t0
+    assert len(r0) == n_images and all(r["max_abs_err"] == 0.0 for r in r0)
+    out["unchanged_reference_config"] = {"mpix_s": round(n_images * H * W / dt0 / 1e6, 2), "ms_per_image": round(dt0 / n_images * 1e3, 3),
+                                         "what": "no container / eval_batch key in the config (configs/llicti_A.json has neither): the agent's defaults -- container auto, eval_batch 24",
+                                         "bytes_equal_explicit_auto": bool(abs(float(np.mean([r["bpsp"] for r in r0])) - out["batched"]["bpsp"]) < 1e-9)}
+    del a0
+    a1 = LLICTIAgent(default_config(test_data=imgs[:1], container="ac", eval_batch=1))
     a1.run()
     a1.config["test_data"] = imgs[:3]
     torch.cuda.synchronize()
@@ -646,8 +663,8 @@ def api_path_leg(torch, dev, B, H, W, n_images=240):
     r1 = a1.run()
     torch.cuda.synchronize()
     dt1 = time.perf_counter() - t0
-    out["one_image_default_container"] = {"mpix_s": round(3 * H * W / dt1 / 1e6, 3), "ms_per_image": round(dt1 / 3 * 1e3, 2), "container": a1.model.container,
-                                          "enc_s": round(float(np.mean([r["enc_s"] for r in r1])), 4), "dec_s": round(float(np.mean([r["dec_s"] for r in r1])), 4)}
+    out["reference_format_one_image_loop"] = {"mpix_s": round(3 * H * W / dt1 / 1e6, 3), "ms_per_image": round(dt1 / 3 * 1e3, 2), "container": a1.model.container,
+                                              "enc_s": round(float(np.mean([r["enc_s"] for r in r1])), 4), "dec_s": round(float(np.mean([r["dec_s"] for r in r1])), 4)}
     logging.getLogger("Agent").setLevel(logging.NOTSET)
     return out
 

@@ -1,4 +1,4 @@
-"""python -m llicti_amd.cli encode IN.(png|ppm|jpg) OUT.llic [--container ac|rans<M>|wrans<M>|xrans<M>] [--checkpoint model_best.pth.tar]
+"""python -m llicti_amd.cli encode IN.(png|ppm|jpg) OUT.llic [--container ac|auto|rans<M>|wrans<M>|xrans<M>] [--checkpoint model_best.pth.tar]
    python -m llicti_amd.cli decode IN.llic OUT.(png|ppm)
    python -m llicti_amd.cli info   IN.llic
 
