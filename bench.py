@@ -1280,7 +1280,7 @@ def main(argv=None):
                 "oracle_tables_vs_reference_tables": fx,
                 "source": fx_path,
                 "note": "reference-format (AC) container: same format, Delta = the table differences of the fixed-arithmetic spec vs the "
-                        "reference's PyTorch floats (fixtures). rANS v3 container: same tables and symbols, about 6 bytes per 64-lane stream, 2 - 3.5 per 256-lane stream over the ideal "
+                        "reference's PyTorch floats (fixtures). rANS containers: same tables and symbols, about 6 bytes per 64-lane stream (v3), 2.5 - 5 per 256-lane stream (v4) over the ideal "
                         "code length (0.001 bpp = 49 bytes per 768x512 image; the AC container's 45 terminations cost about 25) -- see m_sweep"}
             dbpp = out["bpp_delta_vs_reference"]["timed_container_minus_reference_format_bpp"]
             # + what the build's tables cost against the reference's own PyTorch tables on full-size images of this workload (committed
@@ -1301,6 +1301,12 @@ def main(argv=None):
                                        "lossless": True, "what": "timed container vs the reference-format container on the same batch (same tables, same symbols); "
                                                                  "decode(encode(x)) == x asserted on a poisoned workspace; image 0 of both containers == CPU oracle bytes (cpu_baseline)"}
         out.update(legs_out)
+        rt = legs_out.get("roofline_cdf_table") or {}
+        if "bound" in rt:
+            # SURVEY 8(d)(ii) beside 8(d)(i) in the `roofline` object itself (the full record stays at roofline_cdf_table)
+            out["roofline"]["regime_ii_cdf_table"] = {"bound": rt["bound"], "kernel": rt["kernel"], "frac": rt["frac"], "unit": rt["unit"],
+                                                      "hbm_frac": rt["hbm"]["frac"], "hbm_achieved_gbs": rt["hbm"]["achieved"],
+                                                      "traffic": rt["traffic"], "full_record": "roofline_cdf_table"}
         nl = legs_out.get("natural_like") or {}
         if "meets_north_star" in out and out["meets_north_star"] is not None and "bpp_delta_budget_image0" in nl:
             # the budget on natural-like content too (tables + container on the full-size fixture image), and the committed row must be about

@@ -1,6 +1,7 @@
 #!/bin/bash
 # The CPU oracle under AddressSanitizer + UBSan (CPU only; GPU sanitizers are not available on the pool): both containers, every
-# stream-count family incl. wide and xwide streams (two seeded tail chains; narrow-range and flat images for the radix-A seeds), and decodes of
+# stream-count family incl. wide and xwide streams (v4: the arena with its spill, one zero-start chain or two seeded ones; narrow-range and flat images
+# for the radix-A seeds; the encoder's "auto" count), and decodes of
 # corrupted streams (which may fail, but must not read or write out of bounds).
 # Not collected by pytest (a minute of CPU); run from the repo root:  bash tests/sanitize_oracle.sh
 set -e
@@ -29,21 +30,25 @@ for wname in ("trainedlike", "rand1337"):
         else:
             rgb = make_image(kind, H, Wd, 3)
         assert np.array_equal(orc.decode_image(orc.encode_image(rgb, W), W), rgb)
-        for M, wide in ((1, 0), (4, 0), (10, 0), (32, 0), (64, 0), (128, 0), (1, 1), (3, 1), (10, 1), (14, 1), (1, 2), (3, 2), (10, 2), (14, 2), (32, 2), (64, 2)):
+        for M, wide in ((1, 0), (4, 0), (10, 0), (32, 0), (64, 0), (128, 0), (1, 1), (3, 1), (10, 1), (14, 1), (1, 2), (3, 2), (10, 2), (16, 2), (21, 2), (32, 2), (64, 2), (128, 2)):
             bl = orc.encode_image_rans(rgb, W, M, wide)
             assert np.array_equal(orc.decode_image_rans(bl, W), rgb), (kind, M, wide)
+            if wide == 2 and M in (1, 3, 21):                # the encoder's "auto" count (round 6): the same container family, the count from the image itself
+                bl_a = orc.encode_image_rans(rgb, W, M, 2, auto=True)
+                assert np.array_equal(orc.decode_image_rans(bl_a, W), rgb), (kind, M, "auto")
             hit = next(((r, c) for r in range(1, 6) for c in range(9) if len(bl[r][c]) > 8), None)
-            for trial in range(4 if hit else 0):             # flipped bits in the first non-trivial stream: anywhere, its T | pad, its states (the tail payload)
+            for trial in range(5 if hit else 0):             # flipped bits in the first non-trivial stream: anywhere, its first bytes (T | pad; xwide v4: the spill), its states (the tail payload), the top of its bit region (xwide v4: the header field)
                 rows = [list(r) for r in bl]
                 b = bytearray(rows[hit[0]][hit[1]])
-                pos = (int(rng.integers(0, len(b))), int(rng.integers(0, 2)), len(b) - 1 - int(rng.integers(0, min(len(b), 248 << wide))), int(rng.integers(0, len(b))))[trial]
+                pos = (int(rng.integers(0, len(b))), int(rng.integers(0, 2)), len(b) - 1 - int(rng.integers(0, min(len(b), 248 << wide))), int(rng.integers(0, len(b))),
+                       max(0, len(b) - (248 << wide) - 1 - int(rng.integers(0, 2))))[trial]
                 b[pos] ^= 1 << int(rng.integers(0, 8)); rows[hit[0]][hit[1]] = bytes(b)
                 try:
                     orc.decode_image_rans(rows, W)
                 except RuntimeError:
                     pass
         print(wname, kind, H, Wd, "ok", flush=True)
-# round 5: xwide tails beyond 2,047 symbols (12-bit T field, escape) -- a cheap model-drawn source and a flat image large enough for 8,191 tail symbols
+# xwide tails beyond 2,047 symbols (v4: multiples of 32 up to 8,160, one zero-start chain, the spill) -- a cheap model-drawn source and a flat image large enough for the cap
 sys.path.insert(0, "$ROOT/tests")
 from test_oracle_golden import _cheap_case
 for kind in ("sharp", "single"):
@@ -53,7 +58,7 @@ for kind in ("sharp", "single"):
         assert np.array_equal(orc.decode_image_rans(bl, Wc), img), (kind, M)
         for trial in range(3):
             rows = [list(r) for r in bl]
-            b = bytearray(rows[1][0]); b[(0, 1, len(b) - 1)[trial]] ^= 0x80; rows[1][0] = bytes(b)      # T's low / high byte (bit 15!), the escape's count
+            b = bytearray(rows[1][0]); b[(0, len(b) - 993, len(b) - 1)[trial]] ^= 0x80; rows[1][0] = bytes(b)      # the spill, the header field on top of the bit region, the last state
             try:
                 orc.decode_image_rans(rows, Wc)
             except RuntimeError:
