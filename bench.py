@@ -634,6 +634,7 @@ def api_path_leg(torch, dev, B, H, W, n_images=240):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert len(res) == n_images and all(r["max_abs_err"] == 0.0 for r in res)
+    bpsp_auto = [r["bpsp"] for r in res]
     out["batched"] = {"mpix_s": round(n_images * H * W / dt / 1e6, 2), "wall_s": round(dt, 4), "ms_per_image": round(dt / n_images * 1e3, 3),
                       "bpsp": round(float(np.mean([r["bpsp"] for r in res])), 5), "container": agent.model.container,
                       "gpu_enc_ms_per_image": round(float(np.mean([r["enc_s"] for r in res])) * 1e3, 3),
@@ -653,7 +654,7 @@ def api_path_leg(torch, dev, B, H, W, n_images=240):
     assert len(r0) == n_images and all(r["max_abs_err"] == 0.0 for r in r0)
     out["unchanged_reference_config"] = {"mpix_s": round(n_images * H * W / dt0 / 1e6, 2), "ms_per_image": round(dt0 / n_images * 1e3, 3),
                                          "what": "no container / eval_batch key in the config (configs/llicti_A.json has neither): the agent's defaults -- container auto, eval_batch 24",
-                                         "bytes_equal_explicit_auto": bool(abs(float(np.mean([r["bpsp"] for r in r0])) - out["batched"]["bpsp"]) < 1e-9)}
+                                         "bytes_equal_explicit_auto": bool([r["bpsp"] for r in r0] == bpsp_auto)}     # per image, in order
     del a0
     a1 = LLICTIAgent(default_config(test_data=imgs[:1], container="ac", eval_batch=1))
     a1.run()
