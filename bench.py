@@ -670,7 +670,7 @@ def api_path_leg(torch, dev, B, H, W, n_images=240):
     return out
 
 
-def api_path_mixed_leg(torch, dev, B, n_images=500, balance=True):
+def api_path_mixed_leg(torch, dev, B, n_images=500):
     """the drop-in API on the reference's OWN eval workload -- 500 images at the sizes its test set has, in the order its loader
     yields them (tests/golden/eval_shapes.json: parsed out of the reference's eval log, 119 distinct sizes, interleaved; the images themselves
     are not in the reference tree, so the content is the bench's uniform noise) -- through LLICTIAgent.eval_model with eval_batch = B and
@@ -687,7 +687,7 @@ def api_path_mixed_leg(torch, dev, B, n_images=500, balance=True):
     out = {"workload": f"{len(shapes)} uniform-noise RGB images at the sizes and in the order of the reference's own test set ({len(set(map(tuple, shapes)))} distinct sizes, "
                        f"{pix / 1e6:.1f} MPix) through LLICTIAgent.eval_model, eval_batch = {B}, container auto, wall clock incl. transfers, container <-> bytestream_list, "
                        "rates, lossless check, log lines"}
-    agent = LLICTIAgent(default_config(test_data=imgs[:3 * B], eval_batch=B, container="auto", balance_streams=balance))
+    agent = LLICTIAgent(default_config(test_data=imgs[:3 * B], eval_batch=B, container="auto"))
     agent.run()                                                   # warm-up: workspaces, pinned staging buffers, table blocks
     agent.config["test_data"] = imgs
     dts = []
@@ -701,8 +701,8 @@ def api_path_mixed_leg(torch, dev, B, n_images=500, balance=True):
     out["repeats_mpix_s"] = [round(pix / t / 1e6, 1) for t in dts]
     assert len(res) == len(shapes) and all(r["max_abs_err"] == 0.0 for r in res)
     assert [(r["H"], r["W"]) for r in res] == [tuple(s) for s in shapes]              # in order
-    out["stream_counts"] = ("per image, in proportion to its pixels (llicti_amd.codec.balanced_modes -> llicti_encode_images_vm)" if balance else
-                            "one count for the batch (its smallest image's budget)")
+    out["stream_counts"] = ("per image: the encoder mode its own size gives (llicti_amd.codec.auto_modes -> llicti_encode_images_vm), the count picked on the device "
+                            "from what the image's last stage costs -- the bytes of an image do not depend on its neighbours in the batch")
     out["mixed_batches"] = {"mpix_s": round(pix / dt / 1e6, 2), "wall_s": round(dt, 4), "ms_per_image": round(dt / len(shapes) * 1e3, 3),
                             "bpsp": round(float(np.mean([r["bpsp"] for r in res])), 5),
                             "gpu_enc_ms_per_image": round(float(np.mean([r["enc_s"] for r in res])) * 1e3, 3),
