@@ -56,14 +56,17 @@ def run_mixed(sh, mode=mode):
     Hs, Ws = [h for h, _ in sh], [w for _, w in sh]
     flat = torch.from_numpy(np.concatenate([np.random.default_rng(i).integers(0, 256, 3 * h * w, dtype=np.uint8) for i, (h, w) in enumerate(sh)])).to(dev)
     cont, seg = codec.encode_v(flat, Hs, Ws, mode)
-    rec = codec.decode_v(cont, seg, Hs, Ws, mode)
+    dmode = mode
+    if (not isinstance(mode, int)) or (mode & 0x10000):
+        dmode = codec.container_modes(cont)          # encoder modes "auto": the decoder takes every image's own mode from its header
+    rec = codec.decode_v(cont, seg, Hs, Ws, dmode)
     codec.check()
     assert torch.equal(rec, flat)
     te = timed(lambda: codec.encode_v(flat, Hs, Ws, mode, out=cont, seg_len=seg))
-    td = timed(lambda: codec.decode_v(cont, seg, Hs, Ws, mode, out=rec))
+    td = timed(lambda: codec.decode_v(cont, seg, Hs, Ws, dmode, out=rec))
     codec.set_profiling(True)
     codec.encode_v(flat, Hs, Ws, mode, out=cont, seg_len=seg); torch.cuda.synchronize(); ce, _ = codec.last_timing_detail()
-    codec.decode_v(cont, seg, Hs, Ws, mode, out=rec); torch.cuda.synchronize(); cd, _ = codec.last_timing_detail()
+    codec.decode_v(cont, seg, Hs, Ws, dmode, out=rec); torch.cuda.synchronize(); cd, _ = codec.last_timing_detail()
     codec.set_profiling(False)
     mp = sum(h * w for h, w in sh) / 1e6
     return {"megapixels": round(mp, 2), "enc_ms": round(te, 3), "dec_ms": round(td, 3), "encdec_mpix_s": round(mp / (te + td) * 1e3, 1),
@@ -80,11 +83,11 @@ for k0 in (100, 300):
     out[f"eval_set_images_{k0}_{k0 + 24}_mixed"]["sizes"] = sorted(set(map(tuple, sh)))
     sh_sorted = sorted(sh, key=lambda s: s[0] * s[1])
     out[f"eval_set_images_{k0}_{k0 + 24}_sorted_by_size"] = run_mixed(sh_sorted)
-    # (iii) a stream count per image, in proportion to its pixels (llicti_encode_images_vm): all streams equally long
-    from llicti_amd.codec import balanced_modes, name_of_mode
-    bm = balanced_modes([tuple(s) for s in sh], 256)
-    out[f"eval_set_images_{k0}_{k0 + 24}_balanced_stream_counts"] = run_mixed(sh, bm)
-    out[f"eval_set_images_{k0}_{k0 + 24}_balanced_stream_counts"]["streams"] = sorted(set(name_of_mode(m) for m in bm))
+    # (iii) a stream count per image, from its own size (llicti_encode_images_vm; round 5: balanced_modes, in proportion to the pixels)
+    from llicti_amd.codec import auto_modes, name_of_mode
+    bm = auto_modes([tuple(s) for s in sh])
+    out[f"eval_set_images_{k0}_{k0 + 24}_stream_count_per_image"] = run_mixed(sh, bm)
+    out[f"eval_set_images_{k0}_{k0 + 24}_stream_count_per_image"]["encoder_modes"] = sorted(set(name_of_mode(m) for m in bm))
 print(json.dumps(out, indent=1))
 if len(sys.argv) > 1:
     json.dump(out, open(sys.argv[1], "w"), indent=1)

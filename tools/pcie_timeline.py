@@ -42,6 +42,10 @@ def main():
     codec.load_state_dict(LLICTI(default_config()).state_dict())
     rgb_h = bench.make_batch(B, H, W, 0)
     rgb = torch.from_numpy(rgb_h).to(dev)
+    if mode & 0x10000:                      # encoder mode "auto": time the container it writes on this batch (the decoder needs the container's own mode)
+        c0, _ = codec.encode(rgb, mode=mode)
+        mode = sorted(set(codec.container_modes(c0)))[0]
+        del c0
     stride = codec.max_container_bytes(H, W)
     cont = torch.empty((B, stride), dtype=torch.uint8, device=dev)
     seg = torch.zeros((B, 49), dtype=torch.int32, device=dev)
