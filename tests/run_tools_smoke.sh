@@ -17,19 +17,16 @@ run bench_api_mixed python tools/bench_api_mixed.py 24 72
 run probe_tail python tools/probe_tail.py
 run probe_cheap_content python tools/probe_cheap_content.py
 run single_image_trace python tools/single_image_trace.py
-run cheap_step python tools/cheap_step.py auto 2
+run cheap_step python tools/cheap_step.py xauto15 2
 run probe_graph python tools/probe_graph.py
 run run_agent_demo python tools/run_agent_demo.py
-run agent_ranks_demo python tools/agent_ranks_demo.py
+run agent_ranks_demo python tools/agent_ranks_demo.py $out/agent_ranks_demo.json 3 auto
 run bench_table python tools/bench_table.py
 run bench_lift python tools/bench_lift.py
 run bench_cnn python tools/bench_cnn.py
 run probe_scaling python tools/probe_scaling.py
 run ab_side_levels python tools/ab_side_levels.py
-run ab_chunk python tools/ab_chunk.py
 run ab_tiles python tools/ab_tiles.py
 run cnn_gap_probe python tools/cnn_gap_probe.py
-run stamp_rans python tools/stamp_rans.py
-run stamp_cnn python tools/stamp_cnn.py
 run sweep_v4 python tools/sweep_v4.py
 cat $out/summary.txt

@@ -31,6 +31,8 @@ x = codec.decode(torch.from_numpy(ch).to(dev), seg, H, W, mode=MODE_AC).clone()
 torch.cuda.synchronize()
 mode = mode_of_name(name)
 c, s = codec.encode(x, mode=mode); codec.check()
+if mode & 0x10000:               # encoder mode "auto": from here on the container it wrote (the decoder needs the container's own mode)
+    mode = sorted(set(codec.container_modes(c)))[0]
 r = codec.decode(c, s, H, W, mode=mode); codec.check()
 assert torch.equal(r, x)
 torch.cuda.synchronize()
