@@ -384,3 +384,33 @@ def test_no_scratch_in_mfma_and_stage_kernels():
     for r in cnn:                                       # a 1024-thread workgroup has 128 unified registers per lane, a 512-thread one 256
         cap = 512 * 256 // r["max_flat_workgroup_size"]
         assert r["vgpr_count"] + r["agpr_count"] <= cap, (r["demangled"], r)
+
+
+def test_header_mode_c_and_python_agree_on_every_tag():
+    """llicti_header_mode (the C-ABI's reading of a header, what a native caller hands to llicti_decode_images*) against llicti_amd.codec.mode_of_header
+    over EVERY byte 0 and every value of the pad field's stream-count bits: the same mode, or both refuse (retired v2 / xwide-v3 tags, a count in a
+    container that is not xwide v4, unknown tags).  Host code only -- no GPU."""
+    from llicti_amd import _lib
+    from llicti_amd.codec import MODE_AC, MODE_RANS, mode_of_header, rans_pad_hi, rans_tag
+    L = _lib.lib()
+    accepted = set()
+    for b0 in range(256):
+        for u in range(64):
+            hdr = bytes([b0, 3, 3]) + bytes(12) + int(0x036A | (u << 10)).to_bytes(2, "little")       # a 67x93 image's pad flags under the count
+            m = C.c_int(-12345)
+            rc = L.llicti_header_mode((C.c_uint8 * 17).from_buffer_copy(hdr), C.byref(m))
+            try:
+                want = mode_of_header(hdr)
+            except ValueError:
+                want = None
+            if want is None:
+                assert rc == _lib.EFORMAT, (hex(b0), u, rc, m.value)
+            else:
+                assert rc == 0 and m.value == want, (hex(b0), u, rc, m.value, want)
+                accepted.add(want)
+    # what is accepted is exactly what the encoder can write: the reference format, 1 .. 32 / 64 / 128 narrow, 1 .. 14 wide, 1 .. 32 / 64 / 128 xwide streams
+    counts = list(range(1, 33)) + [64, 128]
+    assert accepted == {MODE_AC} | {MODE_RANS(M) for M in counts} | {MODE_RANS(M, wide=1) for M in range(1, 15)} | {MODE_RANS(M, wide=2) for M in counts}
+    for M in counts:
+        hdr = bytes([rans_tag(M, 2), 3, 3]) + bytes(12) + int(0x036A | (rans_pad_hi(M, 2) << 10)).to_bytes(2, "little")
+        assert mode_of_header(hdr) == MODE_RANS(M, wide=2)
